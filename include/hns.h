@@ -1,0 +1,200 @@
+/*
+ * hns.h — C ABI of the MI355X-native HideAndSeek environment step.
+ *
+ * The reference (thu-uav/Multi-UAV-pursuit-evasion) has no FFI: its environment is the Python
+ * class `HideAndSeek(IsaacEnv)` and the physics is PhysX behind `omni.isaac.core`.  This
+ * header is the boundary a maintainer binds *below* that Python class; each entry point names
+ * the reference code it replaces (paths relative to the reference repo):
+ *
+ *   hns_step   <->  TransformedEnv.step = PIDRateController._inv_call
+ *                   (omni_drones/utils/torchrl/transforms.py:425-459)
+ *                   + IsaacEnv._step (omni_drones/envs/isaac_env.py:231-240)
+ *                   = HideAndSeek._pre_sim_step (envs/hide_and_seek/hideandseek.py:725-744)
+ *                   + sim.step() [PhysX; replaced by the documented integrator, DESIGN.md §A5]
+ *                   + _compute_state_and_obs (:746-917) + _compute_reward_and_done (:919-1065)
+ *   hns_reset  <->  IsaacEnv._reset (isaac_env.py:210-225) = HideAndSeek._reset_idx
+ *                   (hideandseek.py:609-723) + MultirotorBase._reset_idx
+ *                   (robots/drone/multirotor.py:635-650) + the reset-time obs pass
+ *   hns_create <->  IsaacEnv.__init__/HideAndSeek.__init__ parameter capture
+ *                   (isaac_env.py:54-151, hideandseek.py:236-325, 435-455)
+ *
+ * Conventions: plain C types only; every `float*`/`uint8_t*` in hns_buffers is a DEVICE
+ * pointer owned by the caller (e.g. torch tensors) that must stay valid while bound;
+ * functions return 0 on success and a negative hns_status on error, never throw, never
+ * allocate device memory after hns_create, never synchronise the stream.  Quaternions are
+ * (w,x,y,z) (omni_drones/utils/torch.py:62,125).  All tensors are C-contiguous fp32 unless noted.
+ */
+#ifndef HNS_H_
+#define HNS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HNS_ABI_VERSION 1
+#define HNS_MAX_AGENTS 7    /* pursuers per env; lane group = next pow2 >= A+1 */
+#define HNS_MAX_CYLINDERS 16
+#define HNS_NUM_STATS 24    /* hideandseek.py:400-425 */
+#define HNS_SELF_DIM 20     /* state_self without TP prediction, hideandseek.py:856-863 */
+
+typedef enum hns_status {
+    HNS_OK = 0,
+    HNS_ERR_INVALID_ARG = -1,
+    HNS_ERR_NOT_BOUND = -2,
+    HNS_ERR_DEVICE = -3,   /* HIP runtime error, see hns_last_error() */
+    HNS_ERR_NO_DEVICE = -4,
+    HNS_ERR_CONFIG = -5    /* e.g. fewer free grid cells than cylinders, hideandseek.py:112-113 */
+} hns_status;
+
+/* row index of each statistic in hns_buffers.stats ([HNS_NUM_STATS][E]); order = spec order */
+typedef enum hns_stat {
+    HNS_ST_SUCCESS = 0, HNS_ST_COLLISION, HNS_ST_BLOCKED, HNS_ST_DISTANCE_REWARD,
+    HNS_ST_DISTANCE_PREDICTED_REWARD, HNS_ST_SPEED_REWARD, HNS_ST_COLLISION_REWARD,
+    HNS_ST_COLLISION_WALL, HNS_ST_COLLISION_CYLINDER, HNS_ST_COLLISION_DRONE,
+    HNS_ST_DETECT_REWARD, HNS_ST_CATCH_REWARD, HNS_ST_SMOOTHNESS_REWARD, HNS_ST_SMOOTHNESS_MEAN,
+    HNS_ST_SMOOTHNESS_MAX, HNS_ST_FIRST_CAPTURE_STEP, HNS_ST_SUM_DETECT_STEP, HNS_ST_RETURN,
+    HNS_ST_ACTION_ERROR_ORDER1_MEAN, HNS_ST_ACTION_ERROR_ORDER1_MAX, HNS_ST_TARGET_PREDICTED_ERROR,
+    HNS_ST_DISTANCE_THRESHOLD_L, HNS_ST_OUT_OF_ARENA, HNS_ST_SMOOTHNESS_COEF
+} hns_stat;
+
+/* How reset places bodies (hideandseek.py:613-689). */
+typedef enum hns_init_mode {
+    HNS_INIT_RANDOM = 0,   /* use_random_cylinder=1, use_eval=0: uniform boxes + grid cylinders */
+    HNS_INIT_EVAL = 1,     /* use_random_cylinder=1, use_eval=1: fixed xy, random z, zero rpy */
+    HNS_INIT_SCENARIO = 2  /* use_random_cylinder=0: fixed drone/target/cylinder positions */
+} hns_init_mode;
+
+/*
+ * All scalars the step/reset math needs, resolved on the host from cfg/task/HideAndSeek*.yaml
+ * and robots/assets/usd/crazyflie.yaml.  Derived values are computed by the host in fp32
+ * exactly as the reference computes them (noted per field).
+ */
+typedef struct hns_cfg {
+    int32_t abi_version;       /* = HNS_ABI_VERSION */
+    int32_t num_envs;          /* E  (this process' shard) */
+    int32_t num_agents;        /* A  cfg.task.num_agents */
+    int32_t num_cylinders;     /* C  cfg.task.cylinder.max_num (slots incl. inactive) */
+    int32_t obs_max_cylinder;  /* k  cfg.task.cylinder.obs_max_cylinder (<= C) */
+    int32_t max_episode_length;
+    int32_t use_deployment;    /* smoothness reward on/off, hideandseek.py:993 */
+    int32_t fixed_yaw;         /* crazyflie.yaml:6 */
+    int32_t ground_clamp;      /* integrator: inelastic ground plane at z=0 */
+    int32_t write_critic_state;/* also fill buffers.state_drones */
+    int32_t init_mode;         /* hns_init_mode */
+    int32_t cyl_min_num;       /* cylinder.min_num */
+    int32_t cyl_fixed_num;     /* cylinder.fixed_num, -1 = null */
+    int32_t grid_num;          /* int(arena*2/(2*size)) = 9, hideandseek.py:579 */
+    int32_t env_index_offset;  /* global index of local env 0 (multi-GPU shard); keys the reset RNG */
+    int32_t reserved0;
+
+    float dt;                  /* cfg.sim.dt */
+    float gravity;             /* 9.81 */
+    /* task */
+    float arena_size, max_height, cylinder_size, cylinder_height;
+    float catch_radius, drone_detect_radius, target_detect_radius, collision_radius;
+    float v_drone;             /* speed-penalty threshold AND PhysX max_linear_velocity (hideandseek.py:539) */
+    float v_prey;              /* v_drone * cfg.task.v_prey (hideandseek.py:263); runtime-updatable */
+    float dist_reward_coef, catch_reward_coef, detect_reward_coef, collision_coef, speed_coef;
+    float smoothness_coef;     /* min(max_smoothness_coef, init + smooth_lr*update_epoch), :988-989 */
+    float mask_value;          /* -5, hideandseek.py:305 */
+    float invalid_z;           /* -20, hideandseek.py:451 */
+    float grid_size;           /* 2*cylinder_size */
+    float arena_sq;            /* fp32(arena_size**2): python-double square, then cast (hideandseek.py:1096,979) */
+    float coll_drone_dist;     /* fp32(2.0*collision_radius) (hideandseek.py:973) */
+    float boundary;            /* arena_size - 0.1 */
+    /* drone (Crazyflie) */
+    float mass;
+    float inertia[3];          /* diagonal */
+    float kf[4];               /* max_rot_vel^2 * force_constant, rotor_group.py:41 */
+    float km[4];               /* max_rot_vel^2 * moment_constant, rotor_group.py:42 */
+    float rotor_dir[4];        /* directions */
+    float rotor_px[4];         /* arm_length*cos(angle): torque_y = -sum(px*T) */
+    float rotor_py[4];         /* arm_length*sin(angle): torque_x =  sum(py*T) */
+    float tau_up, tau_down;    /* dt / clamp(time_constant,0,1), rotor_group.py:58-61 */
+    float max_thrust_ratio, target_clip;
+    float hover_throttle;      /* sqrt(m*g / sum(kf)), multirotor.py:647-648 */
+    float pid_kp[3], pid_ki[3], pid_kd[3], pid_ilimit[3], pid_outlimit; /* lee_position_controller.py:446-452 */
+    /* integrator (PhysX-like) */
+    float lin_damp_factor;     /* max(0, 1 - dt*linear_damping)  (robots/config.py:32) */
+    float ang_damp_factor;     /* max(0, 1 - dt*angular_damping) (robots/config.py:34) */
+    float max_ang_vel;         /* 1000 rad/s (robots/config.py:38) */
+    float max_lin_vel;         /* v_drone*(1-1e-6): PhysX max_linear_velocity (hideandseek.py:539), set a hair
+                                  inside so the clamped speed never trips `speed > v_drone` (:952) by rounding */
+    /* reset distributions (hideandseek.py:283-313) */
+    float drone_xy_lo[2], drone_xy_hi[2], target_xy_lo[2], target_xy_hi[2];
+    float z_lo, z_hi;
+    float rpy_lo[3], rpy_hi[3];
+    /* fixed placements for HNS_INIT_EVAL (xy only) / HNS_INIT_SCENARIO (hideandseek.py:480-531,633-682) */
+    float fixed_drone_pos[HNS_MAX_AGENTS + 1][3];
+    float fixed_target_pos[3];
+    float fixed_cyl_pos[HNS_MAX_CYLINDERS][3];
+    int32_t fixed_cyl_active;  /* HNS_INIT_SCENARIO: number of active cylinders */
+    int32_t reserved1;
+} hns_cfg;
+
+/* Device buffers, caller-owned.  Shapes in brackets; E,A,C,k as in hns_cfg. */
+typedef struct hns_buffers {
+    /* persistent state, updated in place */
+    float *drone_state;    /* [E,A,13] pos3 quat4 linvel3 angvel3, world frame == info.drone_state */
+    float *throttle;       /* [E,A,4]  rotor throttle, multirotor.py:216 */
+    float *pid_integ;      /* [E,A,4]  xyz + pad, lee_position_controller.py:497-502 */
+    float *pid_last_rate;  /* [E,A,4]  xyz + pad */
+    float *prev_action;    /* [E,A,4]  == info.prev_action (ctbr of the last step) */
+    float *target_pos;     /* [E,3]    evader position */
+    float *target_vel;     /* [E,3]    evader linear velocity set this step (hideandseek.py:741) */
+    float *cylinders;      /* [E,C,3]  z<0 => inactive */
+    float *progress;       /* [E]      float step counter, isaac_env.py:142-147 */
+    float *stats;          /* [HNS_NUM_STATS,E] */
+    /* per-step outputs */
+    float *obs_self;       /* [E,A,20]       agents.observation.state_self */
+    float *obs_others;     /* [E,A,A-1,3]    agents.observation.state_others (unused when A==1) */
+    float *obs_cylinders;  /* [E,A,k,5]      agents.observation.cylinders == agents.state.cylinders */
+    float *state_drones;   /* [E,A,20]       agents.state.state_drones; may be NULL if !write_critic_state */
+    float *reward;         /* [E,A]          agents.reward */
+    float *action_error;   /* [E,A]          stats.action_error_order1 (transforms.py:441) */
+    uint8_t *done;         /* [E]            bool */
+} hns_buffers;
+
+typedef struct hns_env hns_env;
+
+/* Validate cfg, select the kernel specialisation, allocate nothing on the device. */
+int hns_create(const hns_cfg *cfg, hns_env **out);
+void hns_destroy(hns_env *env);
+
+/* Attach caller-owned device buffers (may be called again to re-point). */
+int hns_bind(hns_env *env, const hns_buffers *buffers);
+
+/* One environment step for all E envs.  `action` = raw policy output [E,A,4] (pre-tanh),
+ * device pointer.  `stream` is a hipStream_t (NULL = default stream).  Asynchronous. */
+int hns_step(hns_env *env, const float *action, void *stream);
+
+/* Reset the envs whose reset_mask byte is non-zero (NULL = all) and recompute their
+ * observation.  `reset_mask` is a device pointer [E] (e.g. buffers.done).  Random draws come
+ * from Philox4x32-10 keyed by (seed, global env index, reset epoch); the epoch is a host
+ * counter advanced by every call.  Asynchronous. */
+int hns_reset(hns_env *env, const uint8_t *reset_mask, uint64_t seed, void *stream);
+
+/* Curriculum hook (hideandseek.py:1012-1015): change the evader speed. */
+int hns_set_v_prey(hns_env *env, float v_prey);
+/* Smoothness schedule hook (hideandseek.py:988-991). */
+int hns_set_smoothness_coef(hns_env *env, float coef);
+/* Reset epoch (for checkpoint/resume and tests). */
+int hns_set_reset_epoch(hns_env *env, uint32_t epoch);
+uint32_t hns_get_reset_epoch(const hns_env *env);
+
+/* Average device time (ms) of the step kernel over the launches since the last call, measured
+ * with hipEvents on the launch stream when timing was enabled; returns <0 if no sample. */
+int hns_enable_timing(hns_env *env, int on);
+float hns_step_kernel_ms(hns_env *env, int *num_launches);
+
+int hns_abi_version(void);
+size_t hns_cfg_size(void);   /* sizeof(hns_cfg) the library was built with (binding self-check) */
+const char *hns_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNS_H_ */

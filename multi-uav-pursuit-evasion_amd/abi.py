@@ -1,0 +1,152 @@
+"""ctypes mirror of include/hns.h and loader of the HIP shared library (libhns.so).
+
+The product path has no CPU fallback: `load_library()` raises if the HIP extension has not
+been built (`python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes as C
+import os
+
+HNS_ABI_VERSION = 1
+HNS_MAX_AGENTS = 7
+HNS_MAX_CYLINDERS = 16
+HNS_NUM_STATS = 24
+HNS_SELF_DIM = 20
+
+HNS_INIT_RANDOM, HNS_INIT_EVAL, HNS_INIT_SCENARIO = 0, 1, 2
+
+# row order of hns_buffers.stats == stats_spec order (reference hideandseek.py:400-425)
+STAT_NAMES = [
+    "success", "collision", "blocked", "distance_reward", "distance_predicted_reward",
+    "speed_reward", "collision_reward", "collision_wall", "collision_cylinder", "collision_drone",
+    "detect_reward", "catch_reward", "smoothness_reward", "smoothness_mean", "smoothness_max",
+    "first_capture_step", "sum_detect_step", "return", "action_error_order1_mean",
+    "action_error_order1_max", "target_predicted_error", "distance_threshold_L", "out_of_arena",
+    "smoothness_coef",
+]
+assert len(STAT_NAMES) == HNS_NUM_STATS
+
+_f = C.c_float
+_i = C.c_int32
+
+
+class HnsCfg(C.Structure):
+    _fields_ = [
+        ("abi_version", _i), ("num_envs", _i), ("num_agents", _i), ("num_cylinders", _i),
+        ("obs_max_cylinder", _i), ("max_episode_length", _i), ("use_deployment", _i),
+        ("fixed_yaw", _i), ("ground_clamp", _i), ("write_critic_state", _i), ("init_mode", _i),
+        ("cyl_min_num", _i), ("cyl_fixed_num", _i), ("grid_num", _i), ("env_index_offset", _i),
+        ("reserved0", _i),
+        ("dt", _f), ("gravity", _f),
+        ("arena_size", _f), ("max_height", _f), ("cylinder_size", _f), ("cylinder_height", _f),
+        ("catch_radius", _f), ("drone_detect_radius", _f), ("target_detect_radius", _f),
+        ("collision_radius", _f), ("v_drone", _f), ("v_prey", _f),
+        ("dist_reward_coef", _f), ("catch_reward_coef", _f), ("detect_reward_coef", _f),
+        ("collision_coef", _f), ("speed_coef", _f), ("smoothness_coef", _f),
+        ("mask_value", _f), ("invalid_z", _f), ("grid_size", _f), ("arena_sq", _f),
+        ("coll_drone_dist", _f), ("boundary", _f),
+        ("mass", _f), ("inertia", _f * 3), ("kf", _f * 4), ("km", _f * 4), ("rotor_dir", _f * 4),
+        ("rotor_px", _f * 4), ("rotor_py", _f * 4), ("tau_up", _f), ("tau_down", _f),
+        ("max_thrust_ratio", _f), ("target_clip", _f), ("hover_throttle", _f),
+        ("pid_kp", _f * 3), ("pid_ki", _f * 3), ("pid_kd", _f * 3), ("pid_ilimit", _f * 3),
+        ("pid_outlimit", _f),
+        ("lin_damp_factor", _f), ("ang_damp_factor", _f), ("max_ang_vel", _f), ("max_lin_vel", _f),
+        ("drone_xy_lo", _f * 2), ("drone_xy_hi", _f * 2), ("target_xy_lo", _f * 2),
+        ("target_xy_hi", _f * 2), ("z_lo", _f), ("z_hi", _f), ("rpy_lo", _f * 3), ("rpy_hi", _f * 3),
+        ("fixed_drone_pos", (_f * 3) * (HNS_MAX_AGENTS + 1)), ("fixed_target_pos", _f * 3),
+        ("fixed_cyl_pos", (_f * 3) * HNS_MAX_CYLINDERS), ("fixed_cyl_active", _i), ("reserved1", _i),
+    ]
+
+    def copy(self):
+        out = HnsCfg()
+        C.memmove(C.byref(out), C.byref(self), C.sizeof(HnsCfg))
+        return out
+
+
+_fp = C.c_void_p  # device (or, for the oracle, host) pointers travel as integers
+
+BUFFER_FIELDS = [
+    "drone_state", "throttle", "pid_integ", "pid_last_rate", "prev_action", "target_pos",
+    "target_vel", "cylinders", "progress", "stats", "obs_self", "obs_others", "obs_cylinders",
+    "state_drones", "reward", "action_error", "done",
+]
+
+
+class HnsBuffers(C.Structure):
+    _fields_ = [(name, _fp) for name in BUFFER_FIELDS]
+
+
+def buffer_shapes(E, A, Cn, K):
+    """Shape (and dtype name) of every hns_buffers field."""
+    return {
+        "drone_state": ((E, A, 13), "float32"), "throttle": ((E, A, 4), "float32"),
+        "pid_integ": ((E, A, 4), "float32"), "pid_last_rate": ((E, A, 4), "float32"),
+        "prev_action": ((E, A, 4), "float32"), "target_pos": ((E, 3), "float32"),
+        "target_vel": ((E, 3), "float32"), "cylinders": ((E, Cn, 3), "float32"),
+        "progress": ((E,), "float32"), "stats": ((HNS_NUM_STATS, E), "float32"),
+        "obs_self": ((E, A, HNS_SELF_DIM), "float32"), "obs_others": ((E, A, max(A - 1, 0), 3), "float32"),
+        "obs_cylinders": ((E, A, K, 5), "float32"), "state_drones": ((E, A, HNS_SELF_DIM), "float32"),
+        "reward": ((E, A), "float32"), "action_error": ((E, A), "float32"), "done": ((E,), "uint8"),
+    }
+
+
+_LIB = None
+LIB_NAME = "libhns.so"
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+def load_library():
+    """dlopen the HIP extension and declare its C-ABI. Raises if it is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "There is no CPU fallback for the product path.")
+    lib = C.CDLL(path)
+    lib.hns_create.argtypes = [C.POINTER(HnsCfg), C.POINTER(C.c_void_p)]
+    lib.hns_create.restype = C.c_int
+    lib.hns_destroy.argtypes = [C.c_void_p]
+    lib.hns_destroy.restype = None
+    lib.hns_bind.argtypes = [C.c_void_p, C.POINTER(HnsBuffers)]
+    lib.hns_bind.restype = C.c_int
+    lib.hns_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hns_step.restype = C.c_int
+    lib.hns_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.hns_reset.restype = C.c_int
+    lib.hns_set_v_prey.argtypes = [C.c_void_p, C.c_float]
+    lib.hns_set_v_prey.restype = C.c_int
+    lib.hns_set_smoothness_coef.argtypes = [C.c_void_p, C.c_float]
+    lib.hns_set_smoothness_coef.restype = C.c_int
+    lib.hns_set_reset_epoch.argtypes = [C.c_void_p, C.c_uint32]
+    lib.hns_set_reset_epoch.restype = C.c_int
+    lib.hns_get_reset_epoch.argtypes = [C.c_void_p]
+    lib.hns_get_reset_epoch.restype = C.c_uint32
+    lib.hns_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.hns_enable_timing.restype = C.c_int
+    lib.hns_step_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.hns_step_kernel_ms.restype = C.c_float
+    lib.hns_abi_version.argtypes = []
+    lib.hns_abi_version.restype = C.c_int
+    lib.hns_cfg_size.argtypes = []
+    lib.hns_cfg_size.restype = C.c_size_t
+    lib.hns_last_error.argtypes = []
+    lib.hns_last_error.restype = C.c_char_p
+    if lib.hns_abi_version() != HNS_ABI_VERSION:
+        raise RuntimeError("libhns.so ABI version mismatch")
+    if lib.hns_cfg_size() != C.sizeof(HnsCfg):
+        raise RuntimeError("hns_cfg layout mismatch between include/hns.h and abi.py")
+    _LIB = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "hns_create", "hns_destroy", "hns_bind", "hns_step", "hns_reset", "hns_set_v_prey",
+    "hns_set_smoothness_coef", "hns_set_reset_epoch", "hns_get_reset_epoch", "hns_enable_timing",
+    "hns_step_kernel_ms", "hns_abi_version", "hns_cfg_size", "hns_last_error",
+]

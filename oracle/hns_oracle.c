@@ -1,0 +1,837 @@
+/*
+ * hns_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Scalar CPU restatement (plain C, fp32, one env at a time) of the reference's HideAndSeek step
+ * so that the HIP path can be checked against it.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library.  Every function cites the reference lines
+ * (relative to the reference repo) it follows.  Pinned against golden vectors produced by
+ * executing the reference's own torch code (tests/golden/make_golden.py writes the .npz fixtures under tests/golden),
+ * see tests/test_oracle_golden.py.
+ *
+ * PARITY NOTE: the rigid-body integrator (o_integrate) has no reference source — the reference
+ * delegates it to closed-source PhysX (omni_drones/envs/isaac_env.py:233-234).  It follows the
+ * build's own spec; for that one stage parity is UNPINNED by the reference.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (see oracle/Makefile).
+ * All arithmetic is IEEE fp32 with explicit evaluation order; exp/tanh/sin/cos are the fixed
+ * polynomial forms specified in DESIGN.md §Numerics (the HIP kernels implement the same
+ * forms, which is what makes HIP-vs-oracle comparisons exact rather than approximate).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/hns.h"
+
+#define O_PI 3.14159265358979323846f
+
+/* ------------------------------------------------------------------------------------------
+ * elementary functions
+ * ---------------------------------------------------------------------------------------- */
+static inline float o_asfloat(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* expf: Cody-Waite reduction by ln2 (hi 0.693359375, lo -2.12194440e-4), degree-5 Cephes poly */
+static float o_expf(float x) {
+    if (!(x > -87.0f)) return (x != x) ? x : 0.0f;
+    if (x > 88.0f) return INFINITY;
+    float k = rintf(x * 1.44269504088896341f);
+    float r = x - k * 0.693359375f;
+    r = r - k * -2.12194440e-4f;
+    float p = 1.9875691500E-4f;
+    p = p * r + 1.3981999507E-3f;
+    p = p * r + 8.3334519073E-3f;
+    p = p * r + 4.1665795894E-2f;
+    p = p * r + 1.6666665459E-1f;
+    p = p * r + 5.0000001201E-1f;
+    float y = (p * (r * r) + r) + 1.0f;
+    int ki = (int)k;
+    return y * o_asfloat((uint32_t)(ki + 127) << 23);
+}
+
+/* tanhf: Cephes — odd polynomial below 0.625, 1 - 2/(exp(2|x|)+1) above */
+static float o_tanhf(float x) {
+    float ax = fabsf(x);
+    if (x != x) return x;
+    if (!(ax < 9.0f)) return x > 0.0f ? 1.0f : -1.0f;
+    if (ax < 0.625f) {
+        float z = x * x;
+        float p = -5.70498872745E-3f;
+        p = p * z + 2.06390887954E-2f;
+        p = p * z - 5.37397155531E-2f;
+        p = p * z + 1.33314422036E-1f;
+        p = p * z - 3.33332819422E-1f;
+        return (p * z) * x + x;
+    }
+    float e = o_expf(2.0f * ax);
+    float r = 1.0f - 2.0f / (e + 1.0f);
+    return x < 0.0f ? -r : r;
+}
+
+/* sincosf: Cephes octant reduction with the 3-part pi/4, |x| < 8192 */
+static void o_sincosf(float x, float *s_out, float *c_out) {
+    float ax = fabsf(x);
+    int j = (int)(ax * 1.27323954473516f); /* 4/pi */
+    if (j & 1) j += 1;
+    float y = (float)j;
+    j &= 7;
+    float z = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float zz = z * z;
+    float ps = -1.9515295891E-4f;
+    ps = ps * zz + 8.3321608736E-3f;
+    ps = ps * zz - 1.6666654611E-1f;
+    float sp = (ps * zz) * z + z;
+    float pc = 2.443315711809948E-005f;
+    pc = pc * zz - 1.388731625493765E-003f;
+    pc = pc * zz + 4.166664568298827E-002f;
+    float cp = ((pc * zz) * zz - 0.5f * zz) + 1.0f;
+    float s, c;
+    switch (j) {
+        case 0: s = sp; c = cp; break;
+        case 2: s = cp; c = -sp; break;
+        case 4: s = -sp; c = -cp; break;
+        default: s = -cp; c = sp; break; /* 6 */
+    }
+    if (x < 0.0f) s = -s;
+    *s_out = s;
+    *c_out = c;
+}
+
+static inline float o_clamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static inline float o_norm3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
+
+/* omni_drones/utils/torch.py:183-191 (quat_rotate) and :194-202 (quat_rotate_inverse) */
+static void o_quat_rot(const float q[4], const float v[3], float out[3], int inverse) {
+    float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    float s = 2.0f * (qw * qw) - 1.0f;
+    float cx = qy * v[2] - qz * v[1];
+    float cy = qz * v[0] - qx * v[2];
+    float cz = qx * v[1] - qy * v[0];
+    float dot = (qx * v[0] + qy * v[1]) + qz * v[2];
+    float a0 = v[0] * s, a1 = v[1] * s, a2 = v[2] * s;
+    float b0 = (cx * qw) * 2.0f, b1 = (cy * qw) * 2.0f, b2 = (cz * qw) * 2.0f;
+    float c0 = (qx * dot) * 2.0f, c1 = (qy * dot) * 2.0f, c2 = (qz * dot) * 2.0f;
+    if (inverse) {
+        out[0] = (a0 - b0) + c0; out[1] = (a1 - b1) + c1; out[2] = (a2 - b2) + c2;
+    } else {
+        out[0] = (a0 + b0) + c0; out[1] = (a1 + b1) + c1; out[2] = (a2 + b2) + c2;
+    }
+}
+
+/* omni_drones/utils/torch.py:110-127 */
+static void o_euler_to_quat(const float rpy[3], float q[4]) {
+    float sr, cr, sp, cp, sy, cy;
+    o_sincosf(rpy[0] * 0.5f, &sr, &cr);
+    o_sincosf(rpy[1] * 0.5f, &sp, &cp);
+    o_sincosf(rpy[2] * 0.5f, &sy, &cy);
+    q[0] = (cr * cp) * cy + (sr * sp) * sy;
+    q[1] = (sr * cp) * cy - (cr * sp) * sy;
+    q[2] = (cr * sp) * cy + (sr * cp) * sy;
+    q[3] = (cr * cp) * sy - (sr * sp) * cy;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A1+A2: action -> CTBR -> body-rate PID -> motor commands
+ * transforms.py:425-459, lee_position_controller.py:476-550
+ * ---------------------------------------------------------------------------------------- */
+static void o_ctbr_pid(const hns_cfg *c, const float action[4], const float q[4], const float angvel[3],
+                       float prev_action[4], float integ[3], float last[3],
+                       float cmd[4], float *action_error, float ctbr_out[4], float target_rate_out[3]) {
+    float a[4];
+    for (int i = 0; i < 4; ++i) a[i] = o_tanhf(action[i]);
+    float ctbr[4] = {a[0], a[1], a[2], o_clamp((a[3] + 1.0f) / 2.0f, 0.0f, c->max_thrust_ratio)};
+    if (c->fixed_yaw) ctbr[2] = 0.0f;
+    float e2 = 0.0f;
+    for (int i = 0; i < 4; ++i) {
+        float d = ctbr[i] - prev_action[i];
+        e2 = (i == 0) ? d * d : e2 + d * d;
+    }
+    *action_error = sqrtf(e2);
+    for (int i = 0; i < 4; ++i) prev_action[i] = ctbr[i];
+    float target[3];
+    for (int i = 0; i < 3; ++i) target[i] = (ctbr[i] * 180.0f) * c->target_clip;
+    float thrust = ctbr[3] * 65536.0f;
+    if (target_rate_out) for (int i = 0; i < 3; ++i) target_rate_out[i] = target[i];
+
+    float br[3];
+    o_quat_rot(q, angvel, br, 1);
+    float out[3];
+    for (int i = 0; i < 3; ++i) {
+        br[i] = (br[i] * 180.0f) / O_PI;
+        float err = target[i] - br[i];
+        float P = err * c->pid_kp[i];
+        float deriv = -(br[i] - last[i]) / c->dt;
+        if (deriv != deriv) deriv = 0.0f;
+        float D = deriv * c->pid_kd[i];
+        float in = integ[i] + err * c->dt;
+        in = o_clamp(in, -c->pid_ilimit[i], c->pid_ilimit[i]);
+        integ[i] = in;
+        float I = in * c->pid_ki[i];
+        float FF = target[i] * 0.0f;
+        float o = ((P + D) + I) + FF;
+        if (o != o) o = 0.0f;
+        out[i] = o_clamp(o, -c->pid_outlimit, c->pid_outlimit);
+        last[i] = br[i];
+    }
+    float r = out[0] / 2.0f, p = out[1] / 2.0f, y = out[2];
+    float m[4] = {((thrust + r) - p) + y, ((thrust + r) + p) - y, ((thrust - r) + p) + y, ((thrust - r) - p) - y};
+    if (ctbr_out) { ctbr_out[0] = r; ctbr_out[1] = p; ctbr_out[2] = y; ctbr_out[3] = thrust; }
+    for (int i = 0; i < 4; ++i) {
+        float v = (m[i] / 65536.0f) * 2.0f - c->max_thrust_ratio;
+        if (v != v) v = 0.0f;                               /* torch.nan_to_num_(cmds, 0.) */
+        else if (v == INFINITY) v = 3.4028234663852886e38f;
+        else if (v == -INFINITY) v = -3.4028234663852886e38f;
+        cmd[i] = v;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A3: rotor lag + thrust/moment   rotor_group.py:55-71
+ * ---------------------------------------------------------------------------------------- */
+static void o_rotor(const hns_cfg *c, const float cmd[4], float throttle[4], float thrust[4], float moment[4],
+                    float *throttle_difference) {
+    float d2 = 0.0f;
+    for (int i = 0; i < 4; ++i) {
+        float tgt = sqrtf(o_clamp((cmd[i] + 1.0f) / 2.0f, 0.0f, 1.0f));
+        float tau = (tgt > throttle[i]) ? c->tau_up : c->tau_down;
+        float old = throttle[i];
+        float thr = old + tau * (tgt - old);
+        throttle[i] = thr;
+        float t = o_clamp(thr * thr + 0.0f, 0.0f, 1.0f);
+        thrust[i] = t * c->kf[i];
+        moment[i] = (t * c->km[i]) * -c->rotor_dir[i];
+        float d = thr - old;
+        d2 = (i == 0) ? d * d : d2 + d * d;
+    }
+    *throttle_difference = sqrtf(d2);     /* multirotor.py:507 */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A4: downwash of drone j on drone i   multirotor.py:488-494, 725-753
+ * tj_w = quat_rotate(q_j, [0,0,sum thrust_j])
+ * ---------------------------------------------------------------------------------------- */
+static void o_downwash_pair(const float pi[3], const float pj[3], const float tj_w[3], float f[3]) {
+    float n = o_norm3(tj_w[0], tj_w[1], tj_w[2]);
+    float d[3] = {tj_w[0] / (n + 1e-6f), tj_w[1] / (n + 1e-6f), tj_w[2] / (n + 1e-6f)};
+    float rel[3] = {pj[0] - pi[0], pj[1] - pi[1], pj[2] - pi[2]};
+    float zd = (rel[0] * d[0] + rel[1] * d[1]) + rel[2] * d[2];
+    float rx = rel[0] - zd * d[0], ry = rel[1] - zd * d[1], rz = rel[2] - zd * d[2];
+    float r = o_norm3(rx, ry, rz);
+    float z = zd < 0.0f ? 0.0f : zd;
+    float u = (2.0f * r) / z;
+    float den = 1.0f + 0.3f * z;
+    float v = o_expf(-0.5f * (u * u)) / (den * den);
+    f[0] = v * -tj_w[0]; f[1] = v * -tj_w[1]; f[2] = v * -tj_w[2];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A7: line of sight drone->target blocked by a cylinder (xy plane)   hideandseek.py:47-103
+ * ---------------------------------------------------------------------------------------- */
+static int o_blocked(const hns_cfg *c, int C, const float dp[3], const float tp[3], const float *cyl) {
+    float diffx = dp[0] - tp[0], diffy = dp[1] - tp[1];
+    float den = sqrtf(diffx * diffx + diffy * diffy);
+    float dx = tp[0] - dp[0], dy = tp[1] - dp[1];
+    float dent = dx * dx + dy * dy;
+    int any = 0;
+    for (int k = 0; k < C; ++k) {
+        const float *cc = cyl + 3 * k;
+        float d2x = cc[0] - tp[0], d2y = cc[1] - tp[1];
+        float num = fabsf(diffx * d2y - diffy * d2x);
+        float dist = num / (den + 1e-5f);
+        int blocked = dist <= c->cylinder_size;
+        float numt = (cc[0] - dp[0]) * dx + (cc[1] - dp[1]) * dy;
+        float t = numt / (dent + 1e-5f);
+        int on = (t >= 0.0f) && (t <= 1.0f);
+        int ground = cc[2] > 0.0f;
+        any |= (blocked && on && ground);
+    }
+    return any;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A6: evader potential field + per-axis velocity   hideandseek.py:737-744, 1067-1141
+ * drone_pos [A,3]; cyl [C,3]; returns force[3], vel[3]; out_of_arena stat is OR-ed in place
+ * ---------------------------------------------------------------------------------------- */
+static void o_prey(const hns_cfg *c, int A, int C, const float *drone_pos, const float tp[3], const float *cyl,
+                   float force[3], float vel[3], float *out_of_arena_stat) {
+    float F[3] = {0.0f, 0.0f, 0.0f};
+    for (int a = 0; a < A; ++a) {
+        const float *dp = drone_pos + 3 * a;
+        float rp[3] = {dp[0] - tp[0], dp[1] - tp[1], dp[2] - tp[2]};
+        float dist = o_norm3(rp[0], rp[1], rp[2]);
+        int blocked = o_blocked(c, C, dp, tp, cyl);
+        float active = ((dist < c->target_detect_radius) && !blocked) ? 1.0f : 0.0f;
+        float rec = 1.0f / (dist + 1e-5f);
+        for (int i = 0; i < 3; ++i) {
+            float dir = -rp[i] / (dist + 1e-5f);
+            float fp = (dir * rec) * active;
+            F[i] = (a == 0) ? fp : F[i] + fp;
+        }
+    }
+    /* arena  :1094-1112 */
+    float od = sqrtf(tp[0] * tp[0] + tp[1] * tp[1]);
+    float dirx = -tp[0] / (od + 1e-5f), diry = -tp[1] / (od + 1e-5f);
+    int out = (tp[0] * tp[0] + tp[1] * tp[1]) > c->arena_sq;
+    if (out_of_arena_stat) *out_of_arena_stat = ((*out_of_arena_stat != 0.0f) || out) ? 1.0f : 0.0f;
+    float outf = out ? 1.0f : 0.0f, nout = out ? 0.0f : 1.0f;
+    float rin = 1.0f / ((c->arena_size - od) + 1e-5f);
+    float frx = (outf * dirx) * 1e5f + (nout * dirx) * rin;
+    float fry = (outf * diry) * 1e5f + (nout * diry) * rin;
+    float H = c->max_height;
+    int hi = tp[2] > H;
+    float hif = hi ? 1.0f : 0.0f, nhi = hi ? 0.0f : 1.0f;
+    float hz = H - tp[2];
+    float frz = hif * -1e5f + (nhi * -hz) / (hz * hz + 1e-5f);
+    int lo = tp[2] < 0.0f;
+    float lof = lo ? 1.0f : 0.0f, nlo = lo ? 0.0f : 1.0f;
+    float lz = 0.0f - tp[2];
+    frz = frz + (lof * 1e5f + (nlo * -lz) / (lz * lz + 1e-5f));
+    F[0] = F[0] + frx; F[1] = F[1] + fry; F[2] = F[2] + frz;
+    /* cylinders  :1129-1136 (mask = cylinder z < 0, written by the previous obs pass :759) */
+    float fcx = 0.0f, fcy = 0.0f;
+    for (int k = 0; k < C; ++k) {
+        const float *cc = cyl + 3 * k;
+        float rx = tp[0] - cc[0], ry = tp[1] - cc[1];
+        float dc = sqrtf(rx * rx + ry * ry);
+        float db = dc - c->cylinder_size;
+        float act = (!(cc[2] < 0.0f) && (dc < c->target_detect_radius)) ? 1.0f : 0.0f;
+        float rec = 1.0f / (db + 1e-5f);
+        float tx = (act * (rx / (dc + 1e-5f))) * rec;
+        float ty = (act * (ry / (dc + 1e-5f))) * rec;
+        fcx = (k == 0) ? tx : fcx + tx;
+        fcy = (k == 0) ? ty : fcy + ty;
+    }
+    F[0] = F[0] + fcx; F[1] = F[1] + fcy; F[2] = F[2] + 0.0f;
+    for (int i = 0; i < 3; ++i) {
+        force[i] = F[i];
+        vel[i] = (c->v_prey * F[i]) / (fabsf(F[i]) + 1e-5f);   /* :741 norm over a size-1 dim */
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A5: rigid-body integration — the build's own spec, no reference source
+ * ds = [pos3 quat4 linvel3 angvel3]; force_w world force, torque_b body torque
+ * ---------------------------------------------------------------------------------------- */
+static void o_integrate(const hns_cfg *c, float ds[13], const float force_w[3], const float torque_b[3]) {
+    float *pos = ds, *q = ds + 3, *lin = ds + 7, *ang = ds + 10;
+    float acc[3] = {force_w[0] / c->mass, force_w[1] / c->mass, force_w[2] / c->mass - c->gravity};
+    float v[3];
+    for (int i = 0; i < 3; ++i) v[i] = (lin[i] + acc[i] * c->dt) * c->lin_damp_factor;
+    float sp = o_norm3(v[0], v[1], v[2]);
+    if (sp > c->max_lin_vel) {
+        float sc = c->max_lin_vel / sp;
+        v[0] *= sc; v[1] *= sc; v[2] *= sc;
+    }
+    float wb[3];
+    o_quat_rot(q, ang, wb, 1);
+    float Iw[3] = {wb[0] * c->inertia[0], wb[1] * c->inertia[1], wb[2] * c->inertia[2]};
+    float gy[3] = {wb[1] * Iw[2] - wb[2] * Iw[1], wb[2] * Iw[0] - wb[0] * Iw[2], wb[0] * Iw[1] - wb[1] * Iw[0]};
+    float w2[3];
+    for (int i = 0; i < 3; ++i)
+        w2[i] = (wb[i] + ((torque_b[i] - gy[i]) / c->inertia[i]) * c->dt) * c->ang_damp_factor;
+    float wn = o_norm3(w2[0], w2[1], w2[2]);
+    if (wn > c->max_ang_vel) {
+        float sc = c->max_ang_vel / wn;
+        w2[0] *= sc; w2[1] *= sc; w2[2] *= sc;
+    }
+    float ww[3];
+    o_quat_rot(q, w2, ww, 0);
+    float p[3] = {pos[0] + v[0] * c->dt, pos[1] + v[1] * c->dt, pos[2] + v[2] * c->dt};
+    if (c->ground_clamp && p[2] < 0.0f) {
+        p[2] = 0.0f;
+        if (v[2] < 0.0f) v[2] = 0.0f;
+    }
+    float wwn = o_norm3(ww[0], ww[1], ww[2]);
+    float half = (wwn * c->dt) * 0.5f;
+    float s, co;
+    o_sincosf(half, &s, &co);
+    float so = (wwn > 1e-8f) ? s / wwn : 0.5f * c->dt;
+    float w1 = co, x1 = ww[0] * so, y1 = ww[1] * so, z1 = ww[2] * so;
+    float w2q = q[0], x2 = q[1], y2 = q[2], z2 = q[3];
+    float nq[4] = {((w1 * w2q - x1 * x2) - y1 * y2) - z1 * z2,
+                   ((w1 * x2 + x1 * w2q) + y1 * z2) - z1 * y2,
+                   ((w1 * y2 - x1 * z2) + y1 * w2q) + z1 * x2,
+                   ((w1 * z2 + x1 * y2) - y1 * x2) + z1 * w2q};
+    float qn = sqrtf(((nq[0] * nq[0] + nq[1] * nq[1]) + nq[2] * nq[2]) + nq[3] * nq[3]);
+    for (int i = 0; i < 3; ++i) { pos[i] = p[i]; lin[i] = v[i]; ang[i] = ww[i]; }
+    for (int i = 0; i < 4; ++i) q[i] = nq[i] / qn;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A8: observation pass for one env   multirotor.py:599-633, hideandseek.py:746-917
+ * Side products kept for the reward pass: blocked[A], bdetect, knn index/mask.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct o_obs_side {
+    int blocked[HNS_MAX_AGENTS];
+    int bdetect;
+    int knn_idx[HNS_MAX_AGENTS][HNS_MAX_CYLINDERS];
+    int knn_masked[HNS_MAX_AGENTS][HNS_MAX_CYLINDERS];
+} o_obs_side;
+
+static void o_obs(const hns_cfg *c, int A, int C, int K, const float *drone_state /*[A,13]*/, const float tp[3],
+                  const float *cyl, float progress, float *obs_self /*[A,20]*/, float *obs_others /*[A,A-1,3]*/,
+                  float *obs_cyl /*[A,K,5]*/, float *state_drones /*[A,20] or NULL*/, o_obs_side *side) {
+    int det_any = 0;
+    float rt[HNS_MAX_AGENTS][3];
+    for (int a = 0; a < A; ++a) {
+        const float *ds = drone_state + 13 * a;
+        for (int i = 0; i < 3; ++i) rt[a][i] = ds[i] - tp[i];
+        float dist = o_norm3(rt[a][0], rt[a][1], rt[a][2]);
+        side->blocked[a] = o_blocked(c, C, ds, tp, cyl);
+        int det = (dist < c->drone_detect_radius) && !side->blocked[a];
+        det_any |= det;
+    }
+    side->bdetect = det_any;
+    float t = progress / (float)c->max_episode_length;
+    const float ex[3] = {1.0f, 0.0f, 0.0f}, ez[3] = {0.0f, 0.0f, 1.0f};
+    for (int a = 0; a < A; ++a) {
+        const float *ds = drone_state + 13 * a;
+        float heading[3], up[3];
+        o_quat_rot(ds + 3, ex, heading, 0);
+        o_quat_rot(ds + 3, ez, up, 0);
+        float *o = obs_self + HNS_SELF_DIM * a;
+        for (int i = 0; i < 3; ++i) o[i] = det_any ? rt[a][i] : c->mask_value;
+        for (int i = 0; i < 7; ++i) o[3 + i] = ds[3 + i];
+        for (int i = 0; i < 3; ++i) { o[10 + i] = heading[i]; o[13 + i] = up[i]; }
+        for (int i = 0; i < 4; ++i) o[16 + i] = t;
+        if (state_drones) {
+            float *s = state_drones + HNS_SELF_DIM * a;
+            for (int i = 0; i < HNS_SELF_DIM; ++i) s[i] = o[i];
+            for (int i = 0; i < 3; ++i) s[i] = rt[a][i];
+        }
+        /* state_others: p_i - p_j, j != i ascending (utils/torch.py:41-53) */
+        int w = 0;
+        for (int j = 0; j < A; ++j) {
+            if (j == a) continue;
+            const float *dj = drone_state + 13 * j;
+            for (int i = 0; i < 3; ++i) obs_others[((a * (A - 1)) + w) * 3 + i] = ds[i] - dj[i];
+            ++w;
+        }
+        /* k nearest cylinders by (3-D distance - size), ascending, ties -> lower index (:767-778) */
+        float md[HNS_MAX_CYLINDERS];
+        int taken[HNS_MAX_CYLINDERS];
+        for (int k = 0; k < C; ++k) {
+            const float *cc = cyl + 3 * k;
+            md[k] = o_norm3(ds[0] - cc[0], ds[1] - cc[1], ds[2] - cc[2]) - c->cylinder_size;
+            taken[k] = 0;
+        }
+        for (int s = 0; s < K; ++s) {
+            int best = -1;
+            for (int k = 0; k < C; ++k) {
+                if (taken[k]) continue;
+                if (best < 0 || md[k] < md[best]) best = k;
+            }
+            taken[best] = 1;
+            const float *cc = cyl + 3 * best;
+            int masked = cc[2] < 0.0f;
+            side->knn_idx[a][s] = best;
+            side->knn_masked[a][s] = masked;
+            float *oc = obs_cyl + ((a * K) + s) * 5;
+            if (masked) {
+                for (int i = 0; i < 5; ++i) oc[i] = c->mask_value;
+            } else {
+                for (int i = 0; i < 3; ++i) oc[i] = ds[i] - cc[i];
+                oc[3] = c->cylinder_height;
+                oc[4] = c->cylinder_size;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A9: reward / done / stats for one env   hideandseek.py:919-1065
+ * stats: pointer to this env's column, stride = E floats between rows
+ * ---------------------------------------------------------------------------------------- */
+static void o_reward(const hns_cfg *c, int A, int C, int K, const float *drone_state, const float tp[3],
+                     const float *cyl, float progress, const o_obs_side *side, const float *action_error,
+                     const float *thr_diff, float *stats, size_t sstride, float *reward, uint8_t *done_out) {
+    (void)C;
+#define ST(i) stats[(size_t)(i) * sstride]
+    float fA = (float)A;
+    float dist_rew[HNS_MAX_AGENTS], speed_rew[HNS_MAX_AGENTS], coll_rew[HNS_MAX_AGENTS], smooth_rew[HNS_MAX_AGENTS];
+    float sum_dist = 0, sum_speed = 0, sum_cc = 0, sum_cd = 0, sum_cw = 0, sum_coll = 0, sum_smooth = 0, sum_td = 0;
+    float max_td = 0;
+    int any_cap = 0, all_blocked = 1, any_coll = 0;
+    for (int a = 0; a < A; ++a) {
+        const float *ds = drone_state + 13 * a;
+        float d = o_norm3(tp[0] - ds[0], tp[1] - ds[1], tp[2] - ds[2]);
+        float act = (d > c->catch_radius) ? 1.0f : 0.0f;
+        dist_rew[a] = (-c->dist_reward_coef * d) * act;
+        int cap = d < c->catch_radius;
+        any_cap |= (cap && !side->blocked[a]);
+        all_blocked &= side->blocked[a];
+        float sp = o_norm3(ds[7], ds[8], ds[9]);
+        speed_rew[a] = -c->speed_coef * ((sp > c->v_drone) ? 1.0f : 0.0f);
+        float cc = 0.0f;
+        for (int s = 0; s < K; ++s) {
+            const float *cy = cyl + 3 * side->knn_idx[a][s];
+            float rx = ds[0] - cy[0], ry = ds[1] - cy[1];
+            float dxy = sqrtf(rx * rx + ry * ry);
+            float hit = ((dxy - c->cylinder_size) < c->collision_radius) ? 1.0f : 0.0f;
+            if (side->knn_masked[a][s]) hit = 0.0f;
+            cc = (s == 0) ? hit : cc + hit;
+        }
+        float cr = -c->collision_coef * cc;
+        float cd = 0.0f;
+        int first = 1;
+        for (int j = 0; j < A; ++j) {
+            if (j == a) continue;
+            const float *dj = drone_state + 13 * j;
+            float dd = o_norm3(ds[0] - dj[0], ds[1] - dj[1], ds[2] - dj[2]);
+            float hit = (dd < c->coll_drone_dist) ? 1.0f : 0.0f;
+            cd = first ? hit : cd + hit;
+            first = 0;
+        }
+        cr = cr + -c->collision_coef * cd;
+        float cw = ((ds[2] > c->max_height) ? 1.0f : 0.0f)
+                   + (((ds[0] * ds[0] + ds[1] * ds[1]) > c->arena_sq) ? 1.0f : 0.0f);
+        cr = cr + -c->collision_coef * cw;
+        coll_rew[a] = cr;
+        any_coll |= (cr < 0.0f);
+        float sm = c->smoothness_coef * o_expf(-action_error[a]);
+        if (!c->use_deployment) sm = 0.0f;
+        smooth_rew[a] = sm;
+        if (a == 0) {
+            sum_dist = dist_rew[a]; sum_speed = speed_rew[a]; sum_cc = cc; sum_cd = cd; sum_cw = cw;
+            sum_coll = cr; sum_smooth = sm; sum_td = thr_diff[a]; max_td = thr_diff[a];
+        } else {
+            sum_dist += dist_rew[a]; sum_speed += speed_rew[a]; sum_cc += cc; sum_cd += cd; sum_cw += cw;
+            sum_coll += cr; sum_smooth += sm; sum_td += thr_diff[a];
+            if (thr_diff[a] > max_td) max_td = thr_diff[a];
+        }
+    }
+    float detf = side->bdetect ? 1.0f : 0.0f;
+    float detect_rew = c->detect_reward_coef * detf;
+    float catch_rew = c->catch_reward_coef * (any_cap ? 1.0f : 0.0f);
+    int capture_flag = catch_rew != 0.0f;             /* torch.any(catch_reward, dim=1) :945 */
+
+    ST(HNS_ST_DISTANCE_REWARD) += sum_dist / fA;
+    ST(HNS_ST_SUM_DETECT_STEP) += 1.0f * detf;
+    {   /* mean over A identical values (:933), summed the same way */
+        float s = detect_rew;
+        for (int a = 1; a < A; ++a) s += detect_rew;
+        ST(HNS_ST_DETECT_REWARD) += s / fA;
+        s = catch_rew;
+        for (int a = 1; a < A; ++a) s += catch_rew;
+        ST(HNS_ST_BLOCKED) += all_blocked ? 1.0f : 0.0f;
+        ST(HNS_ST_SUCCESS) = (capture_flag || ST(HNS_ST_SUCCESS) != 0.0f) ? 1.0f : 0.0f;
+        float cur = (capture_flag ? 1.0f : 0.0f) * progress + (capture_flag ? 0.0f : 1.0f) * (float)c->max_episode_length;
+        if (cur < ST(HNS_ST_FIRST_CAPTURE_STEP)) ST(HNS_ST_FIRST_CAPTURE_STEP) = cur;
+        ST(HNS_ST_CATCH_REWARD) += s / fA;
+    }
+    ST(HNS_ST_SPEED_REWARD) += sum_speed / fA;
+    ST(HNS_ST_COLLISION_CYLINDER) += sum_cc / fA;
+    ST(HNS_ST_COLLISION_DRONE) += sum_cd / fA;
+    ST(HNS_ST_COLLISION) += any_coll ? 1.0f : 0.0f;
+    ST(HNS_ST_COLLISION_WALL) += sum_cw / fA;
+    ST(HNS_ST_COLLISION_REWARD) += sum_coll / fA;
+    ST(HNS_ST_SMOOTHNESS_COEF) = c->smoothness_coef;
+    ST(HNS_ST_SMOOTHNESS_REWARD) += sum_smooth / fA;
+    ST(HNS_ST_SMOOTHNESS_MEAN) += sum_td / fA;
+    if (max_td > ST(HNS_ST_SMOOTHNESS_MAX)) ST(HNS_ST_SMOOTHNESS_MAX) = max_td;
+
+    float sum_rew = 0.0f;
+    for (int a = 0; a < A; ++a) {
+        float r = ((((dist_rew[a] + detect_rew) + catch_rew) + coll_rew[a]) + speed_rew[a]) + smooth_rew[a];
+        reward[a] = r;
+        sum_rew = (a == 0) ? r : sum_rew + r;
+    }
+    int done = progress >= (float)c->max_episode_length;
+    *done_out = (uint8_t)done;
+    if (done) {
+        static const int div[] = {HNS_ST_COLLISION, HNS_ST_ACTION_ERROR_ORDER1_MEAN, HNS_ST_TARGET_PREDICTED_ERROR,
+                                  HNS_ST_SMOOTHNESS_MEAN, HNS_ST_SMOOTHNESS_REWARD, HNS_ST_DISTANCE_REWARD,
+                                  HNS_ST_DETECT_REWARD, HNS_ST_CATCH_REWARD, HNS_ST_COLLISION_REWARD,
+                                  HNS_ST_COLLISION_WALL, HNS_ST_COLLISION_DRONE, HNS_ST_COLLISION_CYLINDER,
+                                  HNS_ST_SPEED_REWARD};
+        for (size_t i = 0; i < sizeof(div) / sizeof(div[0]); ++i) ST(div[i]) = ST(div[i]) / progress;
+    }
+    ST(HNS_ST_RETURN) += sum_rew / fA;
+#undef ST
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Full step over all envs, on the ABI's buffers (host pointers here).  Order = SURVEY App. C.
+ * ---------------------------------------------------------------------------------------- */
+int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action) {
+    const int E = c->num_envs, A = c->num_agents, C = c->num_cylinders, K = c->obs_max_cylinder;
+    if (A < 1 || A > HNS_MAX_AGENTS || C > HNS_MAX_CYLINDERS || K > C) return HNS_ERR_INVALID_ARG;
+    for (int e = 0; e < E; ++e) {
+        float *ds = b->drone_state + (size_t)e * A * 13;
+        float *tp = b->target_pos + (size_t)e * 3;
+        const float *cyl = b->cylinders + (size_t)e * C * 3;
+        float *stats = b->stats + e;
+        float thrust[HNS_MAX_AGENTS][4], moment[HNS_MAX_AGENTS][4], thr_diff[HNS_MAX_AGENTS];
+        float tw[HNS_MAX_AGENTS][3];
+        float sum_ae = 0.0f;
+        for (int a = 0; a < A; ++a) {
+            size_t ia = (size_t)e * A + a;
+            float cmd[4];
+            o_ctbr_pid(c, action + ia * 4, ds + 13 * a + 3, ds + 13 * a + 10, b->prev_action + ia * 4,
+                       b->pid_integ + ia * 4, b->pid_last_rate + ia * 4, cmd, b->action_error + ia, NULL, NULL);
+            sum_ae = (a == 0) ? b->action_error[ia] : sum_ae + b->action_error[ia];
+            o_rotor(c, cmd, b->throttle + ia * 4, thrust[a], moment[a], &thr_diff[a]);
+            float ts = ((thrust[a][0] + thrust[a][1]) + thrust[a][2]) + thrust[a][3];
+            float tv[3] = {0.0f, 0.0f, ts};
+            o_quat_rot(ds + 13 * a + 3, tv, tw[a], 0);
+        }
+        /* A10  hideandseek.py:731-733 */
+        float mae = sum_ae / (float)A;
+        stats[(size_t)HNS_ST_ACTION_ERROR_ORDER1_MEAN * E] += mae;
+        if (mae > stats[(size_t)HNS_ST_ACTION_ERROR_ORDER1_MAX * E]) stats[(size_t)HNS_ST_ACTION_ERROR_ORDER1_MAX * E] = mae;
+        /* A6 on S_t */
+        float dpos[HNS_MAX_AGENTS * 3];
+        for (int a = 0; a < A; ++a) for (int i = 0; i < 3; ++i) dpos[3 * a + i] = ds[13 * a + i];
+        float force[3], tvel[3];
+        o_prey(c, A, C, dpos, tp, cyl, force, tvel, &stats[(size_t)HNS_ST_OUT_OF_ARENA * E]);
+        /* A4 forces/torques on S_t, then A5 */
+        float fw[HNS_MAX_AGENTS][3], tb[HNS_MAX_AGENTS][3];
+        for (int a = 0; a < A; ++a) {
+            float f[3] = {0.0f, 0.0f, 0.0f};
+            int first = 1;
+            for (int j = 0; j < A; ++j) {
+                if (j == a) continue;
+                float fj[3];
+                o_downwash_pair(dpos + 3 * a, dpos + 3 * j, tw[j], fj);
+                for (int i = 0; i < 3; ++i) f[i] = first ? fj[i] : f[i] + fj[i];
+                first = 0;
+            }
+            for (int i = 0; i < 3; ++i) fw[a][i] = tw[a][i] + f[i];
+            const float *T = thrust[a];
+            tb[a][0] = ((c->rotor_py[0] * T[0] + c->rotor_py[1] * T[1]) + c->rotor_py[2] * T[2]) + c->rotor_py[3] * T[3];
+            tb[a][1] = -(((c->rotor_px[0] * T[0] + c->rotor_px[1] * T[1]) + c->rotor_px[2] * T[2]) + c->rotor_px[3] * T[3]);
+            tb[a][2] = ((moment[a][0] + moment[a][1]) + moment[a][2]) + moment[a][3];
+        }
+        for (int a = 0; a < A; ++a) o_integrate(c, ds + 13 * a, fw[a], tb[a]);
+        for (int i = 0; i < 3; ++i) {
+            b->target_vel[(size_t)e * 3 + i] = tvel[i];
+            tp[i] = tp[i] + tvel[i] * c->dt;
+        }
+        b->progress[e] += 1.0f;
+        o_obs_side side;
+        o_obs(c, A, C, K, ds, tp, cyl, b->progress[e], b->obs_self + (size_t)e * A * HNS_SELF_DIM,
+              b->obs_others + (size_t)e * A * (A - 1) * 3, b->obs_cylinders + (size_t)e * A * K * 5,
+              (c->write_critic_state && b->state_drones) ? b->state_drones + (size_t)e * A * HNS_SELF_DIM : NULL, &side);
+        o_reward(c, A, C, K, ds, tp, cyl, b->progress[e], &side, b->action_error + (size_t)e * A, thr_diff,
+                 stats, (size_t)E, b->reward + (size_t)e * A, b->done + e);
+    }
+    return HNS_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Reset (A11)   hideandseek.py:576-723, multirotor.py:635-650
+ * Random numbers: Philox4x32-10, key = seed, counter = (global env, epoch, draw block, 0);
+ * uniform = (u32 >> 8) * 2^-24.  torch's RNG stream cannot be reproduced, so the
+ * reference is followed in distribution and in every deterministic step.
+ * ---------------------------------------------------------------------------------------- */
+static void o_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+typedef struct o_rng { uint32_t k0, k1, env, epoch, block; uint32_t buf[4]; int have; } o_rng;
+static float o_uniform(o_rng *r) {
+    if (r->have == 0) { o_philox(r->k0, r->k1, r->env, r->epoch, r->block++, 0u, r->buf); r->have = 4; }
+    uint32_t u = r->buf[4 - r->have];
+    r->have--;
+    return (float)(u >> 8) * 5.9604644775390625e-8f;
+}
+
+/* continuous_to_grid :143-164 : round-half-even(offset/grid) + center, clamped */
+static int o_cell(const hns_cfg *c, float x) {
+    int g = (int)rintf(x / c->grid_size) + c->grid_num / 2;
+    return g < 0 ? 0 : (g > c->grid_num - 1 ? c->grid_num - 1 : g);
+}
+
+int hns_oracle_reset(const hns_cfg *c, const hns_buffers *b, const uint8_t *mask, uint64_t seed, uint32_t epoch) {
+    const int E = c->num_envs, A = c->num_agents, C = c->num_cylinders, K = c->obs_max_cylinder, G = c->grid_num;
+    if (G > 16) return HNS_ERR_INVALID_ARG;
+    for (int e = 0; e < E; ++e) {
+        /* :712 sets first_capture_step for ALL envs on any reset call */
+        b->stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * E + e] = (float)c->max_episode_length;
+        if (mask && !mask[e]) continue;
+        o_rng rng = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(e + c->env_index_offset), epoch, 0u, {0, 0, 0, 0}, 0};
+        float *ds = b->drone_state + (size_t)e * A * 13;
+        float *tp = b->target_pos + (size_t)e * 3;
+        float *cyl = b->cylinders + (size_t)e * C * 3;
+        for (int a = 0; a < A; ++a) {
+            float *d = ds + 13 * a;
+            if (c->init_mode == HNS_INIT_RANDOM) {
+                d[0] = c->drone_xy_lo[0] + o_uniform(&rng) * (c->drone_xy_hi[0] - c->drone_xy_lo[0]);
+                d[1] = c->drone_xy_lo[1] + o_uniform(&rng) * (c->drone_xy_hi[1] - c->drone_xy_lo[1]);
+            } else {
+                d[0] = c->fixed_drone_pos[a][0]; d[1] = c->fixed_drone_pos[a][1];
+            }
+            if (c->init_mode == HNS_INIT_SCENARIO) d[2] = c->fixed_drone_pos[a][2];
+            else d[2] = c->z_lo + o_uniform(&rng) * (c->z_hi - c->z_lo);
+            float rpy[3];
+            for (int i = 0; i < 3; ++i) rpy[i] = c->rpy_lo[i] + o_uniform(&rng) * (c->rpy_hi[i] - c->rpy_lo[i]);
+            o_euler_to_quat(rpy, d + 3);
+            for (int i = 7; i < 13; ++i) d[i] = 0.0f;
+            size_t ia = (size_t)e * A + a;
+            float pa = 0.0f;
+            for (int i = 0; i < 4; ++i) {
+                b->throttle[ia * 4 + i] = c->hover_throttle;
+                b->pid_integ[ia * 4 + i] = 0.0f;
+                b->pid_last_rate[ia * 4 + i] = 0.0f;
+                float thr = c->hover_throttle;
+                float ci = 0.5f * (c->max_thrust_ratio + (2.0f * (thr * thr) - 1.0f));   /* :714-716 */
+                pa = (i == 0) ? ci : pa + ci;
+            }
+            b->prev_action[ia * 4 + 3] = pa / 4.0f;       /* components 0..2 are NOT reset (:716) */
+        }
+        if (c->init_mode == HNS_INIT_RANDOM) {
+            tp[0] = c->target_xy_lo[0] + o_uniform(&rng) * (c->target_xy_hi[0] - c->target_xy_lo[0]);
+            tp[1] = c->target_xy_lo[1] + o_uniform(&rng) * (c->target_xy_hi[1] - c->target_xy_lo[1]);
+        } else {
+            tp[0] = c->fixed_target_pos[0]; tp[1] = c->fixed_target_pos[1];
+        }
+        if (c->init_mode == HNS_INIT_SCENARIO) tp[2] = c->fixed_target_pos[2];
+        else tp[2] = c->z_lo + o_uniform(&rng) * (c->z_hi - c->z_lo);
+        for (int i = 0; i < 3; ++i) b->target_vel[(size_t)e * 3 + i] = 0.0f;
+        if (c->init_mode == HNS_INIT_SCENARIO) {
+            for (int k = 0; k < C; ++k) {
+                for (int i = 0; i < 3; ++i) cyl[3 * k + i] = c->fixed_cyl_pos[k][i];
+                if (k >= c->fixed_cyl_active) cyl[3 * k + 2] = c->invalid_z;
+            }
+        } else {
+            /* rejection_sampling_random_cylinder :576-607 */
+            uint8_t occ[16 * 16];
+            int half = G / 2;
+            for (int i = 0; i < G; ++i)
+                for (int j = 0; j < G; ++j) {
+                    float dd = sqrtf((float)((i - half) * (i - half) + (j - half) * (j - half)));
+                    occ[i * G + j] = dd >= (float)half;       /* set_outside_circle_to_one :168-181 */
+                }
+            for (int a = 0; a < A; ++a) occ[o_cell(c, ds[13 * a]) * G + o_cell(c, ds[13 * a + 1])] = 1;
+            occ[o_cell(c, tp[0]) * G + o_cell(c, tp[1])] = 1;
+            int n_active;
+            if (c->cyl_fixed_num >= 0) n_active = c->cyl_fixed_num;
+            else {
+                int span = C + 1 - c->cyl_min_num;
+                int r = (int)(o_uniform(&rng) * (float)span);
+                if (r > span - 1) r = span - 1;
+                n_active = c->cyl_min_num + r;
+            }
+            uint8_t freec[256];
+            int nfree = 0;
+            for (int i = 0; i < G * G; ++i) if (!occ[i]) freec[nfree++] = (uint8_t)i;   /* torch.nonzero order */
+            if (nfree < C) return HNS_ERR_CONFIG;
+            for (int k = 0; k < C; ++k) {   /* randperm[:C] as a partial Fisher-Yates */
+                int span = nfree - k;
+                int j = (int)(o_uniform(&rng) * (float)span);
+                if (j > span - 1) j = span - 1;
+                j += k;
+                uint8_t t = freec[k]; freec[k] = freec[j]; freec[j] = t;
+                int gx = freec[k] / G, gy = freec[k] % G;
+                float x = 0.0f + (float)(gx - half) * c->grid_size, y = 0.0f + (float)(gy - half) * c->grid_size;
+                cyl[3 * k + 0] = o_clamp(x, -c->boundary, c->boundary);   /* grid_to_continuous :121-141 */
+                cyl[3 * k + 1] = o_clamp(y, -c->boundary, c->boundary);
+                cyl[3 * k + 2] = (k >= n_active) ? c->invalid_z : 0.5f * c->cylinder_height;
+            }
+        }
+        for (int s = 0; s < HNS_NUM_STATS; ++s) b->stats[(size_t)s * E + e] = 0.0f;
+        b->stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * E + e] = (float)c->max_episode_length;
+        b->progress[e] = 0.0f;
+        b->done[e] = 0;
+        o_obs_side side;
+        o_obs(c, A, C, K, ds, tp, cyl, 0.0f, b->obs_self + (size_t)e * A * HNS_SELF_DIM,
+              b->obs_others + (size_t)e * A * (A - 1) * 3, b->obs_cylinders + (size_t)e * A * K * 5,
+              (c->write_critic_state && b->state_drones) ? b->state_drones + (size_t)e * A * HNS_SELF_DIM : NULL, &side);
+    }
+    return HNS_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Stage-level entry points for the golden-vector tests (tests/test_oracle_golden.py)
+ * ---------------------------------------------------------------------------------------- */
+void hns_oracle_quat_rotate(int n, const float *q, const float *v, float *out, int inverse) {
+    for (int i = 0; i < n; ++i) o_quat_rot(q + 4 * i, v + 3 * i, out + 3 * i, inverse);
+}
+void hns_oracle_euler_to_quat(int n, const float *rpy, float *q) {
+    for (int i = 0; i < n; ++i) o_euler_to_quat(rpy + 3 * i, q + 4 * i);
+}
+void hns_oracle_elementary(int n, const float *x, float *e, float *t, float *s, float *co) {
+    for (int i = 0; i < n; ++i) { e[i] = o_expf(x[i]); t[i] = o_tanhf(x[i]); o_sincosf(x[i], s + i, co + i); }
+}
+void hns_oracle_rotor(const hns_cfg *c, int n, const float *cmd, float *throttle, float *thrust, float *moment, float *thr_diff) {
+    for (int i = 0; i < n; ++i) o_rotor(c, cmd + 4 * i, throttle + 4 * i, thrust + 4 * i, moment + 4 * i, thr_diff + i);
+}
+/* integ/last are [n,3] here (reference layout); reset_mask zeroes PID state first (lee_position_controller.py:497-502) */
+void hns_oracle_ctbr_pid(const hns_cfg *c, int n, const float *action, const float *rot, const float *angvel,
+                         const uint8_t *reset_mask, float *prev_action, float *integ, float *last, float *cmd,
+                         float *aerr, float *ctbr, float *target_rate) {
+    for (int i = 0; i < n; ++i) {
+        if (reset_mask && reset_mask[i]) for (int k = 0; k < 3; ++k) { integ[3 * i + k] = 0.0f; last[3 * i + k] = 0.0f; }
+        o_ctbr_pid(c, action + 4 * i, rot + 4 * i, angvel + 3 * i, prev_action + 4 * i, integ + 3 * i, last + 3 * i,
+                   cmd + 4 * i, aerr + i, ctbr + 4 * i, target_rate + 3 * i);
+    }
+}
+/* total downwash force on each drone: pos [E,A,3], rot [E,A,4], tsum [E,A] -> f [E,A,3] */
+void hns_oracle_downwash(int E, int A, const float *pos, const float *rot, const float *tsum, float *f) {
+    for (int e = 0; e < E; ++e) {
+        float tw[HNS_MAX_AGENTS][3];
+        for (int a = 0; a < A; ++a) {
+            float tv[3] = {0.0f, 0.0f, tsum[e * A + a]};
+            o_quat_rot(rot + (e * A + a) * 4, tv, tw[a], 0);
+        }
+        for (int a = 0; a < A; ++a) {
+            float acc[3] = {0, 0, 0};
+            int first = 1;
+            for (int j = 0; j < A; ++j) {
+                if (j == a) continue;
+                float fj[3];
+                o_downwash_pair(pos + (e * A + a) * 3, pos + (e * A + j) * 3, tw[j], fj);
+                for (int i = 0; i < 3; ++i) acc[i] = first ? fj[i] : acc[i] + fj[i];
+                first = 0;
+            }
+            for (int i = 0; i < 3; ++i) f[(e * A + a) * 3 + i] = acc[i];
+        }
+    }
+}
+void hns_oracle_blocked(const hns_cfg *c, int E, int A, int C, const float *dpos, const float *tpos, const float *cyl, uint8_t *out) {
+    for (int e = 0; e < E; ++e)
+        for (int a = 0; a < A; ++a)
+            out[e * A + a] = (uint8_t)o_blocked(c, C, dpos + (e * A + a) * 3, tpos + e * 3, cyl + e * C * 3);
+}
+void hns_oracle_prey(const hns_cfg *c, int E, int A, int C, const float *dpos, const float *tpos, const float *cyl,
+                     float *force, float *vel, float *out_of_arena) {
+    for (int e = 0; e < E; ++e)
+        o_prey(c, A, C, dpos + e * A * 3, tpos + e * 3, cyl + e * C * 3, force + e * 3, vel + e * 3, out_of_arena + e);
+}
+void hns_oracle_integrate(const hns_cfg *c, int n, float *ds, const float *force_w, const float *torque_b) {
+    for (int i = 0; i < n; ++i) o_integrate(c, ds + 13 * i, force_w + 3 * i, torque_b + 3 * i);
+}
+/* obs + reward on a given post-physics state (no dynamics): fills outputs and side masks */
+void hns_oracle_obs_reward(const hns_cfg *c, const hns_buffers *b, const float *thr_diff, int do_reward,
+                           uint8_t *blocked /*[E,A]*/, uint8_t *bdetect /*[E]*/, uint8_t *knn_mask /*[E,A,K]*/) {
+    const int E = c->num_envs, A = c->num_agents, C = c->num_cylinders, K = c->obs_max_cylinder;
+    for (int e = 0; e < E; ++e) {
+        o_obs_side side;
+        const float *ds = b->drone_state + (size_t)e * A * 13;
+        const float *tp = b->target_pos + (size_t)e * 3;
+        const float *cyl = b->cylinders + (size_t)e * C * 3;
+        o_obs(c, A, C, K, ds, tp, cyl, b->progress[e], b->obs_self + (size_t)e * A * HNS_SELF_DIM,
+              b->obs_others + (size_t)e * A * (A - 1) * 3, b->obs_cylinders + (size_t)e * A * K * 5,
+              b->state_drones ? b->state_drones + (size_t)e * A * HNS_SELF_DIM : NULL, &side);
+        for (int a = 0; a < A; ++a) {
+            blocked[e * A + a] = (uint8_t)side.blocked[a];
+            for (int s = 0; s < K; ++s) knn_mask[(e * A + a) * K + s] = (uint8_t)side.knn_masked[a][s];
+        }
+        bdetect[e] = (uint8_t)side.bdetect;
+        if (do_reward)
+            o_reward(c, A, C, K, ds, tp, cyl, b->progress[e], &side, b->action_error + (size_t)e * A,
+                     thr_diff + (size_t)e * A, b->stats + e, (size_t)E, b->reward + (size_t)e * A, b->done + e);
+    }
+}
+int hns_oracle_cell(const hns_cfg *c, float x) { return o_cell(c, x); }
+void hns_oracle_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t *out) {
+    o_philox(k0, k1, c0, c1, c2, c3, out);
+}
+size_t hns_oracle_cfg_size(void) { return sizeof(hns_cfg); }

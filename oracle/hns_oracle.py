@@ -1,0 +1,166 @@
+"""ctypes wrapper of oracle/libhns_oracle.so — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+It reuses the ABI struct mirrors (hns_amd.abi) because the oracle operates on the same
+hns_cfg/hns_buffers as the HIP library, with HOST pointers (numpy arrays).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import hns_amd  # noqa: F401  (registers the package alias)
+from hns_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libhns_oracle.so")
+    src = os.path.join(_HERE, "hns_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "hns.h")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libhns_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.hns_oracle_cfg_size.restype = C.c_size_t
+        assert _LIB.hns_oracle_cfg_size() == C.sizeof(abi.HnsCfg), "hns_cfg layout mismatch"
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def alloc_buffers(cfg):
+    """Zero-initialised host arrays for every hns_buffers field."""
+    shapes = abi.buffer_shapes(cfg.num_envs, cfg.num_agents, cfg.num_cylinders, cfg.obs_max_cylinder)
+    return {k: np.zeros(shape, dtype=dt) for k, (shape, dt) in shapes.items()}
+
+
+def as_struct(arrs):
+    b = abi.HnsBuffers()
+    for k in abi.BUFFER_FIELDS:
+        a = arrs[k]
+        assert a.flags["C_CONTIGUOUS"]
+        setattr(b, k, a.ctypes.data)
+    return b
+
+
+def step(cfg, arrs, action):
+    action = f32(action)
+    b = as_struct(arrs)
+    rc = lib().hns_oracle_step(C.byref(cfg), C.byref(b), _p(action))
+    assert rc == 0, rc
+
+
+def reset(cfg, arrs, mask, seed, epoch):
+    b = as_struct(arrs)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    rc = lib().hns_oracle_reset(C.byref(cfg), C.byref(b), _p(m), C.c_uint64(seed), C.c_uint32(epoch))
+    if rc != 0:
+        raise ValueError(f"hns_oracle_reset failed: {rc}")
+
+
+def quat_rotate(q, v, inverse=False):
+    q, v = f32(q).reshape(-1, 4), f32(v).reshape(-1, 3)
+    out = np.empty_like(v)
+    lib().hns_oracle_quat_rotate(len(q), _p(q), _p(v), _p(out), int(inverse))
+    return out
+
+
+def euler_to_quat(rpy):
+    rpy = f32(rpy).reshape(-1, 3)
+    q = np.empty((len(rpy), 4), np.float32)
+    lib().hns_oracle_euler_to_quat(len(rpy), _p(rpy), _p(q))
+    return q
+
+
+def elementary(x):
+    x = f32(x).ravel()
+    e, t, s, c = (np.empty_like(x) for _ in range(4))
+    lib().hns_oracle_elementary(len(x), _p(x), _p(e), _p(t), _p(s), _p(c))
+    return e, t, s, c
+
+
+def rotor(cfg, cmd, throttle):
+    cmd = f32(cmd).reshape(-1, 4)
+    throttle = f32(throttle).reshape(-1, 4).copy()
+    thrust, moment = np.empty_like(cmd), np.empty_like(cmd)
+    td = np.empty(len(cmd), np.float32)
+    lib().hns_oracle_rotor(C.byref(cfg), len(cmd), _p(cmd), _p(throttle), _p(thrust), _p(moment), _p(td))
+    return throttle, thrust, moment, td
+
+
+def ctbr_pid(cfg, action, rot, angvel, reset_mask, prev_action, integ, last):
+    action, rot, angvel = f32(action).reshape(-1, 4), f32(rot).reshape(-1, 4), f32(angvel).reshape(-1, 3)
+    n = len(action)
+    prev_action, integ, last = f32(prev_action).reshape(n, 4).copy(), f32(integ).reshape(n, 3).copy(), f32(last).reshape(n, 3).copy()
+    m = None if reset_mask is None else np.ascontiguousarray(reset_mask, np.uint8).reshape(n)
+    cmd, ctbr = np.empty((n, 4), np.float32), np.empty((n, 4), np.float32)
+    aerr, tr = np.empty(n, np.float32), np.empty((n, 3), np.float32)
+    lib().hns_oracle_ctbr_pid(C.byref(cfg), n, _p(action), _p(rot), _p(angvel), _p(m), _p(prev_action), _p(integ),
+                              _p(last), _p(cmd), _p(aerr), _p(ctbr), _p(tr))
+    return dict(cmd=cmd, ctbr=ctbr, aerr=aerr, target_rate=tr, prev_action=prev_action, integ=integ, last=last)
+
+
+def downwash(pos, rot, tsum):
+    pos, rot, tsum = f32(pos), f32(rot), f32(tsum)
+    E, A = pos.shape[:2]
+    f = np.empty_like(pos)
+    lib().hns_oracle_downwash(E, A, _p(pos), _p(rot), _p(tsum), _p(f))
+    return f
+
+
+def blocked(cfg, dpos, tpos, cyl):
+    dpos, tpos, cyl = f32(dpos), f32(tpos).reshape(len(dpos), 3), f32(cyl)
+    E, A = dpos.shape[:2]
+    out = np.empty((E, A), np.uint8)
+    lib().hns_oracle_blocked(C.byref(cfg), E, A, cyl.shape[1], _p(dpos), _p(tpos), _p(cyl), _p(out))
+    return out.astype(bool)
+
+
+def prey(cfg, dpos, tpos, cyl, out_of_arena=None):
+    dpos, tpos, cyl = f32(dpos), f32(tpos).reshape(len(dpos), 3), f32(cyl)
+    E, A = dpos.shape[:2]
+    force, vel = np.empty((E, 3), np.float32), np.empty((E, 3), np.float32)
+    ooa = np.zeros(E, np.float32) if out_of_arena is None else f32(out_of_arena).reshape(E).copy()
+    lib().hns_oracle_prey(C.byref(cfg), E, A, cyl.shape[1], _p(dpos), _p(tpos), _p(cyl), _p(force), _p(vel), _p(ooa))
+    return force, vel, ooa
+
+
+def integrate(cfg, ds, force_w, torque_b):
+    ds = f32(ds).reshape(-1, 13).copy()
+    fw, tb = f32(force_w).reshape(-1, 3), f32(torque_b).reshape(-1, 3)
+    lib().hns_oracle_integrate(C.byref(cfg), len(ds), _p(ds), _p(fw), _p(tb))
+    return ds
+
+
+def obs_reward(cfg, arrs, thr_diff=None, do_reward=False):
+    E, A, K = cfg.num_envs, cfg.num_agents, cfg.obs_max_cylinder
+    b = as_struct(arrs)
+    blocked_, bdet, knn = np.empty((E, A), np.uint8), np.empty(E, np.uint8), np.empty((E, A, K), np.uint8)
+    td = f32(thr_diff if thr_diff is not None else np.zeros((E, A)))
+    lib().hns_oracle_obs_reward(C.byref(cfg), C.byref(b), _p(td), int(do_reward), _p(blocked_), _p(bdet), _p(knn))
+    return blocked_.astype(bool), bdet.astype(bool), knn.astype(bool)
+
+
+def cell(cfg, x):
+    return lib().hns_oracle_cell(C.byref(cfg), C.c_float(x))
+
+
+def philox(k0, k1, c0, c1, c2, c3):
+    out = (C.c_uint32 * 4)()
+    lib().hns_oracle_philox(C.c_uint32(k0), C.c_uint32(k1), C.c_uint32(c0), C.c_uint32(c1), C.c_uint32(c2), C.c_uint32(c3), out)
+    return list(out)
