@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — env agent-steps/s of the fused HideAndSeek step on MI355X.
+
+Workload = BASELINE.json configs[2]: HideAndSeek 3 pursuers / 1 evader, 8 cylinders
+(k-nearest + line-of-sight sensing), 65 536 envs per GPU, synthetic N(0,1) policy outputs
+resident in HBM.  A "step" is one `hns_step` over the whole env batch (+ the `hns_reset` launch
+at the natural 1/800 episode boundary).  Multi-GPU: one process per GPU (torchrun), contiguous
+env-index shards, weak scaling; the only collective is one RCCL all-gather of 3 floats per
+64-step rollout (the advantage-normalisation moments named by north_star).
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live: every 8th step launch inside the
+timed region is bracketed by hipEvents on the launch stream (hns_enable_timing).
+`cpu_baseline` (N=1 only) times the CPU oracle — test infrastructure, never the product — on a
+bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+NUM_STATS = 24
+
+
+def algorithmic_bytes_per_env(A, C, k, S=NUM_STATS):
+    """mandatory fp32 traffic of one env-step, one read + one write, no temporaries."""
+    return A * (232 + 4 * (20 + 3 * (A - 1) + 5 * k) + 4) + 4 * (3 + 3 * C + 1 + S) + 4 * (7 + S) + 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--agents", type=int, default=3)
+    ap.add_argument("--cylinders", type=int, default=8)
+    ap.add_argument("--episode", type=int, default=800)
+    ap.add_argument("--no-critic-state", action="store_true", help="skip the [E,A,20] critic state output")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=24)
+    ap.add_argument("--time-every", type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import hns_amd  # noqa: F401
+    from hns_amd import config
+    from hns_amd.env import HideAndSeek
+
+    E, A, C, K = args.envs, args.agents, args.cylinders, 3
+    cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": C, "min_num": C, "obs_max_cylinder": K},
+                           "env": {"num_envs": E, "max_episode_length": args.episode},
+                           "sim": {"device": f"cuda:{local_rank}"}})
+    env = HideAndSeek(cfg, headless=True, env_index_offset=rank * E, write_critic_state=not args.no_critic_state)
+    env.set_seed(0)
+    env.reset()
+    lib, henv = env._lib, env._env
+    import ctypes as Cx
+    stream = torch.cuda.current_stream(device)
+    sptr = Cx.c_void_p(stream.cuda_stream)
+
+    # synthetic policy outputs: a ring of pre-generated N(0,1) action batches resident in HBM
+    R = 8
+    gen = torch.Generator(device=device).manual_seed(1000 + rank)
+    actions = [torch.randn(E, A, 4, generator=gen, device=device) for _ in range(R)]
+    aptr = [Cx.c_void_p(a.data_ptr()) for a in actions]
+    done_ptr = Cx.c_void_p(env._bufs["done"].data_ptr())
+    reward = env._bufs["reward"]
+    moments = torch.zeros(3, device=device, dtype=torch.float64)
+    gathered = [torch.zeros(3, device=device, dtype=torch.float64) for _ in range(world)] if world > 1 else None
+    rollout = int(cfg.algo.get("train_every", 64))
+    progress = {"t": 0}
+
+    def run(n):
+        for _ in range(n):
+            i = progress["t"]
+            rc = lib.hns_step(henv, aptr[i % R], sptr)
+            assert rc == 0, lib.hns_last_error()
+            progress["t"] = i + 1
+            if (i + 1) % args.episode == 0:          # lock-step episodes: every env is done now
+                rc = lib.hns_reset(henv, done_ptr, Cx.c_uint64(env.seed), sptr)
+                assert rc == 0, lib.hns_last_error()
+            if world > 1 and (i + 1) % rollout == 0:
+                # per-rollout advantage-normalisation moments (learning/mappo.py:391-396 made DP):
+                # (sum, sum of squares, count) -> ONE all-gather of 3 values per rank
+                r64 = reward.double()
+                moments[0], moments[1], moments[2] = r64.sum(), (r64 * r64).sum(), float(r64.numel())
+                dist.all_gather(gathered, moments)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    run(args.warmup)
+    sync()
+    lib.hns_enable_timing(henv, args.time_every)
+    t0 = time.perf_counter()
+    run(args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    lib.hns_enable_timing(henv, 0)
+    kernel_ms, n_samples = env.kernel_ms()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    assert torch.isfinite(env._bufs["reward"]).all(), "non-finite reward"
+    total_agent_steps = world * E * A * args.steps
+    value = total_agent_steps / elapsed
+    b_env = algorithmic_bytes_per_env(A, C, K)
+    roofline = None
+    if kernel_ms > 0:
+        achieved = b_env * E / (kernel_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": f"hns_step_kernel<{A}>", "kernel_us": round(kernel_ms * 1e3, 2), "samples": n_samples,
+                    "bytes_per_launch": b_env * E}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        import hns_oracle as O
+        host = O.alloc_buffers(env.hcfg)
+        O.reset(env.hcfg, host, None, 0, 0)
+        act = np.random.default_rng(0).standard_normal((E, A, 4)).astype(np.float32)
+        O.step(env.hcfg, host, act)
+        c0 = time.perf_counter()
+        for _ in range(args.cpu_steps):
+            O.step(env.hcfg, host, act)
+        cdt = time.perf_counter() - c0
+        cpu_baseline = {"value": round(E * A * args.cpu_steps / cdt, 1), "unit": "agent-steps/s", "cores": 1,
+                        "kind": "port",
+                        "sample": f"{args.cpu_steps} steps of the same {E}-env workload with the scalar C oracle "
+                                  f"(oracle/hns_oracle.c), 1 thread, {cdt:.1f} s"}
+
+    if rank == 0:
+        out = {
+            "metric": "env agent-steps/sec at 65536 envs, HideAndSeek 3v1; 1/2/4/8 GPU",
+            "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"HideAndSeek {A}v1, {C} random cylinders + LOS/k-nearest sensing, "
+                                   f"{E} envs per GPU (BASELINE configs[2])",
+                       "num_envs_per_gpu": E, "num_agents": A, "num_cylinders": C, "obs_max_cylinder": K,
+                       "episode_length": args.episode, "critic_state_output": not args.no_critic_state,
+                       "sharding": f"contiguous env slices x{world}",
+                       "collective": "1 all-gather of 3 fp64 per 64-step rollout" if world > 1 else "none"},
+            "env_frames_per_s": round(value / A, 1),
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -185,9 +185,10 @@ int hns_set_smoothness_coef(hns_env *env, float coef);
 int hns_set_reset_epoch(hns_env *env, uint32_t epoch);
 uint32_t hns_get_reset_epoch(const hns_env *env);
 
-/* Average device time (ms) of the step kernel over the launches since the last call, measured
- * with hipEvents on the launch stream when timing was enabled; returns <0 if no sample. */
-int hns_enable_timing(hns_env *env, int on);
+/* Kernel timing: hns_enable_timing(env, n) brackets every n-th hns_step launch with hipEvents on
+ * the launch stream (n = 0 disables).  hns_step_kernel_ms returns the average device time (ms)
+ * of the sampled launches since the last call (synchronises on the last sample); <0 if none. */
+int hns_enable_timing(hns_env *env, int every_n);
 float hns_step_kernel_ms(hns_env *env, int *num_launches);
 
 int hns_abi_version(void);

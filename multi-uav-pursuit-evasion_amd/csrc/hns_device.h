@@ -1,0 +1,355 @@
+// hns_device.h — device-side scalar math of the HideAndSeek step (gfx950, wave64).
+//
+// Every routine states the reference lines it implements (paths relative to the reference
+// repo thu-uav/Multi-UAV-pursuit-evasion).  Arithmetic is IEEE fp32 with an explicit evaluation
+// order (compiled with -ffp-contract=off, correctly rounded divide/sqrt), and exp/tanh/sincos are
+// the fixed polynomial forms of DESIGN.md §Numerics, so results are reproducible bit-for-bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hns.h"
+
+#define HNS_DEV static __device__ __forceinline__
+
+namespace hns {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInf = __builtin_huge_valf();
+
+// ---- elementary functions -------------------------------------------
+HNS_DEV float d_expf(float x) {
+    if (!(x > -87.0f)) return (x != x) ? x : 0.0f;
+    if (x > 88.0f) return kInf;
+    float k = __builtin_rintf(x * 1.44269504088896341f);
+    float r = x - k * 0.693359375f;
+    r = r - k * -2.12194440e-4f;
+    float p = 1.9875691500E-4f;
+    p = p * r + 1.3981999507E-3f;
+    p = p * r + 8.3334519073E-3f;
+    p = p * r + 4.1665795894E-2f;
+    p = p * r + 1.6666665459E-1f;
+    p = p * r + 5.0000001201E-1f;
+    float y = (p * (r * r) + r) + 1.0f;
+    int ki = (int)k;
+    return y * __uint_as_float((uint32_t)(ki + 127) << 23);
+}
+
+HNS_DEV float d_tanhf(float x) {
+    float ax = __builtin_fabsf(x);
+    if (x != x) return x;
+    if (!(ax < 9.0f)) return x > 0.0f ? 1.0f : -1.0f;
+    if (ax < 0.625f) {
+        float z = x * x;
+        float p = -5.70498872745E-3f;
+        p = p * z + 2.06390887954E-2f;
+        p = p * z - 5.37397155531E-2f;
+        p = p * z + 1.33314422036E-1f;
+        p = p * z - 3.33332819422E-1f;
+        return (p * z) * x + x;
+    }
+    float e = d_expf(2.0f * ax);
+    float r = 1.0f - 2.0f / (e + 1.0f);
+    return x < 0.0f ? -r : r;
+}
+
+HNS_DEV void d_sincosf(float x, float &s_out, float &c_out) {
+    float ax = __builtin_fabsf(x);
+    int j = (int)(ax * 1.27323954473516f);
+    if (j & 1) j += 1;
+    float y = (float)j;
+    j &= 7;
+    float z = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float zz = z * z;
+    float ps = -1.9515295891E-4f;
+    ps = ps * zz + 8.3321608736E-3f;
+    ps = ps * zz - 1.6666654611E-1f;
+    float sp = (ps * zz) * z + z;
+    float pc = 2.443315711809948E-005f;
+    pc = pc * zz - 1.388731625493765E-003f;
+    pc = pc * zz + 4.166664568298827E-002f;
+    float cp = ((pc * zz) * zz - 0.5f * zz) + 1.0f;
+    float s = (j == 0) ? sp : (j == 2) ? cp : (j == 4) ? -sp : -cp;
+    float c = (j == 0) ? cp : (j == 2) ? -sp : (j == 4) ? -cp : sp;
+    if (x < 0.0f) s = -s;
+    s_out = s;
+    c_out = c;
+}
+
+HNS_DEV float d_clamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+HNS_DEV float d_norm3(float x, float y, float z) { return __builtin_sqrtf((x * x + y * y) + z * z); }
+
+struct V3 { float x, y, z; };
+struct Q4 { float w, x, y, z; };
+
+// omni_drones/utils/torch.py:183-191 (quat_rotate) / :194-202 (quat_rotate_inverse)
+template <bool INVERSE>
+HNS_DEV V3 d_quat_rot(const Q4 &q, const V3 &v) {
+    float s = 2.0f * (q.w * q.w) - 1.0f;
+    float cx = q.y * v.z - q.z * v.y;
+    float cy = q.z * v.x - q.x * v.z;
+    float cz = q.x * v.y - q.y * v.x;
+    float dot = (q.x * v.x + q.y * v.y) + q.z * v.z;
+    float a0 = v.x * s, a1 = v.y * s, a2 = v.z * s;
+    float b0 = (cx * q.w) * 2.0f, b1 = (cy * q.w) * 2.0f, b2 = (cz * q.w) * 2.0f;
+    float c0 = (q.x * dot) * 2.0f, c1 = (q.y * dot) * 2.0f, c2 = (q.z * dot) * 2.0f;
+    V3 o;
+    if (INVERSE) { o.x = (a0 - b0) + c0; o.y = (a1 - b1) + c1; o.z = (a2 - b2) + c2; }
+    else         { o.x = (a0 + b0) + c0; o.y = (a1 + b1) + c1; o.z = (a2 + b2) + c2; }
+    return o;
+}
+
+// omni_drones/utils/torch.py:110-127
+HNS_DEV Q4 d_euler_to_quat(float r, float p, float y) {
+    float sr, cr, sp, cp, sy, cy;
+    d_sincosf(r * 0.5f, sr, cr);
+    d_sincosf(p * 0.5f, sp, cp);
+    d_sincosf(y * 0.5f, sy, cy);
+    Q4 q;
+    q.w = (cr * cp) * cy + (sr * sp) * sy;
+    q.x = (sr * cp) * cy - (cr * sp) * sy;
+    q.y = (cr * sp) * cy + (sr * cp) * sy;
+    q.z = (cr * cp) * sy - (sr * sp) * cy;
+    return q;
+}
+
+// ---- A1 + A2: action -> CTBR -> body-rate PID -> motor commands ------------------------------
+// omni_drones/utils/torchrl/transforms.py:425-459,
+// omni_drones/controllers/lee_position_controller.py:476-550
+HNS_DEV void d_ctbr_pid(const hns_cfg &c, const float4 &action, const Q4 &q, const V3 &angvel,
+                        float4 &prev_action, float4 &integ4, float4 &last4, float cmd[4], float &action_error) {
+    float a0 = d_tanhf(action.x), a1 = d_tanhf(action.y), a2 = d_tanhf(action.z), a3 = d_tanhf(action.w);
+    float ctbr[4] = {a0, a1, a2, d_clamp((a3 + 1.0f) / 2.0f, 0.0f, c.max_thrust_ratio)};
+    if (c.fixed_yaw) ctbr[2] = 0.0f;
+    float d0 = ctbr[0] - prev_action.x, d1 = ctbr[1] - prev_action.y, d2 = ctbr[2] - prev_action.z,
+          d3 = ctbr[3] - prev_action.w;
+    action_error = __builtin_sqrtf(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
+    prev_action = make_float4(ctbr[0], ctbr[1], ctbr[2], ctbr[3]);
+    float target[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) target[i] = (ctbr[i] * 180.0f) * c.target_clip;
+    float thrust = ctbr[3] * 65536.0f;
+    V3 brv = d_quat_rot<true>(q, angvel);
+    float br[3] = {brv.x, brv.y, brv.z};
+    float integ[3] = {integ4.x, integ4.y, integ4.z};
+    float last[3] = {last4.x, last4.y, last4.z};
+    float out[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        br[i] = (br[i] * 180.0f) / kPi;
+        float err = target[i] - br[i];
+        float P = err * c.pid_kp[i];
+        float deriv = -(br[i] - last[i]) / c.dt;
+        if (deriv != deriv) deriv = 0.0f;
+        float D = deriv * c.pid_kd[i];
+        float in = integ[i] + err * c.dt;
+        in = d_clamp(in, -c.pid_ilimit[i], c.pid_ilimit[i]);
+        integ[i] = in;
+        float I = in * c.pid_ki[i];
+        float FF = target[i] * 0.0f;
+        float o = ((P + D) + I) + FF;
+        if (o != o) o = 0.0f;
+        out[i] = d_clamp(o, -c.pid_outlimit, c.pid_outlimit);
+        last[i] = br[i];
+    }
+    integ4 = make_float4(integ[0], integ[1], integ[2], 0.0f);
+    last4 = make_float4(last[0], last[1], last[2], 0.0f);
+    float r = out[0] / 2.0f, p = out[1] / 2.0f, y = out[2];
+    float m[4] = {((thrust + r) - p) + y, ((thrust + r) + p) - y, ((thrust - r) + p) + y, ((thrust - r) - p) - y};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = (m[i] / 65536.0f) * 2.0f - c.max_thrust_ratio;
+        if (v != v) v = 0.0f;                                  // torch.nan_to_num_(cmds, 0.)
+        else if (v == kInf) v = 3.4028234663852886e38f;
+        else if (v == -kInf) v = -3.4028234663852886e38f;
+        cmd[i] = v;
+    }
+}
+
+// ---- A3: rotor lag + thrust/moment   omni_drones/actuators/rotor_group.py:55-71 --------------
+HNS_DEV void d_rotor(const hns_cfg &c, const float cmd[4], float4 &throttle4, float thrust[4], float moment[4],
+                     float &throttle_difference) {
+    float thr_in[4] = {throttle4.x, throttle4.y, throttle4.z, throttle4.w};
+    float thr_out[4];
+    float dd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float tgt = __builtin_sqrtf(d_clamp((cmd[i] + 1.0f) / 2.0f, 0.0f, 1.0f));
+        float tau = (tgt > thr_in[i]) ? c.tau_up : c.tau_down;
+        float thr = thr_in[i] + tau * (tgt - thr_in[i]);
+        thr_out[i] = thr;
+        float t = d_clamp(thr * thr + 0.0f, 0.0f, 1.0f);
+        thrust[i] = t * c.kf[i];
+        moment[i] = (t * c.km[i]) * -c.rotor_dir[i];
+        dd[i] = thr - thr_in[i];
+    }
+    throttle4 = make_float4(thr_out[0], thr_out[1], thr_out[2], thr_out[3]);
+    throttle_difference = __builtin_sqrtf(((dd[0] * dd[0] + dd[1] * dd[1]) + dd[2] * dd[2]) + dd[3] * dd[3]);  // multirotor.py:507
+}
+
+// ---- A4: downwash of drone j on drone i   omni_drones/robots/drone/multirotor.py:488-494,725-753
+HNS_DEV V3 d_downwash_pair(const V3 &pi, const V3 &pj, const V3 &tj_w) {
+    float n = d_norm3(tj_w.x, tj_w.y, tj_w.z);
+    float dx = tj_w.x / (n + 1e-6f), dy = tj_w.y / (n + 1e-6f), dz = tj_w.z / (n + 1e-6f);
+    float rx = pj.x - pi.x, ry = pj.y - pi.y, rz = pj.z - pi.z;
+    float zd = (rx * dx + ry * dy) + rz * dz;
+    float ox = rx - zd * dx, oy = ry - zd * dy, oz = rz - zd * dz;
+    float r = d_norm3(ox, oy, oz);
+    float z = zd < 0.0f ? 0.0f : zd;
+    float u = (2.0f * r) / z;
+    float den = 1.0f + 0.3f * z;
+    float v = d_expf(-0.5f * (u * u)) / (den * den);
+    V3 f = {v * -tj_w.x, v * -tj_w.y, v * -tj_w.z};
+    return f;
+}
+
+// ---- A7: line of sight drone->target blocked by any cylinder (xy plane) ---------------------
+// omni_drones/envs/hide_and_seek/hideandseek.py:47-103.  cyl: this env's [C,3] in LDS.
+HNS_DEV bool d_blocked(const hns_cfg &c, int C, const V3 &dp, const V3 &tp, const float *cyl) {
+    float diffx = dp.x - tp.x, diffy = dp.y - tp.y;
+    float den = __builtin_sqrtf(diffx * diffx + diffy * diffy);
+    float dx = tp.x - dp.x, dy = tp.y - dp.y;
+    float dent = dx * dx + dy * dy;
+    bool any = false;
+    for (int k = 0; k < C; ++k) {
+        float ccx = cyl[3 * k], ccy = cyl[3 * k + 1], ccz = cyl[3 * k + 2];
+        float d2x = ccx - tp.x, d2y = ccy - tp.y;
+        float num = __builtin_fabsf(diffx * d2y - diffy * d2x);
+        float dist = num / (den + 1e-5f);
+        bool blocked = dist <= c.cylinder_size;
+        float numt = (ccx - dp.x) * dx + (ccy - dp.y) * dy;
+        float t = numt / (dent + 1e-5f);
+        bool on = (t >= 0.0f) && (t <= 1.0f);
+        bool ground = ccz > 0.0f;
+        any = any || (blocked && on && ground);
+    }
+    return any;
+}
+
+// ---- A6 pieces: evader potential field   hideandseek.py:1067-1141 -----------------------------
+// pursuer term of one drone (:1074-1088)
+HNS_DEV V3 d_prey_pursuer_term(const hns_cfg &c, const V3 &dp, const V3 &tp, bool blocked) {
+    float rx = dp.x - tp.x, ry = dp.y - tp.y, rz = dp.z - tp.z;
+    float dist = d_norm3(rx, ry, rz);
+    float active = ((dist < c.target_detect_radius) && !blocked) ? 1.0f : 0.0f;
+    float rec = 1.0f / (dist + 1e-5f);
+    V3 f;
+    f.x = ((-rx / (dist + 1e-5f)) * rec) * active;
+    f.y = ((-ry / (dist + 1e-5f)) * rec) * active;
+    f.z = ((-rz / (dist + 1e-5f)) * rec) * active;
+    return f;
+}
+// arena walls/ceiling/floor (:1090-1112); also reports the out-of-arena flag (:1096-1098)
+HNS_DEV V3 d_prey_arena_term(const hns_cfg &c, const V3 &tp, bool &out_of_arena) {
+    float od = __builtin_sqrtf(tp.x * tp.x + tp.y * tp.y);
+    float dirx = -tp.x / (od + 1e-5f), diry = -tp.y / (od + 1e-5f);
+    bool out = (tp.x * tp.x + tp.y * tp.y) > c.arena_sq;
+    out_of_arena = out;
+    float outf = out ? 1.0f : 0.0f, nout = out ? 0.0f : 1.0f;
+    float rin = 1.0f / ((c.arena_size - od) + 1e-5f);
+    V3 f;
+    f.x = (outf * dirx) * 1e5f + (nout * dirx) * rin;
+    f.y = (outf * diry) * 1e5f + (nout * diry) * rin;
+    float H = c.max_height;
+    bool hi = tp.z > H;
+    float hif = hi ? 1.0f : 0.0f, nhi = hi ? 0.0f : 1.0f;
+    float hz = H - tp.z;
+    float frz = hif * -1e5f + (nhi * -hz) / (hz * hz + 1e-5f);
+    bool lo = tp.z < 0.0f;
+    float lof = lo ? 1.0f : 0.0f, nlo = lo ? 0.0f : 1.0f;
+    float lz = 0.0f - tp.z;
+    f.z = frz + (lof * 1e5f + (nlo * -lz) / (lz * lz + 1e-5f));
+    return f;
+}
+// repulsion of one cylinder (:1129-1136)
+HNS_DEV void d_prey_cylinder_term(const hns_cfg &c, const V3 &tp, float ccx, float ccy, float ccz, float &tx, float &ty) {
+    float rx = tp.x - ccx, ry = tp.y - ccy;
+    float dc = __builtin_sqrtf(rx * rx + ry * ry);
+    float db = dc - c.cylinder_size;
+    float act = (!(ccz < 0.0f) && (dc < c.target_detect_radius)) ? 1.0f : 0.0f;
+    float rec = 1.0f / (db + 1e-5f);
+    tx = (act * (rx / (dc + 1e-5f))) * rec;
+    ty = (act * (ry / (dc + 1e-5f))) * rec;
+}
+
+// ---- A5: rigid-body integration — the build's own spec -----------------------
+struct Rigid { V3 pos; Q4 q; V3 lin; V3 ang; };
+
+HNS_DEV void d_integrate(const hns_cfg &c, Rigid &s, const V3 &force_w, const V3 &torque_b) {
+    float ax = force_w.x / c.mass, ay = force_w.y / c.mass, az = force_w.z / c.mass - c.gravity;
+    float vx = (s.lin.x + ax * c.dt) * c.lin_damp_factor;
+    float vy = (s.lin.y + ay * c.dt) * c.lin_damp_factor;
+    float vz = (s.lin.z + az * c.dt) * c.lin_damp_factor;
+    float sp = d_norm3(vx, vy, vz);
+    if (sp > c.max_lin_vel) {
+        float sc = c.max_lin_vel / sp;
+        vx *= sc; vy *= sc; vz *= sc;
+    }
+    V3 wb = d_quat_rot<true>(s.q, s.ang);
+    float Iwx = wb.x * c.inertia[0], Iwy = wb.y * c.inertia[1], Iwz = wb.z * c.inertia[2];
+    float gx = wb.y * Iwz - wb.z * Iwy, gy = wb.z * Iwx - wb.x * Iwz, gz = wb.x * Iwy - wb.y * Iwx;
+    V3 w2;
+    w2.x = (wb.x + ((torque_b.x - gx) / c.inertia[0]) * c.dt) * c.ang_damp_factor;
+    w2.y = (wb.y + ((torque_b.y - gy) / c.inertia[1]) * c.dt) * c.ang_damp_factor;
+    w2.z = (wb.z + ((torque_b.z - gz) / c.inertia[2]) * c.dt) * c.ang_damp_factor;
+    float wn = d_norm3(w2.x, w2.y, w2.z);
+    if (wn > c.max_ang_vel) {
+        float sc = c.max_ang_vel / wn;
+        w2.x *= sc; w2.y *= sc; w2.z *= sc;
+    }
+    V3 ww = d_quat_rot<false>(s.q, w2);
+    float px = s.pos.x + vx * c.dt, py = s.pos.y + vy * c.dt, pz = s.pos.z + vz * c.dt;
+    if (c.ground_clamp && pz < 0.0f) {
+        pz = 0.0f;
+        if (vz < 0.0f) vz = 0.0f;
+    }
+    float wwn = d_norm3(ww.x, ww.y, ww.z);
+    float half = (wwn * c.dt) * 0.5f;
+    float sn, co;
+    d_sincosf(half, sn, co);
+    float so = (wwn > 1e-8f) ? sn / wwn : 0.5f * c.dt;
+    float w1 = co, x1 = ww.x * so, y1 = ww.y * so, z1 = ww.z * so;
+    float w2q = s.q.w, x2 = s.q.x, y2 = s.q.y, z2 = s.q.z;
+    float nw = ((w1 * w2q - x1 * x2) - y1 * y2) - z1 * z2;
+    float nx = ((w1 * x2 + x1 * w2q) + y1 * z2) - z1 * y2;
+    float ny = ((w1 * y2 - x1 * z2) + y1 * w2q) + z1 * x2;
+    float nz = ((w1 * z2 + x1 * y2) - y1 * x2) + z1 * w2q;
+    float qn = __builtin_sqrtf(((nw * nw + nx * nx) + ny * ny) + nz * nz);
+    s.pos = {px, py, pz};
+    s.lin = {vx, vy, vz};
+    s.ang = ww;
+    s.q = {nw / qn, nx / qn, ny / qn, nz / qn};
+}
+
+// ---- Philox4x32-10 (reset RNG) ---------------------------------------------
+HNS_DEV void d_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct Rng {
+    uint32_t k0, k1, env, epoch, block;
+    uint32_t buf[4];
+    int have;
+    __device__ float uniform() {
+        if (have == 0) { d_philox(k0, k1, env, epoch, block++, 0u, buf); have = 4; }
+        uint32_t u = buf[4 - have];
+        have--;
+        return (float)(u >> 8) * 5.9604644775390625e-8f;
+    }
+};
+
+// continuous_to_grid, hideandseek.py:143-164
+HNS_DEV int d_cell(const hns_cfg &c, float x) {
+    int g = (int)__builtin_rintf(x / c.grid_size) + c.grid_num / 2;
+    return g < 0 ? 0 : (g > c.grid_num - 1 ? c.grid_num - 1 : g);
+}
+
+}  // namespace hns

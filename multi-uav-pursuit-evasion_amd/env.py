@@ -1,0 +1,292 @@
+"""`HideAndSeek(cfg, headless)` — the reference's environment class on top of the HIP step.
+
+Mirror of the torchrl `EnvBase` surface the reference's caller uses
+(omni_drones/envs/isaac_env.py:47-57,210-259, omni_drones/envs/hide_and_seek/hideandseek.py:183-433,
+scripts/train.py:110-205): constructor `Env(cfg, headless)`, `REGISTRY`, `reset()`, `step(td)`,
+`set_seed()`, `_reset/_step/_set_seed`, spec trees, `agent_spec["drone"]`, `num_envs`,
+`max_episode_length`, `dt`, `progress_buf`, `stats`, `info`, `drone.params`, `drone.n`.
+
+One deliberate difference: the body-rate PID action transform
+(omni_drones/utils/torchrl/transforms.py:404-459) is fused into the step kernel, so this env
+takes the RAW policy action (what the reference feeds to `TransformedEnv.step`) and needs no
+`PIDRateController` transform around it.
+
+Every tensor returned is a view of a persistent device buffer that the next `step()` overwrites
+in place — the same aliasing contract as the reference (`hideandseek.py:901-902`).
+There is no CPU path: constructing the env without the built HIP library or a GPU raises.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from types import SimpleNamespace
+
+import torch
+
+from . import abi
+from .config import CRAZYFLIE, resolve_hns_cfg
+from .tensordict_shim import CompositeSpec, TensorDict, TensorSpec
+
+
+@dataclass
+class AgentSpec:
+    """omni_drones/utils/torchrl/env.py::AgentSpec (name, n and the four keys)."""
+    name: str
+    n: int
+    observation_key: tuple = ("agents", "observation")
+    action_key: tuple = ("agents", "action")
+    reward_key: tuple = ("agents", "reward")
+    state_key: tuple = ("agents", "state")
+    _env: object = None
+
+    @property
+    def observation_spec(self):
+        return self._env.observation_spec[self.observation_key]
+
+    @property
+    def action_spec(self):
+        return self._env.action_spec[self.action_key]
+
+    @property
+    def reward_spec(self):
+        return self._env.reward_spec[self.reward_key]
+
+    @property
+    def state_spec(self):
+        return self._env.observation_spec[self.state_key]
+
+
+class HnsError(RuntimeError):
+    pass
+
+
+class HideAndSeek:
+    REGISTRY = {}
+
+    def __init__(self, cfg, headless=True, env_index_offset=0, write_critic_state=True):
+        self.cfg = cfg
+        self.headless = headless
+        self.device = torch.device(cfg.sim.get("device", "cuda:0"))
+        if self.device.type != "cuda":
+            raise HnsError("HideAndSeek runs on an AMD GPU only (cfg.sim.device must be a cuda/hip device)")
+        if not torch.cuda.is_available():
+            raise HnsError("no GPU visible: the HIP step has no CPU fallback")
+        self._lib = abi.load_library()
+        self.num_envs = int(cfg.env.num_envs)
+        self.max_episode_length = int(cfg.env.max_episode_length)
+        self.dt = float(cfg.sim.dt)
+        self.batch_size = torch.Size([self.num_envs])
+        self.hcfg = resolve_hns_cfg(cfg, env_index_offset=env_index_offset, write_critic_state=write_critic_state)
+        self.num_agents = self.hcfg.num_agents
+        self.num_cylinders = self.hcfg.num_cylinders
+        self.obs_max_cylinder = self.hcfg.obs_max_cylinder
+        self.v_prey = float(self.hcfg.v_prey)
+        self.update_epoch = 0
+        self.seed = 0
+        self.training = True
+        self._render = not headless
+        E, A, Cn, K = self.num_envs, self.num_agents, self.num_cylinders, self.obs_max_cylinder
+
+        torch.cuda.set_device(self.device)
+        self._bufs = {}
+        for name, (shape, dt) in abi.buffer_shapes(E, A, Cn, K).items():
+            n = 1
+            for s in shape:
+                n *= s
+            self._bufs[name] = torch.zeros(max(n, 1), dtype=getattr(torch, dt), device=self.device)[:n].view(shape)
+        self._hbuf = abi.HnsBuffers()
+        for name in abi.BUFFER_FIELDS:
+            t = self._bufs[name]
+            setattr(self._hbuf, name, t.data_ptr() if t.numel() else None)
+        if not write_critic_state:
+            self._hbuf.state_drones = None
+        self._env = C.c_void_p()
+        self._check(self._lib.hns_create(C.byref(self.hcfg), C.byref(self._env)), "hns_create")
+        self._check(self._lib.hns_bind(self._env, C.byref(self._hbuf)), "hns_bind")
+
+        b = self._bufs
+        self.progress_buf = b["progress"]
+        self._tensordict = TensorDict({"progress": self.progress_buf}, self.batch_size)
+        self.stats = TensorDict({k: b["stats"][i].unsqueeze(-1) for i, k in enumerate(abi.STAT_NAMES)}, self.batch_size)
+        self.stats.set("action_error_order1", b["action_error"])          # transforms.py:441
+        self.info = TensorDict({"drone_state": b["drone_state"], "prev_action": b["prev_action"]}, self.batch_size)
+        self.drone = SimpleNamespace(n=A, params=CRAZYFLIE, throttle=b["throttle"], name="crazyflie",
+                                     MASS_0=torch.tensor([CRAZYFLIE["mass"]]), num_rotors=4)
+        self.TP = None                                                   # algo.use_TP_net=0 only
+        self._set_specs()
+        self._since_full_reset = 0
+        self._needs_reset = True
+
+    # ---- registry (isaac_env.py:154-161) ----------------------------------------------------------
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        HideAndSeek.REGISTRY[cls.__name__] = cls
+        HideAndSeek.REGISTRY[cls.__name__.lower()] = cls
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise HnsError(f"{what} failed ({rc}): {self._lib.hns_last_error().decode()}")
+
+    # ---- specs (hideandseek.py:327-433, use_TP_net=0 branch) ------------------------------------------
+    def _set_specs(self):
+        A, K, E, dev = self.num_agents, self.obs_max_cylinder, self.num_envs, self.device
+        D = abi.HNS_SELF_DIM
+        obs = {"state_self": TensorSpec((1, D)), "cylinders": TensorSpec((K, 5))}
+        if A > 1:
+            obs["state_others"] = TensorSpec((A - 1, 3))
+        observation_spec = CompositeSpec(obs)
+        state_spec = CompositeSpec({"state_drones": TensorSpec((A, D)), "cylinders": TensorSpec((K, 5))})
+        stats_spec = CompositeSpec({k: TensorSpec((1,)) for k in abi.STAT_NAMES})
+        info_spec = CompositeSpec({"drone_state": TensorSpec((A, 13)), "prev_action": TensorSpec((A, 4), low=-1.0, high=1.0)})
+        self.observation_spec = CompositeSpec({
+            "agents": CompositeSpec({"observation": observation_spec.expand(A), "state": state_spec}),
+            "stats": stats_spec, "info": info_spec}).expand(E).to(dev)
+        self.action_spec = CompositeSpec({"agents": CompositeSpec({"action": TensorSpec((A, 4), low=-1.0, high=1.0)})}).expand(E).to(dev)
+        self.reward_spec = CompositeSpec({"agents": CompositeSpec({"reward": TensorSpec((A, 1))})}).expand(E).to(dev)
+        self.done_spec = TensorSpec((E, 1), dtype=torch.bool, device=dev)
+        self.input_spec = CompositeSpec({"_action_spec": self.action_spec})
+        self.agent_spec = {"drone": AgentSpec("drone", A, _env=self)}
+
+    # ---- EnvBase-like public surface -----------------------------------------------------------------
+    def set_seed(self, seed=-1):
+        self._set_seed(seed)
+        return seed
+
+    def _set_seed(self, seed=-1):
+        """isaac_env.py:256-259: seeds torch; here it also keys the reset Philox stream."""
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        torch.manual_seed(int(seed))
+        self._check(self._lib.hns_set_reset_epoch(self._env, 0), "hns_set_reset_epoch")
+
+    @property
+    def reset_epoch(self):
+        return int(self._lib.hns_get_reset_epoch(self._env))
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def enable_render(self, enable=True):
+        self._render = bool(enable)
+        return self._render
+
+    def render(self, mode="human"):
+        return None                                              # rendering is out of scope (SURVEY §2 #17,#19)
+
+    def to(self, device):
+        if torch.device(device) != self.device:                  # isaac_env.py:300-305
+            raise RuntimeError(f"Cannot move HideAndSeek on {self.device} to a different device {device} once it's initialized.")
+        return self
+
+    def close(self):
+        if getattr(self, "_env", None):
+            self._lib.hns_destroy(self._env)
+            self._env = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, tensordict=None, **kwargs):
+        td = self._reset(tensordict, **kwargs)
+        if "done" not in td.keys():
+            td.set("done", torch.zeros(self.num_envs, 1, dtype=torch.bool, device=self.device))
+        return td
+
+    def step(self, tensordict):
+        if self._needs_reset:
+            raise HnsError("step() called before reset()")
+        out = self._step(tensordict)
+        tensordict.set("next", out["next"])
+        return tensordict
+
+    # ---- isaac_env.py:210-225 -----------------------------------------------------------------------------
+    def _reset(self, tensordict=None, **kwargs):
+        mask_t = None
+        if tensordict is not None and tensordict.get("_reset") is not None:
+            mask_t = tensordict.get("_reset").reshape(self.num_envs).to(torch.uint8).contiguous()
+        last_stats = self.stats.clone()
+        ptr = C.c_void_p(mask_t.data_ptr()) if mask_t is not None else None
+        self._check(self._lib.hns_reset(self._env, ptr, C.c_uint64(self.seed), self._stream()), "hns_reset")
+        self._reset_mask_keepalive = mask_t
+        if mask_t is None:
+            self._since_full_reset = 0
+        self._needs_reset = False
+        td = self._obs_tensordict()
+        td.set("stats", last_stats)
+        td.set("truncated", (self.progress_buf > self.max_episode_length).unsqueeze(1))
+        return td
+
+    # ---- transforms.py:425-459 + isaac_env.py:231-240 ------------------------------------------------
+    def _step(self, tensordict):
+        action = tensordict[("agents", "action")]
+        if action.dtype != torch.float32 or not action.is_contiguous():
+            action = action.float().contiguous()
+        if tuple(action.shape) != (self.num_envs, self.num_agents, 4):
+            raise ValueError(f"action shape {tuple(action.shape)} != {(self.num_envs, self.num_agents, 4)}")
+        self._check(self._lib.hns_step(self._env, C.c_void_p(action.data_ptr()), self._stream()), "hns_step")
+        self._action_keepalive = action
+        self._since_full_reset += 1
+        b = self._bufs
+        # hideandseek.py:1012-1015 — evader-speed curriculum; v_prey starts at its 1.3 cap with the
+        # reference's defaults, in which case no host sync is ever needed
+        if self.v_prey < 1.3 and self._since_full_reset >= self.max_episode_length:
+            done = b["done"].bool()
+            if bool(done.any()) and float(self.stats["success"].mean()) >= 0.98:
+                self.v_prey = min(1.3, self.v_prey + 0.05)
+                self._check(self._lib.hns_set_v_prey(self._env, C.c_float(self.v_prey)), "hns_set_v_prey")
+        nxt = self._obs_tensordict()
+        nxt.set(("agents", "reward"), b["reward"].unsqueeze(-1))
+        nxt.set("done", b["done"].view(torch.bool).unsqueeze(-1))
+        return TensorDict({"next": nxt}, self.batch_size)
+
+    def _obs_tensordict(self):
+        b = self._bufs
+        obs = {"state_self": b["obs_self"].unsqueeze(2), "cylinders": b["obs_cylinders"]}
+        if self.num_agents > 1:
+            obs["state_others"] = b["obs_others"]
+        state = {"state_drones": b["state_drones"], "cylinders": b["obs_cylinders"]}
+        return TensorDict({"agents": {"observation": obs, "state": state}, "stats": self.stats, "info": self.info},
+                          self.batch_size)
+
+    # ---- schedule hooks -------------------------------------------------------------------------------------------
+    def set_update_epoch(self, epoch):
+        """smoothness schedule, hideandseek.py:988-991 (train_deploy.py:270 sets update_epoch)."""
+        self.update_epoch = int(epoch)
+        t = self.cfg.task
+        coef = min(float(t.get("max_smoothness_coef", 5.0)),
+                   float(t.get("init_smoothness_coef", 0.0)) + float(t.get("smooth_lr", 0.0)) * self.update_epoch)
+        self._check(self._lib.hns_set_smoothness_coef(self._env, C.c_float(coef)), "hns_set_smoothness_coef")
+
+    def enable_kernel_timing(self, on=True):
+        self._check(self._lib.hns_enable_timing(self._env, int(on)), "hns_enable_timing")
+
+    def kernel_ms(self):
+        n = C.c_int(0)
+        ms = float(self._lib.hns_step_kernel_ms(self._env, C.byref(n)))
+        return ms, n.value
+
+    # ---- helpers for tests / tools --------------------------------------------------------------------------------
+    def rand_step_input(self, action=None):
+        if action is None:
+            action = torch.randn(self.num_envs, self.num_agents, 4, device=self.device)
+        return TensorDict({"agents": {"action": action}}, self.batch_size)
+
+    def export_state(self):
+        torch.cuda.synchronize(self.device)
+        return {k: v.detach().cpu().numpy().copy() for k, v in self._bufs.items()}
+
+    def import_state(self, arrays):
+        for k, v in arrays.items():
+            self._bufs[k].copy_(torch.as_tensor(v).to(self.device).view(self._bufs[k].shape))
+        self._needs_reset = False
+
+
+HideAndSeek.REGISTRY["HideAndSeek"] = HideAndSeek
+HideAndSeek.REGISTRY["hideandseek"] = HideAndSeek

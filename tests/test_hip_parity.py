@@ -1,0 +1,179 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP step/reset kernels, called through
+the C ABI, against the CPU oracle on the same seeded inputs — BIT-EXACT on every buffer
+(floats included: both sides use IEEE fp32 with the same evaluation order and the same
+polynomial exp/tanh/sincos), against the reference-generated golden episodes within 1e-5,
+and size-independent properties at BASELINE's full 65 536-env size."""
+import numpy as np
+import pytest
+import torch
+
+import hns_oracle as O
+from hns_amd import abi, config
+
+pytestmark = pytest.mark.gpu
+
+
+def make_env(E, A, C, max_len=40, K=3, **task):
+    from hns_amd.env import HideAndSeek
+    cyl = {"max_num": C, "obs_max_cylinder": K, "min_num": min(4, C)}
+    cyl.update(task.pop("cylinder", {}))
+    cfg = config.make_cfg({"num_agents": A, "cylinder": cyl, "env": {"num_envs": E, "max_episode_length": max_len}, **task})
+    return HideAndSeek(cfg, headless=True)
+
+
+def assert_same(host, dev, what=""):
+    for k in host:
+        if k == "state_drones" and not host[k].size:
+            continue
+        np.testing.assert_array_equal(host[k], dev[k], err_msg=f"{what}: buffer {k}")
+
+
+CASES = [
+    dict(E=300, A=3, C=8),                                   # headline shape, ragged tail (300 % 64 != 0)
+    dict(E=257, A=3, C=5, cylinder={"fixed_num": 0}),        # BASELINE config 2: no active cylinders
+    dict(E=130, A=6, C=16),                                  # G=8 lane groups
+    dict(E=96, A=2, C=3, K=2),
+    dict(E=70, A=1, C=5),                                    # single pursuer: no state_others
+    dict(E=64, A=4, C=6, K=4, drone_detect_radius=0.7, target_detect_radius=0.8, use_deployment=1, init_smoothness_coef=2.0),
+    dict(E=128, A=3, C=6, use_random_cylinder=0, scenario_flag="narrow_gap"),
+    dict(E=64, A=3, C=5, use_eval=1),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"E{c['E']}A{c['A']}C{c['C']}")
+def test_step_and_reset_bit_exact(case):
+    case = dict(case)
+    env = make_env(max_len=12, **case)
+    env.set_seed(1234)
+    env.reset()
+    host = O.alloc_buffers(env.hcfg)
+    O.reset(env.hcfg, host, None, env.seed, 0)
+    assert_same(host, env.export_state(), "after reset")
+    assert np.isfinite(host["obs_self"]).all()
+    g = torch.Generator().manual_seed(7)
+    E, A = env.num_envs, env.num_agents
+    for t in range(30):
+        action = torch.randn(E, A, 4, generator=g) * 0.7
+        if t == 3:
+            action[0] = float("nan")                         # NaN policy output -> nan_to_num path
+            action[1] = 50.0
+        env.step(env.rand_step_input(action.to(env.device)))
+        O.step(env.hcfg, host, action.numpy())
+        if t in (0, 5, 11, 29):
+            assert_same(host, env.export_state(), f"step {t}")
+        if host["done"].any():
+            # alternate: masked reset of the done envs / partial mask
+            mask = host["done"].copy()
+            if t > 20:
+                mask[::3] = 0
+            td = env.rand_step_input()
+            td.set("_reset", torch.as_tensor(mask.astype(bool), device=env.device))
+            epoch = env.reset_epoch
+            env.reset(td)
+            O.reset(env.hcfg, host, mask, env.seed, epoch)
+            assert_same(host, env.export_state(), f"reset after step {t}")
+    assert_same(host, env.export_state(), "final")
+
+
+@pytest.mark.parametrize("tag", ["a3c8", "a3c5", "a6c16"])
+def test_step_matches_reference_golden(golden, tag):
+    """HIP vs the reference-generated golden episode (teacher forced), tolerance 1e-5."""
+    g = golden(f"g_episode_{tag}")
+    E, A, C, T, max_len = (int(x) for x in g["meta"])
+    env = make_env(E, A, C, max_len=max_len)
+    env.reset()
+    st = env.export_state()
+    st["cylinders"][:] = g["init_cyl"]
+    for t in range(T):
+        if t == 0:
+            pos, rot, vel, tpos = g["init_pos"], g["init_rot"], g["init_vel"], g["init_tpos"]
+            thr, prev, prog, stats = g["init_throttle"], g["init_prev_action"], g["init_progress"], g["init_stats"]
+            integ = last = np.zeros(pos.shape, np.float32)
+        else:
+            pos, rot, vel, tpos = g["pos"][t - 1], g["rot"][t - 1], g["vel"][t - 1], g["tpos"][t - 1]
+            thr, prev, prog, stats = g["throttle"][t - 1], g["prev_action"][t - 1], g["progress"][t - 1], g["stats"][t - 1]
+            integ, last = g["integ"][t - 1], g["last"][t - 1]
+        st["drone_state"][..., 0:3], st["drone_state"][..., 3:7], st["drone_state"][..., 7:13] = pos, rot, vel
+        st["target_pos"][:] = tpos[:, 0]
+        st["throttle"][:], st["prev_action"][:], st["progress"][:] = thr, prev, prog
+        st["stats"][:] = stats.T
+        st["pid_integ"][..., :3], st["pid_last_rate"][..., :3] = integ, last
+        env.import_state(st)
+        env.step(env.rand_step_input(torch.as_tensor(g["action"][t]).to(env.device)))
+        out = env.export_state()
+        kw = dict(rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(out["drone_state"][..., 0:3], g["pos"][t], **kw)
+        np.testing.assert_allclose(out["drone_state"][..., 3:7], g["rot"][t], **kw)
+        np.testing.assert_allclose(out["drone_state"][..., 7:10], g["vel"][t][..., :3], **kw)
+        np.testing.assert_allclose(out["target_pos"], g["tpos"][t][:, 0], **kw)
+        np.testing.assert_allclose(out["obs_self"], g["state_self"][t][:, :, 0], **kw)
+        np.testing.assert_allclose(out["obs_others"], g["state_others"][t], **kw)
+        np.testing.assert_allclose(out["obs_cylinders"], g["cylinders"][t], **kw)
+        np.testing.assert_allclose(out["state_drones"], g["state_drones"][t], **kw)
+        np.testing.assert_allclose(out["reward"], g["reward"][t][..., 0], rtol=1e-5, atol=2e-5)
+        assert (out["done"].astype(bool) == g["done"][t][:, 0]).all()
+
+
+def test_full_size_properties():
+    """BASELINE config 3 at full size (65 536 envs, 3v1, 8 cylinders): invariants + determinism."""
+    E, A, C, L = 65536, 3, 8, 30
+    outs = []
+    for rep in range(2):
+        env = make_env(E, A, C, max_len=L, cylinder={"min_num": 8})
+        env.set_seed(99)
+        td = env.reset()
+        assert td[("agents", "observation", "state_self")].shape == (E, A, 1, 20)
+        assert td[("agents", "observation", "state_others")].shape == (E, A, A - 1, 3)
+        assert td[("agents", "observation", "cylinders")].shape == (E, A, 3, 5)
+        g = torch.Generator(device=env.device).manual_seed(5)
+        n_done = 0
+        for t in range(L + 5):
+            action = torch.randn(E, A, 4, generator=g, device=env.device)
+            td = env.step(env.rand_step_input(action))
+            done = td[("next", "done")]
+            assert done.shape == (E, 1) and done.dtype == torch.bool
+            if t == L - 1:
+                assert bool(done.all())                       # lock-step episodes (hideandseek.py:1008-1010)
+                st = env.export_state()
+                assert (st["progress"] == L).all()
+                n_done += 1
+                rtd = env.rand_step_input()
+                rtd.set("_reset", done.squeeze(-1))
+                env.reset(rtd)
+                assert (env.progress_buf == 0).all()
+            elif t < L - 1:
+                assert not bool(done.any())
+        st = env.export_state()
+        outs.append(st)
+        q = st["drone_state"][..., 3:7]
+        np.testing.assert_allclose(np.linalg.norm(q.astype(np.float64), axis=-1), 1.0, atol=2e-6)
+        speed = np.linalg.norm(st["drone_state"][..., 7:10].astype(np.float64), axis=-1)
+        assert speed.max() <= 1.0                              # clamp sits a hair inside v_drone
+        assert (st["drone_state"][..., 2] >= 0).all()          # ground clamp
+        assert np.isfinite(st["obs_self"]).all() and np.isfinite(st["reward"]).all()
+        assert (np.abs(np.abs(st["target_vel"]) - 1.3) < 0.05).mean() > 0.95   # per-axis +-v_prey quirk (:741)
+        active = st["cylinders"][..., 2] > 0
+        assert (active.sum(1) == 8).all()
+        # the k-nearest rows of active cylinders carry [rpos, 1.2, 0.1]; masked rows are all -5
+        oc = st["obs_cylinders"]
+        assert ((oc[..., 3] == np.float32(1.2)) | (oc[..., 3] == -5)).all()
+        assert set(np.unique(st["stats"][abi.STAT_NAMES.index("success")])) <= {0.0, 1.0}
+        assert n_done == 1
+        env.close()
+    for k in outs[0]:
+        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=f"non-deterministic buffer {k}")
+
+
+def test_error_paths():
+    from hns_amd.env import HideAndSeek, HnsError
+    env = make_env(64, 3, 5)
+    with pytest.raises(HnsError):
+        env.step(env.rand_step_input())                        # step before reset
+    env.reset()
+    with pytest.raises(ValueError):
+        env.step(env.rand_step_input(torch.zeros(64, 2, 4, device=env.device)))
+    with pytest.raises(RuntimeError):
+        env.to("cpu")
+    with pytest.raises(HnsError):
+        make_env(64, 3, 8, K=5)                                # obs_max_cylinder > 4 unsupported by the kernels
+    assert HideAndSeek.REGISTRY["hideandseek"] is HideAndSeek
