@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--episode", type=int, default=800)
     ap.add_argument("--no-critic-state", action="store_true", help="skip the [E,A,20] critic state output")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=24)
+    ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--time-every", type=int, default=8)
     args = ap.parse_args()
 
