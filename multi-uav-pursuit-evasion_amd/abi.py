@@ -131,6 +131,8 @@ def load_library():
     lib.hns_enable_timing.restype = C.c_int
     lib.hns_step_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.hns_step_kernel_ms.restype = C.c_float
+    lib.hns_set_phase_profile.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hns_set_phase_profile.restype = C.c_int
     lib.hns_abi_version.argtypes = []
     lib.hns_abi_version.restype = C.c_int
     lib.hns_cfg_size.argtypes = []
@@ -148,5 +150,5 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "hns_create", "hns_destroy", "hns_bind", "hns_step", "hns_reset", "hns_set_v_prey",
     "hns_set_smoothness_coef", "hns_set_reset_epoch", "hns_get_reset_epoch", "hns_enable_timing",
-    "hns_step_kernel_ms", "hns_abi_version", "hns_cfg_size", "hns_last_error",
+    "hns_step_kernel_ms", "hns_set_phase_profile", "hns_abi_version", "hns_cfg_size", "hns_last_error",
 ]

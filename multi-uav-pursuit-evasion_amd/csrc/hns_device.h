@@ -205,24 +205,51 @@ HNS_DEV V3 d_downwash_pair(const V3 &pi, const V3 &pj, const V3 &tj_w) {
 
 // ---- A7: line of sight drone->target blocked by any cylinder (xy plane) ---------------------
 // omni_drones/envs/hide_and_seek/hideandseek.py:47-103.  cyl: this env's [C,3] in LDS.
+//
+// The reference forms two quotients per (drone, cylinder) and only COMPARES them:
+//     dist = num/(den+1e-5) <= size      t = numt/(dent+1e-5), 0 <= t <= 1
+// Both denominators are per-drone constants > 0, so the IEEE results of the comparisons can be
+// decided without dividing, except in a vanishing band next to the thresholds where the exact
+// division is executed ("division-free line of sight"):
+//   * RN(numt/d) <= 1  <=>  numt <= d   (a quotient in (1, 1+2^-23) needs numt = d*(1+2^-24) for a tie,
+//     which is not representable, so it rounds up; numt <= d gives a quotient <= 1)
+//   * RN(numt/d) >= 0  <=>  numt >= 0   (|numt| >= 1e-30 rules out underflow to -0; else exact path)
+//   * RN(num/d) <= s: with p = s*d, num < p*(1-2^-21) => true, num > p*(1+2^-21) => false
+//     (the margin is 8x the accumulated rounding of p and of the scaling), else exact path.
+// The result is bit-identical to the divide-and-compare form (tests/test_hip_parity.py).
+struct LosLine {          // per (drone, evader) constants of the line-of-sight test
+    float diffx, diffy, dx, dy, d1, dt1, plo, phi, dpx, dpy, tpx, tpy;
+};
+HNS_DEV LosLine d_los_setup(const hns_cfg &c, const V3 &dp, const V3 &tp) {
+    LosLine l;
+    l.diffx = dp.x - tp.x; l.diffy = dp.y - tp.y;
+    float den = __builtin_sqrtf(l.diffx * l.diffx + l.diffy * l.diffy);
+    l.dx = tp.x - dp.x; l.dy = tp.y - dp.y;
+    float dent = l.dx * l.dx + l.dy * l.dy;
+    l.d1 = den + 1e-5f; l.dt1 = dent + 1e-5f;
+    float p = c.cylinder_size * l.d1;
+    l.plo = p * 0.99999952316284f; l.phi = p * 1.00000047683716f;   // 1 -+ 2^-21
+    l.dpx = dp.x; l.dpy = dp.y; l.tpx = tp.x; l.tpy = tp.y;
+    return l;
+}
+HNS_DEV bool d_los_cylinder(const hns_cfg &c, const LosLine &l, float ccx, float ccy, float ccz) {
+    float d2x = ccx - l.tpx, d2y = ccy - l.tpy;
+    float num = __builtin_fabsf(l.diffx * d2y - l.diffy * d2x);
+    float numt = (ccx - l.dpx) * l.dx + (ccy - l.dpy) * l.dy;
+    bool blocked, on;
+    if (num < l.plo) blocked = true;
+    else if (num > l.phi) blocked = false;
+    else blocked = (num / l.d1) <= c.cylinder_size;
+    if (numt >= 0.0f) on = numt <= l.dt1;
+    else if (numt < -1e-30f) on = false;
+    else { float t = numt / l.dt1; on = (t >= 0.0f) && (t <= 1.0f); }
+    return blocked && on && (ccz > 0.0f);
+}
 HNS_DEV bool d_blocked(const hns_cfg &c, int C, const V3 &dp, const V3 &tp, const float *cyl) {
-    float diffx = dp.x - tp.x, diffy = dp.y - tp.y;
-    float den = __builtin_sqrtf(diffx * diffx + diffy * diffy);
-    float dx = tp.x - dp.x, dy = tp.y - dp.y;
-    float dent = dx * dx + dy * dy;
+    const LosLine l = d_los_setup(c, dp, tp);
     bool any = false;
-    for (int k = 0; k < C; ++k) {
-        float ccx = cyl[3 * k], ccy = cyl[3 * k + 1], ccz = cyl[3 * k + 2];
-        float d2x = ccx - tp.x, d2y = ccy - tp.y;
-        float num = __builtin_fabsf(diffx * d2y - diffy * d2x);
-        float dist = num / (den + 1e-5f);
-        bool blocked = dist <= c.cylinder_size;
-        float numt = (ccx - dp.x) * dx + (ccy - dp.y) * dy;
-        float t = numt / (dent + 1e-5f);
-        bool on = (t >= 0.0f) && (t <= 1.0f);
-        bool ground = ccz > 0.0f;
-        any = any || (blocked && on && ground);
-    }
+#pragma unroll 4
+    for (int k = 0; k < C; ++k) any = d_los_cylinder(c, l, cyl[3 * k], cyl[3 * k + 1], cyl[3 * k + 2]) || any;
     return any;
 }
 

@@ -1,13 +1,16 @@
 // hns_kernels.hip — fused HideAndSeek environment step + reset for gfx950 (MI355X), and the
 // C ABI of include/hns.h.
 //
-// Mapping: every env owns a power-of-two LANE GROUP of G lanes inside one
-// wave64 (G = next pow2 >= A+1): lanes 0..A-1 are the pursuers, lane A is the "env lane"
-// (evader + per-env statistics).  A 256-thread workgroup therefore holds EPB = 256/G whole envs;
-// no env straddles a wave, so every intra-env exchange is a width-G shuffle / ballot, and the
-// tensors keep the reference's [E,A,...] layouts: each workgroup's slice of every array is ONE
-// contiguous byte range that is moved HBM<->LDS with 16-byte-per-lane coalesced accesses and
-// picked apart / assembled per agent in LDS.
+// Mapping.  One workgroup owns 64 consecutive envs and is WAVE-SPECIALISED:
+//   * waves 0..A-1  ("agent waves"): thread i <-> pursuer (env i/A, agent i%A) — every lane busy
+//     with per-drone math (controller, rotors, downwash, rigid-body integration, observation);
+//   * wave A        ("env wave"):    lane l   <-> env l — evader policy (line of sight, potential
+//     field), per-env reductions over the pursuers, reward assembly, done, statistics.
+// The two roles are different instruction streams that run CONCURRENTLY on different SIMDs of the
+// CU and meet at workgroup barriers; nothing env-level is recomputed per agent lane.
+// All tensors keep the reference's [E,A,...] layouts: a workgroup's slice of every array is one
+// contiguous byte range, moved HBM<->LDS with coalesced 16-byte-per-lane accesses (per-agent
+// float4 records go straight to registers) and picked apart / assembled in LDS.
 //
 // One launch does the whole step (reference call tree: transforms.py:425-459 ->
 // lee_position_controller.py:476-550 -> hideandseek.py:725-744 -> multirotor.py:466-508 ->
@@ -15,9 +18,9 @@
 // -> :919-1065).  No MFMA: there is no dense contraction on this path.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
-#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -26,13 +29,18 @@
 
 namespace hns {
 
-constexpr int kThreads = 256;
+constexpr int kEPB = 64;   // envs per workgroup = lanes of the env wave
 constexpr int kMaxK = 4;   // top-k insertion network width (obs_max_cylinder <= 4)
+constexpr int kRed = 11;   // per-agent scalars handed to the env wave (odd stride: conflict-free)
+enum { R_AERR = 0, R_TD, R_DIST, R_SPEED, R_CC, R_CD, R_CW, R_COLL, R_SMOOTH, R_FLAGS,
+       // the pursuer's push on the evader is consumed before phase 3 writes the reward terms: same slots
+       R_FX = R_DIST, R_FY = R_SPEED, R_FZ = R_CC };
+enum { F_CAP = 1, F_BLOCKED = 2, F_DET = 4 };
 
 template <int A>
 struct Geo {
-    static constexpr int G = (A + 1 <= 2) ? 2 : (A + 1 <= 4) ? 4 : 8;
-    static constexpr int EPB = kThreads / G;
+    static constexpr int NA = kEPB * A;         // agent threads
+    static constexpr int T = kEPB * (A + 1);    // + the env wave
 };
 
 struct Params {
@@ -41,147 +49,158 @@ struct Params {
     const float *action;        // step
     const uint8_t *reset_mask;  // reset (nullable)
     uint32_t seed_lo, seed_hi, epoch;
+    unsigned long long *prof;   // optional per-wave phase timestamps (diagnostics), else null
+    uint32_t cyl_magic;         // ceil(2^32 / (3*C)): index / (3*C) as a multiply-high
 };
+
+constexpr int kProfSlots = 8;
+// lane 0 of every wave stamps s_memtime at a phase boundary (only when a buffer is attached)
+HNS_DEV void prof_mark(unsigned long long *prof, int slot) {
+    if (prof && (threadIdx.x & 63) == 0) {
+        int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        prof[(size_t)wave * kProfSlots + slot] = __builtin_readcyclecounter();
+    }
+}
 
 // LDS carve-up (float offsets, every region 16-byte aligned)
 struct Lds {
-    int ds, cyl, tp, tvel, stats, self, oth, ocyl, state, total;
+    int ds, cyl, cyl_stride, tp, tvel, tw, red, ocyl, total;
 };
 __host__ __device__ inline int r4(int n) { return (n + 3) & ~3; }
-__host__ __device__ inline Lds lds_layout(int EPB, int A, int C, int K, int with_state) {
+__host__ __device__ inline Lds lds_layout(int A, int C, int K) {
     Lds L;
     int o = 0;
-    L.ds = o;    o += r4(EPB * A * 13);
-    L.cyl = o;   o += r4(EPB * C * 3);
-    L.tp = o;    o += r4(EPB * 3);
-    L.tvel = o;  o += r4(EPB * 3);
-    L.stats = o; o += r4(HNS_NUM_STATS * EPB);
-    L.self = o;  o += r4(EPB * A * HNS_SELF_DIM);
-    L.oth = o;   o += r4(EPB * A * (A - 1) * 3);
-    L.ocyl = o;  o += r4(EPB * A * K * 5);
-    L.state = o; o += with_state ? r4(EPB * A * HNS_SELF_DIM) : 0;
+    L.ds = o;    o += r4(kEPB * A * 13);
+    L.cyl_stride = (3 * C) | 1;                 // odd per-env stride: env-wave reads are conflict-free
+    L.cyl = o;   o += r4(kEPB * L.cyl_stride);
+    L.tp = o;    o += r4(kEPB * 3);
+    L.tvel = o;  o += r4(kEPB * 3);
+    L.tw = o;    o += r4(kEPB * A * 3);
+    L.red = o;   o += r4(kEPB * A * kRed);
+    L.ocyl = o;  o += r4(kEPB * A * K * 5);
     L.total = o;
     return L;
 }
 
 // ---- workgroup-cooperative contiguous copies (16 B per lane where alignment allows) ----------
+template <int T>
 HNS_DEV void coop_g2s(float *__restrict__ dst, const float *__restrict__ src, int n) {
     const int n4 = ((reinterpret_cast<uintptr_t>(src) & 15) == 0) ? (n >> 2) : 0;
     const float4 *s4 = reinterpret_cast<const float4 *>(src);
     float4 *d4 = reinterpret_cast<float4 *>(dst);
-    for (int i = threadIdx.x; i < n4; i += kThreads) d4[i] = s4[i];
-    for (int i = (n4 << 2) + threadIdx.x; i < n; i += kThreads) dst[i] = src[i];
+    for (int i = threadIdx.x; i < n4; i += T) d4[i] = s4[i];
+    for (int i = (n4 << 2) + threadIdx.x; i < n; i += T) dst[i] = src[i];
 }
+template <int T>
 HNS_DEV void coop_s2g(float *__restrict__ dst, const float *__restrict__ src, int n) {
     const int n4 = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) ? (n >> 2) : 0;
     const float4 *s4 = reinterpret_cast<const float4 *>(src);
     float4 *d4 = reinterpret_cast<float4 *>(dst);
-    for (int i = threadIdx.x; i < n4; i += kThreads) d4[i] = s4[i];
-    for (int i = (n4 << 2) + threadIdx.x; i < n; i += kThreads) dst[i] = src[i];
+    for (int i = threadIdx.x; i < n4; i += T) d4[i] = s4[i];
+    for (int i = (n4 << 2) + threadIdx.x; i < n; i += T) dst[i] = src[i];
+}
+// full-workgroup fast path: N floats (N % 4 == 0, both sides 16-byte aligned) known at compile time ->
+// fixed trip count, immediate offsets, no tail code
+template <int T, int N>
+HNS_DEV void coop_copy_full(float *__restrict__ dst, const float *__restrict__ src) {
+    static_assert(N % 4 == 0, "float4 granularity");
+    constexpr int N4 = N / 4;
+    const float4 *s4 = reinterpret_cast<const float4 *>(src) + threadIdx.x;
+    float4 *d4 = reinterpret_cast<float4 *>(dst) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < (N4 + T - 1) / T; ++k)
+        if (k * T + (int)threadIdx.x < N4) d4[k * T] = s4[k * T];
 }
 // same, but only the elements of envs whose mask byte is set (per_env floats per env)
+template <int T>
 HNS_DEV void coop_s2g_masked(float *__restrict__ dst, const float *__restrict__ src, int n, int per_env,
                              const uint8_t *__restrict__ smask) {
-    for (int i = threadIdx.x; i < n; i += kThreads)
+    for (int i = threadIdx.x; i < n; i += T)
         if (smask[i / per_env]) dst[i] = src[i];
 }
-// [HNS_NUM_STATS][E] rows <-> LDS [HNS_NUM_STATS][EPB]
-template <int EPB, bool TO_LDS>
-HNS_DEV void coop_stats(float *__restrict__ lds, float *__restrict__ g, int E, int e0, int nenv) {
-    if ((E & 3) == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0 && nenv == EPB) {
-        constexpr int Q = EPB / 4;
-        for (int i = threadIdx.x; i < HNS_NUM_STATS * Q; i += kThreads) {
-            int row = i / Q, c4 = i % Q;
-            float4 *gp = reinterpret_cast<float4 *>(g + (size_t)row * E + e0) + c4;
-            float4 *lp = reinterpret_cast<float4 *>(lds + row * EPB) + c4;
-            if (TO_LDS) *lp = *gp; else *gp = *lp;
-        }
-    } else {
-        for (int i = threadIdx.x; i < HNS_NUM_STATS * EPB; i += kThreads) {
-            int row = i / EPB, col = i % EPB;
-            if (col < nenv) {
-                if (TO_LDS) lds[row * EPB + col] = g[(size_t)row * E + e0 + col];
-                else g[(size_t)row * E + e0 + col] = lds[row * EPB + col];
-            }
-        }
+// cylinders [nenv, 3C] (contiguous) <-> LDS rows of odd stride
+template <int T, bool TO_LDS>
+HNS_DEV void coop_cyl(float *__restrict__ lds, float *__restrict__ g, int nenv, int c3, int stride, unsigned magic,
+                      const uint8_t *__restrict__ smask) {
+    for (int i = threadIdx.x; i < nenv * c3; i += T) {
+        int le = (int)__umulhi((unsigned)i, magic), j = i - le * c3;     // i / c3 by multiply-high
+        if (TO_LDS) lds[le * stride + j] = g[i];
+        else if (smask[le]) g[i] = lds[le * stride + j];
     }
 }
-
-template <int G>
-HNS_DEV float bcast(float v, int j) { return __shfl(v, j, G); }
-
-// bits of the A agent lanes of this lane's group in a wave-wide ballot
-template <int A, int G>
-HNS_DEV unsigned group_bits(bool pred) {
-    unsigned long long m = __ballot(pred);
-    int shift = (threadIdx.x & 63) & ~(G - 1);
-    return (unsigned)(m >> shift) & ((1u << A) - 1u);
+HNS_DEV void load_rigid(const float *r, Rigid &s) {
+    s.pos = {r[0], r[1], r[2]};
+    s.q = {r[3], r[4], r[5], r[6]};
+    s.lin = {r[7], r[8], r[9]};
+    s.ang = {r[10], r[11], r[12]};
+}
+HNS_DEV void store_rigid(float *r, const Rigid &s) {
+    r[0] = s.pos.x; r[1] = s.pos.y; r[2] = s.pos.z;
+    r[3] = s.q.w; r[4] = s.q.x; r[5] = s.q.y; r[6] = s.q.z;
+    r[7] = s.lin.x; r[8] = s.lin.y; r[9] = s.lin.z;
+    r[10] = s.ang.x; r[11] = s.ang.y; r[12] = s.ang.z;
 }
 
-struct ObsSide {
-    bool blocked;     // this agent's line of sight (post-physics)
-    bool bdetect;     // any agent of the env detects the evader
-    int knn_idx[kMaxK];
-    bool knn_masked[kMaxK];
-};
-
-// ---- A8: observation pass (agent lanes)  multirotor.py:599-633, hideandseek.py:746-917 ----------
-// sDS holds the post-physics [A,13] records of this workgroup's envs.
+// ---- A8 (agent thread): observation of one pursuer on the post-physics state -------------------
+// multirotor.py:599-633, hideandseek.py:746-917.  obs_self / state_drones are stored straight to
+// global memory (5 float4 per thread, thread-contiguous); the relative position of the evader is
+// written UNMASKED and the env wave re-masks it in the rare case that no pursuer detects the
+// evader (:791-794).  Returns the flags and the k-nearest selection the reward pass needs.
 template <int A>
-HNS_DEV void obs_pass(const hns_cfg &c, int C, int K, int le, int a, bool is_agent, const Rigid &s, const V3 &tp,
-                      float progress, const float *cyl, const float *sDS, float *sSelf, float *sOth, float *sOCyl,
-                      float *sState, ObsSide &side) {
-    constexpr int G = Geo<A>::G;
-    float rtx = 0.f, rty = 0.f, rtz = 0.f;
-    bool blocked = false, det = false;
-    if (is_agent) {
-        rtx = s.pos.x - tp.x; rty = s.pos.y - tp.y; rtz = s.pos.z - tp.z;
-        float dist = d_norm3(rtx, rty, rtz);
-        blocked = d_blocked(c, C, s.pos, tp, cyl);
-        det = (dist < c.drone_detect_radius) && !blocked;
-    }
-    const bool det_any = group_bits<A, G>(det && is_agent) != 0u;     // :791
-    side.blocked = blocked;
-    side.bdetect = det_any;
-    if (!is_agent) return;
+HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigid &s, const V3 &tp, float progress,
+                       const float *cyl, const float *sDS, float *gOth, float *sOCyl, float *gSelf, float *gState,
+                       bool &blocked, bool &det, int knn_idx[kMaxK], bool knn_masked[kMaxK]) {
+    float rtx = s.pos.x - tp.x, rty = s.pos.y - tp.y, rtz = s.pos.z - tp.z;
+    float dist = d_norm3(rtx, rty, rtz);
     const float t = progress / (float)c.max_episode_length;          // :796
     const V3 ex = {1.0f, 0.0f, 0.0f}, ez = {0.0f, 0.0f, 1.0f};
     V3 heading = d_quat_rot<false>(s.q, ex);                          // multirotor.py:613-614
     V3 up = d_quat_rot<false>(s.q, ez);
-    float o[HNS_SELF_DIM];
-    o[0] = det_any ? rtx : c.mask_value; o[1] = det_any ? rty : c.mask_value; o[2] = det_any ? rtz : c.mask_value;
-    o[3] = s.q.w; o[4] = s.q.x; o[5] = s.q.y; o[6] = s.q.z;
-    o[7] = s.lin.x; o[8] = s.lin.y; o[9] = s.lin.z;
-    o[10] = heading.x; o[11] = heading.y; o[12] = heading.z;
-    o[13] = up.x; o[14] = up.y; o[15] = up.z;
-    o[16] = t; o[17] = t; o[18] = t; o[19] = t;
-    float4 *so = reinterpret_cast<float4 *>(sSelf + (le * A + a) * HNS_SELF_DIM);
-#pragma unroll
-    for (int i = 0; i < HNS_SELF_DIM / 4; ++i) so[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
-    if (sState) {                                                      // :871-886 (unmasked rpos)
-        float4 *ss = reinterpret_cast<float4 *>(sState + (le * A + a) * HNS_SELF_DIM);
-        ss[0] = make_float4(rtx, rty, rtz, o[3]);
-#pragma unroll
-        for (int i = 1; i < HNS_SELF_DIM / 4; ++i) ss[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+    float4 v0 = make_float4(rtx, rty, rtz, s.q.w);
+    float4 v1 = make_float4(s.q.x, s.q.y, s.q.z, s.lin.x);
+    float4 v2 = make_float4(s.lin.y, s.lin.z, heading.x, heading.y);
+    float4 v3 = make_float4(heading.z, up.x, up.y, up.z);
+    float4 v4 = make_float4(t, t, t, t);
+    float4 *so = reinterpret_cast<float4 *>(gSelf);                   // :856-863
+    so[0] = v0; so[1] = v1; so[2] = v2; so[3] = v3; so[4] = v4;
+    if (gState) {                                                      // :871-886 (never masked)
+        float4 *ss = reinterpret_cast<float4 *>(gState);
+        ss[0] = v0; ss[1] = v1; ss[2] = v2; ss[3] = v3; ss[4] = v4;
     }
-    // state_others: p_i - p_j, j != i ascending (:750-751, utils/torch.py:41-53)
-    {
-        float *w = sOth + (le * A + a) * (A - 1) * 3;
+    // state_others: p_i - p_j, j != i ascending (:750-751, utils/torch.py:41-53); (A-1)*3 floats per
+    // thread, thread-contiguous in global memory
+    if (A > 1) {
+        float o[(A > 1 ? A - 1 : 1) * 3];
+        int w = 0;
 #pragma unroll
         for (int j = 0; j < A; ++j) {
             if (j == a) continue;
             const float *rj = sDS + (le * A + j) * 13;
-            w[0] = s.pos.x - rj[0]; w[1] = s.pos.y - rj[1]; w[2] = s.pos.z - rj[2];
+            o[w] = s.pos.x - rj[0]; o[w + 1] = s.pos.y - rj[1]; o[w + 2] = s.pos.z - rj[2];
             w += 3;
         }
+        if ((((A - 1) * 3) & 1) == 0) {
+            float2 *g2 = reinterpret_cast<float2 *>(gOth);
+#pragma unroll
+            for (int i = 0; i < (A - 1) * 3 / 2; ++i) g2[i] = make_float2(o[2 * i], o[2 * i + 1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < (A - 1) * 3; ++i) gOth[i] = o[i];
+        }
     }
-    // k nearest cylinders by 3-D distance - size; streaming stable insertion, ties -> lower index (:767-778)
+    // ONE pass over the env's cylinders: line of sight to the evader (:786) and the k nearest by
+    // 3-D distance - size with a streaming stable insertion, ties -> lower index (:767-778)
     float bd[kMaxK];
     int bi[kMaxK];
 #pragma unroll
     for (int i = 0; i < kMaxK; ++i) { bd[i] = kInf; bi[i] = 0; }
+    const LosLine los = d_los_setup(c, s.pos, tp);
+    bool any_block = false;
+#pragma unroll 4
     for (int k = 0; k < C; ++k) {
-        float md = d_norm3(s.pos.x - cyl[3 * k], s.pos.y - cyl[3 * k + 1], s.pos.z - cyl[3 * k + 2]) - c.cylinder_size;
+        const float ccx = cyl[3 * k], ccy = cyl[3 * k + 1], ccz = cyl[3 * k + 2];
+        any_block = d_los_cylinder(c, los, ccx, ccy, ccz) || any_block;
+        float md = d_norm3(s.pos.x - ccx, s.pos.y - ccy, s.pos.z - ccz) - c.cylinder_size;
         if (md < bd[kMaxK - 1]) {
             bd[kMaxK - 1] = md; bi[kMaxK - 1] = k;
 #pragma unroll
@@ -193,14 +212,16 @@ HNS_DEV void obs_pass(const hns_cfg &c, int C, int K, int le, int a, bool is_age
             }
         }
     }
+    blocked = any_block;
+    det = (dist < c.drone_detect_radius) && !blocked;                 // :787-789
     float *oc = sOCyl + (le * A + a) * K * 5;
 #pragma unroll
     for (int sidx = 0; sidx < kMaxK; ++sidx) {
         if (sidx < K) {
             const float *cc = cyl + 3 * bi[sidx];
             bool masked = cc[2] < 0.0f;                                // :759,775-778
-            side.knn_idx[sidx] = bi[sidx];
-            side.knn_masked[sidx] = masked;
+            knn_idx[sidx] = bi[sidx];
+            knn_masked[sidx] = masked;
             float *row = oc + sidx * 5;
             row[0] = masked ? c.mask_value : s.pos.x - cc[0];
             row[1] = masked ? c.mask_value : s.pos.y - cc[1];
@@ -215,158 +236,189 @@ HNS_DEV void obs_pass(const hns_cfg &c, int C, int K, int le, int a, bool is_age
 // The fused step kernel
 // =================================================================================================
 template <int A>
-__global__ __launch_bounds__(kThreads) void hns_step_kernel(const Params p) {
-    constexpr int G = Geo<A>::G, EPB = Geo<A>::EPB;
+__global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
+    constexpr int T = Geo<A>::T, NA = Geo<A>::NA;
     extern __shared__ __align__(16) float smem[];
     const hns_cfg &c = p.cfg;
     const hns_buffers &b = p.buf;
     const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.num_envs;
     const bool with_state = c.write_critic_state && b.state_drones != nullptr;
-    const Lds L = lds_layout(EPB, A, C, K, with_state);
+    const Lds L = lds_layout(A, C, K);
     float *sDS = smem + L.ds, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sTvel = smem + L.tvel;
-    float *sStats = smem + L.stats, *sSelf = smem + L.self, *sOth = smem + L.oth, *sOCyl = smem + L.ocyl;
-    float *sState = with_state ? smem + L.state : nullptr;
+    float *sTw = smem + L.tw, *sRed = smem + L.red, *sOCyl = smem + L.ocyl;
 
     const int tid = threadIdx.x;
-    const int e0 = blockIdx.x * EPB;
-    const int nenv = min(EPB, E - e0);
-    const int le = tid / G, a = tid % G;
+    const int e0 = blockIdx.x * kEPB;
+    const int nenv = min(kEPB, E - e0);
+    const bool env_wave = tid >= NA;
+    const int le = env_wave ? tid - NA : tid / A;      // local env
+    const int a = env_wave ? 0 : tid - le * A;         // agent index (agent threads)
     const int e = e0 + le;
-    const bool env_ok = le < nenv;
-    const bool is_agent = env_ok && a < A;
-    const bool is_envlane = env_ok && a == A;
-    const size_t ia = (size_t)e * A + a;
+    const bool valid = le < nenv;
+    const size_t ia = (size_t)e0 * A + (env_wave ? 0 : tid);
 
+    prof_mark(p.prof, 0);
     // ---- load: per-agent float4 records straight to registers, the rest through LDS ------------
     float4 act4 = make_float4(0, 0, 0, 0), thr4 = act4, integ4 = act4, last4 = act4, prev4 = act4;
-    if (is_agent) {
-        act4 = reinterpret_cast<const float4 *>(p.action)[ia];
-        thr4 = reinterpret_cast<const float4 *>(b.throttle)[ia];
-        integ4 = reinterpret_cast<const float4 *>(b.pid_integ)[ia];
-        last4 = reinterpret_cast<const float4 *>(b.pid_last_rate)[ia];
-        prev4 = reinterpret_cast<const float4 *>(b.prev_action)[ia];
+    float progress = 0.0f;
+    if (valid) {
+        progress = b.progress[e];
+        if (!env_wave) {
+            act4 = reinterpret_cast<const float4 *>(p.action)[ia];
+            thr4 = reinterpret_cast<const float4 *>(b.throttle)[ia];
+            integ4 = reinterpret_cast<const float4 *>(b.pid_integ)[ia];
+            last4 = reinterpret_cast<const float4 *>(b.pid_last_rate)[ia];
+            prev4 = reinterpret_cast<const float4 *>(b.prev_action)[ia];
+        }
     }
-    float progress = env_ok ? b.progress[e] : 0.0f;
-    coop_g2s(sDS, b.drone_state + (size_t)e0 * A * 13, nenv * A * 13);
-    coop_g2s(sCyl, b.cylinders + (size_t)e0 * C * 3, nenv * C * 3);
-    coop_g2s(sTp, b.target_pos + (size_t)e0 * 3, nenv * 3);
-    coop_stats<EPB, true>(sStats, b.stats, E, e0, nenv);
+    const bool full = nenv == kEPB;
+    if (full) {
+        coop_copy_full<T, kEPB * A * 13>(sDS, b.drone_state + (size_t)e0 * A * 13);
+        coop_copy_full<T, kEPB * 3>(sTp, b.target_pos + (size_t)e0 * 3);
+    } else {
+        coop_g2s<T>(sDS, b.drone_state + (size_t)e0 * A * 13, nenv * A * 13);
+        coop_g2s<T>(sTp, b.target_pos + (size_t)e0 * 3, nenv * 3);
+    }
+    coop_cyl<T, true>(sCyl, b.cylinders + (size_t)e0 * C * 3, nenv, 3 * C, L.cyl_stride, p.cyl_magic, nullptr);
+    // the env wave keeps its env's statistics in registers: row-major [S][E] makes every row a
+    // fully coalesced 256-byte wave access, no LDS staging needed
+    float st[HNS_NUM_STATS];
+#pragma unroll
+    for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = 0.0f;
+    if (env_wave && valid) {
+#pragma unroll
+        for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = b.stats[(size_t)i * E + e];
+    }
     __syncthreads();
+    prof_mark(p.prof, 1);
 
-    // ---- pre-physics on S_t ------------------------------------------------------------------
-    const float *cyl = sCyl + le * C * 3;
-    V3 tp = {0.f, 0.f, 0.f};
-    if (env_ok) tp = {sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]};
+    const float *cyl = sCyl + le * L.cyl_stride;
     Rigid s = {};
     s.q.w = 1.0f;
     float thrust[4] = {0, 0, 0, 0}, moment[4] = {0, 0, 0, 0};
-    float thr_diff = 0.f, aerr = 0.f;
-    V3 tw = {0.f, 0.f, 0.f}, fp = {0.f, 0.f, 0.f};
-    if (is_agent) {
-        const float *r = sDS + (le * A + a) * 13;
-        s.pos = {r[0], r[1], r[2]};
-        s.q = {r[3], r[4], r[5], r[6]};
-        s.lin = {r[7], r[8], r[9]};
-        s.ang = {r[10], r[11], r[12]};
-        float cmd[4];
-        d_ctbr_pid(c, act4, s.q, s.ang, prev4, integ4, last4, cmd, aerr);        // A1 + A2
-        d_rotor(c, cmd, thr4, thrust, moment, thr_diff);                          // A3
-        float ts = ((thrust[0] + thrust[1]) + thrust[2]) + thrust[3];
-        V3 tv = {0.0f, 0.0f, ts};
-        tw = d_quat_rot<false>(s.q, tv);                                          // multirotor.py:491
-        bool blocked_pre = d_blocked(c, C, s.pos, tp, cyl);                       // hideandseek.py:1080
-        fp = d_prey_pursuer_term(c, s.pos, tp, blocked_pre);
-    }
-    // A6: evader force = sum over pursuers (ascending) + arena + cylinders; per-axis velocity (:741)
-    V3 F = {bcast<G>(fp.x, 0), bcast<G>(fp.y, 0), bcast<G>(fp.z, 0)};
-#pragma unroll
-    for (int j = 1; j < A; ++j) {
-        F.x = F.x + bcast<G>(fp.x, j); F.y = F.y + bcast<G>(fp.y, j); F.z = F.z + bcast<G>(fp.z, j);
-    }
-    bool out_of_arena;
-    V3 fr = d_prey_arena_term(c, tp, out_of_arena);
-    F.x = F.x + fr.x; F.y = F.y + fr.y; F.z = F.z + fr.z;
-    {
+    V3 tw = {0.f, 0.f, 0.f}, tvel = {0.f, 0.f, 0.f}, tpn = {0.f, 0.f, 0.f};
+    bool out_of_arena = false;
+    float aerr = 0.f;
+
+    // ================= phase 1: pre-physics on S_t =================================================
+    V3 Fenv = {0.f, 0.f, 0.f};
+    V3 tp0 = {0.f, 0.f, 0.f};
+    if (valid) tp0 = {sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]};
+    if (!env_wave) {
+        if (valid) {
+            load_rigid(sDS + tid * 13, s);
+            float cmd[4], thr_diff;
+            d_ctbr_pid(c, act4, s.q, s.ang, prev4, integ4, last4, cmd, aerr);    // A1 + A2
+            d_rotor(c, cmd, thr4, thrust, moment, thr_diff);                      // A3
+            float ts = ((thrust[0] + thrust[1]) + thrust[2]) + thrust[3];
+            V3 tv = {0.0f, 0.0f, ts};
+            tw = d_quat_rot<false>(s.q, tv);                                      // multirotor.py:491
+            sTw[tid * 3] = tw.x; sTw[tid * 3 + 1] = tw.y; sTw[tid * 3 + 2] = tw.z;
+            // this pursuer's push on the evader (hideandseek.py:1074-1088), summed by the env wave
+            bool blocked_pre = d_blocked(c, C, s.pos, tp0, cyl);                  // :1080
+            V3 fp = d_prey_pursuer_term(c, s.pos, tp0, blocked_pre);
+            float *red = sRed + tid * kRed;
+            red[R_AERR] = aerr; red[R_TD] = thr_diff;
+            red[R_FX] = fp.x; red[R_FY] = fp.y; red[R_FZ] = fp.z;
+        }
+    } else if (valid) {
+        // A6: arena + cylinder terms of the evader's potential field (hideandseek.py:1090-1136)
+        Fenv = d_prey_arena_term(c, tp0, out_of_arena);
         float fcx = 0.f, fcy = 0.f;
+#pragma unroll 4
         for (int k = 0; k < C; ++k) {
             float tx, ty;
-            d_prey_cylinder_term(c, tp, cyl[3 * k], cyl[3 * k + 1], cyl[3 * k + 2], tx, ty);
+            d_prey_cylinder_term(c, tp0, cyl[3 * k], cyl[3 * k + 1], cyl[3 * k + 2], tx, ty);
             fcx = (k == 0) ? tx : fcx + tx;
             fcy = (k == 0) ? ty : fcy + ty;
         }
-        F.x = F.x + fcx; F.y = F.y + fcy; F.z = F.z + 0.0f;
+        tvel = {fcx, fcy, 0.0f};     // parked until the pursuer terms arrive
     }
-    V3 tvel = {(c.v_prey * F.x) / (__builtin_fabsf(F.x) + 1e-5f), (c.v_prey * F.y) / (__builtin_fabsf(F.y) + 1e-5f),
-               (c.v_prey * F.z) / (__builtin_fabsf(F.z) + 1e-5f)};
-    V3 tpn = {tp.x + tvel.x * c.dt, tp.y + tvel.y * c.dt, tp.z + tvel.z * c.dt};   // evader: p += v dt
-
-    // A4: downwash from the other drones of the env (positions of S_t from LDS, thrust vectors by shuffle)
-    V3 fdw = {0.f, 0.f, 0.f};
-    bool first = true;
+    __syncthreads();
+    if (env_wave && valid) {
+        // force = sum over pursuers (ascending) + arena + cylinders; per-axis velocity (:741)
+        V3 F = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < A; ++j) {
-        V3 twj = {bcast<G>(tw.x, j), bcast<G>(tw.y, j), bcast<G>(tw.z, j)};
-        if (is_agent && j != a) {
-            const float *rj = sDS + (le * A + j) * 13;
-            V3 pj = {rj[0], rj[1], rj[2]};
-            V3 fj = d_downwash_pair(s.pos, pj, twj);
-            fdw.x = first ? fj.x : fdw.x + fj.x;
-            fdw.y = first ? fj.y : fdw.y + fj.y;
-            fdw.z = first ? fj.z : fdw.z + fj.z;
-            first = false;
+        for (int j = 0; j < A; ++j) {
+            const float *red = sRed + (le * A + j) * kRed;
+            F.x = (j == 0) ? red[R_FX] : F.x + red[R_FX];
+            F.y = (j == 0) ? red[R_FY] : F.y + red[R_FY];
+            F.z = (j == 0) ? red[R_FZ] : F.z + red[R_FZ];
+        }
+        F.x = F.x + Fenv.x; F.y = F.y + Fenv.y; F.z = F.z + Fenv.z;
+        F.x = F.x + tvel.x; F.y = F.y + tvel.y; F.z = F.z + 0.0f;
+        tvel = {(c.v_prey * F.x) / (__builtin_fabsf(F.x) + 1e-5f), (c.v_prey * F.y) / (__builtin_fabsf(F.y) + 1e-5f),
+                (c.v_prey * F.z) / (__builtin_fabsf(F.z) + 1e-5f)};
+        tpn = {tp0.x + tvel.x * c.dt, tp0.y + tvel.y * c.dt, tp0.z + tvel.z * c.dt};   // evader: p += v dt
+    }
+    prof_mark(p.prof, 2);
+
+    // ================= phase 2: forces, torques, integration (agent waves) ===========================
+    if (!env_wave) {
+        if (valid) {
+            V3 fdw = {0.f, 0.f, 0.f};                                             // A4: downwash, j ascending
+            bool first = true;
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                if (j == a) continue;
+                const float *rj = sDS + (le * A + j) * 13;
+                const float *tj = sTw + (le * A + j) * 3;
+                V3 pj = {rj[0], rj[1], rj[2]};
+                V3 twj = {tj[0], tj[1], tj[2]};
+                V3 fj = d_downwash_pair(s.pos, pj, twj);
+                fdw.x = first ? fj.x : fdw.x + fj.x;
+                fdw.y = first ? fj.y : fdw.y + fj.y;
+                fdw.z = first ? fj.z : fdw.z + fj.z;
+                first = false;
+            }
+            V3 fw = {tw.x + fdw.x, tw.y + fdw.y, tw.z + fdw.z};
+            V3 tb;
+            tb.x = ((c.rotor_py[0] * thrust[0] + c.rotor_py[1] * thrust[1]) + c.rotor_py[2] * thrust[2]) + c.rotor_py[3] * thrust[3];
+            tb.y = -(((c.rotor_px[0] * thrust[0] + c.rotor_px[1] * thrust[1]) + c.rotor_px[2] * thrust[2]) + c.rotor_px[3] * thrust[3]);
+            tb.z = ((moment[0] + moment[1]) + moment[2]) + moment[3];
+            d_integrate(c, s, fw, tb);                                            // A5
+            reinterpret_cast<float4 *>(b.throttle)[ia] = thr4;
+            reinterpret_cast<float4 *>(b.pid_integ)[ia] = integ4;
+            reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
+            reinterpret_cast<float4 *>(b.prev_action)[ia] = prev4;
+            b.action_error[ia] = aerr;
         }
     }
-    if (is_agent) {
-        V3 fw = {tw.x + fdw.x, tw.y + fdw.y, tw.z + fdw.z};
-        V3 tb;
-        tb.x = ((c.rotor_py[0] * thrust[0] + c.rotor_py[1] * thrust[1]) + c.rotor_py[2] * thrust[2]) + c.rotor_py[3] * thrust[3];
-        tb.y = -(((c.rotor_px[0] * thrust[0] + c.rotor_px[1] * thrust[1]) + c.rotor_px[2] * thrust[2]) + c.rotor_px[3] * thrust[3]);
-        tb.z = ((moment[0] + moment[1]) + moment[2]) + moment[3];
-        d_integrate(c, s, fw, tb);                                                // A5
-    }
     progress += 1.0f;                                                             // isaac_env.py:236
-
-    // ---- publish S_{t+1} to LDS ----------------------------------------------------------------
-    __syncthreads();
-    if (is_agent) {
-        float *r = sDS + (le * A + a) * 13;
-        r[0] = s.pos.x; r[1] = s.pos.y; r[2] = s.pos.z;
-        r[3] = s.q.w; r[4] = s.q.x; r[5] = s.q.y; r[6] = s.q.z;
-        r[7] = s.lin.x; r[8] = s.lin.y; r[9] = s.lin.z;
-        r[10] = s.ang.x; r[11] = s.ang.y; r[12] = s.ang.z;
-        reinterpret_cast<float4 *>(b.throttle)[ia] = thr4;
-        reinterpret_cast<float4 *>(b.pid_integ)[ia] = integ4;
-        reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
-        reinterpret_cast<float4 *>(b.prev_action)[ia] = prev4;
-        b.action_error[ia] = aerr;
-    }
-    if (is_envlane) {
+    prof_mark(p.prof, 3);
+    __syncthreads();            // every read of S_t from sDS / sTp is done
+    if (!env_wave) {
+        if (valid) store_rigid(sDS + tid * 13, s);
+    } else if (valid) {
         sTp[le * 3] = tpn.x; sTp[le * 3 + 1] = tpn.y; sTp[le * 3 + 2] = tpn.z;
         sTvel[le * 3] = tvel.x; sTvel[le * 3 + 1] = tvel.y; sTvel[le * 3 + 2] = tvel.z;
     }
     __syncthreads();
 
-    // ---- post-physics on S_{t+1}: observation, reward, done, stats -------------------------------
-    ObsSide side;
-    obs_pass<A>(c, C, K, le, a, is_agent, s, tpn, progress, cyl, sDS, sSelf, sOth, sOCyl, sState, side);
-
-    float dist_rew = 0.f, speed_rew = 0.f, cc = 0.f, cd = 0.f, cw = 0.f, coll_rew = 0.f, smooth = 0.f;
-    bool cap_ok = false;
-    if (is_agent) {                                                               // hideandseek.py:919-995
-        float d = d_norm3(tpn.x - s.pos.x, tpn.y - s.pos.y, tpn.z - s.pos.z);
+    // ================= phase 3a: observation + per-agent reward terms on S_{t+1} =====================
+    if (!env_wave && valid) {
+        V3 tp = {sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]};
+        bool blocked, det;
+        int knn_idx[kMaxK];
+        bool knn_masked[kMaxK];
+        agent_obs<A>(c, C, K, le, a, s, tp, progress, cyl, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * HNS_SELF_DIM,
+                     with_state ? b.state_drones + ia * HNS_SELF_DIM : nullptr, blocked, det, knn_idx, knn_masked);
+        // hideandseek.py:919-995
+        float d = d_norm3(tp.x - s.pos.x, tp.y - s.pos.y, tp.z - s.pos.z);
         float act = (d > c.catch_radius) ? 1.0f : 0.0f;
-        dist_rew = (-c.dist_reward_coef * d) * act;
-        cap_ok = (d < c.catch_radius) && !side.blocked;
+        float dist_rew = (-c.dist_reward_coef * d) * act;
+        bool cap_ok = (d < c.catch_radius) && !blocked;
         float sp = d_norm3(s.lin.x, s.lin.y, s.lin.z);
-        speed_rew = -c.speed_coef * ((sp > c.v_drone) ? 1.0f : 0.0f);
+        float speed_rew = -c.speed_coef * ((sp > c.v_drone) ? 1.0f : 0.0f);
+        float cc = 0.f, cd = 0.f;
 #pragma unroll
         for (int sidx = 0; sidx < kMaxK; ++sidx) {
             if (sidx < K) {
-                const float *cy = cyl + 3 * side.knn_idx[sidx];
+                const float *cy = cyl + 3 * knn_idx[sidx];
                 float rx = s.pos.x - cy[0], ry = s.pos.y - cy[1];
                 float dxy = __builtin_sqrtf(rx * rx + ry * ry);
                 float hit = ((dxy - c.cylinder_size) < c.collision_radius) ? 1.0f : 0.0f;
-                if (side.knn_masked[sidx]) hit = 0.0f;
+                if (knn_masked[sidx]) hit = 0.0f;
                 cc = (sidx == 0) ? hit : cc + hit;
             }
         }
@@ -382,40 +434,62 @@ __global__ __launch_bounds__(kThreads) void hns_step_kernel(const Params p) {
             firstj = false;
         }
         cr = cr + -c.collision_coef * cd;
-        cw = ((s.pos.z > c.max_height) ? 1.0f : 0.0f) + (((s.pos.x * s.pos.x + s.pos.y * s.pos.y) > c.arena_sq) ? 1.0f : 0.0f);
+        float cw = ((s.pos.z > c.max_height) ? 1.0f : 0.0f) + (((s.pos.x * s.pos.x + s.pos.y * s.pos.y) > c.arena_sq) ? 1.0f : 0.0f);
         cr = cr + -c.collision_coef * cw;
-        coll_rew = cr;
         float sm = c.smoothness_coef * d_expf(-aerr);
         if (!c.use_deployment) sm = 0.0f;
-        smooth = sm;
+        float *red = sRed + tid * kRed;
+        red[R_DIST] = dist_rew; red[R_SPEED] = speed_rew; red[R_CC] = cc; red[R_CD] = cd; red[R_CW] = cw;
+        red[R_COLL] = cr; red[R_SMOOTH] = sm;
+        red[R_FLAGS] = __int_as_float((cap_ok ? F_CAP : 0) | (blocked ? F_BLOCKED : 0) | (det ? F_DET : 0));
     }
-    const bool any_cap = group_bits<A, G>(cap_ok && is_agent) != 0u;
-    const bool all_blocked = group_bits<A, G>(side.blocked && is_agent) == ((1u << A) - 1u);
-    const bool any_coll = group_bits<A, G>((coll_rew < 0.0f) && is_agent) != 0u;
-    const float detf = side.bdetect ? 1.0f : 0.0f;
-    const float detect_rew = c.detect_reward_coef * detf;
-    const float catch_rew = c.catch_reward_coef * (any_cap ? 1.0f : 0.0f);
-    const float rew = ((((dist_rew + detect_rew) + catch_rew) + coll_rew) + speed_rew) + smooth;
-    if (is_agent) b.reward[ia] = rew;
+    prof_mark(p.prof, 4);
+    __syncthreads();
+    prof_mark(p.prof, 5);
 
-    // per-env sums over the agents, ascending order, identical in every lane of the group
-    float sum_dist = bcast<G>(dist_rew, 0), sum_speed = bcast<G>(speed_rew, 0), sum_cc = bcast<G>(cc, 0);
-    float sum_cd = bcast<G>(cd, 0), sum_cw = bcast<G>(cw, 0), sum_coll = bcast<G>(coll_rew, 0);
-    float sum_smooth = bcast<G>(smooth, 0), sum_td = bcast<G>(thr_diff, 0), max_td = sum_td;
-    float sum_ae = bcast<G>(aerr, 0), sum_rew = bcast<G>(rew, 0);
-#pragma unroll
-    for (int j = 1; j < A; ++j) {
-        sum_dist += bcast<G>(dist_rew, j); sum_speed += bcast<G>(speed_rew, j); sum_cc += bcast<G>(cc, j);
-        sum_cd += bcast<G>(cd, j); sum_cw += bcast<G>(cw, j); sum_coll += bcast<G>(coll_rew, j);
-        sum_smooth += bcast<G>(smooth, j);
-        float tdj = bcast<G>(thr_diff, j);
-        sum_td += tdj;
-        if (tdj > max_td) max_td = tdj;
-        sum_ae += bcast<G>(aerr, j); sum_rew += bcast<G>(rew, j);
-    }
-    if (is_envlane) {
-#define ST(i) sStats[(i) * EPB + le]
+    // ================= phase 3b: per-env reductions, reward, done, stats (env wave) ===================
+    if (env_wave && valid) {
         const float fA = (float)A;
+        bool any_cap = false, all_blocked = true, any_coll = false, det_any = false;
+        float sum_dist = 0, sum_speed = 0, sum_cc = 0, sum_cd = 0, sum_cw = 0, sum_coll = 0, sum_smooth = 0;
+        float sum_td = 0, max_td = 0, sum_ae = 0;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float *red = sRed + (le * A + j) * kRed;
+            int fl = __float_as_int(red[R_FLAGS]);
+            any_cap |= (fl & F_CAP) != 0;
+            all_blocked &= (fl & F_BLOCKED) != 0;
+            det_any |= (fl & F_DET) != 0;
+            any_coll |= red[R_COLL] < 0.0f;
+            float td = red[R_TD];
+            if (j == 0) {
+                sum_dist = red[R_DIST]; sum_speed = red[R_SPEED]; sum_cc = red[R_CC]; sum_cd = red[R_CD]; sum_cw = red[R_CW];
+                sum_coll = red[R_COLL]; sum_smooth = red[R_SMOOTH]; sum_td = td; max_td = td; sum_ae = red[R_AERR];
+            } else {
+                sum_dist += red[R_DIST]; sum_speed += red[R_SPEED]; sum_cc += red[R_CC]; sum_cd += red[R_CD]; sum_cw += red[R_CW];
+                sum_coll += red[R_COLL]; sum_smooth += red[R_SMOOTH]; sum_td += td; sum_ae += red[R_AERR];
+                if (td > max_td) max_td = td;
+            }
+        }
+        const float detf = det_any ? 1.0f : 0.0f;
+        const float detect_rew = c.detect_reward_coef * detf;
+        const float catch_rew = c.catch_reward_coef * (any_cap ? 1.0f : 0.0f);
+        float sum_rew = 0.f;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float *red = sRed + (le * A + j) * kRed;
+            float r = ((((red[R_DIST] + detect_rew) + catch_rew) + red[R_COLL]) + red[R_SPEED]) + red[R_SMOOTH];
+            b.reward[(size_t)e * A + j] = r;
+            sum_rew = (j == 0) ? r : sum_rew + r;
+        }
+        if (!det_any) {                                        // hideandseek.py:791-794: mask the evader's rpos
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                float *o = b.obs_self + ((size_t)e * A + j) * HNS_SELF_DIM;
+                o[0] = c.mask_value; o[1] = c.mask_value; o[2] = c.mask_value;
+            }
+        }
+#define ST(i) st[i]
         float mae = sum_ae / fA;                                                  // A10, hideandseek.py:731-733
         ST(HNS_ST_ACTION_ERROR_ORDER1_MEAN) += mae;
         if (mae > ST(HNS_ST_ACTION_ERROR_ORDER1_MAX)) ST(HNS_ST_ACTION_ERROR_ORDER1_MAX) = mae;
@@ -462,61 +536,70 @@ __global__ __launch_bounds__(kThreads) void hns_step_kernel(const Params p) {
 #undef ST
         b.done[e] = (uint8_t)done;
         b.progress[e] = progress;
+#pragma unroll
+        for (int i = 0; i < HNS_NUM_STATS; ++i) b.stats[(size_t)i * E + e] = st[i];
     }
+    prof_mark(p.prof, 6);
     __syncthreads();
 
-    // ---- store: contiguous slices, 16 B per lane -------------------------------------------------
-    coop_s2g(b.drone_state + (size_t)e0 * A * 13, sDS, nenv * A * 13);
-    coop_s2g(b.target_pos + (size_t)e0 * 3, sTp, nenv * 3);
-    coop_s2g(b.target_vel + (size_t)e0 * 3, sTvel, nenv * 3);
-    coop_stats<EPB, false>(sStats, b.stats, E, e0, nenv);
-    coop_s2g(b.obs_self + (size_t)e0 * A * HNS_SELF_DIM, sSelf, nenv * A * HNS_SELF_DIM);
-    if (A > 1) coop_s2g(b.obs_others + (size_t)e0 * A * (A - 1) * 3, sOth, nenv * A * (A - 1) * 3);
-    coop_s2g(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5);
-    if (with_state) coop_s2g(b.state_drones + (size_t)e0 * A * HNS_SELF_DIM, sState, nenv * A * HNS_SELF_DIM);
+    // ================= store: contiguous slices, 16 B per lane =========================================
+    if (full) {
+        coop_copy_full<T, kEPB * A * 13>(b.drone_state + (size_t)e0 * A * 13, sDS);
+        coop_copy_full<T, kEPB * 3>(b.target_pos + (size_t)e0 * 3, sTp);
+        coop_copy_full<T, kEPB * 3>(b.target_vel + (size_t)e0 * 3, sTvel);
+    } else {
+        coop_s2g<T>(b.drone_state + (size_t)e0 * A * 13, sDS, nenv * A * 13);
+        coop_s2g<T>(b.target_pos + (size_t)e0 * 3, sTp, nenv * 3);
+        coop_s2g<T>(b.target_vel + (size_t)e0 * 3, sTvel, nenv * 3);
+    }
+    coop_s2g<T>(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5);
+    prof_mark(p.prof, 7);
 }
 
 // =================================================================================================
 // Reset kernel (A11): hideandseek.py:576-723, multirotor.py:635-650 + the reset-time obs pass
-// (isaac_env.py:221).  The env lane regenerates the env's state into LDS with a Philox stream,
-// then the agent lanes run the same obs_pass as the step kernel.
+// (isaac_env.py:221).  The env wave regenerates the state of the masked envs into LDS with a
+// Philox stream, then the agent waves run the same agent_obs as the step kernel.
 // =================================================================================================
 template <int A>
-__global__ __launch_bounds__(kThreads) void hns_reset_kernel(const Params p) {
-    constexpr int G = Geo<A>::G, EPB = Geo<A>::EPB;
+__global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
+    constexpr int T = Geo<A>::T, NA = Geo<A>::NA;
     extern __shared__ __align__(16) float smem[];
-    __shared__ uint8_t sMask[EPB];
+    __shared__ uint8_t sMask[kEPB];
+    __shared__ uint8_t sDet[kEPB];
     const hns_cfg &c = p.cfg;
     const hns_buffers &b = p.buf;
     const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.num_envs, GN = c.grid_num;
     const bool with_state = c.write_critic_state && b.state_drones != nullptr;
-    const Lds L = lds_layout(EPB, A, C, K, with_state);
+    const Lds L = lds_layout(A, C, K);
     float *sDS = smem + L.ds, *sCyl = smem + L.cyl, *sTp = smem + L.tp;
-    float *sSelf = smem + L.self, *sOth = smem + L.oth, *sOCyl = smem + L.ocyl;
-    float *sState = with_state ? smem + L.state : nullptr;
-    uint8_t *sGrid = reinterpret_cast<uint8_t *>(smem + L.total);   // EPB x 512 B of grid scratch after the step layout
+    float *sOCyl = smem + L.ocyl;
+    uint8_t *sGrid = reinterpret_cast<uint8_t *>(smem + L.total);   // 64 x 512 B of grid scratch after the step layout
 
     const int tid = threadIdx.x;
-    const int e0 = blockIdx.x * EPB;
-    const int nenv = min(EPB, E - e0);
-    const int le = tid / G, a = tid % G;
+    const int e0 = blockIdx.x * kEPB;
+    const int nenv = min(kEPB, E - e0);
+    const bool env_wave = tid >= NA;
+    const int le = env_wave ? tid - NA : tid / A;
+    const int a = env_wave ? 0 : tid - le * A;
     const int e = e0 + le;
-    const bool env_ok = le < nenv;
-    if (tid < EPB) sMask[tid] = (tid < nenv) ? (p.reset_mask ? (p.reset_mask[e0 + tid] != 0) : 1) : 0;
+    const bool valid = le < nenv;
+    if (tid < kEPB) {
+        sMask[tid] = (tid < nenv) ? (p.reset_mask ? (p.reset_mask[e0 + tid] != 0) : 1) : 0;
+        sDet[tid] = 0;
+    }
     __syncthreads();
-    const bool masked = env_ok && sMask[le];
-    const bool is_agent = masked && a < A;
-    const bool is_envlane = env_ok && a == A;
+    const bool masked = valid && sMask[le];
 
-    if (is_envlane) {
+    if (env_wave && valid) {
         // hideandseek.py:712 resets first_capture_step for ALL envs on any reset call
         b.stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * E + e] = (float)c.max_episode_length;
     }
-    if (is_envlane && masked) {
+    if (env_wave && masked) {
         Rng rng = {p.seed_lo, p.seed_hi, (uint32_t)(e + c.env_index_offset), p.epoch, 0u, {0u, 0u, 0u, 0u}, 0};
         float *ds = sDS + le * A * 13;
         float *tp = sTp + le * 3;
-        float *cyl = sCyl + le * C * 3;
+        float *cyl = sCyl + le * L.cyl_stride;
         for (int j = 0; j < A; ++j) {
             float *d = ds + 13 * j;
             if (c.init_mode == HNS_INIT_RANDOM) {
@@ -596,28 +679,29 @@ __global__ __launch_bounds__(kThreads) void hns_reset_kernel(const Params p) {
         b.done[e] = 0;
     }
     __syncthreads();
-    Rigid s = {};
-    s.q.w = 1.0f;
-    V3 tp = {0.f, 0.f, 0.f};
-    if (masked) tp = {sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]};
-    if (is_agent) {
-        const float *r = sDS + (le * A + a) * 13;
-        s.pos = {r[0], r[1], r[2]};
-        s.q = {r[3], r[4], r[5], r[6]};
-        s.lin = {r[7], r[8], r[9]};
-        s.ang = {r[10], r[11], r[12]};
+    if (!env_wave && masked) {
+        Rigid s;
+        load_rigid(sDS + tid * 13, s);
+        V3 tp = {sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]};
+        const size_t ia = (size_t)e0 * A + tid;
+        bool blocked, det;
+        int knn_idx[kMaxK];
+        bool knn_masked[kMaxK];
+        agent_obs<A>(c, C, K, le, a, s, tp, 0.0f, sCyl + le * L.cyl_stride, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * HNS_SELF_DIM,
+                     with_state ? b.state_drones + ia * HNS_SELF_DIM : nullptr, blocked, det, knn_idx, knn_masked);
+        if (det) sDet[le] = 1;
     }
-    ObsSide side;
-    obs_pass<A>(c, C, K, le, a, is_agent, s, tp, 0.0f, sCyl + le * C * 3, sDS, sSelf, sOth, sOCyl, sState, side);
     __syncthreads();
-    coop_s2g_masked(b.drone_state + (size_t)e0 * A * 13, sDS, nenv * A * 13, A * 13, sMask);
-    coop_s2g_masked(b.cylinders + (size_t)e0 * C * 3, sCyl, nenv * C * 3, C * 3, sMask);
-    coop_s2g_masked(b.target_pos + (size_t)e0 * 3, sTp, nenv * 3, 3, sMask);
-    coop_s2g_masked(b.obs_self + (size_t)e0 * A * HNS_SELF_DIM, sSelf, nenv * A * HNS_SELF_DIM, A * HNS_SELF_DIM, sMask);
-    if (A > 1) coop_s2g_masked(b.obs_others + (size_t)e0 * A * (A - 1) * 3, sOth, nenv * A * (A - 1) * 3, A * (A - 1) * 3, sMask);
-    coop_s2g_masked(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5, A * K * 5, sMask);
-    if (with_state)
-        coop_s2g_masked(b.state_drones + (size_t)e0 * A * HNS_SELF_DIM, sState, nenv * A * HNS_SELF_DIM, A * HNS_SELF_DIM, sMask);
+    if (env_wave && masked && !sDet[le]) {                     // hideandseek.py:791-794
+        for (int j = 0; j < A; ++j) {
+            float *o = b.obs_self + ((size_t)e * A + j) * HNS_SELF_DIM;
+            o[0] = c.mask_value; o[1] = c.mask_value; o[2] = c.mask_value;
+        }
+    }
+    coop_s2g_masked<T>(b.drone_state + (size_t)e0 * A * 13, sDS, nenv * A * 13, A * 13, sMask);
+    coop_cyl<T, false>(sCyl, b.cylinders + (size_t)e0 * C * 3, nenv, 3 * C, L.cyl_stride, p.cyl_magic, sMask);
+    coop_s2g_masked<T>(b.target_pos + (size_t)e0 * 3, sTp, nenv * 3, 3, sMask);
+    coop_s2g_masked<T>(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5, A * K * 5, sMask);
 }
 
 }  // namespace hns
@@ -635,10 +719,12 @@ struct hns_env {
     hns_buffers buf;
     bool bound = false;
     uint32_t epoch = 0;
-    int grid = 0;
+    int grid = 0, threads = 0;
     size_t lds_step = 0, lds_reset = 0;
     void (*step_fn)(const Params) = nullptr;
     void (*reset_fn)(const Params) = nullptr;
+    unsigned long long *prof = nullptr;
+    uint32_t cyl_magic = 0;
     int timing = 0;          // 0 = off, n = bracket every n-th step launch with hipEvents
     uint64_t step_count = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // recorded, not yet harvested
@@ -650,11 +736,12 @@ static void select_kernels(hns_env *env) {
     env->step_fn = hns::hns_step_kernel<A>;
     env->reset_fn = hns::hns_reset_kernel<A>;
     const hns_cfg &c = env->cfg;
-    constexpr int EPB = hns::Geo<A>::EPB;
-    env->grid = (c.num_envs + EPB - 1) / EPB;
-    hns::Lds L = hns::lds_layout(EPB, A, c.num_cylinders, c.obs_max_cylinder, c.write_critic_state);
+    env->threads = hns::Geo<A>::T;
+    env->cyl_magic = (uint32_t)(0xFFFFFFFFull / (uint32_t)(3 * c.num_cylinders) + 1ull);
+    env->grid = (c.num_envs + hns::kEPB - 1) / hns::kEPB;
+    hns::Lds L = hns::lds_layout(A, c.num_cylinders, c.obs_max_cylinder);
     env->lds_step = (size_t)L.total * sizeof(float);
-    env->lds_reset = env->lds_step + (size_t)EPB * 512;   // + per-env occupancy grid / free-cell list
+    env->lds_reset = env->lds_step + (size_t)hns::kEPB * 512;   // + per-env occupancy grid / free-cell list
 }
 
 #define HNS_CHECK_HIP(expr)                                                        \
@@ -752,9 +839,15 @@ int hns_bind(hns_env *env, const hns_buffers *buffers) {
         set_error("hns_bind: write_critic_state set but state_drones is null");
         return HNS_ERR_INVALID_ARG;
     }
-    const void *al16[] = {buffers->throttle, buffers->pid_integ, buffers->pid_last_rate, buffers->prev_action};
+    const void *al16[] = {buffers->throttle, buffers->pid_integ, buffers->pid_last_rate, buffers->prev_action,
+                          buffers->drone_state, buffers->target_pos, buffers->target_vel, buffers->obs_self,
+                          buffers->state_drones, buffers->obs_cylinders};
     for (const void *ptr : al16)
-        if (reinterpret_cast<uintptr_t>(ptr) & 15) { set_error("hns_bind: per-agent float4 buffers must be 16-byte aligned"); return HNS_ERR_INVALID_ARG; }
+        if (reinterpret_cast<uintptr_t>(ptr) & 15) { set_error("hns_bind: buffers must be 16-byte aligned"); return HNS_ERR_INVALID_ARG; }
+    if (env->cfg.num_agents > 1 && (reinterpret_cast<uintptr_t>(buffers->obs_others) & 7)) {
+        set_error("hns_bind: obs_others must be 8-byte aligned");
+        return HNS_ERR_INVALID_ARG;
+    }
     env->buf = *buffers;
     env->bound = true;
     return HNS_OK;
@@ -773,7 +866,7 @@ static int launch(hns_env *env, bool is_step, const Params &p, hipStream_t strea
     }
     auto fn = is_step ? env->step_fn : env->reset_fn;
     size_t lds = is_step ? env->lds_step : env->lds_reset;
-    hipLaunchKernelGGL(fn, dim3(env->grid), dim3(hns::kThreads), lds, stream, p);
+    hipLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads), lds, stream, p);
     HNS_CHECK_HIP(hipGetLastError());
     if (time_it) {
         HNS_CHECK_HIP(hipEventRecord(ev.second, stream));
@@ -792,6 +885,8 @@ int hns_step(hns_env *env, const float *action, void *stream) {
     p.action = action;
     p.reset_mask = nullptr;
     p.seed_lo = p.seed_hi = p.epoch = 0;
+    p.prof = env->prof;
+    p.cyl_magic = env->cyl_magic;
     return launch(env, true, p, static_cast<hipStream_t>(stream));
 }
 
@@ -806,6 +901,8 @@ int hns_reset(hns_env *env, const uint8_t *reset_mask, uint64_t seed, void *stre
     p.seed_lo = (uint32_t)seed;
     p.seed_hi = (uint32_t)(seed >> 32);
     p.epoch = env->epoch++;
+    p.prof = nullptr;
+    p.cyl_magic = env->cyl_magic;
     return launch(env, false, p, static_cast<hipStream_t>(stream));
 }
 
@@ -825,6 +922,12 @@ int hns_set_reset_epoch(hns_env *env, uint32_t epoch) {
     return HNS_OK;
 }
 uint32_t hns_get_reset_epoch(const hns_env *env) { return env ? env->epoch : 0u; }
+
+int hns_set_phase_profile(hns_env *env, unsigned long long *device_buf) {
+    if (!env) return HNS_ERR_INVALID_ARG;
+    env->prof = device_buf;
+    return HNS_OK;
+}
 
 int hns_enable_timing(hns_env *env, int on) {
     if (!env) return HNS_ERR_INVALID_ARG;

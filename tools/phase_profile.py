@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-phase wave timing of the fused step kernel (s_memtime stamps, hns_set_phase_profile).
+Run on the GPU box.  Prints mean cycles between phase marks for agent waves and env waves."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ctypes as C
+import numpy as np
+import torch
+import hns_amd
+from hns_amd import config
+from hns_amd.env import HideAndSeek
+
+E, A, Cn = 65536, 3, 8
+cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": Cn, "min_num": Cn}, "env": {"num_envs": E}})
+env = HideAndSeek(cfg, write_critic_state="--no-critic-state" not in sys.argv)
+env.reset()
+nw = (E // 64) * (A + 1)
+buf = torch.zeros(nw, 8, dtype=torch.int64, device=env.device)
+act = torch.randn(E, A, 4, device=env.device)
+for _ in range(20):
+    env.step(env.rand_step_input(act))
+env._lib.hns_set_phase_profile(env._env, C.c_void_p(buf.data_ptr()))
+env.step(env.rand_step_input(act))
+torch.cuda.synchronize()
+env._lib.hns_set_phase_profile(env._env, None)
+t = buf.cpu().numpy().astype(np.int64).reshape(E // 64, A + 1, 8)
+t0 = t[..., 0].min()
+names = ["load+barrier", "phase1", "wait b1", "phase2", "pub+phase3a", "wait b4", "phase3b", "store"]
+d = np.diff(t, axis=-1)
+print("kernel span (cycles): %d" % (t[..., 7].max() - t0))
+print("block start spread: min %d median %d max %d" % ((t[..., 0] - t0).min(), np.median(t[..., 0] - t0), (t[..., 0] - t0).max()))
+print("block duration: median %d  p90 %d" % (np.median(t[:, :, 7].max(1) - t[:, :, 0].min(1)), np.percentile(t[:, :, 7].max(1) - t[:, :, 0].min(1), 90)))
+print("%-14s %10s %10s" % ("segment", "agent", "env"))
+seg = ["0-1 load", "1-2 phase1", "2-3 b1+phase2", "3-4 b2,b3+3a", "4-5 b4", "5-6 phase3b", "6-7 b5+store"]
+for i, n in enumerate(seg):
+    print("%-14s %10.0f %10.0f" % (n, d[:, :A, i].mean(), d[:, A, i].mean()))

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of bench.py.
+# usage: tools/profile_step.sh <tag> [extra bench args]
+set -u
+TAG=${1:-run}; shift || true
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+B="python bench.py --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -- $B --steps 400 --warmup 50 > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc1 -- $B --steps 60 --warmup 10 > $OUT/pmc1.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc2 -- $B --steps 60 --warmup 10 > $OUT/pmc2.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -d $OUT/pmc3 -- $B --steps 60 --warmup 10 > $OUT/pmc3.log 2>&1
+for d in stats pmc1 pmc2 pmc3; do
+  db=$(ls $OUT/$d/*/*.db 2>/dev/null | head -1)
+  [ -n "$db" ] && python tools/rocpd_summary.py "$db" hns_ > $OUT/$d.csv && rm -rf $OUT/$d
+done
+grep -h '"metric"' $OUT/stats.log | cut -c1-120
+cat $OUT/*.csv
