@@ -5,7 +5,7 @@ Workload = BASELINE.json configs[2]: HideAndSeek 3 pursuers / 1 evader, 8 cylind
 (k-nearest + line-of-sight sensing), 65 536 envs per GPU, synthetic N(0,1) policy outputs
 resident in HBM.  A "step" is one `hns_step` over the whole env batch (+ the `hns_reset` launch
 at the natural 1/800 episode boundary).  Multi-GPU: one process per GPU (torchrun), contiguous
-env-index shards, weak scaling; the only collective is one RCCL all-gather of 3 floats per
+env-index shards, weak scaling; the only collective is one RCCL all-gather of 5 fp64 values per
 64-step rollout (the advantage-normalisation moments named by north_star).
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live: every 8th step launch inside the
@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--agents", type=int, default=3)
     ap.add_argument("--cylinders", type=int, default=8)
     ap.add_argument("--episode", type=int, default=800)
-    ap.add_argument("--no-critic-state", action="store_true", help="skip the [E,A,20] critic state output")
+    ap.add_argument("--critic-state", action="store_true", help="also write the [E,A,20] centralised-critic state (critic_input: state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--time-every", type=int, default=8)
@@ -70,7 +70,7 @@ def main():
     cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": C, "min_num": C, "obs_max_cylinder": K},
                            "env": {"num_envs": E, "max_episode_length": args.episode},
                            "sim": {"device": f"cuda:{local_rank}"}})
-    env = HideAndSeek(cfg, headless=True, env_index_offset=rank * E, write_critic_state=not args.no_critic_state)
+    env = HideAndSeek(cfg, headless=True, env_index_offset=rank * E, write_critic_state=args.critic_state)
     env.set_seed(0)
     env.reset()
     lib, henv = env._lib, env._env
@@ -85,8 +85,8 @@ def main():
     aptr = [Cx.c_void_p(a.data_ptr()) for a in actions]
     done_ptr = Cx.c_void_p(env._bufs["done"].data_ptr())
     reward = env._bufs["reward"]
-    moments = torch.zeros(3, device=device, dtype=torch.float64)
-    gathered = [torch.zeros(3, device=device, dtype=torch.float64) for _ in range(world)] if world > 1 else None
+    success = env.stats["success"]
+    from hns_amd import sharding
     rollout = int(cfg.algo.get("train_every", 64))
     progress = {"t": 0}
 
@@ -100,11 +100,10 @@ def main():
                 rc = lib.hns_reset(henv, done_ptr, Cx.c_uint64(env.seed), sptr)
                 assert rc == 0, lib.hns_last_error()
             if world > 1 and (i + 1) % rollout == 0:
-                # per-rollout advantage-normalisation moments (learning/mappo.py:391-396 made DP):
-                # (sum, sum of squares, count) -> ONE all-gather of 3 values per rank
-                r64 = reward.double()
-                moments[0], moments[1], moments[2] = r64.sum(), (r64 * r64).sum(), float(r64.numel())
-                dist.all_gather(gathered, moments)
+                # per-rollout moments for advantage normalisation (learning/mappo.py:391-396 made
+                # data-parallel) + the success rate of the curriculum (hideandseek.py:1012-1015):
+                # ONE all-gather of 5 fp64 values per rank over RCCL/xGMI
+                sharding.allgather_moments(sharding.local_moments(reward, success))
 
     def sync():
         torch.cuda.synchronize(device)
@@ -164,9 +163,9 @@ def main():
             "config": {"workload": f"HideAndSeek {A}v1, {C} random cylinders + LOS/k-nearest sensing, "
                                    f"{E} envs per GPU (BASELINE configs[2])",
                        "num_envs_per_gpu": E, "num_agents": A, "num_cylinders": C, "obs_max_cylinder": K,
-                       "episode_length": args.episode, "critic_state_output": not args.no_critic_state,
+                       "episode_length": args.episode, "critic_state_output": args.critic_state,
                        "sharding": f"contiguous env slices x{world}",
-                       "collective": "1 all-gather of 3 fp64 per 64-step rollout" if world > 1 else "none"},
+                       "collective": "1 all-gather of 5 fp64 per 64-step rollout" if world > 1 else "none"},
             "env_frames_per_s": round(value / A, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -191,8 +191,8 @@ uint32_t hns_get_reset_epoch(const hns_env *env);
 int hns_enable_timing(hns_env *env, int every_n);
 float hns_step_kernel_ms(hns_env *env, int *num_launches);
 
-/* Diagnostics: attach a device buffer of [num_waves, 8] uint64 (num_waves = ceil(E/64)*(A+1)); lane 0
- * of every wave of the step kernel then stamps the shader clock at 8 phase boundaries (NULL detaches). */
+/* Diagnostics: attach a device buffer of [num_waves, 16] uint64 (num_waves = ceil(E/64)*(A+1)); lane 0
+ * of every wave of the step kernel then stamps the shader clock at up to 16 phase boundaries (NULL detaches). */
 int hns_set_phase_profile(hns_env *env, unsigned long long *device_buf);
 
 int hns_abi_version(void);

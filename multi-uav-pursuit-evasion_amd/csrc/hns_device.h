@@ -99,6 +99,26 @@ HNS_DEV V3 d_quat_rot(const Q4 &q, const V3 &v) {
     return o;
 }
 
+// quat_rotate(q, x_hat) and quat_rotate(q, (0,0,t)) with the exact-zero products of the general
+// formula dropped (identical values for finite q): heading/up (multirotor.py:613-614), thrust (:491)
+HNS_DEV V3 d_quat_rot_x(const Q4 &q) {
+    float s = 2.0f * (q.w * q.w) - 1.0f;
+    V3 o;
+    o.x = s + (q.x * q.x) * 2.0f;
+    o.y = (q.z * q.w) * 2.0f + (q.y * q.x) * 2.0f;
+    o.z = (-q.y * q.w) * 2.0f + (q.z * q.x) * 2.0f;
+    return o;
+}
+HNS_DEV V3 d_quat_rot_z(const Q4 &q, float t) {
+    float s = 2.0f * (q.w * q.w) - 1.0f;
+    float dot = q.z * t;
+    V3 o;
+    o.x = ((q.y * t) * q.w) * 2.0f + (q.x * dot) * 2.0f;
+    o.y = ((-(q.x * t)) * q.w) * 2.0f + (q.y * dot) * 2.0f;
+    o.z = t * s + (q.z * dot) * 2.0f;
+    return o;
+}
+
 // omni_drones/utils/torch.py:110-127
 HNS_DEV Q4 d_euler_to_quat(float r, float p, float y) {
     float sr, cr, sp, cp, sy, cy;
@@ -216,7 +236,9 @@ HNS_DEV V3 d_downwash_pair(const V3 &pi, const V3 &pj, const V3 &tj_w) {
 //   * RN(numt/d) >= 0  <=>  numt >= 0   (|numt| >= 1e-30 rules out underflow to -0; else exact path)
 //   * RN(num/d) <= s: with p = s*d, num < p*(1-2^-21) => true, num > p*(1+2^-21) => false
 //     (the margin is 8x the accumulated rounding of p and of the scaling), else exact path.
-// The result is bit-identical to the divide-and-compare form (tests/test_hip_parity.py).
+// The fast tests are branch-free; a lane that meets an undecidable case redoes its whole loop in
+// the exact divide-and-compare form afterwards.  The result is bit-identical to that form
+// (tests/test_hip_parity.py).
 struct LosLine {          // per (drone, evader) constants of the line-of-sight test
     float diffx, diffy, dx, dy, d1, dt1, plo, phi, dpx, dpy, tpx, tpy;
 };
@@ -232,24 +254,38 @@ HNS_DEV LosLine d_los_setup(const hns_cfg &c, const V3 &dp, const V3 &tp) {
     l.dpx = dp.x; l.dpy = dp.y; l.tpx = tp.x; l.tpy = tp.y;
     return l;
 }
+// Branch-free fast test.  Returns the decision when it is certain; sets `uncertain` when either
+// quotient lies in the band where only the exact division can decide (or an input is NaN).
+HNS_DEV bool d_los_cylinder_fast(const LosLine &l, float ccx, float ccy, float ccz, bool &uncertain) {
+    float d2x = ccx - l.tpx, d2y = ccy - l.tpy;
+    float num = __builtin_fabsf(l.diffx * d2y - l.diffy * d2x);
+    float numt = (ccx - l.dpx) * l.dx + (ccy - l.dpy) * l.dy;
+    bool lo = num < l.plo, hi = num > l.phi;
+    bool tpos = numt >= 0.0f, tneg = numt < -1e-30f;
+    uncertain = uncertain || !(lo || hi) || !(tpos || tneg);
+    return lo && tpos && (numt <= l.dt1) && (ccz > 0.0f);
+}
+// Exact form: divide and compare, as the reference does (hideandseek.py:47-103)
 HNS_DEV bool d_los_cylinder(const hns_cfg &c, const LosLine &l, float ccx, float ccy, float ccz) {
     float d2x = ccx - l.tpx, d2y = ccy - l.tpy;
     float num = __builtin_fabsf(l.diffx * d2y - l.diffy * d2x);
     float numt = (ccx - l.dpx) * l.dx + (ccy - l.dpy) * l.dy;
-    bool blocked, on;
-    if (num < l.plo) blocked = true;
-    else if (num > l.phi) blocked = false;
-    else blocked = (num / l.d1) <= c.cylinder_size;
-    if (numt >= 0.0f) on = numt <= l.dt1;
-    else if (numt < -1e-30f) on = false;
-    else { float t = numt / l.dt1; on = (t >= 0.0f) && (t <= 1.0f); }
+    bool blocked = (num / l.d1) <= c.cylinder_size;
+    float t = numt / l.dt1;
+    bool on = (t >= 0.0f) && (t <= 1.0f);
     return blocked && on && (ccz > 0.0f);
+}
+HNS_DEV bool d_blocked_exact(const hns_cfg &c, int C, const LosLine &l, const float *cyl) {
+    bool any = false;
+    for (int k = 0; k < C; ++k) any = d_los_cylinder(c, l, cyl[3 * k], cyl[3 * k + 1], cyl[3 * k + 2]) || any;
+    return any;
 }
 HNS_DEV bool d_blocked(const hns_cfg &c, int C, const V3 &dp, const V3 &tp, const float *cyl) {
     const LosLine l = d_los_setup(c, dp, tp);
-    bool any = false;
+    bool any = false, uncertain = false;
 #pragma unroll 4
-    for (int k = 0; k < C; ++k) any = d_los_cylinder(c, l, cyl[3 * k], cyl[3 * k + 1], cyl[3 * k + 2]) || any;
+    for (int k = 0; k < C; ++k) any = d_los_cylinder_fast(l, cyl[3 * k], cyl[3 * k + 1], cyl[3 * k + 2], uncertain) || any;
+    if (uncertain) any = d_blocked_exact(c, C, l, cyl);      // rare (~1e-6 per test): redo the env exactly
     return any;
 }
 

@@ -53,7 +53,7 @@ struct Params {
     uint32_t cyl_magic;         // ceil(2^32 / (3*C)): index / (3*C) as a multiply-high
 };
 
-constexpr int kProfSlots = 8;
+constexpr int kProfSlots = 16;
 // lane 0 of every wave stamps s_memtime at a phase boundary (only when a buffer is attached)
 HNS_DEV void prof_mark(unsigned long long *prof, int slot) {
     if (prof && (threadIdx.x & 63) == 0) {
@@ -153,9 +153,8 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
     float rtx = s.pos.x - tp.x, rty = s.pos.y - tp.y, rtz = s.pos.z - tp.z;
     float dist = d_norm3(rtx, rty, rtz);
     const float t = progress / (float)c.max_episode_length;          // :796
-    const V3 ex = {1.0f, 0.0f, 0.0f}, ez = {0.0f, 0.0f, 1.0f};
-    V3 heading = d_quat_rot<false>(s.q, ex);                          // multirotor.py:613-614
-    V3 up = d_quat_rot<false>(s.q, ez);
+    V3 heading = d_quat_rot_x(s.q);                                   // multirotor.py:613-614
+    V3 up = d_quat_rot_z(s.q, 1.0f);
     float4 v0 = make_float4(rtx, rty, rtz, s.q.w);
     float4 v1 = make_float4(s.q.x, s.q.y, s.q.z, s.lin.x);
     float4 v2 = make_float4(s.lin.y, s.lin.z, heading.x, heading.y);
@@ -189,25 +188,52 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
         }
     }
     // ONE pass over the env's cylinders: line of sight to the evader (:786) and the k nearest by
-    // 3-D distance - size with a streaming stable insertion, ties -> lower index (:767-778)
-    float bd[kMaxK];
-    int bi[kMaxK];
+    // (3-D distance - size), ties -> lower index (:767-778).  The ordering is decided on SQUARED
+    // distances (no sqrt): md = RN(RN(sqrt(d2)) - size) is monotone in d2, so both orders agree
+    // whenever consecutive candidates differ by more than 2^-16 relative (then their md differ by
+    // >= 4 ulp and cannot tie); otherwise the exact md insertion below decides.
+    constexpr int kTrack = kMaxK + 1;           // one more than k: guards the k-th/(k+1)-th boundary
+    float bd[kTrack];
+    int bi[kTrack];
 #pragma unroll
-    for (int i = 0; i < kMaxK; ++i) { bd[i] = kInf; bi[i] = 0; }
+    for (int i = 0; i < kTrack; ++i) { bd[i] = kInf; bi[i] = 0; }
     const LosLine los = d_los_setup(c, s.pos, tp);
-    bool any_block = false;
+    bool any_block = false, los_uncertain = false;
 #pragma unroll 4
     for (int k = 0; k < C; ++k) {
         const float ccx = cyl[3 * k], ccy = cyl[3 * k + 1], ccz = cyl[3 * k + 2];
-        any_block = d_los_cylinder(c, los, ccx, ccy, ccz) || any_block;
-        float md = d_norm3(s.pos.x - ccx, s.pos.y - ccy, s.pos.z - ccz) - c.cylinder_size;
-        if (md < bd[kMaxK - 1]) {
-            bd[kMaxK - 1] = md; bi[kMaxK - 1] = k;
+        any_block = d_los_cylinder_fast(los, ccx, ccy, ccz, los_uncertain) || any_block;
+        const float ex = s.pos.x - ccx, ey = s.pos.y - ccy, ez = s.pos.z - ccz;
+        const float d2 = (ex * ex + ey * ey) + ez * ez;
+        if (d2 < bd[kTrack - 1]) {
+            bd[kTrack - 1] = d2; bi[kTrack - 1] = k;
 #pragma unroll
-            for (int i = kMaxK - 1; i > 0; --i) {
+            for (int i = kTrack - 1; i > 0; --i) {
                 if (bd[i] < bd[i - 1]) {
                     float td = bd[i]; bd[i] = bd[i - 1]; bd[i - 1] = td;
                     int ti = bi[i]; bi[i] = bi[i - 1]; bi[i - 1] = ti;
+                }
+            }
+        }
+    }
+    if (los_uncertain) any_block = d_blocked_exact(c, C, los, cyl);
+    bool order_safe = bd[0] > 1e-5f;
+#pragma unroll
+    for (int i = 0; i < kMaxK; ++i)
+        if (i < K) order_safe = order_safe && (bd[i + 1] > bd[i] * 1.0000152587890625f);   // 1 + 2^-16
+    if (!order_safe) {                          // rare: exact (distance - size) keys, as the reference sorts
+#pragma unroll
+        for (int i = 0; i < kTrack; ++i) { bd[i] = kInf; bi[i] = 0; }
+        for (int k = 0; k < C; ++k) {
+            float md = d_norm3(s.pos.x - cyl[3 * k], s.pos.y - cyl[3 * k + 1], s.pos.z - cyl[3 * k + 2]) - c.cylinder_size;
+            if (md < bd[kMaxK - 1]) {
+                bd[kMaxK - 1] = md; bi[kMaxK - 1] = k;
+#pragma unroll
+                for (int i = kMaxK - 1; i > 0; --i) {
+                    if (bd[i] < bd[i - 1]) {
+                        float td = bd[i]; bd[i] = bd[i - 1]; bd[i - 1] = td;
+                        int ti = bi[i]; bi[i] = bi[i - 1]; bi[i - 1] = ti;
+                    }
                 }
             }
         }
@@ -309,10 +335,11 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             load_rigid(sDS + tid * 13, s);
             float cmd[4], thr_diff;
             d_ctbr_pid(c, act4, s.q, s.ang, prev4, integ4, last4, cmd, aerr);    // A1 + A2
+            prof_mark(p.prof, 10);
             d_rotor(c, cmd, thr4, thrust, moment, thr_diff);                      // A3
+            prof_mark(p.prof, 11);
             float ts = ((thrust[0] + thrust[1]) + thrust[2]) + thrust[3];
-            V3 tv = {0.0f, 0.0f, ts};
-            tw = d_quat_rot<false>(s.q, tv);                                      // multirotor.py:491
+            tw = d_quat_rot_z(s.q, ts);                                           // multirotor.py:491
             sTw[tid * 3] = tw.x; sTw[tid * 3 + 1] = tw.y; sTw[tid * 3 + 2] = tw.z;
             // this pursuer's push on the evader (hideandseek.py:1074-1088), summed by the env wave
             bool blocked_pre = d_blocked(c, C, s.pos, tp0, cyl);                  // :1080
@@ -376,7 +403,9 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             tb.x = ((c.rotor_py[0] * thrust[0] + c.rotor_py[1] * thrust[1]) + c.rotor_py[2] * thrust[2]) + c.rotor_py[3] * thrust[3];
             tb.y = -(((c.rotor_px[0] * thrust[0] + c.rotor_px[1] * thrust[1]) + c.rotor_px[2] * thrust[2]) + c.rotor_px[3] * thrust[3]);
             tb.z = ((moment[0] + moment[1]) + moment[2]) + moment[3];
+            prof_mark(p.prof, 12);
             d_integrate(c, s, fw, tb);                                            // A5
+            prof_mark(p.prof, 13);
             reinterpret_cast<float4 *>(b.throttle)[ia] = thr4;
             reinterpret_cast<float4 *>(b.pid_integ)[ia] = integ4;
             reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
@@ -394,6 +423,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
         sTvel[le * 3] = tvel.x; sTvel[le * 3 + 1] = tvel.y; sTvel[le * 3 + 2] = tvel.z;
     }
     __syncthreads();
+    prof_mark(p.prof, 8);
 
     // ================= phase 3a: observation + per-agent reward terms on S_{t+1} =====================
     if (!env_wave && valid) {
@@ -403,6 +433,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
         bool knn_masked[kMaxK];
         agent_obs<A>(c, C, K, le, a, s, tp, progress, cyl, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * HNS_SELF_DIM,
                      with_state ? b.state_drones + ia * HNS_SELF_DIM : nullptr, blocked, det, knn_idx, knn_masked);
+        prof_mark(p.prof, 9);
         // hideandseek.py:919-995
         float d = d_norm3(tp.x - s.pos.x, tp.y - s.pos.y, tp.z - s.pos.z);
         float act = (d > c.catch_radius) ? 1.0f : 0.0f;

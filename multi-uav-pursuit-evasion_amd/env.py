@@ -23,7 +23,7 @@ import torch
 
 from . import abi
 from .config import CRAZYFLIE, resolve_hns_cfg
-from .tensordict_shim import CompositeSpec, TensorDict, TensorSpec
+from .tensordict_shim import USING_REAL_TENSORDICT, CompositeSpec, TensorDict, TensorSpec
 
 
 @dataclass
@@ -58,10 +58,28 @@ class HnsError(RuntimeError):
     pass
 
 
+class _LazyState(TensorDict):
+    """`agents.state` whose `state_drones` entry is assembled in torch only if somebody reads it
+    (the kernel skips that output unless `algo.critic_input: state`)."""
+
+    def __init__(self, env, source, batch_size):
+        super().__init__(source, batch_size)
+        object.__setattr__(self, "_hns_env", env)
+
+    def __getitem__(self, key):
+        if key == "state_drones" and not dict.__contains__(self, key):
+            dict.__setitem__(self, key, self._hns_env._lazy_state_drones())
+        return super().__getitem__(key)
+
+    def keys(self, *a, **k):
+        self["state_drones"]
+        return super().keys(*a, **k)
+
+
 class HideAndSeek:
     REGISTRY = {}
 
-    def __init__(self, cfg, headless=True, env_index_offset=0, write_critic_state=True):
+    def __init__(self, cfg, headless=True, env_index_offset=0, write_critic_state=None):
         self.cfg = cfg
         self.headless = headless
         self.device = torch.device(cfg.sim.get("device", "cuda:0"))
@@ -70,6 +88,13 @@ class HideAndSeek:
         if not torch.cuda.is_available():
             raise HnsError("no GPU visible: the HIP step has no CPU fallback")
         self._lib = abi.load_library()
+        if write_critic_state is None:
+            # the centralised-critic state [E,A,20] is extra HBM traffic that only `critic_input: state`
+            # consumes (reference cfg/algo/mappo.yaml:18 defaults to `obs`); when it is not written by
+            # the kernel it is assembled lazily in torch on access (same values)
+            write_critic_state = str(cfg.algo.get("critic_input", "obs")) == "state"
+        self.write_critic_state = bool(write_critic_state) or USING_REAL_TENSORDICT   # lazy state needs the shim
+        write_critic_state = self.write_critic_state
         self.num_envs = int(cfg.env.num_envs)
         self.max_episode_length = int(cfg.env.max_episode_length)
         self.dt = float(cfg.sim.dt)
@@ -251,9 +276,18 @@ class HideAndSeek:
         obs = {"state_self": b["obs_self"].unsqueeze(2), "cylinders": b["obs_cylinders"]}
         if self.num_agents > 1:
             obs["state_others"] = b["obs_others"]
-        state = {"state_drones": b["state_drones"], "cylinders": b["obs_cylinders"]}
+        if self.write_critic_state:
+            state = {"state_drones": b["state_drones"], "cylinders": b["obs_cylinders"]}
+        else:
+            state = _LazyState(self, {"cylinders": b["obs_cylinders"]}, self.batch_size)
         return TensorDict({"agents": {"observation": obs, "state": state}, "stats": self.stats, "info": self.info},
                           self.batch_size)
+
+    def _lazy_state_drones(self):
+        """hideandseek.py:871-886: state_self with the UNMASKED relative position of the evader."""
+        b = self._bufs
+        rpos = b["drone_state"][..., 0:3] - b["target_pos"].unsqueeze(1)
+        return torch.cat([rpos, b["obs_self"][..., 3:]], dim=-1)
 
     # ---- schedule hooks -------------------------------------------------------------------------------------------
     def set_update_epoch(self, epoch):

@@ -118,6 +118,25 @@ static void o_quat_rot(const float q[4], const float v[3], float out[3], int inv
     }
 }
 
+/* quat_rotate(q, x_hat) and quat_rotate(q, (0,0,t)) with the exact-zero products of the general
+ * formula dropped (x*0 = 0 and y+0 = y for finite x, y): identical values for finite q.
+ * Used for heading/up (multirotor.py:613-614) and the thrust vector (multirotor.py:491). */
+static void o_quat_rot_x(const float q[4], float out[3]) {
+    float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    float s = 2.0f * (qw * qw) - 1.0f;
+    out[0] = s + (qx * qx) * 2.0f;
+    out[1] = (qz * qw) * 2.0f + (qy * qx) * 2.0f;
+    out[2] = (-qy * qw) * 2.0f + (qz * qx) * 2.0f;
+}
+static void o_quat_rot_z(const float q[4], float t, float out[3]) {
+    float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    float s = 2.0f * (qw * qw) - 1.0f;
+    float dot = qz * t;
+    out[0] = ((qy * t) * qw) * 2.0f + (qx * dot) * 2.0f;
+    out[1] = ((-(qx * t)) * qw) * 2.0f + (qy * dot) * 2.0f;
+    out[2] = t * s + (qz * dot) * 2.0f;
+}
+
 /* omni_drones/utils/torch.py:110-127 */
 static void o_euler_to_quat(const float rpy[3], float q[4]) {
     float sr, cr, sp, cp, sy, cy;
@@ -383,12 +402,11 @@ static void o_obs(const hns_cfg *c, int A, int C, int K, const float *drone_stat
     }
     side->bdetect = det_any;
     float t = progress / (float)c->max_episode_length;
-    const float ex[3] = {1.0f, 0.0f, 0.0f}, ez[3] = {0.0f, 0.0f, 1.0f};
     for (int a = 0; a < A; ++a) {
         const float *ds = drone_state + 13 * a;
         float heading[3], up[3];
-        o_quat_rot(ds + 3, ex, heading, 0);
-        o_quat_rot(ds + 3, ez, up, 0);
+        o_quat_rot_x(ds + 3, heading);
+        o_quat_rot_z(ds + 3, 1.0f, up);
         float *o = obs_self + HNS_SELF_DIM * a;
         for (int i = 0; i < 3; ++i) o[i] = det_any ? rt[a][i] : c->mask_value;
         for (int i = 0; i < 7; ++i) o[3 + i] = ds[3 + i];
@@ -572,8 +590,7 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
             sum_ae = (a == 0) ? b->action_error[ia] : sum_ae + b->action_error[ia];
             o_rotor(c, cmd, b->throttle + ia * 4, thrust[a], moment[a], &thr_diff[a]);
             float ts = ((thrust[a][0] + thrust[a][1]) + thrust[a][2]) + thrust[a][3];
-            float tv[3] = {0.0f, 0.0f, ts};
-            o_quat_rot(ds + 13 * a + 3, tv, tw[a], 0);
+            o_quat_rot_z(ds + 13 * a + 3, ts, tw[a]);
         }
         /* A10  hideandseek.py:731-733 */
         float mae = sum_ae / (float)A;
@@ -777,10 +794,7 @@ void hns_oracle_ctbr_pid(const hns_cfg *c, int n, const float *action, const flo
 void hns_oracle_downwash(int E, int A, const float *pos, const float *rot, const float *tsum, float *f) {
     for (int e = 0; e < E; ++e) {
         float tw[HNS_MAX_AGENTS][3];
-        for (int a = 0; a < A; ++a) {
-            float tv[3] = {0.0f, 0.0f, tsum[e * A + a]};
-            o_quat_rot(rot + (e * A + a) * 4, tv, tw[a], 0);
-        }
+        for (int a = 0; a < A; ++a) o_quat_rot_z(rot + (e * A + a) * 4, tsum[e * A + a], tw[a]);
         for (int a = 0; a < A; ++a) {
             float acc[3] = {0, 0, 0};
             int first = 1;

@@ -18,7 +18,7 @@ def make_env(E, A, C, max_len=40, K=3, **task):
     cyl = {"max_num": C, "obs_max_cylinder": K, "min_num": min(4, C)}
     cyl.update(task.pop("cylinder", {}))
     cfg = config.make_cfg({"num_agents": A, "cylinder": cyl, "env": {"num_envs": E, "max_episode_length": max_len}, **task})
-    return HideAndSeek(cfg, headless=True)
+    return HideAndSeek(cfg, headless=True, write_critic_state=True)
 
 
 def assert_same(host, dev, what=""):

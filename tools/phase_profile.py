@@ -13,10 +13,10 @@ from hns_amd.env import HideAndSeek
 
 E, A, Cn = 65536, 3, 8
 cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": Cn, "min_num": Cn}, "env": {"num_envs": E}})
-env = HideAndSeek(cfg, write_critic_state="--no-critic-state" not in sys.argv)
+env = HideAndSeek(cfg, write_critic_state="--critic-state" in sys.argv)
 env.reset()
 nw = (E // 64) * (A + 1)
-buf = torch.zeros(nw, 8, dtype=torch.int64, device=env.device)
+buf = torch.zeros(nw, 16, dtype=torch.int64, device=env.device)
 act = torch.randn(E, A, 4, device=env.device)
 for _ in range(20):
     env.step(env.rand_step_input(act))
@@ -24,7 +24,8 @@ env._lib.hns_set_phase_profile(env._env, C.c_void_p(buf.data_ptr()))
 env.step(env.rand_step_input(act))
 torch.cuda.synchronize()
 env._lib.hns_set_phase_profile(env._env, None)
-t = buf.cpu().numpy().astype(np.int64).reshape(E // 64, A + 1, 8)
+t16 = buf.cpu().numpy().astype(np.int64).reshape(E // 64, A + 1, 16)
+t = t16[..., :8]
 t0 = t[..., 0].min()
 names = ["load+barrier", "phase1", "wait b1", "phase2", "pub+phase3a", "wait b4", "phase3b", "store"]
 d = np.diff(t, axis=-1)
@@ -35,3 +36,9 @@ print("%-14s %10s %10s" % ("segment", "agent", "env"))
 seg = ["0-1 load", "1-2 phase1", "2-3 b1+phase2", "3-4 b2,b3+3a", "4-5 b4", "5-6 phase3b", "6-7 b5+store"]
 for i, n in enumerate(seg):
     print("%-14s %10.0f %10.0f" % (n, d[:, :A, i].mean(), d[:, A, i].mean()))
+
+ag = t16[:, :A, :]
+def seg(a, b): return (ag[..., b] - ag[..., a]).mean()
+print("agent detail: pid(1->10) %.0f rotor(10->11) %.0f los+term(11->2) %.0f | downwash(2->12) %.0f integrate(12->13) %.0f statestore(13->3) %.0f"
+      % (seg(1, 10), seg(10, 11), seg(11, 2), seg(2, 12), seg(12, 13), seg(13, 3)))
+print("agent detail: b2+pub+b3(3->8) %.0f obs(8->9) %.0f reward(9->4) %.0f" % (seg(3, 8), seg(8, 9), seg(9, 4)))
