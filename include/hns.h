@@ -121,6 +121,10 @@ typedef struct hns_cfg {
     float lin_damp_factor;     /* max(0, 1 - dt*linear_damping)  (robots/config.py:32) */
     float ang_damp_factor;     /* max(0, 1 - dt*angular_damping) (robots/config.py:34) */
     float max_ang_vel;         /* 1000 rad/s (robots/config.py:38) */
+    float inv_mass;            /* fp32(1/mass), fp32(1/inertia): the integrator multiplies by reciprocals */
+    float inv_inertia[3];
+    float inv_num_agents;      /* 1.0f/A: torch's CUDA mean multiplies the sum by 1/N (ReduceMomentKernel.cu) */
+    float inv_max_episode_length; /* 1.0f/max_len: CUDA `tensor / python_scalar` multiplies by the fp32 reciprocal */
     float max_lin_vel;         /* v_drone*(1-1e-6): PhysX max_linear_velocity (hideandseek.py:539), set a hair
                                   inside so the clamped speed never trips `speed > v_drone` (:952) by rounding */
     /* reset distributions (hideandseek.py:283-313) */

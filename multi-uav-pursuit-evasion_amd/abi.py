@@ -49,7 +49,8 @@ class HnsCfg(C.Structure):
         ("max_thrust_ratio", _f), ("target_clip", _f), ("hover_throttle", _f),
         ("pid_kp", _f * 3), ("pid_ki", _f * 3), ("pid_kd", _f * 3), ("pid_ilimit", _f * 3),
         ("pid_outlimit", _f),
-        ("lin_damp_factor", _f), ("ang_damp_factor", _f), ("max_ang_vel", _f), ("max_lin_vel", _f),
+        ("lin_damp_factor", _f), ("ang_damp_factor", _f), ("max_ang_vel", _f), ("inv_mass", _f), ("inv_inertia", _f * 3), ("inv_num_agents", _f),
+        ("inv_max_episode_length", _f), ("max_lin_vel", _f),
         ("drone_xy_lo", _f * 2), ("drone_xy_hi", _f * 2), ("target_xy_lo", _f * 2),
         ("target_xy_hi", _f * 2), ("z_lo", _f), ("z_hi", _f), ("rpy_lo", _f * 3), ("rpy_hi", _f * 3),
         ("fixed_drone_pos", (_f * 3) * (HNS_MAX_AGENTS + 1)), ("fixed_target_pos", _f * 3),

@@ -262,6 +262,11 @@ def resolve_hns_cfg(cfg, num_envs=None, env_index_offset=0, drone_params=None, w
     c.ang_damp_factor = max(0.0, 1.0 - dt * RIGID_PROPS["angular_damping"])
     c.max_ang_vel = RIGID_PROPS["max_angular_velocity"]
     c.max_lin_vel = float(t.v_drone) * (1.0 - 1e-6)
+    one = torch.tensor(1.0, dtype=torch.float32)
+    c.inv_mass = float(one / torch.tensor(c.mass, dtype=torch.float32))
+    c.inv_inertia[:] = [float(one / torch.tensor(x, dtype=torch.float32)) for x in c.inertia]
+    c.inv_num_agents = float(one / torch.tensor(float(A), dtype=torch.float32))
+    c.inv_max_episode_length = float(one / torch.tensor(float(c.max_episode_length), dtype=torch.float32))
     # reset distributions, hideandseek.py:283-313
     r = float(t.arena_size) / math.sqrt(2.0)
     c.drone_xy_lo[:], c.drone_xy_hi[:] = [0.1, -r + 0.1], [r - 0.1, r - 0.1]

@@ -17,39 +17,31 @@ namespace hns {
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kInf = __builtin_huge_valf();
 
-// ---- elementary functions -------------------------------------------
+// ---- elementary functions; explicit FMA, identical in the oracle ------------
+#define HNS_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+constexpr float kInvPi = 0.31830987334251404f;   // RN(1/fp32(pi)): CUDA `tensor / python_scalar` multiplies by this
+
 HNS_DEV float d_expf(float x) {
     if (!(x > -87.0f)) return (x != x) ? x : 0.0f;
     if (x > 88.0f) return kInf;
     float k = __builtin_rintf(x * 1.44269504088896341f);
-    float r = x - k * 0.693359375f;
-    r = r - k * -2.12194440e-4f;
+    float r = HNS_FMA(k, -0.693359375f, x);
+    r = HNS_FMA(k, 2.12194440e-4f, r);
     float p = 1.9875691500E-4f;
-    p = p * r + 1.3981999507E-3f;
-    p = p * r + 8.3334519073E-3f;
-    p = p * r + 4.1665795894E-2f;
-    p = p * r + 1.6666665459E-1f;
-    p = p * r + 5.0000001201E-1f;
-    float y = (p * (r * r) + r) + 1.0f;
+    p = HNS_FMA(p, r, 1.3981999507E-3f);
+    p = HNS_FMA(p, r, 8.3334519073E-3f);
+    p = HNS_FMA(p, r, 4.1665795894E-2f);
+    p = HNS_FMA(p, r, 1.6666665459E-1f);
+    p = HNS_FMA(p, r, 5.0000001201E-1f);
+    float y = HNS_FMA(p, r * r, r) + 1.0f;
     int ki = (int)k;
     return y * __uint_as_float((uint32_t)(ki + 127) << 23);
 }
 
+// tanh(x) = sign(x) * (1 - e)/(1 + e), e = exp(-2|x|): one path for every x (|err| <= 1.2e-7)
 HNS_DEV float d_tanhf(float x) {
-    float ax = __builtin_fabsf(x);
-    if (x != x) return x;
-    if (!(ax < 9.0f)) return x > 0.0f ? 1.0f : -1.0f;
-    if (ax < 0.625f) {
-        float z = x * x;
-        float p = -5.70498872745E-3f;
-        p = p * z + 2.06390887954E-2f;
-        p = p * z - 5.37397155531E-2f;
-        p = p * z + 1.33314422036E-1f;
-        p = p * z - 3.33332819422E-1f;
-        return (p * z) * x + x;
-    }
-    float e = d_expf(2.0f * ax);
-    float r = 1.0f - 2.0f / (e + 1.0f);
+    float e = d_expf(-2.0f * __builtin_fabsf(x));
+    float r = (1.0f - e) / (1.0f + e);
     return x < 0.0f ? -r : r;
 }
 
@@ -59,16 +51,16 @@ HNS_DEV void d_sincosf(float x, float &s_out, float &c_out) {
     if (j & 1) j += 1;
     float y = (float)j;
     j &= 7;
-    float z = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float z = HNS_FMA(y, -3.77489497744594108e-8f, HNS_FMA(y, -2.4187564849853515625e-4f, HNS_FMA(y, -0.78515625f, ax)));
     float zz = z * z;
     float ps = -1.9515295891E-4f;
-    ps = ps * zz + 8.3321608736E-3f;
-    ps = ps * zz - 1.6666654611E-1f;
-    float sp = (ps * zz) * z + z;
+    ps = HNS_FMA(ps, zz, 8.3321608736E-3f);
+    ps = HNS_FMA(ps, zz, -1.6666654611E-1f);
+    float sp = HNS_FMA(ps * zz, z, z);
     float pc = 2.443315711809948E-005f;
-    pc = pc * zz - 1.388731625493765E-003f;
-    pc = pc * zz + 4.166664568298827E-002f;
-    float cp = ((pc * zz) * zz - 0.5f * zz) + 1.0f;
+    pc = HNS_FMA(pc, zz, -1.388731625493765E-003f);
+    pc = HNS_FMA(pc, zz, 4.166664568298827E-002f);
+    float cp = HNS_FMA(pc * zz, zz, HNS_FMA(-0.5f, zz, 1.0f));
     float s = (j == 0) ? sp : (j == 2) ? cp : (j == 4) ? -sp : -cp;
     float c = (j == 0) ? cp : (j == 2) ? -sp : (j == 4) ? -cp : sp;
     if (x < 0.0f) s = -s;
@@ -156,7 +148,7 @@ HNS_DEV void d_ctbr_pid(const hns_cfg &c, const float4 &action, const Q4 &q, con
     float out[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        br[i] = (br[i] * 180.0f) / kPi;
+        br[i] = (br[i] * 180.0f) * kInvPi;       // `* 180.0 / torch.pi` (lee_position_controller.py:505), CUDA scalar-division form
         float err = target[i] - br[i];
         float P = err * c.pid_kp[i];
         float deriv = -(br[i] - last[i]) / c.dt;
@@ -339,49 +331,50 @@ HNS_DEV void d_prey_cylinder_term(const hns_cfg &c, const V3 &tp, float ccx, flo
 struct Rigid { V3 pos; Q4 q; V3 lin; V3 ang; };
 
 HNS_DEV void d_integrate(const hns_cfg &c, Rigid &s, const V3 &force_w, const V3 &torque_b) {
-    float ax = force_w.x / c.mass, ay = force_w.y / c.mass, az = force_w.z / c.mass - c.gravity;
-    float vx = (s.lin.x + ax * c.dt) * c.lin_damp_factor;
-    float vy = (s.lin.y + ay * c.dt) * c.lin_damp_factor;
-    float vz = (s.lin.z + az * c.dt) * c.lin_damp_factor;
-    float sp = d_norm3(vx, vy, vz);
+    const float dt = c.dt;
+    float ax = force_w.x * c.inv_mass, ay = force_w.y * c.inv_mass, az = HNS_FMA(force_w.z, c.inv_mass, -c.gravity);
+    float vx = HNS_FMA(ax, dt, s.lin.x) * c.lin_damp_factor;
+    float vy = HNS_FMA(ay, dt, s.lin.y) * c.lin_damp_factor;
+    float vz = HNS_FMA(az, dt, s.lin.z) * c.lin_damp_factor;
+    float sp = __builtin_sqrtf(HNS_FMA(vz, vz, HNS_FMA(vy, vy, vx * vx)));
     if (sp > c.max_lin_vel) {
         float sc = c.max_lin_vel / sp;
         vx *= sc; vy *= sc; vz *= sc;
     }
     V3 wb = d_quat_rot<true>(s.q, s.ang);
     float Iwx = wb.x * c.inertia[0], Iwy = wb.y * c.inertia[1], Iwz = wb.z * c.inertia[2];
-    float gx = wb.y * Iwz - wb.z * Iwy, gy = wb.z * Iwx - wb.x * Iwz, gz = wb.x * Iwy - wb.y * Iwx;
+    float gx = HNS_FMA(wb.y, Iwz, -(wb.z * Iwy)), gy = HNS_FMA(wb.z, Iwx, -(wb.x * Iwz)), gz = HNS_FMA(wb.x, Iwy, -(wb.y * Iwx));
     V3 w2;
-    w2.x = (wb.x + ((torque_b.x - gx) / c.inertia[0]) * c.dt) * c.ang_damp_factor;
-    w2.y = (wb.y + ((torque_b.y - gy) / c.inertia[1]) * c.dt) * c.ang_damp_factor;
-    w2.z = (wb.z + ((torque_b.z - gz) / c.inertia[2]) * c.dt) * c.ang_damp_factor;
-    float wn = d_norm3(w2.x, w2.y, w2.z);
+    w2.x = HNS_FMA((torque_b.x - gx) * c.inv_inertia[0], dt, wb.x) * c.ang_damp_factor;
+    w2.y = HNS_FMA((torque_b.y - gy) * c.inv_inertia[1], dt, wb.y) * c.ang_damp_factor;
+    w2.z = HNS_FMA((torque_b.z - gz) * c.inv_inertia[2], dt, wb.z) * c.ang_damp_factor;
+    float wn = __builtin_sqrtf(HNS_FMA(w2.z, w2.z, HNS_FMA(w2.y, w2.y, w2.x * w2.x)));
     if (wn > c.max_ang_vel) {
         float sc = c.max_ang_vel / wn;
         w2.x *= sc; w2.y *= sc; w2.z *= sc;
     }
     V3 ww = d_quat_rot<false>(s.q, w2);
-    float px = s.pos.x + vx * c.dt, py = s.pos.y + vy * c.dt, pz = s.pos.z + vz * c.dt;
+    float px = HNS_FMA(vx, dt, s.pos.x), py = HNS_FMA(vy, dt, s.pos.y), pz = HNS_FMA(vz, dt, s.pos.z);
     if (c.ground_clamp && pz < 0.0f) {
         pz = 0.0f;
         if (vz < 0.0f) vz = 0.0f;
     }
-    float wwn = d_norm3(ww.x, ww.y, ww.z);
-    float half = (wwn * c.dt) * 0.5f;
+    float wwn = __builtin_sqrtf(HNS_FMA(ww.z, ww.z, HNS_FMA(ww.y, ww.y, ww.x * ww.x)));
+    float half = (wwn * dt) * 0.5f;
     float sn, co;
     d_sincosf(half, sn, co);
-    float so = (wwn > 1e-8f) ? sn / wwn : 0.5f * c.dt;
+    float so = (wwn > 1e-8f) ? sn / wwn : 0.5f * dt;
     float w1 = co, x1 = ww.x * so, y1 = ww.y * so, z1 = ww.z * so;
     float w2q = s.q.w, x2 = s.q.x, y2 = s.q.y, z2 = s.q.z;
-    float nw = ((w1 * w2q - x1 * x2) - y1 * y2) - z1 * z2;
-    float nx = ((w1 * x2 + x1 * w2q) + y1 * z2) - z1 * y2;
-    float ny = ((w1 * y2 - x1 * z2) + y1 * w2q) + z1 * x2;
-    float nz = ((w1 * z2 + x1 * y2) - y1 * x2) + z1 * w2q;
-    float qn = __builtin_sqrtf(((nw * nw + nx * nx) + ny * ny) + nz * nz);
+    float nw = HNS_FMA(-z1, z2, HNS_FMA(-y1, y2, HNS_FMA(-x1, x2, w1 * w2q)));
+    float nx = HNS_FMA(-z1, y2, HNS_FMA(y1, z2, HNS_FMA(x1, w2q, w1 * x2)));
+    float ny = HNS_FMA(z1, x2, HNS_FMA(y1, w2q, HNS_FMA(-x1, z2, w1 * y2)));
+    float nz = HNS_FMA(z1, w2q, HNS_FMA(-y1, x2, HNS_FMA(x1, y2, w1 * z2)));
+    float iq = 1.0f / __builtin_sqrtf(HNS_FMA(nz, nz, HNS_FMA(ny, ny, HNS_FMA(nx, nx, nw * nw))));
     s.pos = {px, py, pz};
     s.lin = {vx, vy, vz};
     s.ang = ww;
-    s.q = {nw / qn, nx / qn, ny / qn, nz / qn};
+    s.q = {nw * iq, nx * iq, ny * iq, nz * iq};
 }
 
 // ---- Philox4x32-10 (reset RNG) ---------------------------------------------

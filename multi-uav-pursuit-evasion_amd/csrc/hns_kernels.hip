@@ -152,7 +152,7 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
                        bool &blocked, bool &det, int knn_idx[kMaxK], bool knn_masked[kMaxK]) {
     float rtx = s.pos.x - tp.x, rty = s.pos.y - tp.y, rtz = s.pos.z - tp.z;
     float dist = d_norm3(rtx, rty, rtz);
-    const float t = progress / (float)c.max_episode_length;          // :796
+    const float t = progress * c.inv_max_episode_length;              // :796 (CUDA scalar-division form)
     V3 heading = d_quat_rot_x(s.q);                                   // multirotor.py:613-614
     V3 up = d_quat_rot_z(s.q, 1.0f);
     float4 v0 = make_float4(rtx, rty, rtz, s.q.w);
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
 
     // ================= phase 3b: per-env reductions, reward, done, stats (env wave) ===================
     if (env_wave && valid) {
-        const float fA = (float)A;
+        const float iA = c.inv_num_agents;             // mean over agents = sum * (1/A), as torch's CUDA mean
         bool any_cap = false, all_blocked = true, any_coll = false, det_any = false;
         float sum_dist = 0, sum_speed = 0, sum_cc = 0, sum_cd = 0, sum_cw = 0, sum_coll = 0, sum_smooth = 0;
         float sum_td = 0, max_td = 0, sum_ae = 0;
@@ -521,31 +521,31 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             }
         }
 #define ST(i) st[i]
-        float mae = sum_ae / fA;                                                  // A10, hideandseek.py:731-733
+        float mae = sum_ae * iA;                                                  // A10, hideandseek.py:731-733
         ST(HNS_ST_ACTION_ERROR_ORDER1_MEAN) += mae;
         if (mae > ST(HNS_ST_ACTION_ERROR_ORDER1_MAX)) ST(HNS_ST_ACTION_ERROR_ORDER1_MAX) = mae;
         ST(HNS_ST_OUT_OF_ARENA) = ((ST(HNS_ST_OUT_OF_ARENA) != 0.0f) || out_of_arena) ? 1.0f : 0.0f;   // :1097-1098
-        ST(HNS_ST_DISTANCE_REWARD) += sum_dist / fA;
+        ST(HNS_ST_DISTANCE_REWARD) += sum_dist * iA;
         ST(HNS_ST_SUM_DETECT_STEP) += 1.0f * detf;
         float sdet = detect_rew, scat = catch_rew;
 #pragma unroll
         for (int j = 1; j < A; ++j) { sdet += detect_rew; scat += catch_rew; }
-        ST(HNS_ST_DETECT_REWARD) += sdet / fA;
+        ST(HNS_ST_DETECT_REWARD) += sdet * iA;
         const bool capture_flag = catch_rew != 0.0f;                              // :945
         ST(HNS_ST_BLOCKED) += all_blocked ? 1.0f : 0.0f;
         ST(HNS_ST_SUCCESS) = (capture_flag || ST(HNS_ST_SUCCESS) != 0.0f) ? 1.0f : 0.0f;
         float cur = (capture_flag ? 1.0f : 0.0f) * progress + (capture_flag ? 0.0f : 1.0f) * (float)c.max_episode_length;
         if (cur < ST(HNS_ST_FIRST_CAPTURE_STEP)) ST(HNS_ST_FIRST_CAPTURE_STEP) = cur;
-        ST(HNS_ST_CATCH_REWARD) += scat / fA;
-        ST(HNS_ST_SPEED_REWARD) += sum_speed / fA;
-        ST(HNS_ST_COLLISION_CYLINDER) += sum_cc / fA;
-        ST(HNS_ST_COLLISION_DRONE) += sum_cd / fA;
+        ST(HNS_ST_CATCH_REWARD) += scat * iA;
+        ST(HNS_ST_SPEED_REWARD) += sum_speed * iA;
+        ST(HNS_ST_COLLISION_CYLINDER) += sum_cc * iA;
+        ST(HNS_ST_COLLISION_DRONE) += sum_cd * iA;
         ST(HNS_ST_COLLISION) += any_coll ? 1.0f : 0.0f;
-        ST(HNS_ST_COLLISION_WALL) += sum_cw / fA;
-        ST(HNS_ST_COLLISION_REWARD) += sum_coll / fA;
+        ST(HNS_ST_COLLISION_WALL) += sum_cw * iA;
+        ST(HNS_ST_COLLISION_REWARD) += sum_coll * iA;
         ST(HNS_ST_SMOOTHNESS_COEF) = c.smoothness_coef;
-        ST(HNS_ST_SMOOTHNESS_REWARD) += sum_smooth / fA;
-        ST(HNS_ST_SMOOTHNESS_MEAN) += sum_td / fA;
+        ST(HNS_ST_SMOOTHNESS_REWARD) += sum_smooth * iA;
+        ST(HNS_ST_SMOOTHNESS_MEAN) += sum_td * iA;
         if (max_td > ST(HNS_ST_SMOOTHNESS_MAX)) ST(HNS_ST_SMOOTHNESS_MAX) = max_td;
         const bool done = progress >= (float)c.max_episode_length;                // :1008-1010
         if (done) {                                                               // :1017-1056
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             ST(HNS_ST_COLLISION_CYLINDER) = ST(HNS_ST_COLLISION_CYLINDER) / progress;
             ST(HNS_ST_SPEED_REWARD) = ST(HNS_ST_SPEED_REWARD) / progress;
         }
-        ST(HNS_ST_RETURN) += sum_rew / fA;
+        ST(HNS_ST_RETURN) += sum_rew * iA;
 #undef ST
         b.done[e] = (uint8_t)done;
         b.progress[e] = progress;

@@ -31,60 +31,51 @@
  * ---------------------------------------------------------------------------------------- */
 static inline float o_asfloat(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-/* expf: Cody-Waite reduction by ln2 (hi 0.693359375, lo -2.12194440e-4), degree-5 Cephes poly */
+#define O_FMA(a, b, c) fmaf((a), (b), (c))
+#define O_INV_PI 0.31830987334251404f   /* RN(1/fp32(pi)) */
+
+/* expf: Cody-Waite reduction by ln2 (hi 0.693359375, lo -2.12194440e-4), degree-5 Cephes poly, FMA */
 static float o_expf(float x) {
     if (!(x > -87.0f)) return (x != x) ? x : 0.0f;
     if (x > 88.0f) return INFINITY;
     float k = rintf(x * 1.44269504088896341f);
-    float r = x - k * 0.693359375f;
-    r = r - k * -2.12194440e-4f;
+    float r = O_FMA(k, -0.693359375f, x);
+    r = O_FMA(k, 2.12194440e-4f, r);
     float p = 1.9875691500E-4f;
-    p = p * r + 1.3981999507E-3f;
-    p = p * r + 8.3334519073E-3f;
-    p = p * r + 4.1665795894E-2f;
-    p = p * r + 1.6666665459E-1f;
-    p = p * r + 5.0000001201E-1f;
-    float y = (p * (r * r) + r) + 1.0f;
+    p = O_FMA(p, r, 1.3981999507E-3f);
+    p = O_FMA(p, r, 8.3334519073E-3f);
+    p = O_FMA(p, r, 4.1665795894E-2f);
+    p = O_FMA(p, r, 1.6666665459E-1f);
+    p = O_FMA(p, r, 5.0000001201E-1f);
+    float y = O_FMA(p, r * r, r) + 1.0f;
     int ki = (int)k;
     return y * o_asfloat((uint32_t)(ki + 127) << 23);
 }
 
-/* tanhf: Cephes — odd polynomial below 0.625, 1 - 2/(exp(2|x|)+1) above */
+/* tanh(x) = sign(x) * (1 - e)/(1 + e), e = exp(-2|x|) */
 static float o_tanhf(float x) {
-    float ax = fabsf(x);
-    if (x != x) return x;
-    if (!(ax < 9.0f)) return x > 0.0f ? 1.0f : -1.0f;
-    if (ax < 0.625f) {
-        float z = x * x;
-        float p = -5.70498872745E-3f;
-        p = p * z + 2.06390887954E-2f;
-        p = p * z - 5.37397155531E-2f;
-        p = p * z + 1.33314422036E-1f;
-        p = p * z - 3.33332819422E-1f;
-        return (p * z) * x + x;
-    }
-    float e = o_expf(2.0f * ax);
-    float r = 1.0f - 2.0f / (e + 1.0f);
+    float e = o_expf(-2.0f * fabsf(x));
+    float r = (1.0f - e) / (1.0f + e);
     return x < 0.0f ? -r : r;
 }
 
-/* sincosf: Cephes octant reduction with the 3-part pi/4, |x| < 8192 */
+/* sincosf: Cephes octant reduction with the 3-part pi/4, |x| < 8192, FMA */
 static void o_sincosf(float x, float *s_out, float *c_out) {
     float ax = fabsf(x);
     int j = (int)(ax * 1.27323954473516f); /* 4/pi */
     if (j & 1) j += 1;
     float y = (float)j;
     j &= 7;
-    float z = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float z = O_FMA(y, -3.77489497744594108e-8f, O_FMA(y, -2.4187564849853515625e-4f, O_FMA(y, -0.78515625f, ax)));
     float zz = z * z;
     float ps = -1.9515295891E-4f;
-    ps = ps * zz + 8.3321608736E-3f;
-    ps = ps * zz - 1.6666654611E-1f;
-    float sp = (ps * zz) * z + z;
+    ps = O_FMA(ps, zz, 8.3321608736E-3f);
+    ps = O_FMA(ps, zz, -1.6666654611E-1f);
+    float sp = O_FMA(ps * zz, z, z);
     float pc = 2.443315711809948E-005f;
-    pc = pc * zz - 1.388731625493765E-003f;
-    pc = pc * zz + 4.166664568298827E-002f;
-    float cp = ((pc * zz) * zz - 0.5f * zz) + 1.0f;
+    pc = O_FMA(pc, zz, -1.388731625493765E-003f);
+    pc = O_FMA(pc, zz, 4.166664568298827E-002f);
+    float cp = O_FMA(pc * zz, zz, O_FMA(-0.5f, zz, 1.0f));
     float s, c;
     switch (j) {
         case 0: s = sp; c = cp; break;
@@ -176,7 +167,7 @@ static void o_ctbr_pid(const hns_cfg *c, const float action[4], const float q[4]
     o_quat_rot(q, angvel, br, 1);
     float out[3];
     for (int i = 0; i < 3; ++i) {
-        br[i] = (br[i] * 180.0f) / O_PI;
+        br[i] = (br[i] * 180.0f) * O_INV_PI;   /* CUDA `tensor / python_scalar` = multiply by the fp32 reciprocal */
         float err = target[i] - br[i];
         float P = err * c->pid_kp[i];
         float deriv = -(br[i] - last[i]) / c->dt;
@@ -333,10 +324,11 @@ static void o_prey(const hns_cfg *c, int A, int C, const float *drone_pos, const
  * ---------------------------------------------------------------------------------------- */
 static void o_integrate(const hns_cfg *c, float ds[13], const float force_w[3], const float torque_b[3]) {
     float *pos = ds, *q = ds + 3, *lin = ds + 7, *ang = ds + 10;
-    float acc[3] = {force_w[0] / c->mass, force_w[1] / c->mass, force_w[2] / c->mass - c->gravity};
+    const float dt = c->dt;
+    float acc[3] = {force_w[0] * c->inv_mass, force_w[1] * c->inv_mass, O_FMA(force_w[2], c->inv_mass, -c->gravity)};
     float v[3];
-    for (int i = 0; i < 3; ++i) v[i] = (lin[i] + acc[i] * c->dt) * c->lin_damp_factor;
-    float sp = o_norm3(v[0], v[1], v[2]);
+    for (int i = 0; i < 3; ++i) v[i] = O_FMA(acc[i], dt, lin[i]) * c->lin_damp_factor;
+    float sp = sqrtf(O_FMA(v[2], v[2], O_FMA(v[1], v[1], v[0] * v[0])));
     if (sp > c->max_lin_vel) {
         float sc = c->max_lin_vel / sp;
         v[0] *= sc; v[1] *= sc; v[2] *= sc;
@@ -344,36 +336,35 @@ static void o_integrate(const hns_cfg *c, float ds[13], const float force_w[3], 
     float wb[3];
     o_quat_rot(q, ang, wb, 1);
     float Iw[3] = {wb[0] * c->inertia[0], wb[1] * c->inertia[1], wb[2] * c->inertia[2]};
-    float gy[3] = {wb[1] * Iw[2] - wb[2] * Iw[1], wb[2] * Iw[0] - wb[0] * Iw[2], wb[0] * Iw[1] - wb[1] * Iw[0]};
+    float gy[3] = {O_FMA(wb[1], Iw[2], -(wb[2] * Iw[1])), O_FMA(wb[2], Iw[0], -(wb[0] * Iw[2])), O_FMA(wb[0], Iw[1], -(wb[1] * Iw[0]))};
     float w2[3];
-    for (int i = 0; i < 3; ++i)
-        w2[i] = (wb[i] + ((torque_b[i] - gy[i]) / c->inertia[i]) * c->dt) * c->ang_damp_factor;
-    float wn = o_norm3(w2[0], w2[1], w2[2]);
+    for (int i = 0; i < 3; ++i) w2[i] = O_FMA((torque_b[i] - gy[i]) * c->inv_inertia[i], dt, wb[i]) * c->ang_damp_factor;
+    float wn = sqrtf(O_FMA(w2[2], w2[2], O_FMA(w2[1], w2[1], w2[0] * w2[0])));
     if (wn > c->max_ang_vel) {
         float sc = c->max_ang_vel / wn;
         w2[0] *= sc; w2[1] *= sc; w2[2] *= sc;
     }
     float ww[3];
     o_quat_rot(q, w2, ww, 0);
-    float p[3] = {pos[0] + v[0] * c->dt, pos[1] + v[1] * c->dt, pos[2] + v[2] * c->dt};
+    float p[3] = {O_FMA(v[0], dt, pos[0]), O_FMA(v[1], dt, pos[1]), O_FMA(v[2], dt, pos[2])};
     if (c->ground_clamp && p[2] < 0.0f) {
         p[2] = 0.0f;
         if (v[2] < 0.0f) v[2] = 0.0f;
     }
-    float wwn = o_norm3(ww[0], ww[1], ww[2]);
-    float half = (wwn * c->dt) * 0.5f;
+    float wwn = sqrtf(O_FMA(ww[2], ww[2], O_FMA(ww[1], ww[1], ww[0] * ww[0])));
+    float half = (wwn * dt) * 0.5f;
     float s, co;
     o_sincosf(half, &s, &co);
-    float so = (wwn > 1e-8f) ? s / wwn : 0.5f * c->dt;
+    float so = (wwn > 1e-8f) ? s / wwn : 0.5f * dt;
     float w1 = co, x1 = ww[0] * so, y1 = ww[1] * so, z1 = ww[2] * so;
     float w2q = q[0], x2 = q[1], y2 = q[2], z2 = q[3];
-    float nq[4] = {((w1 * w2q - x1 * x2) - y1 * y2) - z1 * z2,
-                   ((w1 * x2 + x1 * w2q) + y1 * z2) - z1 * y2,
-                   ((w1 * y2 - x1 * z2) + y1 * w2q) + z1 * x2,
-                   ((w1 * z2 + x1 * y2) - y1 * x2) + z1 * w2q};
-    float qn = sqrtf(((nq[0] * nq[0] + nq[1] * nq[1]) + nq[2] * nq[2]) + nq[3] * nq[3]);
+    float nq[4] = {O_FMA(-z1, z2, O_FMA(-y1, y2, O_FMA(-x1, x2, w1 * w2q))),
+                   O_FMA(-z1, y2, O_FMA(y1, z2, O_FMA(x1, w2q, w1 * x2))),
+                   O_FMA(z1, x2, O_FMA(y1, w2q, O_FMA(-x1, z2, w1 * y2))),
+                   O_FMA(z1, w2q, O_FMA(-y1, x2, O_FMA(x1, y2, w1 * z2)))};
+    float iq = 1.0f / sqrtf(O_FMA(nq[3], nq[3], O_FMA(nq[2], nq[2], O_FMA(nq[1], nq[1], nq[0] * nq[0]))));
     for (int i = 0; i < 3; ++i) { pos[i] = p[i]; lin[i] = v[i]; ang[i] = ww[i]; }
-    for (int i = 0; i < 4; ++i) q[i] = nq[i] / qn;
+    for (int i = 0; i < 4; ++i) q[i] = nq[i] * iq;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -401,7 +392,7 @@ static void o_obs(const hns_cfg *c, int A, int C, int K, const float *drone_stat
         det_any |= det;
     }
     side->bdetect = det_any;
-    float t = progress / (float)c->max_episode_length;
+    float t = progress * c->inv_max_episode_length;   /* :796, CUDA scalar-division form */
     for (int a = 0; a < A; ++a) {
         const float *ds = drone_state + 13 * a;
         float heading[3], up[3];
@@ -465,7 +456,7 @@ static void o_reward(const hns_cfg *c, int A, int C, int K, const float *drone_s
                      const float *thr_diff, float *stats, size_t sstride, float *reward, uint8_t *done_out) {
     (void)C;
 #define ST(i) stats[(size_t)(i) * sstride]
-    float fA = (float)A;
+    float iA = c->inv_num_agents;   /* mean over agents = sum * (1/A), as torch's CUDA mean */
     float dist_rew[HNS_MAX_AGENTS], speed_rew[HNS_MAX_AGENTS], coll_rew[HNS_MAX_AGENTS], smooth_rew[HNS_MAX_AGENTS];
     float sum_dist = 0, sum_speed = 0, sum_cc = 0, sum_cd = 0, sum_cw = 0, sum_coll = 0, sum_smooth = 0, sum_td = 0;
     float max_td = 0;
@@ -523,29 +514,29 @@ static void o_reward(const hns_cfg *c, int A, int C, int K, const float *drone_s
     float catch_rew = c->catch_reward_coef * (any_cap ? 1.0f : 0.0f);
     int capture_flag = catch_rew != 0.0f;             /* torch.any(catch_reward, dim=1) :945 */
 
-    ST(HNS_ST_DISTANCE_REWARD) += sum_dist / fA;
+    ST(HNS_ST_DISTANCE_REWARD) += sum_dist * iA;
     ST(HNS_ST_SUM_DETECT_STEP) += 1.0f * detf;
     {   /* mean over A identical values (:933), summed the same way */
         float s = detect_rew;
         for (int a = 1; a < A; ++a) s += detect_rew;
-        ST(HNS_ST_DETECT_REWARD) += s / fA;
+        ST(HNS_ST_DETECT_REWARD) += s * iA;
         s = catch_rew;
         for (int a = 1; a < A; ++a) s += catch_rew;
         ST(HNS_ST_BLOCKED) += all_blocked ? 1.0f : 0.0f;
         ST(HNS_ST_SUCCESS) = (capture_flag || ST(HNS_ST_SUCCESS) != 0.0f) ? 1.0f : 0.0f;
         float cur = (capture_flag ? 1.0f : 0.0f) * progress + (capture_flag ? 0.0f : 1.0f) * (float)c->max_episode_length;
         if (cur < ST(HNS_ST_FIRST_CAPTURE_STEP)) ST(HNS_ST_FIRST_CAPTURE_STEP) = cur;
-        ST(HNS_ST_CATCH_REWARD) += s / fA;
+        ST(HNS_ST_CATCH_REWARD) += s * iA;
     }
-    ST(HNS_ST_SPEED_REWARD) += sum_speed / fA;
-    ST(HNS_ST_COLLISION_CYLINDER) += sum_cc / fA;
-    ST(HNS_ST_COLLISION_DRONE) += sum_cd / fA;
+    ST(HNS_ST_SPEED_REWARD) += sum_speed * iA;
+    ST(HNS_ST_COLLISION_CYLINDER) += sum_cc * iA;
+    ST(HNS_ST_COLLISION_DRONE) += sum_cd * iA;
     ST(HNS_ST_COLLISION) += any_coll ? 1.0f : 0.0f;
-    ST(HNS_ST_COLLISION_WALL) += sum_cw / fA;
-    ST(HNS_ST_COLLISION_REWARD) += sum_coll / fA;
+    ST(HNS_ST_COLLISION_WALL) += sum_cw * iA;
+    ST(HNS_ST_COLLISION_REWARD) += sum_coll * iA;
     ST(HNS_ST_SMOOTHNESS_COEF) = c->smoothness_coef;
-    ST(HNS_ST_SMOOTHNESS_REWARD) += sum_smooth / fA;
-    ST(HNS_ST_SMOOTHNESS_MEAN) += sum_td / fA;
+    ST(HNS_ST_SMOOTHNESS_REWARD) += sum_smooth * iA;
+    ST(HNS_ST_SMOOTHNESS_MEAN) += sum_td * iA;
     if (max_td > ST(HNS_ST_SMOOTHNESS_MAX)) ST(HNS_ST_SMOOTHNESS_MAX) = max_td;
 
     float sum_rew = 0.0f;
@@ -564,7 +555,7 @@ static void o_reward(const hns_cfg *c, int A, int C, int K, const float *drone_s
                                   HNS_ST_SPEED_REWARD};
         for (size_t i = 0; i < sizeof(div) / sizeof(div[0]); ++i) ST(div[i]) = ST(div[i]) / progress;
     }
-    ST(HNS_ST_RETURN) += sum_rew / fA;
+    ST(HNS_ST_RETURN) += sum_rew * iA;
 #undef ST
 }
 
@@ -593,7 +584,7 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
             o_quat_rot_z(ds + 13 * a + 3, ts, tw[a]);
         }
         /* A10  hideandseek.py:731-733 */
-        float mae = sum_ae / (float)A;
+        float mae = sum_ae * c->inv_num_agents;
         stats[(size_t)HNS_ST_ACTION_ERROR_ORDER1_MEAN * E] += mae;
         if (mae > stats[(size_t)HNS_ST_ACTION_ERROR_ORDER1_MAX * E]) stats[(size_t)HNS_ST_ACTION_ERROR_ORDER1_MAX * E] = mae;
         /* A6 on S_t */
