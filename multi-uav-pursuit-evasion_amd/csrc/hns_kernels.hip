@@ -34,7 +34,9 @@ constexpr int kMaxK = 4;   // top-k insertion network width (obs_max_cylinder <=
 constexpr int kRed = 11;   // per-agent scalars handed to the env wave (odd stride: conflict-free)
 enum { R_AERR = 0, R_TD, R_DIST, R_SPEED, R_CC, R_CD, R_CW, R_COLL, R_SMOOTH, R_FLAGS,
        // the pursuer's push on the evader is consumed before phase 3 writes the reward terms: same slots
-       R_FX = R_DIST, R_FY = R_SPEED, R_FZ = R_CC };
+       R_FX = R_DIST, R_FY = R_SPEED, R_FZ = R_CC,
+       // so is the thrust vector handed to the downwash partners (3 consecutive slots)
+       R_TWX = R_CD };
 enum { F_CAP = 1, F_BLOCKED = 2, F_DET = 4 };
 
 template <int A>
@@ -64,7 +66,7 @@ HNS_DEV void prof_mark(unsigned long long *prof, int slot) {
 
 // LDS carve-up (float offsets, every region 16-byte aligned)
 struct Lds {
-    int ds, cyl, cyl_stride, tp, tvel, tw, red, ocyl, total;
+    int ds, cyl, cyl_stride, tp, tvel, red, ocyl, total;
 };
 __host__ __device__ inline int r4(int n) { return (n + 3) & ~3; }
 __host__ __device__ inline Lds lds_layout(int A, int C, int K) {
@@ -75,7 +77,6 @@ __host__ __device__ inline Lds lds_layout(int A, int C, int K) {
     L.cyl = o;   o += r4(kEPB * L.cyl_stride);
     L.tp = o;    o += r4(kEPB * 3);
     L.tvel = o;  o += r4(kEPB * 3);
-    L.tw = o;    o += r4(kEPB * A * 3);
     L.red = o;   o += r4(kEPB * A * kRed);
     L.ocyl = o;  o += r4(kEPB * A * K * 5);
     L.total = o;
@@ -170,13 +171,11 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
     // thread, thread-contiguous in global memory
     if (A > 1) {
         float o[(A > 1 ? A - 1 : 1) * 3];
-        int w = 0;
 #pragma unroll
-        for (int j = 0; j < A; ++j) {
-            if (j == a) continue;
+        for (int w = 0; w < A - 1; ++w) {
+            const int j = w + (w >= a ? 1 : 0);
             const float *rj = sDS + (le * A + j) * 13;
-            o[w] = s.pos.x - rj[0]; o[w + 1] = s.pos.y - rj[1]; o[w + 2] = s.pos.z - rj[2];
-            w += 3;
+            o[3 * w] = s.pos.x - rj[0]; o[3 * w + 1] = s.pos.y - rj[1]; o[3 * w + 2] = s.pos.z - rj[2];
         }
         if ((((A - 1) * 3) & 1) == 0) {
             float2 *g2 = reinterpret_cast<float2 *>(gOth);
@@ -192,11 +191,13 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
     // distances (no sqrt): md = RN(RN(sqrt(d2)) - size) is monotone in d2, so both orders agree
     // whenever consecutive candidates differ by more than 2^-16 relative (then their md differ by
     // >= 4 ulp and cannot tie); otherwise the exact md insertion below decides.
+    // Fast path: 32-bit keys = squared-distance bits with the cylinder index in the 4 low mantissa
+    // bits (non-negative floats order like unsigned ints), kept sorted by a branch-free min/max
+    // insertion network.  The 2^-19 truncation is covered by the 2^-16 gap test below.
     constexpr int kTrack = kMaxK + 1;           // one more than k: guards the k-th/(k+1)-th boundary
-    float bd[kTrack];
-    int bi[kTrack];
+    uint32_t key[kTrack];
 #pragma unroll
-    for (int i = 0; i < kTrack; ++i) { bd[i] = kInf; bi[i] = 0; }
+    for (int i = 0; i < kTrack; ++i) key[i] = 0x7F80000Fu;             // +inf | 15
     const LosLine los = d_los_setup(c, s.pos, tp);
     bool any_block = false, los_uncertain = false;
 #pragma unroll 4
@@ -205,18 +206,19 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
         any_block = d_los_cylinder_fast(los, ccx, ccy, ccz, los_uncertain) || any_block;
         const float ex = s.pos.x - ccx, ey = s.pos.y - ccy, ez = s.pos.z - ccz;
         const float d2 = (ex * ex + ey * ey) + ez * ez;
-        if (d2 < bd[kTrack - 1]) {
-            bd[kTrack - 1] = d2; bi[kTrack - 1] = k;
+        uint32_t nk = (__float_as_uint(d2) & 0xFFFFFFF0u) | (uint32_t)k;
 #pragma unroll
-            for (int i = kTrack - 1; i > 0; --i) {
-                if (bd[i] < bd[i - 1]) {
-                    float td = bd[i]; bd[i] = bd[i - 1]; bd[i - 1] = td;
-                    int ti = bi[i]; bi[i] = bi[i - 1]; bi[i - 1] = ti;
-                }
-            }
+        for (int i = 0; i < kTrack; ++i) {
+            uint32_t lo = min(key[i], nk);
+            nk = max(key[i], nk);
+            key[i] = lo;
         }
     }
     if (los_uncertain) any_block = d_blocked_exact(c, C, los, cyl);
+    float bd[kTrack];
+    int bi[kTrack];
+#pragma unroll
+    for (int i = 0; i < kTrack; ++i) { bd[i] = __uint_as_float(key[i] & 0xFFFFFFF0u); bi[i] = (int)(key[i] & 15u); }
     bool order_safe = bd[0] > 1e-5f;
 #pragma unroll
     for (int i = 0; i < kMaxK; ++i)
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
     const bool with_state = c.write_critic_state && b.state_drones != nullptr;
     const Lds L = lds_layout(A, C, K);
     float *sDS = smem + L.ds, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sTvel = smem + L.tvel;
-    float *sTw = smem + L.tw, *sRed = smem + L.red, *sOCyl = smem + L.ocyl;
+    float *sRed = smem + L.red, *sOCyl = smem + L.ocyl;
 
     const int tid = threadIdx.x;
     const int e0 = blockIdx.x * kEPB;
@@ -340,13 +342,13 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             prof_mark(p.prof, 11);
             float ts = ((thrust[0] + thrust[1]) + thrust[2]) + thrust[3];
             tw = d_quat_rot_z(s.q, ts);                                           // multirotor.py:491
-            sTw[tid * 3] = tw.x; sTw[tid * 3 + 1] = tw.y; sTw[tid * 3 + 2] = tw.z;
             // this pursuer's push on the evader (hideandseek.py:1074-1088), summed by the env wave
             bool blocked_pre = d_blocked(c, C, s.pos, tp0, cyl);                  // :1080
             V3 fp = d_prey_pursuer_term(c, s.pos, tp0, blocked_pre);
             float *red = sRed + tid * kRed;
             red[R_AERR] = aerr; red[R_TD] = thr_diff;
             red[R_FX] = fp.x; red[R_FY] = fp.y; red[R_FZ] = fp.z;
+            red[R_TWX] = tw.x; red[R_TWX + 1] = tw.y; red[R_TWX + 2] = tw.z;
         }
     } else if (valid) {
         // A6: arena + cylinder terms of the evader's potential field (hideandseek.py:1090-1136)
@@ -356,8 +358,8 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
         for (int k = 0; k < C; ++k) {
             float tx, ty;
             d_prey_cylinder_term(c, tp0, cyl[3 * k], cyl[3 * k + 1], cyl[3 * k + 2], tx, ty);
-            fcx = (k == 0) ? tx : fcx + tx;
-            fcy = (k == 0) ? ty : fcy + ty;
+            fcx += tx;
+            fcy += ty;
         }
         tvel = {fcx, fcy, 0.0f};     // parked until the pursuer terms arrive
     }
@@ -383,20 +385,18 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
     // ================= phase 2: forces, torques, integration (agent waves) ===========================
     if (!env_wave) {
         if (valid) {
-            V3 fdw = {0.f, 0.f, 0.f};                                             // A4: downwash, j ascending
-            bool first = true;
+            V3 fdw = {0.f, 0.f, 0.f};                                             // A4: downwash, partners ascending
 #pragma unroll
-            for (int j = 0; j < A; ++j) {
-                if (j == a) continue;
+            for (int o = 0; o < A - 1; ++o) {
+                const int j = o + (o >= a ? 1 : 0);
                 const float *rj = sDS + (le * A + j) * 13;
-                const float *tj = sTw + (le * A + j) * 3;
+                const float *tj = sRed + (le * A + j) * kRed + R_TWX;
                 V3 pj = {rj[0], rj[1], rj[2]};
                 V3 twj = {tj[0], tj[1], tj[2]};
                 V3 fj = d_downwash_pair(s.pos, pj, twj);
-                fdw.x = first ? fj.x : fdw.x + fj.x;
-                fdw.y = first ? fj.y : fdw.y + fj.y;
-                fdw.z = first ? fj.z : fdw.z + fj.z;
-                first = false;
+                fdw.x = (o == 0) ? fj.x : fdw.x + fj.x;
+                fdw.y = (o == 0) ? fj.y : fdw.y + fj.y;
+                fdw.z = (o == 0) ? fj.z : fdw.z + fj.z;
             }
             V3 fw = {tw.x + fdw.x, tw.y + fdw.y, tw.z + fdw.z};
             V3 tb;
@@ -454,15 +454,13 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             }
         }
         float cr = -c.collision_coef * cc;
-        bool firstj = true;
 #pragma unroll
-        for (int j = 0; j < A; ++j) {
-            if (j == a) continue;
+        for (int o = 0; o < A - 1; ++o) {
+            const int j = o + (o >= a ? 1 : 0);
             const float *rj = sDS + (le * A + j) * 13;
             float dd = d_norm3(s.pos.x - rj[0], s.pos.y - rj[1], s.pos.z - rj[2]);
             float hit = (dd < c.coll_drone_dist) ? 1.0f : 0.0f;
-            cd = firstj ? hit : cd + hit;
-            firstj = false;
+            cd = (o == 0) ? hit : cd + hit;
         }
         cr = cr + -c.collision_coef * cd;
         float cw = ((s.pos.z > c.max_height) ? 1.0f : 0.0f) + (((s.pos.x * s.pos.x + s.pos.y * s.pos.y) > c.arena_sq) ? 1.0f : 0.0f);

@@ -308,8 +308,8 @@ static void o_prey(const hns_cfg *c, int A, int C, const float *drone_pos, const
         float rec = 1.0f / (db + 1e-5f);
         float tx = (act * (rx / (dc + 1e-5f))) * rec;
         float ty = (act * (ry / (dc + 1e-5f))) * rec;
-        fcx = (k == 0) ? tx : fcx + tx;
-        fcy = (k == 0) ? ty : fcy + ty;
+        fcx += tx;
+        fcy += ty;
     }
     F[0] = F[0] + fcx; F[1] = F[1] + fcy; F[2] = F[2] + 0.0f;
     for (int i = 0; i < 3; ++i) {
