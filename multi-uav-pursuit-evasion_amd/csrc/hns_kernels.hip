@@ -60,13 +60,14 @@ constexpr int kProfSlots = 16;
 HNS_DEV void prof_mark(unsigned long long *prof, int slot) {
     if (prof && (threadIdx.x & 63) == 0) {
         int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        prof[(size_t)wave * kProfSlots + slot] = __builtin_readcyclecounter();
+        // slots 14/15 use the chip-wide constant 100 MHz clock (comparable across XCDs)
+        prof[(size_t)wave * kProfSlots + slot] = (slot >= 14) ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter();
     }
 }
 
 // LDS carve-up (float offsets, every region 16-byte aligned)
 struct Lds {
-    int ds, cyl, cyl_stride, tp, tvel, red, ocyl, total;
+    int ds, cyl, cyl_stride, tp, red, ocyl, total;
 };
 __host__ __device__ inline int r4(int n) { return (n + 3) & ~3; }
 __host__ __device__ inline Lds lds_layout(int A, int C, int K) {
@@ -76,7 +77,6 @@ __host__ __device__ inline Lds lds_layout(int A, int C, int K) {
     L.cyl_stride = (3 * C) | 1;                 // odd per-env stride: env-wave reads are conflict-free
     L.cyl = o;   o += r4(kEPB * L.cyl_stride);
     L.tp = o;    o += r4(kEPB * 3);
-    L.tvel = o;  o += r4(kEPB * 3);
     L.red = o;   o += r4(kEPB * A * kRed);
     L.ocyl = o;  o += r4(kEPB * A * K * 5);
     L.total = o;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
     const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.num_envs;
     const bool with_state = c.write_critic_state && b.state_drones != nullptr;
     const Lds L = lds_layout(A, C, K);
-    float *sDS = smem + L.ds, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sTvel = smem + L.tvel;
+    float *sDS = smem + L.ds, *sCyl = smem + L.cyl, *sTp = smem + L.tp;
     float *sRed = smem + L.red, *sOCyl = smem + L.ocyl;
 
     const int tid = threadIdx.x;
@@ -286,6 +286,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
     const size_t ia = (size_t)e0 * A + (env_wave ? 0 : tid);
 
     prof_mark(p.prof, 0);
+    prof_mark(p.prof, 14);
     // ---- load: per-agent float4 records straight to registers, the rest through LDS ------------
     float4 act4 = make_float4(0, 0, 0, 0), thr4 = act4, integ4 = act4, last4 = act4, prev4 = act4;
     float progress = 0.0f;
@@ -379,6 +380,24 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
         tvel = {(c.v_prey * F.x) / (__builtin_fabsf(F.x) + 1e-5f), (c.v_prey * F.y) / (__builtin_fabsf(F.y) + 1e-5f),
                 (c.v_prey * F.z) / (__builtin_fabsf(F.z) + 1e-5f)};
         tpn = {tp0.x + tvel.x * c.dt, tp0.y + tvel.y * c.dt, tp0.z + tvel.z * c.dt};   // evader: p += v dt
+        // statistics that only need phase-1 data are folded in now, while the agent waves integrate
+        // (A10 hideandseek.py:731-733, :1097-1098, :996-997)
+        float sum_ae = 0.f, sum_td = 0.f, max_td = 0.f;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float *red = sRed + (le * A + j) * kRed;
+            const float td = red[R_TD];
+            sum_ae = (j == 0) ? red[R_AERR] : sum_ae + red[R_AERR];
+            sum_td = (j == 0) ? td : sum_td + td;
+            max_td = (j == 0) ? td : (td > max_td ? td : max_td);
+        }
+        const float mae = sum_ae * c.inv_num_agents;
+        st[HNS_ST_ACTION_ERROR_ORDER1_MEAN] += mae;
+        if (mae > st[HNS_ST_ACTION_ERROR_ORDER1_MAX]) st[HNS_ST_ACTION_ERROR_ORDER1_MAX] = mae;
+        st[HNS_ST_OUT_OF_ARENA] = ((st[HNS_ST_OUT_OF_ARENA] != 0.0f) || out_of_arena) ? 1.0f : 0.0f;
+        st[HNS_ST_SMOOTHNESS_COEF] = c.smoothness_coef;
+        st[HNS_ST_SMOOTHNESS_MEAN] += sum_td * c.inv_num_agents;
+        if (max_td > st[HNS_ST_SMOOTHNESS_MAX]) st[HNS_ST_SMOOTHNESS_MAX] = max_td;
     }
     prof_mark(p.prof, 2);
 
@@ -420,10 +439,28 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
         if (valid) store_rigid(sDS + tid * 13, s);
     } else if (valid) {
         sTp[le * 3] = tpn.x; sTp[le * 3 + 1] = tpn.y; sTp[le * 3 + 2] = tpn.z;
-        sTvel[le * 3] = tvel.x; sTvel[le * 3 + 1] = tvel.y; sTvel[le * 3 + 2] = tvel.z;
     }
     __syncthreads();
     prof_mark(p.prof, 8);
+    if (env_wave) {
+        // the env wave is idle during phase 3a: it writes back S_{t+1} (drone_state slice, evader)
+        const int lane = tid - NA;
+        const float4 *s4 = reinterpret_cast<const float4 *>(sDS);
+        float4 *g4 = reinterpret_cast<float4 *>(b.drone_state + (size_t)e0 * A * 13);
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < (kEPB * A * 13 / 4 + 63) / 64; ++k)
+                if (k * 64 + lane < kEPB * A * 13 / 4) g4[k * 64 + lane] = s4[k * 64 + lane];
+        } else {
+            float *g = b.drone_state + (size_t)e0 * A * 13;
+            for (int i = lane; i < nenv * A * 13; i += 64) g[i] = sDS[i];
+        }
+        if (valid) {
+            float *gp = b.target_pos + (size_t)e * 3, *gv = b.target_vel + (size_t)e * 3;
+            gp[0] = tpn.x; gp[1] = tpn.y; gp[2] = tpn.z;
+            gv[0] = tvel.x; gv[1] = tvel.y; gv[2] = tvel.z;
+        }
+    }
 
     // ================= phase 3a: observation + per-agent reward terms on S_{t+1} =====================
     if (!env_wave && valid) {
@@ -481,7 +518,6 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
         const float iA = c.inv_num_agents;             // mean over agents = sum * (1/A), as torch's CUDA mean
         bool any_cap = false, all_blocked = true, any_coll = false, det_any = false;
         float sum_dist = 0, sum_speed = 0, sum_cc = 0, sum_cd = 0, sum_cw = 0, sum_coll = 0, sum_smooth = 0;
-        float sum_td = 0, max_td = 0, sum_ae = 0;
 #pragma unroll
         for (int j = 0; j < A; ++j) {
             const float *red = sRed + (le * A + j) * kRed;
@@ -490,14 +526,12 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             all_blocked &= (fl & F_BLOCKED) != 0;
             det_any |= (fl & F_DET) != 0;
             any_coll |= red[R_COLL] < 0.0f;
-            float td = red[R_TD];
             if (j == 0) {
                 sum_dist = red[R_DIST]; sum_speed = red[R_SPEED]; sum_cc = red[R_CC]; sum_cd = red[R_CD]; sum_cw = red[R_CW];
-                sum_coll = red[R_COLL]; sum_smooth = red[R_SMOOTH]; sum_td = td; max_td = td; sum_ae = red[R_AERR];
+                sum_coll = red[R_COLL]; sum_smooth = red[R_SMOOTH];
             } else {
                 sum_dist += red[R_DIST]; sum_speed += red[R_SPEED]; sum_cc += red[R_CC]; sum_cd += red[R_CD]; sum_cw += red[R_CW];
-                sum_coll += red[R_COLL]; sum_smooth += red[R_SMOOTH]; sum_td += td; sum_ae += red[R_AERR];
-                if (td > max_td) max_td = td;
+                sum_coll += red[R_COLL]; sum_smooth += red[R_SMOOTH];
             }
         }
         const float detf = det_any ? 1.0f : 0.0f;
@@ -519,10 +553,6 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             }
         }
 #define ST(i) st[i]
-        float mae = sum_ae * iA;                                                  // A10, hideandseek.py:731-733
-        ST(HNS_ST_ACTION_ERROR_ORDER1_MEAN) += mae;
-        if (mae > ST(HNS_ST_ACTION_ERROR_ORDER1_MAX)) ST(HNS_ST_ACTION_ERROR_ORDER1_MAX) = mae;
-        ST(HNS_ST_OUT_OF_ARENA) = ((ST(HNS_ST_OUT_OF_ARENA) != 0.0f) || out_of_arena) ? 1.0f : 0.0f;   // :1097-1098
         ST(HNS_ST_DISTANCE_REWARD) += sum_dist * iA;
         ST(HNS_ST_SUM_DETECT_STEP) += 1.0f * detf;
         float sdet = detect_rew, scat = catch_rew;
@@ -541,10 +571,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
         ST(HNS_ST_COLLISION) += any_coll ? 1.0f : 0.0f;
         ST(HNS_ST_COLLISION_WALL) += sum_cw * iA;
         ST(HNS_ST_COLLISION_REWARD) += sum_coll * iA;
-        ST(HNS_ST_SMOOTHNESS_COEF) = c.smoothness_coef;
         ST(HNS_ST_SMOOTHNESS_REWARD) += sum_smooth * iA;
-        ST(HNS_ST_SMOOTHNESS_MEAN) += sum_td * iA;
-        if (max_td > ST(HNS_ST_SMOOTHNESS_MAX)) ST(HNS_ST_SMOOTHNESS_MAX) = max_td;
         const bool done = progress >= (float)c.max_episode_length;                // :1008-1010
         if (done) {                                                               // :1017-1056
             ST(HNS_ST_COLLISION) = ST(HNS_ST_COLLISION) / progress;
@@ -572,17 +599,9 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
     __syncthreads();
 
     // ================= store: contiguous slices, 16 B per lane =========================================
-    if (full) {
-        coop_copy_full<T, kEPB * A * 13>(b.drone_state + (size_t)e0 * A * 13, sDS);
-        coop_copy_full<T, kEPB * 3>(b.target_pos + (size_t)e0 * 3, sTp);
-        coop_copy_full<T, kEPB * 3>(b.target_vel + (size_t)e0 * 3, sTvel);
-    } else {
-        coop_s2g<T>(b.drone_state + (size_t)e0 * A * 13, sDS, nenv * A * 13);
-        coop_s2g<T>(b.target_pos + (size_t)e0 * 3, sTp, nenv * 3);
-        coop_s2g<T>(b.target_vel + (size_t)e0 * 3, sTvel, nenv * 3);
-    }
     coop_s2g<T>(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5);
     prof_mark(p.prof, 7);
+    prof_mark(p.prof, 15);
 }
 
 // =================================================================================================

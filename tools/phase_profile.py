@@ -42,3 +42,10 @@ def seg(a, b): return (ag[..., b] - ag[..., a]).mean()
 print("agent detail: pid(1->10) %.0f rotor(10->11) %.0f los+term(11->2) %.0f | downwash(2->12) %.0f integrate(12->13) %.0f statestore(13->3) %.0f"
       % (seg(1, 10), seg(10, 11), seg(11, 2), seg(2, 12), seg(12, 13), seg(13, 3)))
 print("agent detail: b2+pub+b3(3->8) %.0f obs(8->9) %.0f reward(9->4) %.0f" % (seg(3, 8), seg(8, 9), seg(9, 4)))
+
+rt0, rt1 = t16[..., 14].astype(np.float64) * 10.0, t16[..., 15].astype(np.float64) * 10.0   # ns
+z = rt0.min()
+print("global clock (ns): first start 0, last start %.0f, first end %.0f, last end %.0f" % (rt0.max() - z, rt1.min() - z, rt1.max() - z))
+print("per-block duration (ns): median %.0f p10 %.0f p90 %.0f" % tuple(np.percentile((rt1.max(1) - rt0.min(1)), [50, 10, 90])))
+order = np.argsort(rt0.min(1))
+print("start time of blocks by dispatch rank (ns): ", [int(rt0.min(1)[order[i]] - z) for i in (0, 255, 256, 511, 512, 767, 768, 1023)])
