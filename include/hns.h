@@ -162,6 +162,41 @@ typedef struct hns_buffers {
     uint8_t *done;         /* [E]            bool */
 } hns_buffers;
 
+/*
+ * Hover task (BASELINE config 1, reference omni_drones/envs/single/hover.py): one Crazyflie per env,
+ * 20-dim observation, position/heading/uprightness reward.  Plumbing-scale (tens of envs), so the
+ * entry points are stateless: cfg (drone + sim fields of hns_cfg; num_agents = 1) and buffers per call.
+ */
+#define HNS_HOVER_NUM_STATS 39  /* hover.py:238-278, spec order */
+#define HNS_HOVER_NUM_ACC 12    /* *_episode accumulators and last_* values, hover.py:150-155,313-320 */
+typedef struct hns_hover_cfg {
+    float reward_distance_scale, reward_v_scale, reward_acc_scale, reward_jerk_scale;
+    float linear_vel_max, linear_acc_max;
+    float alpha;                /* 0.8, hover.py:148 */
+    float target_pos[3];        /* (0,0,1), hover.py:146 */
+    float target_heading[3];    /* quat_axis(target_rot, 0) with target rpy = 0 -> (1,0,0), hover.py:301-303 */
+    float pos_lo[3], pos_hi[3]; /* hover.py:129-132 */
+    float rpy_lo[3], rpy_hi[3]; /* hover.py:137-140 */
+} hns_hover_cfg;
+typedef struct hns_hover_buffers {
+    float *drone_state;   /* [E,1,13] */
+    float *throttle, *pid_integ, *pid_last_rate, *prev_action;   /* [E,1,4] */
+    float *progress;      /* [E] */
+    float *stats;         /* [HNS_HOVER_NUM_STATS,E] */
+    float *acc;           /* [HNS_HOVER_NUM_ACC,E] */
+    float *obs;           /* [E,1,20] */
+    float *reward;        /* [E,1] */
+    uint8_t *done;        /* [E] */
+} hns_hover_buffers;
+/* One Hover step = PIDRateController._inv_call + Hover._pre_sim_step + integrator + _compute_state_and_obs
+ * + _compute_reward_and_done (hover.py:322-523).  `cfg` supplies num_envs, max_episode_length, dt and the
+ * drone/controller/integrator constants. */
+int hns_hover_step(const hns_cfg *cfg, const hns_hover_cfg *hover, const hns_hover_buffers *buffers,
+                   const float *action, void *stream);
+/* Hover._reset_idx (hover.py:285-320) for the masked envs (NULL = all) + their observation. */
+int hns_hover_reset(const hns_cfg *cfg, const hns_hover_cfg *hover, const hns_hover_buffers *buffers,
+                    const uint8_t *reset_mask, uint64_t seed, uint32_t epoch, void *stream);
+
 typedef struct hns_env hns_env;
 
 /* Validate cfg, select the kernel specialisation, allocate nothing on the device. */

@@ -90,6 +90,40 @@ def buffer_shapes(E, A, Cn, K):
     }
 
 
+HNS_HOVER_NUM_STATS = 39
+HNS_HOVER_NUM_ACC = 12
+HOVER_STAT_NAMES = [
+    "return", "pos_bonus", "head_bonus", "reward_pos", "reward_up", "reward_vel", "reward_acc", "reward_jerk",
+    "episode_len", "pos_error", "heading_alignment", "uprightness", "action_smoothness", "linear_v_max",
+    "angular_v_max", "linear_a_max", "angular_a_max", "linear_jerk_max", "angular_jerk_max", "linear_v_mean",
+    "angular_v_mean", "linear_a_mean", "angular_a_mean", "linear_jerk_mean", "angular_jerk_mean", "motor1",
+    "motor2", "motor3", "motor4", "cmd_r", "cmd_p", "cmd_y", "cmd_thrust", "target_r_rate", "target_p_rate",
+    "target_y_rate", "real_r_rate", "real_p_rate", "real_y_rate",
+]
+assert len(HOVER_STAT_NAMES) == HNS_HOVER_NUM_STATS
+
+
+class HnsHoverCfg(C.Structure):
+    _fields_ = [("reward_distance_scale", _f), ("reward_v_scale", _f), ("reward_acc_scale", _f), ("reward_jerk_scale", _f),
+                ("linear_vel_max", _f), ("linear_acc_max", _f), ("alpha", _f), ("target_pos", _f * 3),
+                ("target_heading", _f * 3), ("pos_lo", _f * 3), ("pos_hi", _f * 3), ("rpy_lo", _f * 3), ("rpy_hi", _f * 3)]
+
+
+HOVER_BUFFER_FIELDS = ["drone_state", "throttle", "pid_integ", "pid_last_rate", "prev_action", "progress", "stats",
+                       "acc", "obs", "reward", "done"]
+
+
+class HnsHoverBuffers(C.Structure):
+    _fields_ = [(name, _fp) for name in HOVER_BUFFER_FIELDS]
+
+
+def hover_buffer_shapes(E):
+    return {"drone_state": ((E, 1, 13), "float32"), "throttle": ((E, 1, 4), "float32"), "pid_integ": ((E, 1, 4), "float32"),
+            "pid_last_rate": ((E, 1, 4), "float32"), "prev_action": ((E, 1, 4), "float32"), "progress": ((E,), "float32"),
+            "stats": ((HNS_HOVER_NUM_STATS, E), "float32"), "acc": ((HNS_HOVER_NUM_ACC, E), "float32"),
+            "obs": ((E, 1, HNS_SELF_DIM), "float32"), "reward": ((E, 1), "float32"), "done": ((E,), "uint8")}
+
+
 _LIB = None
 LIB_NAME = "libhns.so"
 
@@ -134,6 +168,11 @@ def load_library():
     lib.hns_step_kernel_ms.restype = C.c_float
     lib.hns_set_phase_profile.argtypes = [C.c_void_p, C.c_void_p]
     lib.hns_set_phase_profile.restype = C.c_int
+    lib.hns_hover_step.argtypes = [C.POINTER(HnsCfg), C.POINTER(HnsHoverCfg), C.POINTER(HnsHoverBuffers), C.c_void_p, C.c_void_p]
+    lib.hns_hover_step.restype = C.c_int
+    lib.hns_hover_reset.argtypes = [C.POINTER(HnsCfg), C.POINTER(HnsHoverCfg), C.POINTER(HnsHoverBuffers), C.c_void_p,
+                                    C.c_uint64, C.c_uint32, C.c_void_p]
+    lib.hns_hover_reset.restype = C.c_int
     lib.hns_abi_version.argtypes = []
     lib.hns_abi_version.restype = C.c_int
     lib.hns_cfg_size.argtypes = []
@@ -151,5 +190,5 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "hns_create", "hns_destroy", "hns_bind", "hns_step", "hns_reset", "hns_set_v_prey",
     "hns_set_smoothness_coef", "hns_set_reset_epoch", "hns_get_reset_epoch", "hns_enable_timing",
-    "hns_step_kernel_ms", "hns_set_phase_profile", "hns_abi_version", "hns_cfg_size", "hns_last_error",
+    "hns_step_kernel_ms", "hns_set_phase_profile", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
 ]

@@ -174,6 +174,52 @@ def load_cfg(path, **task_overrides):
     return make_cfg(raw, None, True, **task_overrides)
 
 
+# Hover task (reference cfg/task/Hover.yaml, omni_drones/envs/single/hover.py:76-146)
+DEFAULT_HOVER_TASK = {
+    "name": "Hover",
+    "env": {"num_envs": 100, "env_spacing": 5, "max_episode_length": 500, "min_episode_length": 50},
+    "sim": {"dt": 0.01, "substeps": 1, "gravity": [0, 0, -9.81], "device": "cuda:0"},
+    "drone_model": "crazyflie", "force_sensor": False,
+    "reward_action_smoothness_weight": 0.0, "reward_distance_scale": 10.0, "reward_v_scale": 0.0,
+    "reward_acc_scale": 0.0, "reward_jerk_scale": 0.0, "linear_vel_max": 3.0, "linear_acc_max": 10.0,
+    "omega": False, "motor": False, "time_encoding": True, "action_transform": "PIDrate",
+    "add_noise": False, "action_filter": False, "latency": False, "action_noise": False,
+}
+
+
+def make_hover_cfg(task=None, **task_overrides):
+    t = copy.deepcopy(DEFAULT_HOVER_TASK)
+    _merge(t, task or {})
+    _merge(t, task_overrides)
+    return Cfg({"task": t, "algo": copy.deepcopy(DEFAULT_ALGO), "env": t["env"], "sim": t["sim"], "headless": True,
+                "physics": copy.deepcopy(DEFAULT_PHYSICS)})
+
+
+def resolve_hover_cfg(cfg, env_index_offset=0):
+    """(hns_cfg with the drone/controller/integrator constants, hns_hover_cfg) for the Hover task."""
+    t = cfg.task
+    for k in ("omega", "motor", "add_noise", "latency", "action_noise"):
+        if t.get(k, False):
+            raise NotImplementedError(f"Hover option task.{k}=true is not built (plumbing configuration only)")
+    if "randomization" in t:
+        raise NotImplementedError("Hover domain randomization is not built")
+    base = make_cfg({"num_agents": 1, "env": dict(cfg.env), "sim": dict(cfg.sim)})
+    base["physics"] = cfg.get("physics", DEFAULT_PHYSICS)
+    c = resolve_hns_cfg(base, env_index_offset=env_index_offset)
+    c.max_lin_vel = 1000.0 * (1.0 - 1e-6)       # Hover keeps the default max_linear_velocity (robots/config.py:36)
+    h = abi.HnsHoverCfg()
+    h.reward_distance_scale, h.reward_v_scale = float(t.reward_distance_scale), float(t.reward_v_scale)
+    h.reward_acc_scale, h.reward_jerk_scale = float(t.reward_acc_scale), float(t.reward_jerk_scale)
+    h.linear_vel_max, h.linear_acc_max = float(t.linear_vel_max), float(t.linear_acc_max)
+    h.alpha = 0.8
+    h.target_pos[:] = [0.0, 0.0, 1.0]
+    h.target_heading[:] = [1.0, 0.0, 0.0]
+    h.pos_lo[:], h.pos_hi[:] = [-1.0, -1.0, 0.05], [1.0, 1.0, 2.0]
+    h.rpy_lo[:] = (torch.tensor([-0.2, -0.2, 0.0]) * torch.pi).tolist()
+    h.rpy_hi[:] = (torch.tensor([0.2, 0.2, 0.5]) * torch.pi).tolist()
+    return c, h
+
+
 # --------------------------------------------------------------------------------------------
 # cfg -> hns_cfg
 # --------------------------------------------------------------------------------------------

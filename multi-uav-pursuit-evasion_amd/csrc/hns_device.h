@@ -129,7 +129,8 @@ HNS_DEV Q4 d_euler_to_quat(float r, float p, float y) {
 // omni_drones/utils/torchrl/transforms.py:425-459,
 // omni_drones/controllers/lee_position_controller.py:476-550
 HNS_DEV void d_ctbr_pid(const hns_cfg &c, const float4 &action, const Q4 &q, const V3 &angvel,
-                        float4 &prev_action, float4 &integ4, float4 &last4, float cmd[4], float &action_error) {
+                        float4 &prev_action, float4 &integ4, float4 &last4, float cmd[4], float &action_error,
+                        float *ctbr_out = nullptr, float *target_out = nullptr) {
     float a0 = d_tanhf(action.x), a1 = d_tanhf(action.y), a2 = d_tanhf(action.z), a3 = d_tanhf(action.w);
     float ctbr[4] = {a0, a1, a2, d_clamp((a3 + 1.0f) / 2.0f, 0.0f, c.max_thrust_ratio)};
     if (c.fixed_yaw) ctbr[2] = 0.0f;
@@ -168,6 +169,8 @@ HNS_DEV void d_ctbr_pid(const hns_cfg &c, const float4 &action, const Q4 &q, con
     last4 = make_float4(last[0], last[1], last[2], 0.0f);
     float r = out[0] / 2.0f, p = out[1] / 2.0f, y = out[2];
     float m[4] = {((thrust + r) - p) + y, ((thrust + r) + p) - y, ((thrust - r) + p) + y, ((thrust - r) - p) - y};
+    if (ctbr_out) { ctbr_out[0] = r; ctbr_out[1] = p; ctbr_out[2] = y; ctbr_out[3] = thrust; }
+    if (target_out) { target_out[0] = target[0]; target_out[1] = target[1]; target_out[2] = target[2]; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float v = (m[i] / 65536.0f) * 2.0f - c.max_thrust_ratio;

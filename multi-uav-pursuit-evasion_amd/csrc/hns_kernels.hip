@@ -752,6 +752,171 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
     coop_s2g_masked<T>(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5, A * K * 5, sMask);
 }
 
+// =================================================================================================
+// Hover task (BASELINE config 1; reference omni_drones/envs/single/hover.py:322-523): one thread per
+// env — a plumbing-scale task (tens of envs), written for clarity, reusing the drone math above.
+// =================================================================================================
+enum { HS_RETURN = 0, HS_POS_BONUS, HS_HEAD_BONUS, HS_REWARD_POS, HS_REWARD_UP, HS_REWARD_VEL, HS_REWARD_ACC, HS_REWARD_JERK,
+       HS_EPISODE_LEN, HS_POS_ERROR, HS_HEADING_ALIGNMENT, HS_UPRIGHTNESS, HS_ACTION_SMOOTHNESS, HS_LINEAR_V_MAX,
+       HS_ANGULAR_V_MAX, HS_LINEAR_A_MAX, HS_ANGULAR_A_MAX, HS_LINEAR_JERK_MAX, HS_ANGULAR_JERK_MAX, HS_LINEAR_V_MEAN,
+       HS_ANGULAR_V_MEAN, HS_LINEAR_A_MEAN, HS_ANGULAR_A_MEAN, HS_LINEAR_JERK_MEAN, HS_ANGULAR_JERK_MEAN, HS_MOTOR1,
+       HS_MOTOR2, HS_MOTOR3, HS_MOTOR4, HS_CMD_R, HS_CMD_P, HS_CMD_Y, HS_CMD_THRUST, HS_TARGET_R_RATE, HS_TARGET_P_RATE,
+       HS_TARGET_Y_RATE, HS_REAL_R_RATE, HS_REAL_P_RATE, HS_REAL_Y_RATE };
+enum { HA_LV_EP = 0, HA_AV_EP, HA_LA_EP, HA_AA_EP, HA_LJ_EP, HA_AJ_EP, HA_LAST_LV, HA_LAST_AV, HA_LAST_LA, HA_LAST_AA,
+       HA_LAST_LJ, HA_LAST_AJ };
+
+struct HoverParams {
+    hns_cfg cfg;
+    hns_hover_cfg hover;
+    hns_hover_buffers buf;
+    const float *action;
+    const uint8_t *reset_mask;
+    uint32_t seed_lo, seed_hi, epoch;
+};
+
+// hover.py:361-437 (_compute_state_and_obs) for one env
+HNS_DEV void hover_obs(const hns_cfg &c, const hns_hover_cfg &h, const Rigid &s, float progress, float *st, float *ac, int E,
+                       float *obs, V3 &heading, V3 &up, float &lv, float &la, float &lj) {
+#define ST(i) st[(size_t)(i) * E]
+#define AC(i) ac[(size_t)(i) * E]
+    V3 br = d_quat_rot<true>(s.q, s.ang);
+    ST(HS_REAL_R_RATE) = (br.x * 180.0f) * kInvPi;
+    ST(HS_REAL_P_RATE) = (br.y * 180.0f) * kInvPi;
+    ST(HS_REAL_Y_RATE) = (br.z * 180.0f) * kInvPi;
+    heading = d_quat_rot_x(s.q);
+    up = d_quat_rot_z(s.q, 1.0f);
+    const float t = progress * c.inv_max_episode_length;
+    obs[0] = h.target_pos[0] - s.pos.x; obs[1] = h.target_pos[1] - s.pos.y; obs[2] = h.target_pos[2] - s.pos.z;
+    obs[3] = s.q.w; obs[4] = s.q.x; obs[5] = s.q.y; obs[6] = s.q.z;
+    obs[7] = s.lin.x; obs[8] = s.lin.y; obs[9] = s.lin.z;
+    obs[10] = heading.x; obs[11] = heading.y; obs[12] = heading.z;
+    obs[13] = up.x; obs[14] = up.y; obs[15] = up.z;
+    obs[16] = t; obs[17] = t; obs[18] = t; obs[19] = t;
+    lv = d_norm3(s.lin.x, s.lin.y, s.lin.z);
+    const float av = d_norm3(s.ang.x, s.ang.y, s.ang.z);
+    const float n = progress + 1.0f;
+    if (__builtin_fabsf(lv) > ST(HS_LINEAR_V_MAX)) ST(HS_LINEAR_V_MAX) = __builtin_fabsf(lv);
+    AC(HA_LV_EP) += __builtin_fabsf(lv); ST(HS_LINEAR_V_MEAN) = AC(HA_LV_EP) / n;
+    if (__builtin_fabsf(av) > ST(HS_ANGULAR_V_MAX)) ST(HS_ANGULAR_V_MAX) = __builtin_fabsf(av);
+    AC(HA_AV_EP) += __builtin_fabsf(av); ST(HS_ANGULAR_V_MEAN) = AC(HA_AV_EP) / n;
+    la = __builtin_fabsf(lv - AC(HA_LAST_LV)) / c.dt;
+    const float aa = __builtin_fabsf(av - AC(HA_LAST_AV)) / c.dt;
+    if (__builtin_fabsf(la) > ST(HS_LINEAR_A_MAX)) ST(HS_LINEAR_A_MAX) = __builtin_fabsf(la);
+    AC(HA_LA_EP) += __builtin_fabsf(la); ST(HS_LINEAR_A_MEAN) = AC(HA_LA_EP) / n;
+    if (__builtin_fabsf(aa) > ST(HS_ANGULAR_A_MAX)) ST(HS_ANGULAR_A_MAX) = __builtin_fabsf(aa);
+    AC(HA_AA_EP) += __builtin_fabsf(aa); ST(HS_ANGULAR_A_MEAN) = AC(HA_AA_EP) / n;
+    lj = __builtin_fabsf(la - AC(HA_LAST_LA)) / c.dt;
+    const float aj = __builtin_fabsf(aa - AC(HA_LAST_AA)) / c.dt;
+    if (__builtin_fabsf(lj) > ST(HS_LINEAR_JERK_MAX)) ST(HS_LINEAR_JERK_MAX) = __builtin_fabsf(lj);
+    AC(HA_LJ_EP) += __builtin_fabsf(lj); ST(HS_LINEAR_JERK_MEAN) = AC(HA_LJ_EP) / n;
+    if (__builtin_fabsf(aj) > ST(HS_ANGULAR_JERK_MAX)) ST(HS_ANGULAR_JERK_MAX) = __builtin_fabsf(aj);
+    AC(HA_AJ_EP) += __builtin_fabsf(aj); ST(HS_ANGULAR_JERK_MEAN) = AC(HA_AJ_EP) / n;
+    AC(HA_LAST_LV) = lv; AC(HA_LAST_AV) = av; AC(HA_LAST_LA) = la; AC(HA_LAST_AA) = aa; AC(HA_LAST_LJ) = lj; AC(HA_LAST_AJ) = aj;
+#undef ST
+#undef AC
+}
+
+__global__ __launch_bounds__(64) void hns_hover_step_kernel(const HoverParams p) {
+    const hns_cfg &c = p.cfg;
+    const hns_hover_cfg &h = p.hover;
+    const hns_hover_buffers &b = p.buf;
+    const int E = c.num_envs;
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= E) return;
+    float *st = b.stats + e, *ac = b.acc + e;
+#define ST(i) st[(size_t)(i) * E]
+    Rigid s;
+    load_rigid(b.drone_state + (size_t)e * 13, s);
+    float4 act4 = reinterpret_cast<const float4 *>(p.action)[e];
+    float4 thr4 = reinterpret_cast<float4 *>(b.throttle)[e], integ4 = reinterpret_cast<float4 *>(b.pid_integ)[e];
+    float4 last4 = reinterpret_cast<float4 *>(b.pid_last_rate)[e], prev4 = reinterpret_cast<float4 *>(b.prev_action)[e];
+    float cmd[4], aerr, ctbr[4], trate[3], thrust[4], moment[4], td;
+    d_ctbr_pid(c, act4, s.q, s.ang, prev4, integ4, last4, cmd, aerr, ctbr, trate);
+    ST(HS_MOTOR1) = cmd[0]; ST(HS_MOTOR2) = cmd[1]; ST(HS_MOTOR3) = cmd[2]; ST(HS_MOTOR4) = cmd[3];          // hover.py:326-329
+    d_rotor(c, cmd, thr4, thrust, moment, td);
+    ST(HS_CMD_R) = ctbr[0]; ST(HS_CMD_P) = ctbr[1]; ST(HS_CMD_Y) = ctbr[2]; ST(HS_CMD_THRUST) = ctbr[3];      // :334-338
+    ST(HS_TARGET_R_RATE) = trate[0]; ST(HS_TARGET_P_RATE) = trate[1]; ST(HS_TARGET_Y_RATE) = trate[2];         // :341-344
+    const float ts = ((thrust[0] + thrust[1]) + thrust[2]) + thrust[3];
+    V3 fw = d_quat_rot_z(s.q, ts), tb;
+    tb.x = ((c.rotor_py[0] * thrust[0] + c.rotor_py[1] * thrust[1]) + c.rotor_py[2] * thrust[2]) + c.rotor_py[3] * thrust[3];
+    tb.y = -(((c.rotor_px[0] * thrust[0] + c.rotor_px[1] * thrust[1]) + c.rotor_px[2] * thrust[2]) + c.rotor_px[3] * thrust[3]);
+    tb.z = ((moment[0] + moment[1]) + moment[2]) + moment[3];
+    d_integrate(c, s, fw, tb);
+    const float progress = b.progress[e] + 1.0f;
+    float obs[HNS_SELF_DIM], lv, la, lj;
+    V3 heading, up;
+    hover_obs(c, h, s, progress, st, ac, E, obs, heading, up, lv, la, lj);
+    // hover.py:439-523
+    const float pos_error = d_norm3(obs[0], obs[1], obs[2]);
+    const float hx = h.target_heading[0] - heading.x, hy = h.target_heading[1] - heading.y, hz = h.target_heading[2] - heading.z;
+    const float head_error = d_norm3(hx, hy, hz);
+    const float align = (heading.x * h.target_heading[0] + heading.y * h.target_heading[1]) + heading.z * h.target_heading[2];
+    const float reward_pos = -pos_error * h.reward_distance_scale;
+    const float bonus = (pos_error <= 0.02f) ? 10.0f : 0.0f;
+    const float bpos = bonus > 0.0f ? 1.0f : 0.0f;
+    const float reward_head = -head_error * bpos;
+    const float head_bonus = ((head_error <= 0.02f) ? 10.0f : 0.0f) * bpos;
+    const float u = (up.z + 1.0f) / 2.0f;
+    const float reward_up = u * u;
+    const float reward_v = (h.reward_v_scale * bpos) * ((lv < h.linear_vel_max) ? 1.0f : 0.0f);
+    const float reward_acc = (h.reward_acc_scale * bpos) * ((la < h.linear_acc_max) ? 1.0f : 0.0f);
+    const float reward_jerk = (h.reward_jerk_scale * bpos) * -lj;
+    const float reward = ((((((reward_pos + bonus) + reward_head) + head_bonus) + reward_up) + reward_v) + reward_acc) + reward_jerk;
+    const float w = 1.0f - h.alpha;
+    ST(HS_POS_ERROR) += w * (pos_error - ST(HS_POS_ERROR));                    // lerp_ :506-509
+    ST(HS_HEADING_ALIGNMENT) += w * (align - ST(HS_HEADING_ALIGNMENT));
+    ST(HS_UPRIGHTNESS) += w * (up.z - ST(HS_UPRIGHTNESS));
+    ST(HS_ACTION_SMOOTHNESS) += w * (-td - ST(HS_ACTION_SMOOTHNESS));
+    ST(HS_RETURN) += reward;
+    ST(HS_REWARD_POS) = reward_pos; ST(HS_POS_BONUS) = bonus; ST(HS_HEAD_BONUS) = head_bonus;
+    ST(HS_REWARD_VEL) = reward_v; ST(HS_REWARD_ACC) = reward_acc; ST(HS_REWARD_JERK) = reward_jerk;
+    ST(HS_EPISODE_LEN) = progress;
+#undef ST
+    store_rigid(b.drone_state + (size_t)e * 13, s);
+    reinterpret_cast<float4 *>(b.throttle)[e] = thr4;
+    reinterpret_cast<float4 *>(b.pid_integ)[e] = integ4;
+    reinterpret_cast<float4 *>(b.pid_last_rate)[e] = last4;
+    reinterpret_cast<float4 *>(b.prev_action)[e] = prev4;
+    for (int i = 0; i < HNS_SELF_DIM; ++i) b.obs[(size_t)e * HNS_SELF_DIM + i] = obs[i];
+    b.reward[e] = reward;
+    b.done[e] = (uint8_t)(progress >= (float)c.max_episode_length);
+    b.progress[e] = progress;
+}
+
+// hover.py:285-320 (_reset_idx) + the reset-time observation of the masked envs
+__global__ __launch_bounds__(64) void hns_hover_reset_kernel(const HoverParams p) {
+    const hns_cfg &c = p.cfg;
+    const hns_hover_cfg &h = p.hover;
+    const hns_hover_buffers &b = p.buf;
+    const int E = c.num_envs;
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= E) return;
+    for (int i = HA_LV_EP; i <= HA_AJ_EP; ++i) b.acc[(size_t)i * E + e] = 0.0f;      // all envs, :313-320
+    if (p.reset_mask && !p.reset_mask[e]) return;
+    Rng rng = {p.seed_lo, p.seed_hi, (uint32_t)(e + c.env_index_offset), p.epoch, 0u, {0u, 0u, 0u, 0u}, 0};
+    Rigid s = {};
+    s.pos.x = h.pos_lo[0] + rng.uniform() * (h.pos_hi[0] - h.pos_lo[0]);
+    s.pos.y = h.pos_lo[1] + rng.uniform() * (h.pos_hi[1] - h.pos_lo[1]);
+    s.pos.z = h.pos_lo[2] + rng.uniform() * (h.pos_hi[2] - h.pos_lo[2]);
+    float r0 = h.rpy_lo[0] + rng.uniform() * (h.rpy_hi[0] - h.rpy_lo[0]);
+    float r1 = h.rpy_lo[1] + rng.uniform() * (h.rpy_hi[1] - h.rpy_lo[1]);
+    float r2 = h.rpy_lo[2] + rng.uniform() * (h.rpy_hi[2] - h.rpy_lo[2]);
+    s.q = d_euler_to_quat(r0, r1, r2);
+    store_rigid(b.drone_state + (size_t)e * 13, s);
+    const float thr = c.hover_throttle;
+    reinterpret_cast<float4 *>(b.throttle)[e] = make_float4(thr, thr, thr, thr);
+    reinterpret_cast<float4 *>(b.pid_integ)[e] = make_float4(0, 0, 0, 0);
+    reinterpret_cast<float4 *>(b.pid_last_rate)[e] = make_float4(0, 0, 0, 0);
+    for (int i = 0; i < HNS_HOVER_NUM_STATS; ++i) b.stats[(size_t)i * E + e] = 0.0f;
+    for (int i = HA_LAST_LV; i <= HA_LAST_AJ; ++i) b.acc[(size_t)i * E + e] = 0.0f;
+    b.progress[e] = 0.0f;
+    b.done[e] = 0;
+    float obs[HNS_SELF_DIM], lv, la, lj;
+    V3 heading, up;
+    hover_obs(c, h, s, 0.0f, b.stats + e, b.acc + e, E, obs, heading, up, lv, la, lj);
+    for (int i = 0; i < HNS_SELF_DIM; ++i) b.obs[(size_t)e * HNS_SELF_DIM + i] = obs[i];
+}
+
 }  // namespace hns
 
 // =================================================================================================
@@ -952,6 +1117,49 @@ int hns_reset(hns_env *env, const uint8_t *reset_mask, uint64_t seed, void *stre
     p.prof = nullptr;
     p.cyl_magic = env->cyl_magic;
     return launch(env, false, p, static_cast<hipStream_t>(stream));
+}
+
+static int hover_check(const hns_cfg *cfg, const hns_hover_cfg *hover, const hns_hover_buffers *b) {
+    if (!cfg || !hover || !b) { set_error("hns_hover: null argument"); return HNS_ERR_INVALID_ARG; }
+    if (cfg->abi_version != HNS_ABI_VERSION || cfg->num_envs < 1 || cfg->num_agents != 1) {
+        set_error("hns_hover: bad cfg (abi_version, num_envs >= 1, num_agents == 1)");
+        return HNS_ERR_INVALID_ARG;
+    }
+    const void *req[] = {b->drone_state, b->throttle, b->pid_integ, b->pid_last_rate, b->prev_action, b->progress,
+                         b->stats, b->acc, b->obs, b->reward, b->done};
+    for (const void *ptr : req)
+        if (!ptr) { set_error("hns_hover: a buffer pointer is null"); return HNS_ERR_INVALID_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("hns_hover: no HIP device visible (this library has no CPU path)");
+        return HNS_ERR_NO_DEVICE;
+    }
+    return HNS_OK;
+}
+
+int hns_hover_step(const hns_cfg *cfg, const hns_hover_cfg *hover, const hns_hover_buffers *buffers, const float *action,
+                   void *stream) {
+    int rc = hover_check(cfg, hover, buffers);
+    if (rc != HNS_OK) return rc;
+    if (!action) { set_error("hns_hover_step: null action"); return HNS_ERR_INVALID_ARG; }
+    hns::HoverParams p;
+    p.cfg = *cfg; p.hover = *hover; p.buf = *buffers; p.action = action; p.reset_mask = nullptr;
+    p.seed_lo = p.seed_hi = p.epoch = 0;
+    hipLaunchKernelGGL(hns::hns_hover_step_kernel, dim3((cfg->num_envs + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), p);
+    HNS_CHECK_HIP(hipGetLastError());
+    return HNS_OK;
+}
+
+int hns_hover_reset(const hns_cfg *cfg, const hns_hover_cfg *hover, const hns_hover_buffers *buffers,
+                    const uint8_t *reset_mask, uint64_t seed, uint32_t epoch, void *stream) {
+    int rc = hover_check(cfg, hover, buffers);
+    if (rc != HNS_OK) return rc;
+    hns::HoverParams p;
+    p.cfg = *cfg; p.hover = *hover; p.buf = *buffers; p.action = nullptr; p.reset_mask = reset_mask;
+    p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.epoch = epoch;
+    hipLaunchKernelGGL(hns::hns_hover_reset_kernel, dim3((cfg->num_envs + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), p);
+    HNS_CHECK_HIP(hipGetLastError());
+    return HNS_OK;
 }
 
 int hns_set_v_prey(hns_env *env, float v_prey) {

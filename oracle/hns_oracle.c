@@ -840,3 +840,139 @@ void hns_oracle_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint3
     o_philox(k0, k1, c0, c1, c2, c3, out);
 }
 size_t hns_oracle_cfg_size(void) { return sizeof(hns_cfg); }
+
+/* ------------------------------------------------------------------------------------------
+ * Hover task (BASELINE config 1)   omni_drones/envs/single/hover.py:322-523
+ * stats rows: hover.py:238-278 order; acc rows: linear_v/angular_v/linear_a/angular_a/
+ * linear_jerk/angular_jerk _episode, then last_ of the same six (hover.py:150-155,313-320)
+ * ---------------------------------------------------------------------------------------- */
+enum { HS_RETURN = 0, HS_POS_BONUS, HS_HEAD_BONUS, HS_REWARD_POS, HS_REWARD_UP, HS_REWARD_VEL, HS_REWARD_ACC, HS_REWARD_JERK,
+       HS_EPISODE_LEN, HS_POS_ERROR, HS_HEADING_ALIGNMENT, HS_UPRIGHTNESS, HS_ACTION_SMOOTHNESS, HS_LINEAR_V_MAX,
+       HS_ANGULAR_V_MAX, HS_LINEAR_A_MAX, HS_ANGULAR_A_MAX, HS_LINEAR_JERK_MAX, HS_ANGULAR_JERK_MAX, HS_LINEAR_V_MEAN,
+       HS_ANGULAR_V_MEAN, HS_LINEAR_A_MEAN, HS_ANGULAR_A_MEAN, HS_LINEAR_JERK_MEAN, HS_ANGULAR_JERK_MEAN, HS_MOTOR1,
+       HS_MOTOR2, HS_MOTOR3, HS_MOTOR4, HS_CMD_R, HS_CMD_P, HS_CMD_Y, HS_CMD_THRUST, HS_TARGET_R_RATE, HS_TARGET_P_RATE,
+       HS_TARGET_Y_RATE, HS_REAL_R_RATE, HS_REAL_P_RATE, HS_REAL_Y_RATE };
+enum { HA_LV_EP = 0, HA_AV_EP, HA_LA_EP, HA_AA_EP, HA_LJ_EP, HA_AJ_EP, HA_LAST_LV, HA_LAST_AV, HA_LAST_LA, HA_LAST_AA,
+       HA_LAST_LJ, HA_LAST_AJ };
+
+/* _compute_state_and_obs (hover.py:361-437) for one env; returns linear_v/linear_a/linear_jerk for the reward */
+static void o_hover_obs(const hns_cfg *c, const hns_hover_cfg *h, const float ds[13], float progress, float *st, float *ac,
+                        size_t E, float obs[20], float heading[3], float up[3], float *lin_v, float *lin_a, float *lin_j) {
+#define ST(i) st[(size_t)(i) * E]
+#define AC(i) ac[(size_t)(i) * E]
+    float br[3];
+    o_quat_rot(ds + 3, ds + 10, br, 1);
+    ST(HS_REAL_R_RATE) = (br[0] * 180.0f) * O_INV_PI;
+    ST(HS_REAL_P_RATE) = (br[1] * 180.0f) * O_INV_PI;
+    ST(HS_REAL_Y_RATE) = (br[2] * 180.0f) * O_INV_PI;
+    o_quat_rot_x(ds + 3, heading);
+    o_quat_rot_z(ds + 3, 1.0f, up);
+    for (int i = 0; i < 3; ++i) obs[i] = h->target_pos[i] - ds[i];
+    for (int i = 0; i < 7; ++i) obs[3 + i] = ds[3 + i];
+    for (int i = 0; i < 3; ++i) { obs[10 + i] = heading[i]; obs[13 + i] = up[i]; }
+    float t = progress * c->inv_max_episode_length;
+    for (int i = 0; i < 4; ++i) obs[16 + i] = t;
+    float lv = o_norm3(ds[7], ds[8], ds[9]), av = o_norm3(ds[10], ds[11], ds[12]);
+    float n = progress + 1.0f;
+    if (fabsf(lv) > ST(HS_LINEAR_V_MAX)) ST(HS_LINEAR_V_MAX) = fabsf(lv);
+    AC(HA_LV_EP) += fabsf(lv); ST(HS_LINEAR_V_MEAN) = AC(HA_LV_EP) / n;
+    if (fabsf(av) > ST(HS_ANGULAR_V_MAX)) ST(HS_ANGULAR_V_MAX) = fabsf(av);
+    AC(HA_AV_EP) += fabsf(av); ST(HS_ANGULAR_V_MEAN) = AC(HA_AV_EP) / n;
+    float la = fabsf(lv - AC(HA_LAST_LV)) / c->dt, aa = fabsf(av - AC(HA_LAST_AV)) / c->dt;
+    if (fabsf(la) > ST(HS_LINEAR_A_MAX)) ST(HS_LINEAR_A_MAX) = fabsf(la);
+    AC(HA_LA_EP) += fabsf(la); ST(HS_LINEAR_A_MEAN) = AC(HA_LA_EP) / n;
+    if (fabsf(aa) > ST(HS_ANGULAR_A_MAX)) ST(HS_ANGULAR_A_MAX) = fabsf(aa);
+    AC(HA_AA_EP) += fabsf(aa); ST(HS_ANGULAR_A_MEAN) = AC(HA_AA_EP) / n;
+    float lj = fabsf(la - AC(HA_LAST_LA)) / c->dt, aj = fabsf(aa - AC(HA_LAST_AA)) / c->dt;
+    if (fabsf(lj) > ST(HS_LINEAR_JERK_MAX)) ST(HS_LINEAR_JERK_MAX) = fabsf(lj);
+    AC(HA_LJ_EP) += fabsf(lj); ST(HS_LINEAR_JERK_MEAN) = AC(HA_LJ_EP) / n;
+    if (fabsf(aj) > ST(HS_ANGULAR_JERK_MAX)) ST(HS_ANGULAR_JERK_MAX) = fabsf(aj);
+    AC(HA_AJ_EP) += fabsf(aj); ST(HS_ANGULAR_JERK_MEAN) = AC(HA_AJ_EP) / n;
+    AC(HA_LAST_LV) = lv; AC(HA_LAST_AV) = av; AC(HA_LAST_LA) = la; AC(HA_LAST_AA) = aa; AC(HA_LAST_LJ) = lj; AC(HA_LAST_AJ) = aj;
+    *lin_v = lv; *lin_a = la; *lin_j = lj;
+#undef ST
+#undef AC
+}
+
+int hns_oracle_hover_step(const hns_cfg *c, const hns_hover_cfg *h, const hns_hover_buffers *b, const float *action) {
+    const size_t E = (size_t)c->num_envs;
+    for (size_t e = 0; e < E; ++e) {
+        float *ds = b->drone_state + e * 13, *st = b->stats + e, *ac = b->acc + e;
+#define ST(i) st[(size_t)(i) * E]
+        float cmd[4], aerr, ctbr[4], trate[3], thrust[4], moment[4], td;
+        o_ctbr_pid(c, action + e * 4, ds + 3, ds + 10, b->prev_action + e * 4, b->pid_integ + e * 4, b->pid_last_rate + e * 4,
+                   cmd, &aerr, ctbr, trate);
+        ST(HS_MOTOR1) = cmd[0]; ST(HS_MOTOR2) = cmd[1]; ST(HS_MOTOR3) = cmd[2]; ST(HS_MOTOR4) = cmd[3];   /* hover.py:326-329 */
+        o_rotor(c, cmd, b->throttle + e * 4, thrust, moment, &td);
+        ST(HS_CMD_R) = ctbr[0]; ST(HS_CMD_P) = ctbr[1]; ST(HS_CMD_Y) = ctbr[2]; ST(HS_CMD_THRUST) = ctbr[3];   /* :334-338 */
+        ST(HS_TARGET_R_RATE) = trate[0]; ST(HS_TARGET_P_RATE) = trate[1]; ST(HS_TARGET_Y_RATE) = trate[2];   /* :341-344 */
+        float ts = ((thrust[0] + thrust[1]) + thrust[2]) + thrust[3], fw[3], tb[3];
+        o_quat_rot_z(ds + 3, ts, fw);
+        tb[0] = ((c->rotor_py[0] * thrust[0] + c->rotor_py[1] * thrust[1]) + c->rotor_py[2] * thrust[2]) + c->rotor_py[3] * thrust[3];
+        tb[1] = -(((c->rotor_px[0] * thrust[0] + c->rotor_px[1] * thrust[1]) + c->rotor_px[2] * thrust[2]) + c->rotor_px[3] * thrust[3]);
+        tb[2] = ((moment[0] + moment[1]) + moment[2]) + moment[3];
+        o_integrate(c, ds, fw, tb);
+        b->progress[e] += 1.0f;
+        float progress = b->progress[e], heading[3], up[3], lv, la, lj;
+        o_hover_obs(c, h, ds, progress, st, ac, E, b->obs + e * 20, heading, up, &lv, &la, &lj);
+        /* _compute_reward_and_done  hover.py:439-523 */
+        const float *obs = b->obs + e * 20;
+        float pos_error = o_norm3(obs[0], obs[1], obs[2]);
+        float rh[3] = {h->target_heading[0] - heading[0], h->target_heading[1] - heading[1], h->target_heading[2] - heading[2]};
+        float head_error = o_norm3(rh[0], rh[1], rh[2]);
+        float align = (heading[0] * h->target_heading[0] + heading[1] * h->target_heading[1]) + heading[2] * h->target_heading[2];
+        float reward_pos = -pos_error * h->reward_distance_scale;
+        float bonus = (pos_error <= 0.02f) ? 10.0f : 0.0f;
+        float bpos = bonus > 0.0f ? 1.0f : 0.0f;
+        float reward_head = -head_error * bpos;
+        float head_bonus = ((head_error <= 0.02f) ? 10.0f : 0.0f) * bpos;
+        float u = (up[2] + 1.0f) / 2.0f;
+        float reward_up = u * u;
+        float reward_v = (h->reward_v_scale * bpos) * ((lv < h->linear_vel_max) ? 1.0f : 0.0f);
+        float reward_acc = (h->reward_acc_scale * bpos) * ((la < h->linear_acc_max) ? 1.0f : 0.0f);
+        float reward_jerk = (h->reward_jerk_scale * bpos) * -lj;
+        float reward = ((((((reward_pos + bonus) + reward_head) + head_bonus) + reward_up) + reward_v) + reward_acc) + reward_jerk;
+        b->reward[e] = reward;
+        b->done[e] = (uint8_t)(progress >= (float)c->max_episode_length);
+        float w = 1.0f - h->alpha;
+        ST(HS_POS_ERROR) += w * (pos_error - ST(HS_POS_ERROR));                 /* lerp_  :506-509 */
+        ST(HS_HEADING_ALIGNMENT) += w * (align - ST(HS_HEADING_ALIGNMENT));
+        ST(HS_UPRIGHTNESS) += w * (up[2] - ST(HS_UPRIGHTNESS));
+        ST(HS_ACTION_SMOOTHNESS) += w * (-td - ST(HS_ACTION_SMOOTHNESS));
+        ST(HS_RETURN) += reward;
+        ST(HS_REWARD_POS) = reward_pos; ST(HS_POS_BONUS) = bonus; ST(HS_HEAD_BONUS) = head_bonus;
+        ST(HS_REWARD_VEL) = reward_v; ST(HS_REWARD_ACC) = reward_acc; ST(HS_REWARD_JERK) = reward_jerk;
+        ST(HS_EPISODE_LEN) = progress;
+#undef ST
+    }
+    return HNS_OK;
+}
+
+int hns_oracle_hover_reset(const hns_cfg *c, const hns_hover_cfg *h, const hns_hover_buffers *b, const uint8_t *mask,
+                           uint64_t seed, uint32_t epoch) {
+    const size_t E = (size_t)c->num_envs;
+    for (size_t e = 0; e < E; ++e) {
+        /* hover.py:313-320 re-creates the six *_episode accumulators for ALL envs on any reset call */
+        for (int i = HA_LV_EP; i <= HA_AJ_EP; ++i) b->acc[(size_t)i * E + e] = 0.0f;
+        if (mask && !mask[e]) continue;
+        o_rng rng = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(e + c->env_index_offset), epoch, 0u, {0, 0, 0, 0}, 0};
+        float *ds = b->drone_state + e * 13;
+        for (int i = 0; i < 3; ++i) ds[i] = h->pos_lo[i] + o_uniform(&rng) * (h->pos_hi[i] - h->pos_lo[i]);
+        float rpy[3];
+        for (int i = 0; i < 3; ++i) rpy[i] = h->rpy_lo[i] + o_uniform(&rng) * (h->rpy_hi[i] - h->rpy_lo[i]);
+        o_euler_to_quat(rpy, ds + 3);
+        for (int i = 7; i < 13; ++i) ds[i] = 0.0f;
+        for (int i = 0; i < 4; ++i) {
+            b->throttle[e * 4 + i] = c->hover_throttle;       /* multirotor.py:647-648 */
+            b->pid_integ[e * 4 + i] = 0.0f;
+            b->pid_last_rate[e * 4 + i] = 0.0f;
+        }
+        for (int i = 0; i < HNS_HOVER_NUM_STATS; ++i) b->stats[(size_t)i * E + e] = 0.0f;
+        for (int i = HA_LAST_LV; i <= HA_LAST_AJ; ++i) b->acc[(size_t)i * E + e] = 0.0f;
+        b->progress[e] = 0.0f;
+        b->done[e] = 0;
+        float heading[3], up[3], lv, la, lj;
+        o_hover_obs(c, h, ds, 0.0f, b->stats + e, b->acc + e, E, b->obs + e * 20, heading, up, &lv, &la, &lj);
+    }
+    return HNS_OK;
+}

@@ -164,3 +164,30 @@ def philox(k0, k1, c0, c1, c2, c3):
     out = (C.c_uint32 * 4)()
     lib().hns_oracle_philox(C.c_uint32(k0), C.c_uint32(k1), C.c_uint32(c0), C.c_uint32(c1), C.c_uint32(c2), C.c_uint32(c3), out)
     return list(out)
+
+
+# ---- Hover (BASELINE config 1) --------------------------------------------------------------------
+def alloc_hover_buffers(cfg):
+    return {k: np.zeros(shape, dtype=dt) for k, (shape, dt) in abi.hover_buffer_shapes(cfg.num_envs).items()}
+
+
+def _hover_struct(arrs):
+    b = abi.HnsHoverBuffers()
+    for k in abi.HOVER_BUFFER_FIELDS:
+        assert arrs[k].flags["C_CONTIGUOUS"]
+        setattr(b, k, arrs[k].ctypes.data)
+    return b
+
+
+def hover_step(cfg, hcfg, arrs, action):
+    action = f32(action)
+    b = _hover_struct(arrs)
+    rc = lib().hns_oracle_hover_step(C.byref(cfg), C.byref(hcfg), C.byref(b), _p(action))
+    assert rc == 0, rc
+
+
+def hover_reset(cfg, hcfg, arrs, mask, seed, epoch):
+    b = _hover_struct(arrs)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    rc = lib().hns_oracle_hover_reset(C.byref(cfg), C.byref(hcfg), C.byref(b), _p(m), C.c_uint64(seed), C.c_uint32(epoch))
+    assert rc == 0, rc

@@ -809,3 +809,120 @@ if __name__ == "__main__":
     gen_episode("a3c8", E=24, A=3, C=8, T=40, seed=20241001, max_len=60)
     gen_episode("a3c5", E=24, A=3, C=5, T=30, seed=20241002, max_len=60, n_active=0)
     gen_episode("a6c16", E=12, A=6, C=16, T=20, seed=20241003, max_len=60)
+
+
+# --------------------------------------------------------------------------------------
+# Hover (config 1): omni_drones/envs/single/hover.py
+# --------------------------------------------------------------------------------------
+HOVER = "omni_drones/envs/single/hover.py"
+HOVER_TASK = yaml.safe_load(open(os.path.join(REF, "cfg/task/Hover.yaml")))
+hov_ns = dict(torch=torch, TensorDict=TensorDict, TensorDictBase=TensorDict, quat_rotate_inverse=ref_torch.quat_rotate_inverse,
+              collections=__import__("collections"))
+hov_m = exec_functions(extract_source(HOVER, ["_pre_sim_step", "_compute_state_and_obs", "_compute_reward_and_done"],
+                                      classname="Hover"), hov_ns)
+HOVER_STATS = ["return", "pos_bonus", "head_bonus", "reward_pos", "reward_up", "reward_vel", "reward_acc", "reward_jerk",
+               "episode_len", "pos_error", "heading_alignment", "uprightness", "action_smoothness", "linear_v_max",
+               "angular_v_max", "linear_a_max", "angular_a_max", "linear_jerk_max", "angular_jerk_max", "linear_v_mean",
+               "angular_v_mean", "linear_a_mean", "angular_a_mean", "linear_jerk_mean", "angular_jerk_mean", "motor1",
+               "motor2", "motor3", "motor4", "cmd_r", "cmd_p", "cmd_y", "cmd_thrust", "target_r_rate", "target_p_rate",
+               "target_y_rate", "real_r_rate", "real_p_rate", "real_y_rate"]
+HOVER_ACC = ["linear_v_episode", "angular_v_episode", "linear_a_episode", "angular_a_episode", "linear_jerk_episode",
+             "angular_jerk_episode", "last_linear_v", "last_angular_v", "last_linear_a", "last_angular_a",
+             "last_linear_jerk", "last_angular_jerk"]
+
+
+class ShimHover:
+    """`self` for the Hover methods (attributes per hover.py:76-155)."""
+
+    def __init__(self, E, max_len=500):
+        t = HOVER_TASK
+        self.num_envs, self.device, self.batch_size = E, "cpu", [E]
+        self.max_episode_length = max_len
+        self.dt = DT
+        self.cfg = types.SimpleNamespace(task=types.SimpleNamespace(
+            action_noise=False, omega=False, motor=False, add_noise=False))
+        self.time_encoding, self.time_encoding_dim, self.latency = True, 4, 0
+        self.reward_distance_scale = t["reward_distance_scale"]
+        self.reward_v_scale, self.reward_acc_scale, self.reward_jerk_scale = t["reward_v_scale"], t["reward_acc_scale"], t["reward_jerk_scale"]
+        self.linear_vel_max, self.linear_acc_max = t["linear_vel_max"], t["linear_acc_max"]
+        self.alpha = 0.8
+        self.drone = ShimDrone(E, 1)
+        self.drone.intrinsics = torch.zeros(E, 1, 1)
+        self.target_pos = torch.tensor([[0.0, 0.0, 1.0]])
+        self.target_heading = torch.zeros(E, 1, 3)
+        self.target_heading[..., 0] = 1.0
+        self.progress_buf = torch.zeros(E)
+        self.stats = TensorDict({k: torch.zeros(E, 1) for k in HOVER_STATS}, [E])
+        self.info = TensorDict({"drone_state": torch.zeros(E, 1, 13), "prev_action": torch.zeros(E, 1, 4)}, [E])
+        for k in HOVER_ACC:
+            setattr(self, k, torch.zeros(E, 1))
+
+    def acc(self):
+        return torch.cat([getattr(self, k) for k in HOVER_ACC], dim=1)
+
+
+def gen_hover():
+    g = torch.Generator().manual_seed(20241010)
+    E, T, max_len = 16, 30, 40
+    env = ShimHover(E, max_len)
+    tr = ShimTransform()
+    d = env.drone
+    pos = (torch.rand(E, 1, 3, generator=g) * 2 - 1) * torch.tensor([1.0, 1.0, 0.0]) + torch.tensor([0.0, 0.0, 0.05]) \
+        + torch.rand(E, 1, 3, generator=g) * torch.tensor([0.0, 0.0, 1.95])
+    pos[0, 0] = torch.tensor([0.005, -0.004, 1.003])     # inside the 0.02 bonus ball
+    rot = rand_quat(g, E, 1, max_tilt=0.5)
+    rot[0, 0] = torch.tensor([1.0, 0.0, 0.0, 0.0])
+    vel = torch.randn(E, 1, 6, generator=g) * 0.2
+    hover = math.sqrt(CF["mass"] * 9.81 / (4 * float(d.rotor_module.KF.data[0, 0, 0])))
+    d.rotor_module.throttle.data.fill_(hover)
+    d.set_state(pos, rot, vel)
+    env.progress_buf = torch.randint(0, 4, (E,), generator=g).float() + (max_len - T + 5)
+    env._compute_state = lambda: hov_m["_compute_state_and_obs"](env)
+    td0 = hov_m["_compute_state_and_obs"](env)
+    init = dict(pos=pos, rot=rot, vel=vel, throttle=d.throttle.data.clone(), progress=env.progress_buf.clone(),
+                stats=torch.cat([env.stats[k] for k in HOVER_STATS], 1), acc=env.acc(),
+                obs=td0[("agents", "observation")].clone())
+    rec = {k: [] for k in ["action", "pos", "rot", "vel", "throttle", "integ", "last", "prev_action", "progress", "stats",
+                           "acc", "obs", "reward", "done"]}
+    prev = torch.zeros(E, 1, 4)
+    for t in range(T):
+        action = torch.randn(E, 1, 4, generator=g) * 0.5
+        action[..., 3] += 0.3
+        td = TensorDict({"agents": {"action": action.clone()},
+                         "info": {"drone_state": env.info["drone_state"].clone(), "prev_action": prev.clone()},
+                         "stats": {}, "done": torch.zeros(E, 1, dtype=torch.bool)}, [E])
+        td = tr.inv(td)
+        prev = td[("info", "prev_action")].clone()
+        hov_m["_pre_sim_step"](env, td)
+        rotor_f = d.rotor_rec.calls[-1]["forces"].reshape(E, 1, 4, 3)
+        base = d.base_link.calls[-1]
+        T_i = rotor_f[..., 2]
+        ang = torch.tensor(CF["rotor_configuration"]["rotor_angles"], dtype=torch.float32)
+        l = torch.tensor(CF["rotor_configuration"]["arm_lengths"], dtype=torch.float32)
+        tsum = ((T_i[..., 0] + T_i[..., 1]) + T_i[..., 2]) + T_i[..., 3]
+        tvec = torch.zeros(E, 1, 3); tvec[..., 2] = tsum
+        force_w = ref_torch.quat_rotate(d.w_rot, tvec) + base["forces"].reshape(E, 1, 3)
+        yaw = ref_torch.quat_rotate_inverse(d.w_rot, base["torques"].reshape(E, 1, 3))[..., 2]
+        sx, cx = torch.sin(ang) * l, torch.cos(ang) * l
+        torque_b = torch.stack([
+            ((sx[0] * T_i[..., 0] + sx[1] * T_i[..., 1]) + sx[2] * T_i[..., 2]) + sx[3] * T_i[..., 3],
+            -(((cx[0] * T_i[..., 0] + cx[1] * T_i[..., 1]) + cx[2] * T_i[..., 2]) + cx[3] * T_i[..., 3]),
+            yaw], dim=-1)
+        phys = dict(PHYS); phys["v_max"] = 1000.0          # Hover keeps the default max_linear_velocity (robots/config.py:36)
+        npos, nrot, nvel, _ = integrate_spec(d.w_pos, d.w_rot, d.w_vel, force_w, torque_b, torch.zeros(E, 1, 3), torch.zeros(E, 1, 3), phys)
+        d.set_state(npos, nrot, nvel)
+        env.progress_buf = env.progress_buf + 1
+        tdo = hov_m["_compute_state_and_obs"](env)
+        out = hov_m["_compute_reward_and_done"](env)
+        for k, v in dict(action=action, pos=npos, rot=nrot, vel=nvel, throttle=d.throttle.data,
+                         integ=tr.controller.integ.reshape(E, 1, 3), last=tr.controller.last_body_rate.reshape(E, 1, 3),
+                         prev_action=prev, progress=env.progress_buf, stats=torch.cat([env.stats[k] for k in HOVER_STATS], 1),
+                         acc=env.acc(), obs=tdo[("agents", "observation")], reward=out[("agents", "reward")],
+                         done=out["done"]).items():
+            rec[k].append(v.clone())
+    save("g_hover", **{"init_" + k: v for k, v in init.items()}, **{k: torch.stack(v) for k, v in rec.items()},
+         meta=np.array([E, T, max_len], dtype=np.int64))
+
+
+if __name__ == "__main__":
+    gen_hover()
