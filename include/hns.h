@@ -216,6 +216,13 @@ int hns_step(hns_env *env, const float *action, void *stream);
  * counter advanced by every call.  Asynchronous. */
 int hns_reset(hns_env *env, const uint8_t *reset_mask, uint64_t seed, void *stream);
 
+/* envgen reset (hideandseek_envgen.py:875-902): like hns_reset, but the masked envs with index >=
+ * task_first take their placement from `tasks` (device pointer, [E, 3A+3+3C] rows = drone positions,
+ * evader position, cylinder positions — the reference's task vector) instead of sampling it;
+ * orientations are still drawn from the Philox stream.  Envs < task_first reset as in hns_reset. */
+int hns_reset_tasks(hns_env *env, const uint8_t *reset_mask, const float *tasks, int32_t task_first, uint64_t seed,
+                    void *stream);
+
 /* Curriculum hook (hideandseek.py:1012-1015): change the evader speed. */
 int hns_set_v_prey(hns_env *env, float v_prey);
 /* Smoothness schedule hook (hideandseek.py:988-991). */

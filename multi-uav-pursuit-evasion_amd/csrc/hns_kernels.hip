@@ -53,6 +53,8 @@ struct Params {
     uint32_t seed_lo, seed_hi, epoch;
     unsigned long long *prof;   // optional per-wave phase timestamps (diagnostics), else null
     uint32_t cyl_magic;         // ceil(2^32 / (3*C)): index / (3*C) as a multiply-high
+    const float *tasks;         // reset: optional [E, 3A+3+3C] task vectors (envgen), else null
+    int32_t task_first;         // envs >= task_first take their placement from `tasks`
 };
 
 constexpr int kProfSlots = 16;
@@ -648,15 +650,20 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
         float *ds = sDS + le * A * 13;
         float *tp = sTp + le * 3;
         float *cyl = sCyl + le * L.cyl_stride;
+        // envgen (hideandseek_envgen.py:896-898): placement given by a task vector [drones | evader | cylinders]
+        const float *task = (p.tasks && e >= p.task_first) ? p.tasks + (size_t)e * (3 * A + 3 + 3 * C) : nullptr;
         for (int j = 0; j < A; ++j) {
             float *d = ds + 13 * j;
-            if (c.init_mode == HNS_INIT_RANDOM) {
+            if (task) {
+                d[0] = task[3 * j]; d[1] = task[3 * j + 1];
+            } else if (c.init_mode == HNS_INIT_RANDOM) {
                 d[0] = c.drone_xy_lo[0] + rng.uniform() * (c.drone_xy_hi[0] - c.drone_xy_lo[0]);
                 d[1] = c.drone_xy_lo[1] + rng.uniform() * (c.drone_xy_hi[1] - c.drone_xy_lo[1]);
             } else {
                 d[0] = c.fixed_drone_pos[j][0]; d[1] = c.fixed_drone_pos[j][1];
             }
-            if (c.init_mode == HNS_INIT_SCENARIO) d[2] = c.fixed_drone_pos[j][2];
+            if (task) d[2] = task[3 * j + 2];
+            else if (c.init_mode == HNS_INIT_SCENARIO) d[2] = c.fixed_drone_pos[j][2];
             else d[2] = c.z_lo + rng.uniform() * (c.z_hi - c.z_lo);
             float r0 = c.rpy_lo[0] + rng.uniform() * (c.rpy_hi[0] - c.rpy_lo[0]);
             float r1 = c.rpy_lo[1] + rng.uniform() * (c.rpy_hi[1] - c.rpy_lo[1]);
@@ -673,16 +680,22 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
             reinterpret_cast<float4 *>(b.pid_last_rate)[ja] = make_float4(0, 0, 0, 0);
             b.prev_action[ja * 4 + 3] = pa / 4.0f;                                // hideandseek.py:714-716
         }
-        if (c.init_mode == HNS_INIT_RANDOM) {
-            tp[0] = c.target_xy_lo[0] + rng.uniform() * (c.target_xy_hi[0] - c.target_xy_lo[0]);
-            tp[1] = c.target_xy_lo[1] + rng.uniform() * (c.target_xy_hi[1] - c.target_xy_lo[1]);
+        if (task) {
+            tp[0] = task[3 * A]; tp[1] = task[3 * A + 1]; tp[2] = task[3 * A + 2];
         } else {
-            tp[0] = c.fixed_target_pos[0]; tp[1] = c.fixed_target_pos[1];
+            if (c.init_mode == HNS_INIT_RANDOM) {
+                tp[0] = c.target_xy_lo[0] + rng.uniform() * (c.target_xy_hi[0] - c.target_xy_lo[0]);
+                tp[1] = c.target_xy_lo[1] + rng.uniform() * (c.target_xy_hi[1] - c.target_xy_lo[1]);
+            } else {
+                tp[0] = c.fixed_target_pos[0]; tp[1] = c.fixed_target_pos[1];
+            }
+            if (c.init_mode == HNS_INIT_SCENARIO) tp[2] = c.fixed_target_pos[2];
+            else tp[2] = c.z_lo + rng.uniform() * (c.z_hi - c.z_lo);
         }
-        if (c.init_mode == HNS_INIT_SCENARIO) tp[2] = c.fixed_target_pos[2];
-        else tp[2] = c.z_lo + rng.uniform() * (c.z_hi - c.z_lo);
         b.target_vel[(size_t)e * 3] = 0.0f; b.target_vel[(size_t)e * 3 + 1] = 0.0f; b.target_vel[(size_t)e * 3 + 2] = 0.0f;
-        if (c.init_mode == HNS_INIT_SCENARIO) {
+        if (task) {
+            for (int k = 0; k < 3 * C; ++k) cyl[k] = task[3 * A + 3 + k];
+        } else if (c.init_mode == HNS_INIT_SCENARIO) {
             for (int k = 0; k < C; ++k) {
                 cyl[3 * k] = c.fixed_cyl_pos[k][0]; cyl[3 * k + 1] = c.fixed_cyl_pos[k][1];
                 cyl[3 * k + 2] = (k >= c.fixed_cyl_active) ? c.invalid_z : c.fixed_cyl_pos[k][2];
@@ -1100,6 +1113,8 @@ int hns_step(hns_env *env, const float *action, void *stream) {
     p.seed_lo = p.seed_hi = p.epoch = 0;
     p.prof = env->prof;
     p.cyl_magic = env->cyl_magic;
+    p.tasks = nullptr;
+    p.task_first = 0;
     return launch(env, true, p, static_cast<hipStream_t>(stream));
 }
 
@@ -1116,6 +1131,27 @@ int hns_reset(hns_env *env, const uint8_t *reset_mask, uint64_t seed, void *stre
     p.epoch = env->epoch++;
     p.prof = nullptr;
     p.cyl_magic = env->cyl_magic;
+    p.tasks = nullptr;
+    p.task_first = 0;
+    return launch(env, false, p, static_cast<hipStream_t>(stream));
+}
+
+int hns_reset_tasks(hns_env *env, const uint8_t *reset_mask, const float *tasks, int32_t task_first, uint64_t seed, void *stream) {
+    if (!env || !tasks) { set_error("hns_reset_tasks: null argument"); return HNS_ERR_INVALID_ARG; }
+    if (!env->bound) { set_error("hns_reset_tasks: buffers not bound"); return HNS_ERR_NOT_BOUND; }
+    if (task_first < 0 || task_first > env->cfg.num_envs) { set_error("hns_reset_tasks: task_first out of range"); return HNS_ERR_INVALID_ARG; }
+    Params p;
+    p.cfg = env->cfg;
+    p.buf = env->buf;
+    p.action = nullptr;
+    p.reset_mask = reset_mask;
+    p.seed_lo = (uint32_t)seed;
+    p.seed_hi = (uint32_t)(seed >> 32);
+    p.epoch = env->epoch++;
+    p.prof = nullptr;
+    p.cyl_magic = env->cyl_magic;
+    p.tasks = tasks;
+    p.task_first = task_first;
     return launch(env, false, p, static_cast<hipStream_t>(stream));
 }
 

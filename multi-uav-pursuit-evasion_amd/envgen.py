@@ -1,0 +1,306 @@
+"""HideAndSeek_envgen — the Adaptive Environment Generator variant (BASELINE config 4).
+
+The per-step math is the HideAndSeek step kernel unchanged; what differs is per-episode
+bookkeeping on the host (reference omni_drones/envs/hide_and_seek/hideandseek_envgen.py):
+  * `GenBuffer` (:209-377): a history of task vectors `[drone xyz * A | evader xyz | cylinder xyz * C]`,
+    `samplenearby` perturbation with a grid sanity check, success-weighted insertion and
+    farthest-point-sampling (FPS) trimming to 5000 entries;
+  * `_reset_idx` (:875-902): every `eval_iter` episodes a new task batch = `ratio_unif` uniform tasks
+    + perturbed buffer tasks, replayed for `eval_iter` episodes;
+  * the curriculum block at episode end (:1302-1333) and the extra statistics (:617-651, :1241-1246).
+
+Differences from the reference, all distribution-preserving (the generator's RNG streams
+and DGL's FPS start point are unpinned):
+  * `samplenearby` is vectorised (all tasks perturbed at once, failed ones retried up to 10 times)
+    instead of a Python loop per task — needed at 65 536 envs;
+  * FPS is an iterative torch implementation (runs on the env's GPU) instead of
+    `dgl.geometry.farthest_point_sampler` (not installed; its version is unpinned in the reference);
+  * task placement on the device goes through `hns_reset_tasks`; uniform tasks are sampled by the
+    reset kernel itself and read back once per task batch;
+  * `success_buffer` / `success_unif` are refreshed at episode end (where `EpisodeStats` reads them)
+    rather than every step, which would need a cross-env reduction per step.
+"""
+import ctypes as C
+import math
+from collections import deque
+
+import numpy as np
+import torch
+
+from .env import HideAndSeek, HnsError
+
+
+def farthest_point_sampling(points, k, start=0):
+    """Indices of k points chosen by iterative farthest-point sampling (torch, any device)."""
+    n = points.shape[0]
+    if k >= n:
+        return torch.arange(n, device=points.device)
+    idx = torch.empty(k, dtype=torch.long, device=points.device)
+    dist = torch.full((n,), float("inf"), device=points.device, dtype=points.dtype)
+    cur = torch.tensor(int(start) % n, device=points.device)
+    for i in range(k):
+        idx[i] = cur
+        d = ((points - points[cur]) ** 2).sum(-1)
+        dist = torch.minimum(dist, d)
+        cur = torch.argmax(dist)
+    return idx
+
+
+class GenBuffer:
+    """hideandseek_envgen.py:209-377."""
+
+    def __init__(self, num_agents, num_cylinders, device="cpu", arena_size=0.9, cylinder_size=0.1, max_height=1.2,
+                 buffer_length=5000, seed=0):
+        self.num_agents, self.num_cylinders, self.device = num_agents, num_cylinders, device
+        self.task_dim = 3 * num_agents + 3 + 3 * num_cylinders       # reference: 18 + 3A (C = 5)
+        self._state_buffer = np.zeros((0, 1), dtype=np.float32)
+        self._history_buffer = np.zeros((0, self.task_dim), dtype=np.float32)
+        self._weight_buffer = np.zeros((0, 1), dtype=np.float32)
+        self.buffer_length = buffer_length
+        self.eps = 1e-5
+        self.update_method = "fps"
+        self._temp_state_buffer = []
+        self._temp_weight_buffer = []
+        self.arena_size, self.cylinder_size, self.max_height = arena_size, cylinder_size, max_height
+        self.grid_size = 2 * cylinder_size
+        self.num_grid = int(arena_size * 2 / self.grid_size)
+        self.boundary = arena_size - 0.1
+        half = self.num_grid // 2
+        ii, jj = np.meshgrid(np.arange(self.num_grid), np.arange(self.num_grid), indexing="ij")
+        self.grid_map = (np.sqrt((ii - half) ** 2 + (jj - half) ** 2) >= half).astype(np.int64)   # :168-181
+        self.rng = np.random.default_rng(seed)
+
+    # -- grid helpers (:121-164) ------------------------------------------------------------------
+    def to_grid(self, xy):
+        g = np.rint(np.asarray(xy, dtype=np.float64) / self.grid_size).astype(np.int64) + self.num_grid // 2
+        return np.clip(g, 0, self.num_grid - 1)
+
+    def sanity_ok(self, tasks):
+        """:187-207 vectorised: every object sits in its own free cell of the disc."""
+        A, Cn = self.num_agents, self.num_cylinders
+        n = tasks.shape[0]
+        xyz = tasks.reshape(n, A + 1 + Cn, 3)
+        g = self.to_grid(xyz[..., :2])
+        cell = g[..., 0] * self.num_grid + g[..., 1]
+        free = self.grid_map.reshape(-1)[cell] == 0
+        cs = np.sort(cell, axis=1)
+        distinct = (np.diff(cs, axis=1) != 0).all(axis=1)
+        return free.all(axis=1) & distinct
+
+    # -- buffer maintenance ---------------------------------------------------------------------------
+    def init_history(self, init_tasks):
+        self._history_buffer = np.asarray(init_tasks, dtype=np.float32).reshape(-1, self.task_dim)
+
+    def init_easy_cases(self):
+        """:235-277: evader on a random free cell, pursuers on the nearest free cells (BFS)."""
+        n, out = self.num_grid, []
+        free = np.argwhere(self.grid_map == 0)
+        for _ in range(self.buffer_length):
+            x, y = free[self.rng.integers(len(free))]
+            visited = np.zeros((n, n), dtype=bool)
+            visited[x, y] = True
+            queue, found = deque([(x, y)]), []
+            while queue and len(found) < self.num_agents:
+                cx, cy = queue.popleft()
+                for dx, dy in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+                    nx, ny = cx + dx, cy + dy
+                    if 0 <= nx < n and 0 <= ny < n and not visited[nx, ny]:
+                        visited[nx, ny] = True
+                        if self.grid_map[nx, ny] == 0:
+                            found.append((nx, ny))
+                            if len(found) == 4:
+                                break
+                        queue.append((nx, ny))
+            out.append(found[:self.num_agents] + [(x, y)])
+        cells = np.asarray(out, dtype=np.float64)
+        xy = np.clip((cells - n // 2) * self.grid_size, -self.boundary, self.boundary)
+        z = (self.rng.random((self.buffer_length, self.num_agents + 1, 1)) * 0.2 - 0.1) + self.max_height / 2
+        return np.concatenate([xy, z], axis=-1).astype(np.float32)
+
+    def insert(self, states):
+        self._temp_state_buffer.extend(np.array(states, dtype=np.float32, copy=True))
+
+    def insert_weights(self, weights):
+        self._temp_weight_buffer.append(np.asarray(weights, dtype=np.float32).reshape(-1, 1))
+
+    def update(self):
+        self._state_buffer = np.array(self._temp_state_buffer)
+        self._weight_buffer = np.stack(self._temp_weight_buffer, axis=-1).mean(-1)
+        self._temp_state_buffer, self._temp_weight_buffer = [], []
+
+    def insert_history(self, states):
+        states = np.asarray(states, dtype=np.float32).reshape(-1, self.task_dim)
+        if len(states) == 0:
+            return
+        all_states = np.concatenate([self._history_buffer, states])
+        if self.update_method == "fifo":
+            self._history_buffer = all_states[-self.buffer_length:]
+        elif all_states.shape[0] > self.buffer_length:
+            lo, hi = all_states.min(0), all_states.max(0)
+            normed = torch.as_tensor((all_states - lo) / (hi - lo + self.eps), device=self.device)
+            idx = farthest_point_sampling(normed, self.buffer_length, start=int(self.rng.integers(all_states.shape[0])))
+            self._history_buffer = all_states[idx.cpu().numpy()]
+        else:
+            self._history_buffer = all_states
+
+    def task_bounds(self):
+        """:320-333 (incl. the reference's z window [max_height-0.1, max_height+0.1] for drones/evader)."""
+        cb = int(self.arena_size / self.grid_size) * self.grid_size
+        bxy = self.arena_size / math.sqrt(2.0) - 0.1
+        drone = [[-bxy, bxy], [-bxy, bxy], [self.max_height - 0.1, self.max_height + 0.1]]
+        cyl = [[-cb, cb], [-cb, cb], [-20.0, self.max_height / 2]]
+        return np.array(drone * (self.num_agents + 1) + cyl * self.num_cylinders)
+
+    def samplenearby(self, num_tasks, expand_cylinders, expand_step):
+        """:316-370, vectorised: perturb, clip, sanity-check, retry the failures (<= 10 rounds)."""
+        idx = self.rng.integers(self._history_buffer.shape[0], size=num_tasks)
+        origin = self._history_buffer[idx].astype(np.float64)
+        b = self.task_bounds()
+        nd = self.task_dim - 3 * self.num_cylinders
+        out = np.zeros_like(origin)
+        done = np.zeros(num_tasks, dtype=bool)
+        for _ in range(10):
+            todo = np.flatnonzero(~done)
+            if todo.size == 0:
+                break
+            noise = np.zeros((todo.size, self.task_dim))
+            noise[:, :nd] = self.rng.uniform(-1, 1, size=(todo.size, nd)) * expand_step
+            if expand_cylinders:
+                cn = np.zeros((todo.size, self.num_cylinders, 3))
+                cn[..., :2] = self.rng.choice([-1, 0, 1], size=(todo.size, self.num_cylinders, 2)) * self.grid_size
+                noise[:, nd:] = cn.reshape(todo.size, -1)
+            cand = np.clip(origin[todo] + noise, b[:, 0], b[:, 1])
+            ok = self.sanity_ok(cand)
+            out[todo[ok]] = cand[ok]
+            done[todo[ok]] = True
+        good = out[done]
+        if good.shape[0] == 0:
+            raise ValueError("samplenearby: no perturbed task passed the grid sanity check")
+        if good.shape[0] < num_tasks:                                      # :363-368
+            add = good[self.rng.integers(good.shape[0], size=num_tasks - good.shape[0])]
+            good = np.concatenate([add, good])
+        return good.astype(np.float32)
+
+    def sample(self, num_tasks):
+        return self._history_buffer[self.rng.integers(self._history_buffer.shape[0], size=num_tasks)]
+
+    def save_task(self, model_dir, episode):
+        np.save("{}/history_{}.npy".format(model_dir, episode), self._history_buffer)
+
+
+class HideAndSeek_envgen(HideAndSeek):
+    def __init__(self, cfg, headless=True, env_index_offset=0, write_critic_state=None):
+        super().__init__(cfg, headless, env_index_offset, write_critic_state)
+        t = cfg.task
+        self.use_particle_generator = int(t.get("use_particle_generator", 1))
+        self.ratio_unif = float(t.get("ratio_unif", 0.3))
+        self.eval_iter = int(t.get("eval_iter", 3))
+        self.R_min, self.R_max = float(t.get("R_min", 0.5)), float(t.get("R_max", 0.9))
+        self.success_threshold = float(t.get("success_threshold", 1.0))
+        self.expand_cylinders, self.expand_step = int(t.get("expand_cylinders", 0)), float(t.get("expand_step", 0.1))
+        self.use_init_easy = int(t.get("use_init_easy", 0))
+        self.update_iter = 0
+        self.num_unif = self.num_envs
+        A, Cn, E = self.num_agents, self.num_cylinders, self.num_envs
+        self.gen_buffer = GenBuffer(A, Cn, device=self.device, arena_size=float(t.arena_size), cylinder_size=float(t.cylinder.size),
+                                    max_height=float(t.max_height), seed=int(cfg.get("seed", 0)))
+        if self.use_init_easy:                                                # :485-495
+            easy = self.gen_buffer.init_easy_cases()
+            cyl = np.tile(np.array([0.0, 0.0, -20.0], np.float32), (easy.shape[0], Cn, 1))
+            self.gen_buffer.init_history(np.concatenate([easy.reshape(easy.shape[0], -1), cyl.reshape(easy.shape[0], -1)], axis=1))
+        self.task_dim = self.gen_buffer.task_dim
+        self._tasks_dev = torch.zeros(E, self.task_dim, device=self.device)
+        self.all_tasks = None
+        self.active_cylinders = torch.zeros(E, 1, device=self.device)
+        extra = ["success_buffer", "success_unif", "history_buffer", "add_history", "ratio_unif"]
+        extra += [f"ratio_cylinders_{i}" for i in range(Cn + 1)] + [f"success_cylinders_{i}" for i in range(Cn + 1)]
+        self._extra = {k: torch.zeros(E, 1, device=self.device) for k in extra}   # :617-651
+        for k, v in self._extra.items():
+            self.stats.set(k, v)
+        self.generator_seconds = 0.0
+
+    # ---- hideandseek_envgen.py:875-902 ------------------------------------------------------------------
+    def _reset(self, tensordict=None, **kwargs):
+        if not (self.use_particle_generator and int(self.cfg.task.use_random_cylinder)):
+            return super()._reset(tensordict, **kwargs)
+        import time
+        mask_t = None
+        if tensordict is not None and tensordict.get("_reset") is not None:
+            mask_t = tensordict.get("_reset").reshape(self.num_envs).to(torch.uint8).contiguous()
+        last_stats = self.stats.clone()
+        E = self.num_envs
+        t0 = time.perf_counter()
+        mptr = C.c_void_p(mask_t.data_ptr()) if mask_t is not None else None
+        if self.update_iter == 0:
+            hist = self.gen_buffer._history_buffer.shape[0]
+            num_buffer = min(hist, int(E * (1 - self.ratio_unif)))
+            self.num_unif = E - num_buffer
+            if num_buffer > 0:
+                tasks_buffer = self.gen_buffer.samplenearby(num_buffer, self.expand_cylinders, self.expand_step)
+                self._tasks_dev[self.num_unif:].copy_(torch.from_numpy(tasks_buffer))
+            self._check(self._lib.hns_reset_tasks(self._env, mptr, C.c_void_p(self._tasks_dev.data_ptr()),
+                                                  C.c_int32(self.num_unif), C.c_uint64(self.seed), self._stream()), "hns_reset_tasks")
+            # the uniform tasks were sampled on the device: read the placement back as task vectors
+            b = self._bufs
+            placed = torch.cat([b["drone_state"][..., :3].reshape(E, -1), b["target_pos"], b["cylinders"].reshape(E, -1)], dim=1)
+            self._tasks_dev[:self.num_unif].copy_(placed[:self.num_unif])
+            self.all_tasks = self._tasks_dev.cpu().numpy().copy()
+            self.gen_buffer.insert(self.all_tasks)
+        else:
+            self._check(self._lib.hns_reset_tasks(self._env, mptr, C.c_void_p(self._tasks_dev.data_ptr()),
+                                                  C.c_int32(0), C.c_uint64(self.seed), self._stream()), "hns_reset_tasks")
+        self.active_cylinders = (self._bufs["cylinders"][..., 2] > 0.0).float().sum(-1, keepdim=True)   # :902
+        self.generator_seconds += time.perf_counter() - t0
+        self._keep_mask = mask_t
+        if mask_t is None:
+            self._since_full_reset = 0
+        self._needs_reset = False
+        td = self._obs_tensordict()
+        td.set("stats", last_stats)
+        td.set("truncated", (self.progress_buf > self.max_episode_length).unsqueeze(1))
+        return td
+
+    # ---- curriculum at episode end, hideandseek_envgen.py:1241-1246, 1302-1333 ----------------------------
+    def _step(self, tensordict):
+        out = super()._step(tensordict)
+        if self.use_particle_generator and self._since_full_reset >= self.max_episode_length:
+            done = self._bufs["done"]
+            if bool(done.any()):
+                self._episode_end()
+        return out
+
+    def _episode_end(self):
+        import time
+        t0 = time.perf_counter()
+        E, Cn = self.num_envs, self.num_cylinders
+        success = self.stats["success"]
+        ex = self._extra
+        if self.num_unif < E:
+            ex["success_buffer"].fill_(float(success[self.num_unif:].mean()))
+            ex["success_unif"].fill_(float(success[:self.num_unif].mean()))
+        else:
+            ex["success_buffer"].zero_()
+            ex["success_unif"].copy_(success)
+        if float(success.mean()) > self.success_threshold:
+            self.ratio_unif = 1.0
+        self.gen_buffer.insert_weights(success.cpu().numpy())
+        self.update_iter += 1
+        if self.update_iter >= self.eval_iter:
+            self.update_iter = 0
+            self.gen_buffer.update()
+            act = self.active_cylinders.reshape(-1).cpu().numpy()
+            w = self.gen_buffer._weight_buffer.reshape(-1)
+            for i in range(Cn + 1):
+                sel = act == i
+                ex[f"ratio_cylinders_{i}"].fill_(float(sel.mean()))
+                ex[f"success_cylinders_{i}"].fill_(float(w[sel].mean()) if sel.any() else 0.0)
+            keep = (w <= self.R_max) & (w >= self.R_min)
+            self.gen_buffer.insert_history(self.gen_buffer._state_buffer[keep])
+            ex["add_history"].fill_(float(keep.sum()))
+        ex["history_buffer"].fill_(float(len(self.gen_buffer._history_buffer)))
+        ex["ratio_unif"].fill_(self.ratio_unif)
+        self.generator_seconds += time.perf_counter() - t0
+
+
+HideAndSeek.REGISTRY["HideAndSeek_envgen"] = HideAndSeek_envgen
+HideAndSeek.REGISTRY["hideandseek_envgen"] = HideAndSeek_envgen

@@ -657,7 +657,18 @@ static int o_cell(const hns_cfg *c, float x) {
     return g < 0 ? 0 : (g > c->grid_num - 1 ? c->grid_num - 1 : g);
 }
 
+static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *mask, uint64_t seed, uint32_t epoch,
+                        const float *tasks, int task_first);
 int hns_oracle_reset(const hns_cfg *c, const hns_buffers *b, const uint8_t *mask, uint64_t seed, uint32_t epoch) {
+    return o_reset_impl(c, b, mask, seed, epoch, NULL, 0);
+}
+/* envgen: placement of envs >= task_first from task vectors (hideandseek_envgen.py:896-898) */
+int hns_oracle_reset_tasks(const hns_cfg *c, const hns_buffers *b, const uint8_t *mask, uint64_t seed, uint32_t epoch,
+                           const float *tasks, int task_first) {
+    return o_reset_impl(c, b, mask, seed, epoch, tasks, task_first);
+}
+static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *mask, uint64_t seed, uint32_t epoch,
+                        const float *tasks, int task_first) {
     const int E = c->num_envs, A = c->num_agents, C = c->num_cylinders, K = c->obs_max_cylinder, G = c->grid_num;
     if (G > 16) return HNS_ERR_INVALID_ARG;
     for (int e = 0; e < E; ++e) {
@@ -668,15 +679,19 @@ int hns_oracle_reset(const hns_cfg *c, const hns_buffers *b, const uint8_t *mask
         float *ds = b->drone_state + (size_t)e * A * 13;
         float *tp = b->target_pos + (size_t)e * 3;
         float *cyl = b->cylinders + (size_t)e * C * 3;
+        const float *task = (tasks && e >= task_first) ? tasks + (size_t)e * (3 * A + 3 + 3 * C) : NULL;
         for (int a = 0; a < A; ++a) {
             float *d = ds + 13 * a;
-            if (c->init_mode == HNS_INIT_RANDOM) {
+            if (task) {
+                d[0] = task[3 * a]; d[1] = task[3 * a + 1];
+            } else if (c->init_mode == HNS_INIT_RANDOM) {
                 d[0] = c->drone_xy_lo[0] + o_uniform(&rng) * (c->drone_xy_hi[0] - c->drone_xy_lo[0]);
                 d[1] = c->drone_xy_lo[1] + o_uniform(&rng) * (c->drone_xy_hi[1] - c->drone_xy_lo[1]);
             } else {
                 d[0] = c->fixed_drone_pos[a][0]; d[1] = c->fixed_drone_pos[a][1];
             }
-            if (c->init_mode == HNS_INIT_SCENARIO) d[2] = c->fixed_drone_pos[a][2];
+            if (task) d[2] = task[3 * a + 2];
+            else if (c->init_mode == HNS_INIT_SCENARIO) d[2] = c->fixed_drone_pos[a][2];
             else d[2] = c->z_lo + o_uniform(&rng) * (c->z_hi - c->z_lo);
             float rpy[3];
             for (int i = 0; i < 3; ++i) rpy[i] = c->rpy_lo[i] + o_uniform(&rng) * (c->rpy_hi[i] - c->rpy_lo[i]);
@@ -694,16 +709,22 @@ int hns_oracle_reset(const hns_cfg *c, const hns_buffers *b, const uint8_t *mask
             }
             b->prev_action[ia * 4 + 3] = pa / 4.0f;       /* components 0..2 are NOT reset (:716) */
         }
-        if (c->init_mode == HNS_INIT_RANDOM) {
-            tp[0] = c->target_xy_lo[0] + o_uniform(&rng) * (c->target_xy_hi[0] - c->target_xy_lo[0]);
-            tp[1] = c->target_xy_lo[1] + o_uniform(&rng) * (c->target_xy_hi[1] - c->target_xy_lo[1]);
+        if (task) {
+            for (int i = 0; i < 3; ++i) tp[i] = task[3 * A + i];
         } else {
-            tp[0] = c->fixed_target_pos[0]; tp[1] = c->fixed_target_pos[1];
+            if (c->init_mode == HNS_INIT_RANDOM) {
+                tp[0] = c->target_xy_lo[0] + o_uniform(&rng) * (c->target_xy_hi[0] - c->target_xy_lo[0]);
+                tp[1] = c->target_xy_lo[1] + o_uniform(&rng) * (c->target_xy_hi[1] - c->target_xy_lo[1]);
+            } else {
+                tp[0] = c->fixed_target_pos[0]; tp[1] = c->fixed_target_pos[1];
+            }
+            if (c->init_mode == HNS_INIT_SCENARIO) tp[2] = c->fixed_target_pos[2];
+            else tp[2] = c->z_lo + o_uniform(&rng) * (c->z_hi - c->z_lo);
         }
-        if (c->init_mode == HNS_INIT_SCENARIO) tp[2] = c->fixed_target_pos[2];
-        else tp[2] = c->z_lo + o_uniform(&rng) * (c->z_hi - c->z_lo);
         for (int i = 0; i < 3; ++i) b->target_vel[(size_t)e * 3 + i] = 0.0f;
-        if (c->init_mode == HNS_INIT_SCENARIO) {
+        if (task) {
+            for (int k = 0; k < 3 * C; ++k) cyl[k] = task[3 * A + 3 + k];
+        } else if (c->init_mode == HNS_INIT_SCENARIO) {
             for (int k = 0; k < C; ++k) {
                 for (int i = 0; i < 3; ++i) cyl[3 * k + i] = c->fixed_cyl_pos[k][i];
                 if (k >= c->fixed_cyl_active) cyl[3 * k + 2] = c->invalid_z;

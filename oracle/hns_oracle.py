@@ -73,6 +73,15 @@ def reset(cfg, arrs, mask, seed, epoch):
         raise ValueError(f"hns_oracle_reset failed: {rc}")
 
 
+def reset_tasks(cfg, arrs, mask, seed, epoch, tasks, task_first):
+    b = as_struct(arrs)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    t = f32(tasks)
+    rc = lib().hns_oracle_reset_tasks(C.byref(cfg), C.byref(b), _p(m), C.c_uint64(seed), C.c_uint32(epoch), _p(t), int(task_first))
+    if rc != 0:
+        raise ValueError(f"hns_oracle_reset_tasks failed: {rc}")
+
+
 def quat_rotate(q, v, inverse=False):
     q, v = f32(q).reshape(-1, 4), f32(v).reshape(-1, 3)
     out = np.empty_like(v)

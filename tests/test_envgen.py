@@ -1,0 +1,131 @@
+"""Adaptive Environment Generator (BASELINE config 4): host-side GenBuffer logic
+(reference hideandseek_envgen.py:209-377) and the task-vector reset."""
+import numpy as np
+import pytest
+import torch
+
+import hns_oracle as O
+from hns_amd import config
+from hns_amd.envgen import GenBuffer, farthest_point_sampling
+
+
+def test_farthest_point_sampling_properties():
+    g = torch.Generator().manual_seed(0)
+    pts = torch.rand(400, 5, generator=g)
+    idx = farthest_point_sampling(pts, 50, start=3)
+    assert idx[0] == 3 and len(set(idx.tolist())) == 50
+    # greedy property: every new point is the farthest from the already chosen set
+    chosen = [3]
+    for i in range(1, 50):
+        d = torch.cdist(pts, pts[chosen]).min(1).values
+        assert abs(float(d[idx[i]]) - float(d.max())) < 1e-6
+        chosen.append(int(idx[i]))
+    # the sample covers the cloud far better than a prefix
+    cover_fps = torch.cdist(pts, pts[idx]).min(1).values.max()
+    cover_prefix = torch.cdist(pts, pts[:50]).min(1).values.max()
+    assert cover_fps < cover_prefix
+    assert farthest_point_sampling(pts[:10], 50).tolist() == list(range(10))
+
+
+def _valid_tasks(gb, n, rng):
+    """n tasks with all objects on distinct free grid cells."""
+    free = np.argwhere(gb.grid_map == 0)
+    A, Cn = gb.num_agents, gb.num_cylinders
+    out = []
+    for _ in range(n):
+        cells = free[rng.permutation(len(free))[:A + 1 + Cn]]
+        xy = (cells - gb.num_grid // 2) * gb.grid_size
+        z = np.concatenate([np.full(A + 1, 1.2), np.where(np.arange(Cn) < 3, 0.6, -20.0)])
+        out.append(np.concatenate([xy, z[:, None]], axis=1).reshape(-1))
+    return np.asarray(out, dtype=np.float32)
+
+
+def test_genbuffer_samplenearby_and_history():
+    rng = np.random.default_rng(1)
+    gb = GenBuffer(3, 5, seed=2, buffer_length=64)
+    assert gb.task_dim == 18 + 3 * 3 and int((gb.grid_map == 0).sum()) == 45   # reference task_dim, 45 free cells
+    base = _valid_tasks(gb, 40, rng)
+    assert gb.sanity_ok(base).all()
+    bad = base.copy()
+    bad[:, 3:5] = bad[:, 0:2]                       # two drones in one cell -> rejected (:187-207)
+    assert not gb.sanity_ok(bad).any()
+    gb.init_history(base)
+    near = gb.samplenearby(500, expand_cylinders=1, expand_step=0.1)
+    assert near.shape == (500, gb.task_dim) and gb.sanity_ok(near).all()
+    b = gb.task_bounds()
+    assert (near >= b[:, 0] - 1e-6).all() and (near <= b[:, 1] + 1e-6).all()
+    assert (np.abs(near[:, :12].reshape(500, 4, 3)[..., 2] - 1.2) <= 0.1 + 1e-6).all()   # reference z window
+    # weights over eval_iter episodes -> mean; R_min..R_max filter; FPS trim to buffer_length
+    gb.insert(near)
+    for _ in range(3):
+        gb.insert_weights(rng.random(500) > 0.4)
+    gb.update()
+    assert gb._weight_buffer.shape == (500, 1) and gb._state_buffer.shape == near.shape
+    keep = ((gb._weight_buffer <= 0.9) & (gb._weight_buffer >= 0.5)).reshape(-1)
+    gb.insert_history(gb._state_buffer[keep])
+    assert gb._history_buffer.shape == (64, gb.task_dim)
+    easy = GenBuffer(3, 5, seed=0, buffer_length=20).init_easy_cases()
+    assert easy.shape == (20, 4, 3) and (np.abs(easy[..., 2] - 0.6) <= 0.1).all()
+
+
+def test_oracle_reset_from_task_vectors():
+    E, A, Cn = 40, 3, 5
+    cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": Cn, "min_num": 4}, "env": {"num_envs": E}})
+    c = config.resolve_hns_cfg(cfg)
+    gb = GenBuffer(A, Cn, seed=3)
+    tasks = _valid_tasks(gb, E, np.random.default_rng(4))
+    arrs = O.alloc_buffers(c)
+    O.reset_tasks(c, arrs, None, 5, 0, tasks, 16)
+    t3 = tasks.reshape(E, A + 1 + Cn, 3)
+    np.testing.assert_array_equal(arrs["drone_state"][16:, :, :3], t3[16:, :A])
+    np.testing.assert_array_equal(arrs["target_pos"][16:], t3[16:, A])
+    np.testing.assert_array_equal(arrs["cylinders"][16:], t3[16:, A + 1:])
+    # envs below task_first are sampled as in the plain reset (same Philox draws)
+    ref = O.alloc_buffers(c)
+    O.reset(c, ref, None, 5, 0)
+    np.testing.assert_array_equal(arrs["drone_state"][:16], ref["drone_state"][:16])
+    np.testing.assert_array_equal(arrs["cylinders"][:16], ref["cylinders"][:16])
+    np.testing.assert_allclose(np.linalg.norm(arrs["drone_state"][..., 3:7], axis=-1), 1.0, atol=1e-6)
+    assert np.isfinite(arrs["obs_self"]).all() and not arrs["progress"].any()
+
+
+@pytest.mark.gpu
+def test_envgen_env_on_gpu():
+    from hns_amd.env import HideAndSeek
+    from hns_amd.envgen import HideAndSeek_envgen
+    E, L = 512, 6
+    cfg = config.make_cfg({"name": "HideAndSeek_envgen", "num_agents": 3, "ratio_unif": 0.3, "eval_iter": 2, "R_min": 0.0, "R_max": 1.0,
+                           "use_particle_generator": 1, "expand_cylinders": 1,
+                           "cylinder": {"max_num": 5, "min_num": 4}, "env": {"num_envs": E, "max_episode_length": L}})
+    env = HideAndSeek.REGISTRY[cfg.task.name](cfg, headless=True)
+    assert isinstance(env, HideAndSeek_envgen)
+    env.set_seed(3)
+    env.reset()
+    assert env.num_unif == E and env.all_tasks.shape == (E, 27)      # empty history: everything uniform
+    first_tasks = env.all_tasks.copy()
+    g = torch.Generator(device=env.device).manual_seed(0)
+    for ep in range(5):
+        for t in range(L):
+            td = env.step(env.rand_step_input(torch.randn(E, 3, 4, generator=g, device=env.device)))
+        assert bool(td[("next", "done")].all())
+        rtd = env.rand_step_input()
+        rtd.set("_reset", td[("next", "done")].squeeze(-1))
+        epoch = env.reset_epoch
+        env.reset(rtd)
+        st = env.export_state()
+        placed = np.concatenate([st["drone_state"][..., :3].reshape(E, -1), st["target_pos"], st["cylinders"].reshape(E, -1)], axis=1)
+        np.testing.assert_array_equal(placed, env.all_tasks)          # every env sits on its task vector
+        if ep == 0:
+            np.testing.assert_array_equal(env.all_tasks, first_tasks)  # replayed for eval_iter episodes
+        # HIP task reset == oracle task reset
+        host = O.alloc_buffers(env.hcfg)
+        O.reset_tasks(env.hcfg, host, None, env.seed, epoch, env.all_tasks, 0 if ep % 2 == 0 else env.num_unif)
+        if ep % 2 == 0:
+            for k in ("drone_state", "target_pos", "cylinders", "obs_self", "obs_others", "obs_cylinders", "throttle"):
+                np.testing.assert_array_equal(host[k], st[k], err_msg=k)
+    hist = len(env.gen_buffer._history_buffer)
+    assert hist > 0 and float(env.stats["history_buffer"][0]) == hist
+    assert env.num_unif == E - min(hist, int(E * 0.7)) or env.update_iter != 0
+    assert float(env.stats["ratio_unif"][0]) == pytest.approx(0.3)
+    assert sum(float(env.stats[f"ratio_cylinders_{i}"][0]) for i in range(6)) == pytest.approx(1.0)
+    assert env.generator_seconds > 0
