@@ -8,7 +8,7 @@ at the natural 1/800 episode boundary).  Multi-GPU: one process per GPU (torchru
 env-index shards, weak scaling; the only collective is one RCCL all-gather of 5 fp64 values per
 64-step rollout (the advantage-normalisation moments named by north_star).
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live: every 8th step launch inside the
+Prints ONE JSON line (rank 0).  `roofline` is measured live: every 32nd step launch inside the
 timed region is bracketed by hipEvents on the launch stream (hns_enable_timing).
 `cpu_baseline` (N=1 only) times the CPU oracle — test infrastructure, never the product — on a
 bounded sample of the same workload.
@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--critic-state", action="store_true", help="also write the [E,A,20] centralised-critic state (critic_input: state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=200)
-    ap.add_argument("--time-every", type=int, default=8)
+    ap.add_argument("--time-every", type=int, default=32)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,10 +130,17 @@ def main():
     value = total_agent_steps / elapsed
     b_env = algorithmic_bytes_per_env(A, C, K)
     roofline = None
+    traffic = None
+    try:   # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), see profiles/
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        key = f"hns_step_kernel<{A}>|E{E}|C{C}|k{K}|critic_state_{'on' if args.critic_state else 'off'}"
+        traffic = tj.get(key, {}).get("traffic_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        pass
     if kernel_ms > 0:
         achieved = b_env * E / (kernel_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": f"hns_step_kernel<{A}>", "kernel_us": round(kernel_ms * 1e3, 2), "samples": n_samples,
                     "bytes_per_launch": b_env * E}
 

@@ -139,6 +139,8 @@ class HideAndSeek:
         self._set_specs()
         self._since_full_reset = 0
         self._needs_reset = True
+        self._next_cache = None
+        self._action_shape = torch.Size([self.num_envs, self.num_agents, 4])
 
     # ---- registry (isaac_env.py:154-161) ----------------------------------------------------------
     def __init_subclass__(cls, **kw):
@@ -253,23 +255,30 @@ class HideAndSeek:
         action = tensordict[("agents", "action")]
         if action.dtype != torch.float32 or not action.is_contiguous():
             action = action.float().contiguous()
-        if tuple(action.shape) != (self.num_envs, self.num_agents, 4):
-            raise ValueError(f"action shape {tuple(action.shape)} != {(self.num_envs, self.num_agents, 4)}")
-        self._check(self._lib.hns_step(self._env, C.c_void_p(action.data_ptr()), self._stream()), "hns_step")
+        if action.shape != self._action_shape:
+            raise ValueError(f"action shape {tuple(action.shape)} != {tuple(self._action_shape)}")
+        rc = self._lib.hns_step(self._env, action.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != 0:
+            self._check(rc, "hns_step")
         self._action_keepalive = action
         self._since_full_reset += 1
         b = self._bufs
         # hideandseek.py:1012-1015 — evader-speed curriculum; v_prey starts at its 1.3 cap with the
         # reference's defaults, in which case no host sync is ever needed
-        if self.v_prey < 1.3 and self._since_full_reset >= self.max_episode_length:
+        if self.v_prey < 1.3 - 1e-6 and self._since_full_reset >= self.max_episode_length:
             done = b["done"].bool()
             if bool(done.any()) and float(self.stats["success"].mean()) >= 0.98:
                 self.v_prey = min(1.3, self.v_prey + 0.05)
                 self._check(self._lib.hns_set_v_prey(self._env, C.c_float(self.v_prey)), "hns_set_v_prey")
-        nxt = self._obs_tensordict()
-        nxt.set(("agents", "reward"), b["reward"].unsqueeze(-1))
-        nxt.set("done", b["done"].view(torch.bool).unsqueeze(-1))
-        return TensorDict({"next": nxt}, self.batch_size)
+        if self._next_cache is None:
+            # every leaf is a view of a persistent buffer that the kernel just rewrote in place, so
+            # the output tree is built once and handed out again (the reference's collector runs
+            # with return_same_td=True, scripts/train.py:204)
+            nxt = self._obs_tensordict()
+            nxt.set(("agents", "reward"), b["reward"].unsqueeze(-1))
+            nxt.set("done", b["done"].view(torch.bool).unsqueeze(-1))
+            self._next_cache = TensorDict({"next": nxt}, self.batch_size)
+        return self._next_cache
 
     def _obs_tensordict(self):
         b = self._bufs
