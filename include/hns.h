@@ -160,6 +160,7 @@ typedef struct hns_buffers {
     float *reward;         /* [E,A]          agents.reward */
     float *action_error;   /* [E,A]          stats.action_error_order1 (transforms.py:441) */
     uint8_t *done;         /* [E]            bool */
+    uint8_t *detect;       /* [E]            bool, nullable: broadcast_detect (hideandseek.py:791), used by the TP_net input */
 } hns_buffers;
 
 /*

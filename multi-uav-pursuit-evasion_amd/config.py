@@ -229,10 +229,8 @@ def _f32(x):
 
 def resolve_hns_cfg(cfg, num_envs=None, env_index_offset=0, drone_params=None, write_critic_state=True):
     t = cfg.task
-    if int(cfg.algo.get("use_TP_net", 0)):
-        raise NotImplementedError(
-            "algo.use_TP_net=1 (trajectory-prediction LSTM inside the observation path, reference "
-            "hideandseek.py:805-854) is not built yet (SURVEY §8 N2); set algo.use_TP_net=0")
+    if int(cfg.algo.get("use_TP_net", 0)) and int(t.get("use_obstacles", 0)):
+        raise NotImplementedError("task.use_obstacles=1 (cylinders in the TP_net input, hideandseek.py:806-814) is not built")
     if t.get("drone_model", "Crazyflie").lower() != "crazyflie":
         raise NotImplementedError("only drone_model=Crazyflie is on the hot path")
     if not t.get("time_encoding", True):

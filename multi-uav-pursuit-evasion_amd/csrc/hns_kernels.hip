@@ -593,6 +593,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
         ST(HNS_ST_RETURN) += sum_rew * iA;
 #undef ST
         b.done[e] = (uint8_t)done;
+        if (b.detect) b.detect[e] = (uint8_t)det_any;
         b.progress[e] = progress;
 #pragma unroll
         for (int i = 0; i < HNS_NUM_STATS; ++i) b.stats[(size_t)i * E + e] = st[i];
@@ -692,7 +693,6 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
             if (c.init_mode == HNS_INIT_SCENARIO) tp[2] = c.fixed_target_pos[2];
             else tp[2] = c.z_lo + rng.uniform() * (c.z_hi - c.z_lo);
         }
-        b.target_vel[(size_t)e * 3] = 0.0f; b.target_vel[(size_t)e * 3 + 1] = 0.0f; b.target_vel[(size_t)e * 3 + 2] = 0.0f;
         if (task) {
             for (int k = 0; k < 3 * C; ++k) cyl[k] = task[3 * A + 3 + k];
         } else if (c.init_mode == HNS_INIT_SCENARIO) {
@@ -759,6 +759,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
             o[0] = c.mask_value; o[1] = c.mask_value; o[2] = c.mask_value;
         }
     }
+    if (env_wave && masked && b.detect) b.detect[e] = sDet[le];
     coop_s2g_masked<T>(b.drone_state + (size_t)e0 * A * 13, sDS, nenv * A * 13, A * 13, sMask);
     coop_cyl<T, false>(sCyl, b.cylinders + (size_t)e0 * C * 3, nenv, 3 * C, L.cyl_stride, p.cyl_magic, sMask);
     coop_s2g_masked<T>(b.target_pos + (size_t)e0 * 3, sTp, nenv * 3, 3, sMask);

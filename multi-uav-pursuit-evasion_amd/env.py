@@ -135,7 +135,17 @@ class HideAndSeek:
         self.info = TensorDict({"drone_state": b["drone_state"], "prev_action": b["prev_action"]}, self.batch_size)
         self.drone = SimpleNamespace(n=A, params=CRAZYFLIE, throttle=b["throttle"], name="crazyflie",
                                      MASS_0=torch.tensor([CRAZYFLIE["mass"]]), num_rotors=4)
-        self.TP = None                                                   # algo.use_TP_net=0 only
+        # algo.use_TP_net=1 (reference default): the trajectory predictor runs between the step kernel and
+        # the consumer (tp_net.py); the env owns the module, the learner trains it (scripts/train.py:180)
+        self.use_TP_net = int(cfg.algo.get("use_TP_net", 0))
+        self.TP, self._tp_obs = None, None
+        if self.use_TP_net:
+            from .tp_net import TPNet, TPObservation
+            t = cfg.task
+            fut = int(t.get("future_predcition_step", 5))
+            self.TP = TPNet(1 + 3 + 3 + 3 * A, 3 * fut, fut, int(t.get("window_step", 1))).to(self.device)   # hideandseek.py:317
+            self._tp_obs = TPObservation(self.TP, A, float(t.arena_size), float(t.max_height), self.max_episode_length,
+                                         int(t.get("history_step", 10)), fut, float(self.hcfg.mask_value))
         self._set_specs()
         self._since_full_reset = 0
         self._needs_reset = True
@@ -155,7 +165,7 @@ class HideAndSeek:
     # ---- specs (hideandseek.py:327-433, use_TP_net=0 branch) ------------------------------------------
     def _set_specs(self):
         A, K, E, dev = self.num_agents, self.obs_max_cylinder, self.num_envs, self.device
-        D = abi.HNS_SELF_DIM
+        D = abi.HNS_SELF_DIM + (3 * self._tp_obs.future_step if self.use_TP_net else 0)      # 20 or 35
         obs = {"state_self": TensorSpec((1, D)), "cylinders": TensorSpec((K, 5))}
         if A > 1:
             obs["state_others"] = TensorSpec((A - 1, 3))
@@ -163,9 +173,12 @@ class HideAndSeek:
         state_spec = CompositeSpec({"state_drones": TensorSpec((A, D)), "cylinders": TensorSpec((K, 5))})
         stats_spec = CompositeSpec({k: TensorSpec((1,)) for k in abi.STAT_NAMES})
         info_spec = CompositeSpec({"drone_state": TensorSpec((A, 13)), "prev_action": TensorSpec((A, 4), low=-1.0, high=1.0)})
+        agents = {"observation": observation_spec.expand(A), "state": state_spec}
+        if self.use_TP_net:                                              # hideandseek.py:368-374
+            agents["TP"] = CompositeSpec({"TP_input": TensorSpec((self._tp_obs.history_step, 7 + 3 * A)),
+                                          "TP_groundtruth": TensorSpec((1, 3)), "TP_done": TensorSpec((1, 3))})
         self.observation_spec = CompositeSpec({
-            "agents": CompositeSpec({"observation": observation_spec.expand(A), "state": state_spec}),
-            "stats": stats_spec, "info": info_spec}).expand(E).to(dev)
+            "agents": CompositeSpec(agents), "stats": stats_spec, "info": info_spec}).expand(E).to(dev)
         self.action_spec = CompositeSpec({"agents": CompositeSpec({"action": TensorSpec((A, 4), low=-1.0, high=1.0)})}).expand(E).to(dev)
         self.reward_spec = CompositeSpec({"agents": CompositeSpec({"reward": TensorSpec((A, 1))})}).expand(E).to(dev)
         self.done_spec = TensorSpec((E, 1), dtype=torch.bool, device=dev)
@@ -270,7 +283,7 @@ class HideAndSeek:
             if bool(done.any()) and float(self.stats["success"].mean()) >= 0.98:
                 self.v_prey = min(1.3, self.v_prey + 0.05)
                 self._check(self._lib.hns_set_v_prey(self._env, C.c_float(self.v_prey)), "hns_set_v_prey")
-        if self._next_cache is None:
+        if self._next_cache is None or self.use_TP_net:
             # every leaf is a view of a persistent buffer that the kernel just rewrote in place, so
             # the output tree is built once and handed out again (the reference's collector runs
             # with return_same_td=True, scripts/train.py:204)
@@ -282,6 +295,15 @@ class HideAndSeek:
 
     def _obs_tensordict(self):
         b = self._bufs
+        if self.use_TP_net:
+            ss, sd, tp = self._tp_obs(b["obs_self"], b["drone_state"][..., :3], b["target_pos"], b["target_vel"],
+                                      self.progress_buf, b["detect"])
+            obs = {"state_self": ss.unsqueeze(2), "cylinders": b["obs_cylinders"]}
+            if self.num_agents > 1:
+                obs["state_others"] = b["obs_others"]
+            state = {"state_drones": sd, "cylinders": b["obs_cylinders"]}
+            return TensorDict({"agents": {"observation": obs, "state": state, "TP": tp}, "stats": self.stats, "info": self.info},
+                              self.batch_size)
         obs = {"state_self": b["obs_self"].unsqueeze(2), "cylinders": b["obs_cylinders"]}
         if self.num_agents > 1:
             obs["state_others"] = b["obs_others"]

@@ -622,6 +622,7 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
               (c->write_critic_state && b->state_drones) ? b->state_drones + (size_t)e * A * HNS_SELF_DIM : NULL, &side);
         o_reward(c, A, C, K, ds, tp, cyl, b->progress[e], &side, b->action_error + (size_t)e * A, thr_diff,
                  stats, (size_t)E, b->reward + (size_t)e * A, b->done + e);
+        if (b->detect) b->detect[e] = (uint8_t)side.bdetect;
     }
     return HNS_OK;
 }
@@ -721,7 +722,6 @@ static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *m
             if (c->init_mode == HNS_INIT_SCENARIO) tp[2] = c->fixed_target_pos[2];
             else tp[2] = c->z_lo + o_uniform(&rng) * (c->z_hi - c->z_lo);
         }
-        for (int i = 0; i < 3; ++i) b->target_vel[(size_t)e * 3 + i] = 0.0f;
         if (task) {
             for (int k = 0; k < 3 * C; ++k) cyl[k] = task[3 * A + 3 + k];
         } else if (c->init_mode == HNS_INIT_SCENARIO) {
@@ -773,6 +773,7 @@ static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *m
         o_obs(c, A, C, K, ds, tp, cyl, 0.0f, b->obs_self + (size_t)e * A * HNS_SELF_DIM,
               b->obs_others + (size_t)e * A * (A - 1) * 3, b->obs_cylinders + (size_t)e * A * K * 5,
               (c->write_critic_state && b->state_drones) ? b->state_drones + (size_t)e * A * HNS_SELF_DIM : NULL, &side);
+        if (b->detect) b->detect[e] = (uint8_t)side.bdetect;
     }
     return HNS_OK;
 }

@@ -924,5 +924,61 @@ def gen_hover():
          meta=np.array([E, T, max_len], dtype=np.int64))
 
 
+# --------------------------------------------------------------------------------------
+# TP_net inside the observation: omni_drones/learning/mappo.py:572-589 +
+# hideandseek.py:805-854.  TP_net is a plain nn.Module; its class is AST-extracted because the
+# module top of mappo.py imports torchrl.
+# --------------------------------------------------------------------------------------
+tp_ns = dict(torch=torch, nn=torch.nn)
+tp_cls = None
+
+
+def _tp_class():
+    global tp_cls
+    if tp_cls is None:
+        src = open(os.path.join(REF, "omni_drones/learning/mappo.py")).read()
+        tree = ast.parse(src)
+        node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "TP_net"][0]
+        exec(compile(ast.get_source_segment(src, node), "<ref:TP_net>", "exec"), tp_ns)
+        tp_cls = tp_ns["TP_net"]
+    return tp_cls
+
+
+def gen_tp_obs():
+    import collections
+    g = torch.Generator().manual_seed(20241020)
+    E, A, C, T = 48, 3, 5, 14
+    env = ShimEnv(E, A, C, {"drone_detect_radius": 0.9}, max_len=20)
+    env.use_TP_net = 1
+    env.future_predcition_step, env.history_step, env.window_step = 5, 10, 1
+    torch.manual_seed(123)
+    env.TP = _tp_class()(input_dim=1 + 3 + 3 + 3 * A, output_dim=15, future_predcition_step=5, window_step=1)
+    env.history_data = collections.deque(maxlen=10)
+    weights = {k: v.detach().clone() for k, v in env.TP.state_dict().items()}
+    rec = {k: [] for k in ["pos", "rot", "vel", "throttle", "tpos", "tvel", "progress", "state_self", "state_drones",
+                           "TP_input", "TP_groundtruth", "TP_done", "broadcast_detect"]}
+    cyl = rand_scene(g, E, A, C)["cyl"]
+    env.cylinders.pos = cyl
+    for t in range(T):
+        s = rand_scene(g, E, A, C)
+        thr = torch.rand(E, A, 4, generator=g)
+        env.drone.rotor_module.throttle.data.copy_(thr)
+        env.drone.set_state(s["pos"], s["rot"], s["vel"])
+        env.target.pos = s["tpos"]
+        env.target.vel = torch.randn(E, 1, 6, generator=g)
+        env.progress_buf = torch.full((E,), float(t + 6))
+        with torch.no_grad():
+            td = env._compute_state_and_obs()
+        tp = td[("agents", "TP")]
+        for k, v in dict(pos=s["pos"], rot=s["rot"], vel=s["vel"], throttle=thr, tpos=s["tpos"], tvel=env.target.vel[..., :3],
+                         progress=env.progress_buf, state_self=td[("agents", "observation")]["state_self"],
+                         state_drones=td[("agents", "state")]["state_drones"], TP_input=tp["TP_input"],
+                         TP_groundtruth=tp["TP_groundtruth"], TP_done=tp["TP_done"], broadcast_detect=env.broadcast_detect).items():
+            rec[k].append(v.clone())
+    save("g_tp_obs", cyl=cyl, **{k: torch.stack(v) for k, v in rec.items()},
+         **{"w_" + k.replace(".", "_"): v for k, v in weights.items()}, meta=np.array([E, A, C, T, 20], dtype=np.int64))
+
+
 if __name__ == "__main__":
     gen_hover()
+    gen_tp_obs()

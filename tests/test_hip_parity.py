@@ -177,3 +177,50 @@ def test_error_paths():
     with pytest.raises(HnsError):
         make_env(64, 3, 8, K=5)                                # obs_max_cylinder > 4 unsupported by the kernels
     assert HideAndSeek.REGISTRY["hideandseek"] is HideAndSeek
+
+
+def test_tp_net_observation_on_gpu(golden):
+    """algo.use_TP_net=1 (the reference's default): 35-dim rows and the TP TensorDict on the GPU path."""
+    from hns_amd.env import HideAndSeek
+    g = golden("g_tp_obs")
+    E, A, C, T, max_len = (int(x) for x in g["meta"])
+    cfg = config.make_cfg({"num_agents": A, "drone_detect_radius": 0.9, "cylinder": {"max_num": C, "min_num": 4},
+                           "env": {"num_envs": E, "max_episode_length": max_len}}, algo={"use_TP_net": 1})
+    env = HideAndSeek(cfg, headless=True)
+    sd = {k: torch.from_numpy(g["w_" + k.replace(".", "_")]) for k in env.TP.state_dict()}
+    env.TP.load_state_dict(sd)
+    td = env.reset()
+    assert td[("agents", "observation", "state_self")].shape == (E, A, 1, 35)
+    assert td[("agents", "TP", "TP_input")].shape == (E, 10, 16)
+    td = env.step(env.rand_step_input())
+    nxt = td["next"]
+    assert nxt[("agents", "state", "state_drones")].shape == (E, A, 35)
+    assert nxt[("agents", "TP", "TP_done")].shape == (E, 1) and nxt[("agents", "TP", "TP_groundtruth")].shape == (E, 3)
+    # the assembled rows keep the kernel's 20 values around the 15 predicted relative positions
+    ss = nxt[("agents", "observation", "state_self")][:, :, 0]
+    assert torch.equal(ss[..., :3], env._bufs["obs_self"][..., :3]) and torch.equal(ss[..., 18:], env._bufs["obs_self"][..., 3:])
+    pred = env.export_state()["drone_state"][..., None, :3] - ss[..., 3:18].reshape(E, A, 5, 3).cpu().numpy()
+    assert np.allclose(pred[:, 0], pred[:, 1], atol=1e-5)            # every pursuer sees the same predicted evader path
+    assert (np.abs(pred[..., :2]) <= 0.45 + 1e-5).all() and (pred[..., 2] >= -1e-5).all() and (pred[..., 2] <= 1.2 + 1e-5).all()
+    # replay the golden call sequence through the GPU path (kernel obs + MIOpen LSTM)
+    env2 = HideAndSeek(cfg, headless=True)
+    env2.TP.load_state_dict(sd)
+    env2.reset()
+    env2._tp_obs.history.clear()
+    st = env2.export_state()
+    st["cylinders"][:] = g["cyl"]
+    for t in range(T):
+        st["drone_state"][..., 0:3], st["drone_state"][..., 3:7], st["drone_state"][..., 7:13] = g["pos"][t], g["rot"][t], g["vel"][t]
+        st["target_pos"][:] = g["tpos"][t][:, 0]
+        st["target_vel"][:] = g["tvel"][t][:, 0]
+        st["progress"][:] = g["progress"][t]
+        env2.import_state(st)
+        host = {k: v.copy() for k, v in st.items()}
+        O.obs_reward(env2.hcfg, host)                                   # oracle obs on the same state -> device buffers
+        env2._bufs["obs_self"].copy_(torch.from_numpy(host["obs_self"]))
+        _, bdet, _ = O.obs_reward(env2.hcfg, host)
+        env2._bufs["detect"].copy_(torch.from_numpy(bdet.astype(np.uint8)))
+        o = env2._obs_tensordict()
+        np.testing.assert_allclose(o[("agents", "observation", "state_self")][:, :, 0].cpu().numpy(), g["state_self"][t][:, :, 0],
+                                   rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(o[("agents", "TP", "TP_input")].cpu().numpy(), g["TP_input"][t], rtol=1e-6, atol=1e-6)

@@ -1,0 +1,50 @@
+"""SURVEY §8 N2 — TP_net inside the observation: oracle observation (20-dim rows, broadcast_detect)
++ hns_amd.tp_net assembly against the reference's `_compute_state_and_obs` with use_TP_net=1
+(golden g_tp_obs: 14 consecutive calls, so the 10-frame history is exercised)."""
+import numpy as np
+import torch
+
+import hns_oracle as O
+from hns_amd import config
+from hns_amd.tp_net import TPNet, TPObservation
+
+
+def _load_weights(tp, g):
+    sd = {k: torch.from_numpy(g["w_" + k.replace(".", "_")]) for k in tp.state_dict()}
+    tp.load_state_dict(sd)
+
+
+def test_tp_observation_matches_reference(golden):
+    g = golden("g_tp_obs")
+    E, A, C, T, max_len = (int(x) for x in g["meta"])
+    cfg = config.make_cfg({"num_agents": A, "drone_detect_radius": 0.9, "cylinder": {"max_num": C, "min_num": 4},
+                           "env": {"num_envs": E, "max_episode_length": max_len}})
+    c = config.resolve_hns_cfg(cfg)
+    tp = TPNet(7 + 3 * A, 15, 5, 1)
+    _load_weights(tp, g)
+    helper = TPObservation(tp, A, 0.9, 1.2, max_len)
+    arrs = O.alloc_buffers(c)
+    arrs["cylinders"][:] = g["cyl"]
+    saw_masked = False
+    for t in range(T):
+        arrs["drone_state"][..., 0:3], arrs["drone_state"][..., 3:7], arrs["drone_state"][..., 7:13] = g["pos"][t], g["rot"][t], g["vel"][t]
+        arrs["throttle"][:] = g["throttle"][t]
+        arrs["target_pos"][:] = g["tpos"][t][:, 0]
+        arrs["progress"][:] = g["progress"][t]
+        _, bdet, _ = O.obs_reward(c, arrs)
+        assert (bdet == g["broadcast_detect"][t][:, 0]).all()
+        saw_masked |= bool((~bdet).any())
+        ss, sd, tpd = helper(torch.from_numpy(arrs["obs_self"]), torch.from_numpy(g["pos"][t]), torch.from_numpy(g["tpos"][t][:, 0]),
+                             torch.from_numpy(g["tvel"][t][:, 0]), torch.from_numpy(g["progress"][t]), torch.from_numpy(bdet))
+        np.testing.assert_allclose(tpd["TP_input"].numpy(), g["TP_input"][t], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(ss.numpy(), g["state_self"][t][:, :, 0], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(sd.numpy(), g["state_drones"][t], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(tpd["TP_groundtruth"].numpy(), g["TP_groundtruth"][t], rtol=1e-6, atol=1e-6)
+        assert (tpd["TP_done"].numpy() == g["TP_done"][t]).all()
+    assert saw_masked and ss.shape == (E, A, 35)
+
+
+def test_tp_net_state_dict_is_reference_compatible():
+    tp = TPNet(16, 15, 5, 1)
+    assert set(tp.state_dict()) == {"lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0", "fc.weight", "fc.bias"}
+    assert tp(torch.zeros(4, 10, 16)).shape == (4, 15)
