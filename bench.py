@@ -56,9 +56,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm; HNS_DIST_BACKEND=gloo only for smoke-testing the N>1 path on a 1-GPU box
+        dist.init_process_group(os.environ.get("HNS_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -121,7 +123,7 @@ def main():
     lib.hns_enable_timing(henv, 0)
     kernel_ms, n_samples = env.kernel_ms()
     if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

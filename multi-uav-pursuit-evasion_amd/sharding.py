@@ -40,9 +40,10 @@ def allgather_moments(local):
     """The rollout's single collective: every rank gets the [world, MOMENT_DIM] table."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local.unsqueeze(0)
-    parts = [torch.empty_like(local) for _ in range(dist.get_world_size())]
-    dist.all_gather(parts, local.contiguous())
-    return torch.stack(parts)
+    src = local.contiguous() if dist.get_backend() == "nccl" else local.cpu()   # gloo (CPU tests) gathers host tensors
+    parts = [torch.empty_like(src) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, src)
+    return torch.stack(parts).to(local.device)
 
 
 def global_mean_std(table):
