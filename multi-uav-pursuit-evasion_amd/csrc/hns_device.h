@@ -69,45 +69,47 @@ HNS_DEV void d_sincosf(float x, float &s_out, float &c_out) {
 }
 
 HNS_DEV float d_clamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
-HNS_DEV float d_norm3(float x, float y, float z) { return __builtin_sqrtf((x * x + y * y) + z * z); }
+HNS_DEV float d_norm3(float x, float y, float z) { return __builtin_sqrtf(HNS_FMA(z, z, HNS_FMA(y, y, x * x))); }
+HNS_DEV float d_norm2(float x, float y) { return __builtin_sqrtf(HNS_FMA(y, y, x * x)); }
 
 struct V3 { float x, y, z; };
 struct Q4 { float w, x, y, z; };
 
-// omni_drones/utils/torch.py:183-191 (quat_rotate) / :194-202 (quat_rotate_inverse)
+// omni_drones/utils/torch.py:183-191 (quat_rotate) / :194-202 (quat_rotate_inverse):
+// a = v(2w^2-1), b = 2w (q_vec x v), c = 2 q_vec (q_vec . v); result a +- b + c, fused
 template <bool INVERSE>
 HNS_DEV V3 d_quat_rot(const Q4 &q, const V3 &v) {
-    float s = 2.0f * (q.w * q.w) - 1.0f;
-    float cx = q.y * v.z - q.z * v.y;
-    float cy = q.z * v.x - q.x * v.z;
-    float cz = q.x * v.y - q.y * v.x;
-    float dot = (q.x * v.x + q.y * v.y) + q.z * v.z;
-    float a0 = v.x * s, a1 = v.y * s, a2 = v.z * s;
-    float b0 = (cx * q.w) * 2.0f, b1 = (cy * q.w) * 2.0f, b2 = (cz * q.w) * 2.0f;
-    float c0 = (q.x * dot) * 2.0f, c1 = (q.y * dot) * 2.0f, c2 = (q.z * dot) * 2.0f;
+    float w2 = 2.0f * q.w;
+    float s = HNS_FMA(w2, q.w, -1.0f);
+    float cx = HNS_FMA(q.y, v.z, -(q.z * v.y));
+    float cy = HNS_FMA(q.z, v.x, -(q.x * v.z));
+    float cz = HNS_FMA(q.x, v.y, -(q.y * v.x));
+    float dot2 = 2.0f * HNS_FMA(q.z, v.z, HNS_FMA(q.y, v.y, q.x * v.x));
+    float bw = INVERSE ? -w2 : w2;
     V3 o;
-    if (INVERSE) { o.x = (a0 - b0) + c0; o.y = (a1 - b1) + c1; o.z = (a2 - b2) + c2; }
-    else         { o.x = (a0 + b0) + c0; o.y = (a1 + b1) + c1; o.z = (a2 + b2) + c2; }
+    o.x = HNS_FMA(q.x, dot2, HNS_FMA(cx, bw, v.x * s));
+    o.y = HNS_FMA(q.y, dot2, HNS_FMA(cy, bw, v.y * s));
+    o.z = HNS_FMA(q.z, dot2, HNS_FMA(cz, bw, v.z * s));
     return o;
 }
 
-// quat_rotate(q, x_hat) and quat_rotate(q, (0,0,t)) with the exact-zero products of the general
-// formula dropped (identical values for finite q): heading/up (multirotor.py:613-614), thrust (:491)
+// quat_rotate(q, x_hat) and quat_rotate(q, (0,0,t)): the same formula with the zero products of the
+// basis vector dropped: heading/up (multirotor.py:613-614), thrust vector (:491)
 HNS_DEV V3 d_quat_rot_x(const Q4 &q) {
-    float s = 2.0f * (q.w * q.w) - 1.0f;
+    float s = HNS_FMA(2.0f * q.w, q.w, -1.0f);
     V3 o;
-    o.x = s + (q.x * q.x) * 2.0f;
-    o.y = (q.z * q.w) * 2.0f + (q.y * q.x) * 2.0f;
-    o.z = (-q.y * q.w) * 2.0f + (q.z * q.x) * 2.0f;
+    o.x = HNS_FMA(2.0f * q.x, q.x, s);
+    o.y = 2.0f * HNS_FMA(q.z, q.w, q.y * q.x);
+    o.z = 2.0f * HNS_FMA(q.z, q.x, -(q.y * q.w));
     return o;
 }
 HNS_DEV V3 d_quat_rot_z(const Q4 &q, float t) {
-    float s = 2.0f * (q.w * q.w) - 1.0f;
+    float s = HNS_FMA(2.0f * q.w, q.w, -1.0f);
     float dot = q.z * t;
     V3 o;
-    o.x = ((q.y * t) * q.w) * 2.0f + (q.x * dot) * 2.0f;
-    o.y = ((-(q.x * t)) * q.w) * 2.0f + (q.y * dot) * 2.0f;
-    o.z = t * s + (q.z * dot) * 2.0f;
+    o.x = 2.0f * HNS_FMA(q.y * t, q.w, q.x * dot);
+    o.y = 2.0f * HNS_FMA(q.y, dot, -((q.x * t) * q.w));
+    o.z = HNS_FMA(2.0f * q.z, dot, t * s);
     return o;
 }
 
@@ -207,12 +209,12 @@ HNS_DEV V3 d_downwash_pair(const V3 &pi, const V3 &pj, const V3 &tj_w) {
     float n = d_norm3(tj_w.x, tj_w.y, tj_w.z);
     float dx = tj_w.x / (n + 1e-6f), dy = tj_w.y / (n + 1e-6f), dz = tj_w.z / (n + 1e-6f);
     float rx = pj.x - pi.x, ry = pj.y - pi.y, rz = pj.z - pi.z;
-    float zd = (rx * dx + ry * dy) + rz * dz;
-    float ox = rx - zd * dx, oy = ry - zd * dy, oz = rz - zd * dz;
+    float zd = HNS_FMA(rz, dz, HNS_FMA(ry, dy, rx * dx));
+    float ox = HNS_FMA(-zd, dx, rx), oy = HNS_FMA(-zd, dy, ry), oz = HNS_FMA(-zd, dz, rz);
     float r = d_norm3(ox, oy, oz);
     float z = zd < 0.0f ? 0.0f : zd;
     float u = (2.0f * r) / z;
-    float den = 1.0f + 0.3f * z;
+    float den = HNS_FMA(0.3f, z, 1.0f);
     float v = d_expf(-0.5f * (u * u)) / (den * den);
     V3 f = {v * -tj_w.x, v * -tj_w.y, v * -tj_w.z};
     return f;
@@ -240,9 +242,9 @@ struct LosLine {          // per (drone, evader) constants of the line-of-sight 
 HNS_DEV LosLine d_los_setup(const hns_cfg &c, const V3 &dp, const V3 &tp) {
     LosLine l;
     l.diffx = dp.x - tp.x; l.diffy = dp.y - tp.y;
-    float den = __builtin_sqrtf(l.diffx * l.diffx + l.diffy * l.diffy);
+    float den = d_norm2(l.diffx, l.diffy);
     l.dx = tp.x - dp.x; l.dy = tp.y - dp.y;
-    float dent = l.dx * l.dx + l.dy * l.dy;
+    float dent = HNS_FMA(l.dy, l.dy, l.dx * l.dx);
     l.d1 = den + 1e-5f; l.dt1 = dent + 1e-5f;
     float p = c.cylinder_size * l.d1;
     l.plo = p * 0.99999952316284f; l.phi = p * 1.00000047683716f;   // 1 -+ 2^-21
@@ -253,8 +255,8 @@ HNS_DEV LosLine d_los_setup(const hns_cfg &c, const V3 &dp, const V3 &tp) {
 // quotient lies in the band where only the exact division can decide (or an input is NaN).
 HNS_DEV bool d_los_cylinder_fast(const LosLine &l, float ccx, float ccy, float ccz, bool &uncertain) {
     float d2x = ccx - l.tpx, d2y = ccy - l.tpy;
-    float num = __builtin_fabsf(l.diffx * d2y - l.diffy * d2x);
-    float numt = (ccx - l.dpx) * l.dx + (ccy - l.dpy) * l.dy;
+    float num = __builtin_fabsf(HNS_FMA(l.diffx, d2y, -(l.diffy * d2x)));
+    float numt = HNS_FMA(ccy - l.dpy, l.dy, (ccx - l.dpx) * l.dx);
     bool lo = num < l.plo, hi = num > l.phi;
     bool tpos = numt >= 0.0f, tneg = numt < -1e-30f;
     uncertain = uncertain || !(lo || hi) || !(tpos || tneg);
@@ -263,8 +265,8 @@ HNS_DEV bool d_los_cylinder_fast(const LosLine &l, float ccx, float ccy, float c
 // Exact form: divide and compare, as the reference does (hideandseek.py:47-103)
 HNS_DEV bool d_los_cylinder(const hns_cfg &c, const LosLine &l, float ccx, float ccy, float ccz) {
     float d2x = ccx - l.tpx, d2y = ccy - l.tpy;
-    float num = __builtin_fabsf(l.diffx * d2y - l.diffy * d2x);
-    float numt = (ccx - l.dpx) * l.dx + (ccy - l.dpy) * l.dy;
+    float num = __builtin_fabsf(HNS_FMA(l.diffx, d2y, -(l.diffy * d2x)));
+    float numt = HNS_FMA(ccy - l.dpy, l.dy, (ccx - l.dpx) * l.dx);
     bool blocked = (num / l.d1) <= c.cylinder_size;
     float t = numt / l.dt1;
     bool on = (t >= 0.0f) && (t <= 1.0f);
@@ -299,9 +301,9 @@ HNS_DEV V3 d_prey_pursuer_term(const hns_cfg &c, const V3 &dp, const V3 &tp, boo
 }
 // arena walls/ceiling/floor (:1090-1112); also reports the out-of-arena flag (:1096-1098)
 HNS_DEV V3 d_prey_arena_term(const hns_cfg &c, const V3 &tp, bool &out_of_arena) {
-    float od = __builtin_sqrtf(tp.x * tp.x + tp.y * tp.y);
+    float od = d_norm2(tp.x, tp.y);
     float dirx = -tp.x / (od + 1e-5f), diry = -tp.y / (od + 1e-5f);
-    bool out = (tp.x * tp.x + tp.y * tp.y) > c.arena_sq;
+    bool out = HNS_FMA(tp.y, tp.y, tp.x * tp.x) > c.arena_sq;
     out_of_arena = out;
     float outf = out ? 1.0f : 0.0f, nout = out ? 0.0f : 1.0f;
     float rin = 1.0f / ((c.arena_size - od) + 1e-5f);
@@ -322,7 +324,7 @@ HNS_DEV V3 d_prey_arena_term(const hns_cfg &c, const V3 &tp, bool &out_of_arena)
 // repulsion of one cylinder (:1129-1136)
 HNS_DEV void d_prey_cylinder_term(const hns_cfg &c, const V3 &tp, float ccx, float ccy, float ccz, float &tx, float &ty) {
     float rx = tp.x - ccx, ry = tp.y - ccy;
-    float dc = __builtin_sqrtf(rx * rx + ry * ry);
+    float dc = d_norm2(rx, ry);
     float db = dc - c.cylinder_size;
     float act = (!(ccz < 0.0f) && (dc < c.target_detect_radius)) ? 1.0f : 0.0f;
     float rec = 1.0f / (db + 1e-5f);

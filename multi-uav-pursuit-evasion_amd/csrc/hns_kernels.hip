@@ -207,7 +207,7 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
         const float ccx = cyl[3 * k], ccy = cyl[3 * k + 1], ccz = cyl[3 * k + 2];
         any_block = d_los_cylinder_fast(los, ccx, ccy, ccz, los_uncertain) || any_block;
         const float ex = s.pos.x - ccx, ey = s.pos.y - ccy, ez = s.pos.z - ccz;
-        const float d2 = (ex * ex + ey * ey) + ez * ez;
+        const float d2 = HNS_FMA(ez, ez, HNS_FMA(ey, ey, ex * ex));          // the radicand of d_norm3
         uint32_t nk = (__float_as_uint(d2) & 0xFFFFFFF0u) | (uint32_t)k;
 #pragma unroll
         for (int i = 0; i < kTrack; ++i) {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             if (sidx < K) {
                 const float *cy = cyl + 3 * knn_idx[sidx];
                 float rx = s.pos.x - cy[0], ry = s.pos.y - cy[1];
-                float dxy = __builtin_sqrtf(rx * rx + ry * ry);
+                float dxy = d_norm2(rx, ry);
                 float hit = ((dxy - c.cylinder_size) < c.collision_radius) ? 1.0f : 0.0f;
                 if (knn_masked[sidx]) hit = 0.0f;
                 cc = (sidx == 0) ? hit : cc + hit;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             cd = (o == 0) ? hit : cd + hit;
         }
         cr = cr + -c.collision_coef * cd;
-        float cw = ((s.pos.z > c.max_height) ? 1.0f : 0.0f) + (((s.pos.x * s.pos.x + s.pos.y * s.pos.y) > c.arena_sq) ? 1.0f : 0.0f);
+        float cw = ((s.pos.z > c.max_height) ? 1.0f : 0.0f) + ((HNS_FMA(s.pos.y, s.pos.y, s.pos.x * s.pos.x) > c.arena_sq) ? 1.0f : 0.0f);
         cr = cr + -c.collision_coef * cw;
         float sm = c.smoothness_coef * d_expf(-aerr);
         if (!c.use_deployment) sm = 0.0f;

@@ -89,43 +89,41 @@ static void o_sincosf(float x, float *s_out, float *c_out) {
 }
 
 static inline float o_clamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
-static inline float o_norm3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
+static inline float o_norm3(float x, float y, float z) { return sqrtf(O_FMA(z, z, O_FMA(y, y, x * x))); }
+static inline float o_norm2(float x, float y) { return sqrtf(O_FMA(y, y, x * x)); }
 
 /* omni_drones/utils/torch.py:183-191 (quat_rotate) and :194-202 (quat_rotate_inverse) */
 static void o_quat_rot(const float q[4], const float v[3], float out[3], int inverse) {
+    /* a = v(2w^2-1), b = 2w (q_vec x v), c = 2 q_vec (q_vec . v); result a +- b + c, fused */
     float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
-    float s = 2.0f * (qw * qw) - 1.0f;
-    float cx = qy * v[2] - qz * v[1];
-    float cy = qz * v[0] - qx * v[2];
-    float cz = qx * v[1] - qy * v[0];
-    float dot = (qx * v[0] + qy * v[1]) + qz * v[2];
-    float a0 = v[0] * s, a1 = v[1] * s, a2 = v[2] * s;
-    float b0 = (cx * qw) * 2.0f, b1 = (cy * qw) * 2.0f, b2 = (cz * qw) * 2.0f;
-    float c0 = (qx * dot) * 2.0f, c1 = (qy * dot) * 2.0f, c2 = (qz * dot) * 2.0f;
-    if (inverse) {
-        out[0] = (a0 - b0) + c0; out[1] = (a1 - b1) + c1; out[2] = (a2 - b2) + c2;
-    } else {
-        out[0] = (a0 + b0) + c0; out[1] = (a1 + b1) + c1; out[2] = (a2 + b2) + c2;
-    }
+    float w2 = 2.0f * qw;
+    float s = O_FMA(w2, qw, -1.0f);
+    float cx = O_FMA(qy, v[2], -(qz * v[1]));
+    float cy = O_FMA(qz, v[0], -(qx * v[2]));
+    float cz = O_FMA(qx, v[1], -(qy * v[0]));
+    float dot2 = 2.0f * O_FMA(qz, v[2], O_FMA(qy, v[1], qx * v[0]));
+    float bw = inverse ? -w2 : w2;
+    out[0] = O_FMA(qx, dot2, O_FMA(cx, bw, v[0] * s));
+    out[1] = O_FMA(qy, dot2, O_FMA(cy, bw, v[1] * s));
+    out[2] = O_FMA(qz, dot2, O_FMA(cz, bw, v[2] * s));
 }
 
-/* quat_rotate(q, x_hat) and quat_rotate(q, (0,0,t)) with the exact-zero products of the general
- * formula dropped (x*0 = 0 and y+0 = y for finite x, y): identical values for finite q.
- * Used for heading/up (multirotor.py:613-614) and the thrust vector (multirotor.py:491). */
+/* quat_rotate(q, x_hat) and quat_rotate(q, (0,0,t)): the same formula with the zero products of the
+ * basis vector dropped.  Used for heading/up (multirotor.py:613-614) and the thrust vector (:491). */
 static void o_quat_rot_x(const float q[4], float out[3]) {
     float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
-    float s = 2.0f * (qw * qw) - 1.0f;
-    out[0] = s + (qx * qx) * 2.0f;
-    out[1] = (qz * qw) * 2.0f + (qy * qx) * 2.0f;
-    out[2] = (-qy * qw) * 2.0f + (qz * qx) * 2.0f;
+    float s = O_FMA(2.0f * qw, qw, -1.0f);
+    out[0] = O_FMA(2.0f * qx, qx, s);
+    out[1] = 2.0f * O_FMA(qz, qw, qy * qx);
+    out[2] = 2.0f * O_FMA(qz, qx, -(qy * qw));
 }
 static void o_quat_rot_z(const float q[4], float t, float out[3]) {
     float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
-    float s = 2.0f * (qw * qw) - 1.0f;
+    float s = O_FMA(2.0f * qw, qw, -1.0f);
     float dot = qz * t;
-    out[0] = ((qy * t) * qw) * 2.0f + (qx * dot) * 2.0f;
-    out[1] = ((-(qx * t)) * qw) * 2.0f + (qy * dot) * 2.0f;
-    out[2] = t * s + (qz * dot) * 2.0f;
+    out[0] = 2.0f * O_FMA(qy * t, qw, qx * dot);
+    out[1] = 2.0f * O_FMA(qy, dot, -((qx * t) * qw));
+    out[2] = O_FMA(2.0f * qz, dot, t * s);
 }
 
 /* omni_drones/utils/torch.py:110-127 */
@@ -224,12 +222,12 @@ static void o_downwash_pair(const float pi[3], const float pj[3], const float tj
     float n = o_norm3(tj_w[0], tj_w[1], tj_w[2]);
     float d[3] = {tj_w[0] / (n + 1e-6f), tj_w[1] / (n + 1e-6f), tj_w[2] / (n + 1e-6f)};
     float rel[3] = {pj[0] - pi[0], pj[1] - pi[1], pj[2] - pi[2]};
-    float zd = (rel[0] * d[0] + rel[1] * d[1]) + rel[2] * d[2];
-    float rx = rel[0] - zd * d[0], ry = rel[1] - zd * d[1], rz = rel[2] - zd * d[2];
+    float zd = O_FMA(rel[2], d[2], O_FMA(rel[1], d[1], rel[0] * d[0]));
+    float rx = O_FMA(-zd, d[0], rel[0]), ry = O_FMA(-zd, d[1], rel[1]), rz = O_FMA(-zd, d[2], rel[2]);
     float r = o_norm3(rx, ry, rz);
     float z = zd < 0.0f ? 0.0f : zd;
     float u = (2.0f * r) / z;
-    float den = 1.0f + 0.3f * z;
+    float den = O_FMA(0.3f, z, 1.0f);
     float v = o_expf(-0.5f * (u * u)) / (den * den);
     f[0] = v * -tj_w[0]; f[1] = v * -tj_w[1]; f[2] = v * -tj_w[2];
 }
@@ -239,17 +237,17 @@ static void o_downwash_pair(const float pi[3], const float pj[3], const float tj
  * ---------------------------------------------------------------------------------------- */
 static int o_blocked(const hns_cfg *c, int C, const float dp[3], const float tp[3], const float *cyl) {
     float diffx = dp[0] - tp[0], diffy = dp[1] - tp[1];
-    float den = sqrtf(diffx * diffx + diffy * diffy);
+    float den = o_norm2(diffx, diffy);
     float dx = tp[0] - dp[0], dy = tp[1] - dp[1];
-    float dent = dx * dx + dy * dy;
+    float dent = O_FMA(dy, dy, dx * dx);
     int any = 0;
     for (int k = 0; k < C; ++k) {
         const float *cc = cyl + 3 * k;
         float d2x = cc[0] - tp[0], d2y = cc[1] - tp[1];
-        float num = fabsf(diffx * d2y - diffy * d2x);
+        float num = fabsf(O_FMA(diffx, d2y, -(diffy * d2x)));
         float dist = num / (den + 1e-5f);
         int blocked = dist <= c->cylinder_size;
-        float numt = (cc[0] - dp[0]) * dx + (cc[1] - dp[1]) * dy;
+        float numt = O_FMA(cc[1] - dp[1], dy, (cc[0] - dp[0]) * dx);
         float t = numt / (dent + 1e-5f);
         int on = (t >= 0.0f) && (t <= 1.0f);
         int ground = cc[2] > 0.0f;
@@ -279,9 +277,9 @@ static void o_prey(const hns_cfg *c, int A, int C, const float *drone_pos, const
         }
     }
     /* arena  :1094-1112 */
-    float od = sqrtf(tp[0] * tp[0] + tp[1] * tp[1]);
+    float od = o_norm2(tp[0], tp[1]);
     float dirx = -tp[0] / (od + 1e-5f), diry = -tp[1] / (od + 1e-5f);
-    int out = (tp[0] * tp[0] + tp[1] * tp[1]) > c->arena_sq;
+    int out = O_FMA(tp[1], tp[1], tp[0] * tp[0]) > c->arena_sq;
     if (out_of_arena_stat) *out_of_arena_stat = ((*out_of_arena_stat != 0.0f) || out) ? 1.0f : 0.0f;
     float outf = out ? 1.0f : 0.0f, nout = out ? 0.0f : 1.0f;
     float rin = 1.0f / ((c->arena_size - od) + 1e-5f);
@@ -302,7 +300,7 @@ static void o_prey(const hns_cfg *c, int A, int C, const float *drone_pos, const
     for (int k = 0; k < C; ++k) {
         const float *cc = cyl + 3 * k;
         float rx = tp[0] - cc[0], ry = tp[1] - cc[1];
-        float dc = sqrtf(rx * rx + ry * ry);
+        float dc = o_norm2(rx, ry);
         float db = dc - c->cylinder_size;
         float act = (!(cc[2] < 0.0f) && (dc < c->target_detect_radius)) ? 1.0f : 0.0f;
         float rec = 1.0f / (db + 1e-5f);
@@ -475,7 +473,7 @@ static void o_reward(const hns_cfg *c, int A, int C, int K, const float *drone_s
         for (int s = 0; s < K; ++s) {
             const float *cy = cyl + 3 * side->knn_idx[a][s];
             float rx = ds[0] - cy[0], ry = ds[1] - cy[1];
-            float dxy = sqrtf(rx * rx + ry * ry);
+            float dxy = o_norm2(rx, ry);
             float hit = ((dxy - c->cylinder_size) < c->collision_radius) ? 1.0f : 0.0f;
             if (side->knn_masked[a][s]) hit = 0.0f;
             cc = (s == 0) ? hit : cc + hit;
@@ -493,7 +491,7 @@ static void o_reward(const hns_cfg *c, int A, int C, int K, const float *drone_s
         }
         cr = cr + -c->collision_coef * cd;
         float cw = ((ds[2] > c->max_height) ? 1.0f : 0.0f)
-                   + (((ds[0] * ds[0] + ds[1] * ds[1]) > c->arena_sq) ? 1.0f : 0.0f);
+                   + ((O_FMA(ds[1], ds[1], ds[0] * ds[0]) > c->arena_sq) ? 1.0f : 0.0f);
         cr = cr + -c->collision_coef * cw;
         coll_rew[a] = cr;
         any_coll |= (cr < 0.0f);
