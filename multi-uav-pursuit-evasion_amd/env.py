@@ -352,6 +352,30 @@ class HideAndSeek:
             self._bufs[k].copy_(torch.as_tensor(v).to(self.device).view(self._bufs[k].shape))
         self._needs_reset = False
 
+    # ---- checkpoint / resume of the env state (the reference checkpoints the policy only, train.py:288-292) ----
+    def save_state(self, path):
+        """Snapshot every bound buffer + the host-side counters to an .npz file."""
+        import numpy as np
+        meta = np.array([self.seed & 0x7FFFFFFFFFFFFFFF, self.reset_epoch, self._since_full_reset, self.update_epoch], dtype=np.int64)
+        np.savez_compressed(path, _meta=meta, _v_prey=np.float64(self.v_prey), **self.export_state())
+
+    def load_state(self, path):
+        import numpy as np
+        z = np.load(path)
+        for k in self._bufs:
+            if tuple(z[k].shape) != tuple(self._bufs[k].shape):
+                raise ValueError(f"snapshot field {k} has shape {z[k].shape}, env expects {tuple(self._bufs[k].shape)}")
+        self.import_state({k: z[k] for k in self._bufs})
+        self.seed, epoch, self._since_full_reset, self.update_epoch = (int(x) for x in z["_meta"])
+        self._check(self._lib.hns_set_reset_epoch(self._env, C.c_uint32(epoch)), "hns_set_reset_epoch")
+        self.v_prey = float(z["_v_prey"])
+        self._check(self._lib.hns_set_v_prey(self._env, C.c_float(self.v_prey)), "hns_set_v_prey")
+        self.set_update_epoch(self.update_epoch)
+
+    def check_finite(self):
+        """Failure detection: True iff every state/output buffer is finite (one device reduction per buffer)."""
+        return all(bool(torch.isfinite(v).all()) for k, v in self._bufs.items() if v.dtype.is_floating_point)
+
 
 HideAndSeek.REGISTRY["HideAndSeek"] = HideAndSeek
 HideAndSeek.REGISTRY["hideandseek"] = HideAndSeek

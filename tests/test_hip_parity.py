@@ -224,3 +224,30 @@ def test_tp_net_observation_on_gpu(golden):
         np.testing.assert_allclose(o[("agents", "observation", "state_self")][:, :, 0].cpu().numpy(), g["state_self"][t][:, :, 0],
                                    rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(o[("agents", "TP", "TP_input")].cpu().numpy(), g["TP_input"][t], rtol=1e-6, atol=1e-6)
+
+
+def test_snapshot_resume_is_bit_exact(tmp_path):
+    """env.save_state / load_state: a resumed env continues bit-identically (state + reset RNG epoch)."""
+    a = make_env(200, 3, 8, max_len=7)
+    a.set_seed(5)
+    a.reset()
+    g = torch.Generator().manual_seed(1)
+    acts = [torch.randn(200, 3, 4, generator=g) for _ in range(12)]
+    for t in range(5):
+        a.step(a.rand_step_input(acts[t].to(a.device)))
+    assert a.check_finite()
+    a.save_state(str(tmp_path / "snap.npz"))
+    b = make_env(200, 3, 8, max_len=7)
+    b.load_state(str(tmp_path / "snap.npz"))
+    for env in (a, b):
+        for t in range(5, 12):
+            td = env.step(env.rand_step_input(acts[t].to(env.device)))
+            if bool(td[("next", "done")].any()):
+                r = env.rand_step_input()
+                r.set("_reset", td[("next", "done")].squeeze(-1))
+                env.reset(r)
+    assert_same(a.export_state(), b.export_state(), "resumed")
+    st = a.export_state()
+    st["drone_state"][0, 0, 0] = np.nan
+    a.import_state(st)
+    assert not a.check_finite()
