@@ -224,6 +224,11 @@ int hns_reset(hns_env *env, const uint8_t *reset_mask, uint64_t seed, void *stre
 int hns_reset_tasks(hns_env *env, const uint8_t *reset_mask, const float *tasks, int32_t task_first, uint64_t seed,
                     void *stream);
 
+/* Extension, not in the reference: planar ray-fan range sensor on the bound state.
+ * out: device pointer [E,A,num_rays]; ray r of a pursuer points along its horizontal heading rotated by
+ * 2*pi*r/num_rays; range = distance to the first active cylinder or the arena wall, clamped to max_range. */
+int hns_raycast(hns_env *env, int num_rays, float max_range, float *out, void *stream);
+
 /* Curriculum hook (hideandseek.py:1012-1015): change the evader speed. */
 int hns_set_v_prey(hns_env *env, float v_prey);
 /* Smoothness schedule hook (hideandseek.py:988-991). */

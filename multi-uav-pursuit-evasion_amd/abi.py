@@ -157,6 +157,8 @@ def load_library():
     lib.hns_reset.restype = C.c_int
     lib.hns_reset_tasks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p]
     lib.hns_reset_tasks.restype = C.c_int
+    lib.hns_raycast.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    lib.hns_raycast.restype = C.c_int
     lib.hns_set_v_prey.argtypes = [C.c_void_p, C.c_float]
     lib.hns_set_v_prey.restype = C.c_int
     lib.hns_set_smoothness_coef.argtypes = [C.c_void_p, C.c_float]
@@ -191,7 +193,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "hns_create", "hns_destroy", "hns_bind", "hns_step", "hns_reset", "hns_reset_tasks", "hns_set_v_prey",
+    "hns_create", "hns_destroy", "hns_bind", "hns_step", "hns_reset", "hns_reset_tasks", "hns_raycast", "hns_set_v_prey",
     "hns_set_smoothness_coef", "hns_set_reset_epoch", "hns_get_reset_epoch", "hns_enable_timing",
     "hns_step_kernel_ms", "hns_set_phase_profile", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
 ]

@@ -931,6 +931,68 @@ __global__ __launch_bounds__(64) void hns_hover_reset_kernel(const HoverParams p
     for (int i = 0; i < HNS_SELF_DIM; ++i) b.obs[(size_t)e * HNS_SELF_DIM + i] = obs[i];
 }
 
+// =================================================================================================
+// Extension (not in the reference): planar ray-fan range sensor.  One thread per
+// (env, pursuer, ray); a workgroup stages the cylinder sets and the ray origins/headings of its envs
+// in LDS once.  Geometry exactly as oracle/hns_oracle.c::hns_oracle_raycast.
+// =================================================================================================
+struct RayParams {
+    hns_cfg cfg;
+    const float *drone_state, *cylinders;
+    float *out;
+    int num_rays, envs_per_block;
+    float max_range;
+};
+
+__global__ __launch_bounds__(256) void hns_raycast_kernel(const RayParams p) {
+    extern __shared__ __align__(16) float smem[];
+    const hns_cfg &c = p.cfg;
+    const int E = c.num_envs, A = c.num_agents, C = c.num_cylinders, N = p.num_rays, EPB = p.envs_per_block;
+    const int e0 = blockIdx.x * EPB;
+    const int nenv = min(EPB, E - e0);
+    float *sCyl = smem;                         // [EPB][C][3]
+    float *sOrg = smem + EPB * C * 3;           // [EPB][A][4] = ox, oy, ux0, uy0
+    for (int i = threadIdx.x; i < nenv * C * 3; i += 256) sCyl[i] = p.cylinders[(size_t)e0 * C * 3 + i];
+    for (int i = threadIdx.x; i < nenv * A; i += 256) {
+        const float *ds = p.drone_state + ((size_t)e0 * A + i) * 13;
+        Q4 q = {ds[3], ds[4], ds[5], ds[6]};
+        V3 h = d_quat_rot_x(q);
+        float hn = d_norm2(h.x, h.y);
+        sOrg[4 * i] = ds[0]; sOrg[4 * i + 1] = ds[1];
+        sOrg[4 * i + 2] = hn > 1e-6f ? h.x / hn : 1.0f;
+        sOrg[4 * i + 3] = hn > 1e-6f ? h.y / hn : 0.0f;
+    }
+    __syncthreads();
+    const float step = 6.283185307179586f / (float)N;
+    for (int i = threadIdx.x; i < nenv * A * N; i += 256) {
+        const int ea = i / N, r = i - ea * N, le = ea / A;
+        const float ox = sOrg[4 * ea], oy = sOrg[4 * ea + 1], ux0 = sOrg[4 * ea + 2], uy0 = sOrg[4 * ea + 3];
+        float sn, cs;
+        d_sincosf(step * (float)r, sn, cs);
+        const float ux = HNS_FMA(ux0, cs, -(uy0 * sn)), uy = HNS_FMA(ux0, sn, uy0 * cs);
+        const float oo = HNS_FMA(oy, oy, ox * ox);
+        const float ou = HNS_FMA(oy, uy, ox * ux);
+        const float dw = HNS_FMA(ou, ou, -(oo - c.arena_sq));
+        float best = dw >= 0.0f ? __builtin_sqrtf(dw) - ou : 0.0f;
+        if (!(best >= 0.0f)) best = 0.0f;
+        const float *cyl = sCyl + le * C * 3;
+        for (int k = 0; k < C; ++k) {
+            const float ccx = cyl[3 * k], ccy = cyl[3 * k + 1], ccz = cyl[3 * k + 2];
+            if (!(ccz > 0.0f)) continue;
+            const float mx = ccx - ox, my = ccy - oy;
+            const float bq = HNS_FMA(my, uy, mx * ux);
+            const float cq = HNS_FMA(my, my, mx * mx) - c.cylinder_size * c.cylinder_size;
+            const float disc = HNS_FMA(bq, bq, -cq);
+            if (disc >= 0.0f) {
+                float t = bq - __builtin_sqrtf(disc);
+                if (cq <= 0.0f) t = 0.0f;
+                if (t >= 0.0f && t < best) best = t;
+            }
+        }
+        p.out[(size_t)e0 * A * N + i] = best > p.max_range ? p.max_range : best;
+    }
+}
+
 }  // namespace hns
 
 // =================================================================================================
@@ -1195,6 +1257,29 @@ int hns_hover_reset(const hns_cfg *cfg, const hns_hover_cfg *hover, const hns_ho
     p.cfg = *cfg; p.hover = *hover; p.buf = *buffers; p.action = nullptr; p.reset_mask = reset_mask;
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.epoch = epoch;
     hipLaunchKernelGGL(hns::hns_hover_reset_kernel, dim3((cfg->num_envs + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), p);
+    HNS_CHECK_HIP(hipGetLastError());
+    return HNS_OK;
+}
+
+int hns_raycast(hns_env *env, int num_rays, float max_range, float *out, void *stream) {
+    if (!env || !out) { set_error("hns_raycast: null argument"); return HNS_ERR_INVALID_ARG; }
+    if (!env->bound) { set_error("hns_raycast: buffers not bound"); return HNS_ERR_NOT_BOUND; }
+    if (num_rays < 1 || num_rays > 1024 || !(max_range > 0.0f)) { set_error("hns_raycast: num_rays in [1,1024], max_range > 0"); return HNS_ERR_INVALID_ARG; }
+    hns::RayParams p;
+    p.cfg = env->cfg;
+    p.drone_state = env->buf.drone_state;
+    p.cylinders = env->buf.cylinders;
+    p.out = out;
+    p.num_rays = num_rays;
+    p.max_range = max_range;
+    const int A = env->cfg.num_agents, C = env->cfg.num_cylinders;
+    int epb = 1024 / (A * num_rays);                 // ~4 rays per thread
+    if (epb < 1) epb = 1;
+    if (epb > 64) epb = 64;
+    p.envs_per_block = epb;
+    size_t lds = (size_t)epb * (C * 3 + A * 4) * sizeof(float);
+    hipLaunchKernelGGL(hns::hns_raycast_kernel, dim3((env->cfg.num_envs + epb - 1) / epb), dim3(256), lds,
+                       static_cast<hipStream_t>(stream), p);
     HNS_CHECK_HIP(hipGetLastError());
     return HNS_OK;
 }

@@ -352,6 +352,14 @@ class HideAndSeek:
             self._bufs[k].copy_(torch.as_tensor(v).to(self.device).view(self._bufs[k].shape))
         self._needs_reset = False
 
+    def raycast(self, num_rays=16, max_range=2.0, out=None):
+        """Extension (not in the reference): planar ray-fan ranges [E,A,num_rays] on the current state."""
+        if out is None:
+            out = torch.empty(self.num_envs, self.num_agents, num_rays, device=self.device)
+        self._check(self._lib.hns_raycast(self._env, int(num_rays), C.c_float(max_range), C.c_void_p(out.data_ptr()),
+                                          self._stream()), "hns_raycast")
+        return out
+
     # ---- checkpoint / resume of the env state (the reference checkpoints the policy only, train.py:288-292) ----
     def save_state(self, path):
         """Snapshot every bound buffer + the host-side counters to an .npz file."""

@@ -996,3 +996,51 @@ int hns_oracle_hover_reset(const hns_cfg *c, const hns_hover_cfg *h, const hns_h
     }
     return HNS_OK;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Extension (NOT in the reference, which only has the line-of-sight test and the k-nearest
+ * selection): planar ray-fan range sensor.  For pursuer (e,a), ray r points along
+ * the drone's horizontal heading rotated by 2*pi*r/N in the world xy-plane; the range is the
+ * distance to the first active cylinder (radius cylinder_size) or to the arena wall (radius
+ * arena_size, seen from inside), clamped to [0, max_range].
+ * ---------------------------------------------------------------------------------------- */
+void hns_oracle_raycast(const hns_cfg *c, const hns_buffers *b, int N, float max_range, float *out) {
+    const int E = c->num_envs, A = c->num_agents, C = c->num_cylinders;
+    const float step = 6.283185307179586f / (float)N;
+    for (int e = 0; e < E; ++e) {
+        const float *cyl = b->cylinders + (size_t)e * C * 3;
+        for (int a = 0; a < A; ++a) {
+            const float *ds = b->drone_state + ((size_t)e * A + a) * 13;
+            float h[3];
+            o_quat_rot_x(ds + 3, h);
+            float hn = o_norm2(h[0], h[1]);
+            float ux0 = hn > 1e-6f ? h[0] / hn : 1.0f, uy0 = hn > 1e-6f ? h[1] / hn : 0.0f;
+            float ox = ds[0], oy = ds[1];
+            float oo = O_FMA(oy, oy, ox * ox);
+            for (int r = 0; r < N; ++r) {
+                float sn, cs;
+                o_sincosf(step * (float)r, &sn, &cs);
+                float ux = O_FMA(ux0, cs, -(uy0 * sn)), uy = O_FMA(ux0, sn, uy0 * cs);
+                /* arena wall from inside: t = -o.u + sqrt((o.u)^2 - (|o|^2 - R^2)) */
+                float ou = O_FMA(oy, uy, ox * ux);
+                float dw = O_FMA(ou, ou, -(oo - c->arena_sq));
+                float best = dw >= 0.0f ? sqrtf(dw) - ou : 0.0f;
+                if (!(best >= 0.0f)) best = 0.0f;
+                for (int k = 0; k < C; ++k) {
+                    const float *cc = cyl + 3 * k;
+                    if (!(cc[2] > 0.0f)) continue;
+                    float mx = cc[0] - ox, my = cc[1] - oy;
+                    float bq = O_FMA(my, uy, mx * ux);
+                    float cq = O_FMA(my, my, mx * mx) - c->cylinder_size * c->cylinder_size;
+                    float disc = O_FMA(bq, bq, -cq);
+                    if (disc >= 0.0f) {
+                        float t = bq - sqrtf(disc);
+                        if (cq <= 0.0f) t = 0.0f;               /* origin inside the cylinder */
+                        if (t >= 0.0f && t < best) best = t;
+                    }
+                }
+                out[((size_t)e * A + a) * N + r] = best > max_range ? max_range : best;
+            }
+        }
+    }
+}

@@ -200,3 +200,10 @@ def hover_reset(cfg, hcfg, arrs, mask, seed, epoch):
     m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
     rc = lib().hns_oracle_hover_reset(C.byref(cfg), C.byref(hcfg), C.byref(b), _p(m), C.c_uint64(seed), C.c_uint32(epoch))
     assert rc == 0, rc
+
+
+def raycast(cfg, arrs, num_rays, max_range):
+    b = as_struct(arrs)
+    out = np.empty((cfg.num_envs, cfg.num_agents, num_rays), np.float32)
+    lib().hns_oracle_raycast(C.byref(cfg), C.byref(b), int(num_rays), C.c_float(max_range), _p(out))
+    return out
