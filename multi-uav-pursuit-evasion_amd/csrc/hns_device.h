@@ -22,10 +22,11 @@ constexpr float kInf = __builtin_huge_valf();
 constexpr float kInvPi = 0.31830987334251404f;   // RN(1/fp32(pi)): CUDA `tensor / python_scalar` multiplies by this
 
 HNS_DEV float d_expf(float x) {
-    if (!(x > -87.0f)) return (x != x) ? x : 0.0f;
-    if (x > 88.0f) return kInf;
-    float k = __builtin_rintf(x * 1.44269504088896341f);
-    float r = HNS_FMA(k, -0.693359375f, x);
+    // branch-free: evaluate on a clamped argument, pick the special cases at the end (same values
+    // as the guarded form in the oracle: 0 for x <= -87 and -inf, +inf above 88, NaN for NaN)
+    float xc = x < -87.5f ? -87.5f : (x > 88.5f ? 88.5f : x);
+    float k = __builtin_rintf(xc * 1.44269504088896341f);
+    float r = HNS_FMA(k, -0.693359375f, xc);
     r = HNS_FMA(k, 2.12194440e-4f, r);
     float p = 1.9875691500E-4f;
     p = HNS_FMA(p, r, 1.3981999507E-3f);
@@ -35,7 +36,10 @@ HNS_DEV float d_expf(float x) {
     p = HNS_FMA(p, r, 5.0000001201E-1f);
     float y = HNS_FMA(p, r * r, r) + 1.0f;
     int ki = (int)k;
-    return y * __uint_as_float((uint32_t)(ki + 127) << 23);
+    float v = y * __uint_as_float((uint32_t)(ki + 127) << 23);
+    v = (x > 88.0f) ? kInf : v;
+    v = (x > -87.0f) ? v : ((x != x) ? x : 0.0f);
+    return v;
 }
 
 // tanh(x) = sign(x) * (1 - e)/(1 + e), e = exp(-2|x|): one path for every x (|err| <= 1.2e-7)
