@@ -229,6 +229,37 @@ int hns_reset_tasks(hns_env *env, const uint8_t *reset_mask, const float *tasks,
  * 2*pi*r/num_rays; range = distance to the first active cylinder or the arena wall, clamped to max_range. */
 int hns_raycast(hns_env *env, int num_rays, float max_range, float *out, void *stream);
 
+/*
+ * Trajectory predictor in the observation (reference default `algo.use_TP_net: 1`).
+ * Replaces the TP branch of HideAndSeek._compute_state_and_obs (hideandseek.py:805-854,871-880)
+ * incl. the TP_net forward (learning/mappo.py:572-589: LSTM(I -> 64, 1 layer, zero initial state)
+ * + Linear(64 -> 3F) + tanh) evaluated on a T-frame history, I = 7 + 3A:
+ *   frame = [progress, evader pos (masked), evader vel (masked), pursuer positions]   (:815-820)
+ * The parameters are the caller's tensors in PyTorch layouts (the learner trains them,
+ * scripts/train.py:180); they are read on every call, so in-place optimiser updates are seen.
+ */
+#define HNS_TP_HIDDEN 64           /* TP_net.hidden_dim, mappo.py:576 */
+typedef struct hns_tp_buffers {
+    const float *w_ih;        /* [4*64, I]   lstm.weight_ih_l0, gate order i,f,g,o */
+    const float *w_hh;        /* [4*64, 64]  lstm.weight_hh_l0 */
+    const float *b_ih;        /* [4*64]      lstm.bias_ih_l0 */
+    const float *b_hh;        /* [4*64]      lstm.bias_hh_l0 */
+    const float *w_fc;        /* [3F, 64]    fc.weight */
+    const float *b_fc;        /* [3F]        fc.bias */
+    float *history;           /* [E,T,I]  state: the sliding window == agents.TP.TP_input, oldest frame first */
+    float *pred;              /* [E,F,3]  out: predicted evader positions, arena units (hideandseek.py:834-836) */
+    float *obs_self;          /* [E,A,20+3F] out: agents.observation.state_self rows (:846-854) */
+    float *state_drones;      /* [E,A,20+3F] out, nullable: agents.state.state_drones (:873-880) */
+    float *groundtruth;       /* [E,3]    out: agents.TP.TP_groundtruth (:839-842) */
+    uint8_t *tp_done;         /* [E]      out: agents.TP.TP_done (:838) */
+} hns_tp_buffers;
+/* history_step T in [1,16], future_step F in [1,10]. */
+int hns_tp_bind(hns_env *env, const hns_tp_buffers *buffers, int32_t history_step, int32_t future_step);
+/* Run after hns_step / hns_reset on the same stream: appends the frame of the bound step buffers to
+ * the window (fill_history != 0: the window is filled with this frame, as the reference does on its
+ * first call, hideandseek.py:825-828), evaluates TP_net, writes the 20+3F-value rows. */
+int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream);
+
 /* Curriculum hook (hideandseek.py:1012-1015): change the evader speed. */
 int hns_set_v_prey(hns_env *env, float v_prey);
 /* Smoothness schedule hook (hideandseek.py:988-991). */

@@ -125,6 +125,30 @@ def hover_buffer_shapes(E):
             "obs": ((E, 1, HNS_SELF_DIM), "float32"), "reward": ((E, 1), "float32"), "done": ((E,), "uint8")}
 
 
+HNS_OK, HNS_ERR_INVALID_ARG, HNS_ERR_NOT_BOUND, HNS_ERR_DEVICE, HNS_ERR_NO_DEVICE, HNS_ERR_CONFIG = 0, -1, -2, -3, -4, -5
+
+# ---- trajectory predictor (include/hns.h: hns_tp_buffers) ------------------------------------------------
+HNS_TP_HIDDEN = 64
+TP_WEIGHT_FIELDS = ["w_ih", "w_hh", "b_ih", "b_hh", "w_fc", "b_fc"]
+TP_BUFFER_FIELDS = TP_WEIGHT_FIELDS + ["history", "pred", "obs_self", "state_drones", "groundtruth", "tp_done"]
+# hns_tp_buffers weight field -> TP_net.state_dict() key (learning/mappo.py:572-589)
+TP_STATE_DICT_KEYS = {"w_ih": "lstm.weight_ih_l0", "w_hh": "lstm.weight_hh_l0", "b_ih": "lstm.bias_ih_l0",
+                      "b_hh": "lstm.bias_hh_l0", "w_fc": "fc.weight", "b_fc": "fc.bias"}
+
+
+class HnsTpBuffers(C.Structure):
+    _fields_ = [(name, _fp) for name in TP_BUFFER_FIELDS]
+
+
+def tp_buffer_shapes(E, A, T, F):
+    I, D = 7 + 3 * A, HNS_SELF_DIM + 3 * F
+    return {"w_ih": ((4 * HNS_TP_HIDDEN, I), "float32"), "w_hh": ((4 * HNS_TP_HIDDEN, HNS_TP_HIDDEN), "float32"),
+            "b_ih": ((4 * HNS_TP_HIDDEN,), "float32"), "b_hh": ((4 * HNS_TP_HIDDEN,), "float32"),
+            "w_fc": ((3 * F, HNS_TP_HIDDEN), "float32"), "b_fc": ((3 * F,), "float32"),
+            "history": ((E, T, I), "float32"), "pred": ((E, F, 3), "float32"), "obs_self": ((E, A, D), "float32"),
+            "state_drones": ((E, A, D), "float32"), "groundtruth": ((E, 3), "float32"), "tp_done": ((E,), "uint8")}
+
+
 _LIB = None
 LIB_NAME = "libhns.so"
 
@@ -178,6 +202,10 @@ def load_library():
     lib.hns_hover_reset.argtypes = [C.POINTER(HnsCfg), C.POINTER(HnsHoverCfg), C.POINTER(HnsHoverBuffers), C.c_void_p,
                                     C.c_uint64, C.c_uint32, C.c_void_p]
     lib.hns_hover_reset.restype = C.c_int
+    lib.hns_tp_bind.argtypes = [C.c_void_p, C.POINTER(HnsTpBuffers), C.c_int32, C.c_int32]
+    lib.hns_tp_bind.restype = C.c_int
+    lib.hns_tp_observe.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.hns_tp_observe.restype = C.c_int
     lib.hns_abi_version.argtypes = []
     lib.hns_abi_version.restype = C.c_int
     lib.hns_cfg_size.argtypes = []
@@ -195,5 +223,5 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "hns_create", "hns_destroy", "hns_bind", "hns_step", "hns_reset", "hns_reset_tasks", "hns_raycast", "hns_set_v_prey",
     "hns_set_smoothness_coef", "hns_set_reset_epoch", "hns_get_reset_epoch", "hns_enable_timing",
-    "hns_step_kernel_ms", "hns_set_phase_profile", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
+    "hns_step_kernel_ms", "hns_set_phase_profile", "hns_tp_bind", "hns_tp_observe", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
 ]

@@ -1,0 +1,50 @@
+// hns_host.h — host-side state shared by the translation units of libhns.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/hns.h"
+
+namespace hns {
+struct Params;
+}
+
+void hns_set_error(const std::string &m);
+
+// trajectory-predictor binding (hns_tp.hip)
+struct hns_tp_state {
+    hns_tp_buffers buf;
+    int history_step = 0, future_step = 0;
+    bool bound = false;
+};
+
+struct hns_env {
+    hns_cfg cfg;
+    hns_buffers buf;
+    bool bound = false;
+    uint32_t epoch = 0;
+    int grid = 0, threads = 0;
+    size_t lds_step = 0, lds_reset = 0;
+    void (*step_fn)(const hns::Params) = nullptr;
+    void (*reset_fn)(const hns::Params) = nullptr;
+    unsigned long long *prof = nullptr;
+    uint32_t cyl_magic = 0;
+    int timing = 0;          // 0 = off, n = bracket every n-th step launch with hipEvents
+    uint64_t step_count = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // recorded, not yet harvested
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;     // free event pairs
+    hns_tp_state tp;
+};
+
+#define HNS_CHECK_HIP(expr)                                                        \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            hns_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));      \
+            return HNS_ERR_DEVICE;                                                 \
+        }                                                                          \
+    } while (0)

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "hns_device.h"
+#include "hns_host.h"
 
 namespace hns {
 
@@ -1001,24 +1002,9 @@ __global__ __launch_bounds__(256) void hns_raycast_kernel(const RayParams p) {
 using hns::Params;
 
 static thread_local std::string g_last_error;
+void hns_set_error(const std::string &m) { g_last_error = m; }
 static void set_error(const std::string &m) { g_last_error = m; }
 
-struct hns_env {
-    hns_cfg cfg;
-    hns_buffers buf;
-    bool bound = false;
-    uint32_t epoch = 0;
-    int grid = 0, threads = 0;
-    size_t lds_step = 0, lds_reset = 0;
-    void (*step_fn)(const Params) = nullptr;
-    void (*reset_fn)(const Params) = nullptr;
-    unsigned long long *prof = nullptr;
-    uint32_t cyl_magic = 0;
-    int timing = 0;          // 0 = off, n = bracket every n-th step launch with hipEvents
-    uint64_t step_count = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // recorded, not yet harvested
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;     // free event pairs
-};
 
 template <int A>
 static void select_kernels(hns_env *env) {
@@ -1033,14 +1019,6 @@ static void select_kernels(hns_env *env) {
     env->lds_reset = env->lds_step + (size_t)hns::kEPB * 512;   // + per-env occupancy grid / free-cell list
 }
 
-#define HNS_CHECK_HIP(expr)                                                        \
-    do {                                                                           \
-        hipError_t _e = (expr);                                                    \
-        if (_e != hipSuccess) {                                                    \
-            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));          \
-            return HNS_ERR_DEVICE;                                                 \
-        }                                                                          \
-    } while (0)
 
 extern "C" {
 

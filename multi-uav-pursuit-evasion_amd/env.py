@@ -138,14 +138,20 @@ class HideAndSeek:
         # algo.use_TP_net=1 (reference default): the trajectory predictor runs between the step kernel and
         # the consumer (tp_net.py); the env owns the module, the learner trains it (scripts/train.py:180)
         self.use_TP_net = int(cfg.algo.get("use_TP_net", 0))
-        self.TP, self._tp_obs = None, None
+        self.TP = None
         if self.use_TP_net:
-            from .tp_net import TPNet, TPObservation
+            from .tp_net import TPNet
             t = cfg.task
-            fut = int(t.get("future_predcition_step", 5))
-            self.TP = TPNet(1 + 3 + 3 + 3 * A, 3 * fut, fut, int(t.get("window_step", 1))).to(self.device)   # hideandseek.py:317
-            self._tp_obs = TPObservation(self.TP, A, float(t.arena_size), float(t.max_height), self.max_episode_length,
-                                         int(t.get("history_step", 10)), fut, float(self.hcfg.mask_value))
+            self.tp_future_step = int(t.get("future_predcition_step", 5))
+            self.tp_history_step = int(t.get("history_step", 10))
+            self.TP = TPNet(1 + 3 + 3 + 3 * A, 3 * self.tp_future_step, self.tp_future_step,
+                            int(t.get("window_step", 1))).to(self.device)                       # hideandseek.py:317
+            self._tp_bufs = {}
+            for name, (shape, dt) in abi.tp_buffer_shapes(E, A, self.tp_history_step, self.tp_future_step).items():
+                if name not in abi.TP_WEIGHT_FIELDS:
+                    self._tp_bufs[name] = torch.zeros(shape, dtype=getattr(torch, dt), device=self.device)
+            self._tp_weight_ptrs = None
+            self._tp_filled = False
         self._set_specs()
         self._since_full_reset = 0
         self._needs_reset = True
@@ -165,7 +171,7 @@ class HideAndSeek:
     # ---- specs (hideandseek.py:327-433, use_TP_net=0 branch) ------------------------------------------
     def _set_specs(self):
         A, K, E, dev = self.num_agents, self.obs_max_cylinder, self.num_envs, self.device
-        D = abi.HNS_SELF_DIM + (3 * self._tp_obs.future_step if self.use_TP_net else 0)      # 20 or 35
+        D = abi.HNS_SELF_DIM + (3 * self.tp_future_step if self.use_TP_net else 0)      # 20 or 35
         obs = {"state_self": TensorSpec((1, D)), "cylinders": TensorSpec((K, 5))}
         if A > 1:
             obs["state_others"] = TensorSpec((A - 1, 3))
@@ -175,7 +181,7 @@ class HideAndSeek:
         info_spec = CompositeSpec({"drone_state": TensorSpec((A, 13)), "prev_action": TensorSpec((A, 4), low=-1.0, high=1.0)})
         agents = {"observation": observation_spec.expand(A), "state": state_spec}
         if self.use_TP_net:                                              # hideandseek.py:368-374
-            agents["TP"] = CompositeSpec({"TP_input": TensorSpec((self._tp_obs.history_step, 7 + 3 * A)),
+            agents["TP"] = CompositeSpec({"TP_input": TensorSpec((self.tp_history_step, 7 + 3 * A)),
                                           "TP_groundtruth": TensorSpec((1, 3)), "TP_done": TensorSpec((1, 3))})
         self.observation_spec = CompositeSpec({
             "agents": CompositeSpec(agents), "stats": stats_spec, "info": info_spec}).expand(E).to(dev)
@@ -258,6 +264,8 @@ class HideAndSeek:
         if mask_t is None:
             self._since_full_reset = 0
         self._needs_reset = False
+        if self.use_TP_net:
+            self._tp_observe()
         td = self._obs_tensordict()
         td.set("stats", last_stats)
         td.set("truncated", (self.progress_buf > self.max_episode_length).unsqueeze(1))
@@ -283,7 +291,9 @@ class HideAndSeek:
             if bool(done.any()) and float(self.stats["success"].mean()) >= 0.98:
                 self.v_prey = min(1.3, self.v_prey + 0.05)
                 self._check(self._lib.hns_set_v_prey(self._env, C.c_float(self.v_prey)), "hns_set_v_prey")
-        if self._next_cache is None or self.use_TP_net:
+        if self.use_TP_net:
+            self._tp_observe()
+        if self._next_cache is None:
             # every leaf is a view of a persistent buffer that the kernel just rewrote in place, so
             # the output tree is built once and handed out again (the reference's collector runs
             # with return_same_td=True, scripts/train.py:204)
@@ -296,12 +306,15 @@ class HideAndSeek:
     def _obs_tensordict(self):
         b = self._bufs
         if self.use_TP_net:
-            ss, sd, tp = self._tp_obs(b["obs_self"], b["drone_state"][..., :3], b["target_pos"], b["target_vel"],
-                                      self.progress_buf, b["detect"])
-            obs = {"state_self": ss.unsqueeze(2), "cylinders": b["obs_cylinders"]}
+            tb = self._tp_bufs
+            obs = {"state_self": tb["obs_self"].unsqueeze(2), "cylinders": b["obs_cylinders"]}
             if self.num_agents > 1:
                 obs["state_others"] = b["obs_others"]
-            state = {"state_drones": sd, "cylinders": b["obs_cylinders"]}
+            if self.write_critic_state:
+                state = {"state_drones": tb["state_drones"], "cylinders": b["obs_cylinders"]}
+            else:
+                state = _LazyState(self, {"cylinders": b["obs_cylinders"]}, self.batch_size)
+            tp = {"TP_input": tb["history"], "TP_groundtruth": tb["groundtruth"], "TP_done": tb["tp_done"].view(torch.bool).unsqueeze(-1)}
             return TensorDict({"agents": {"observation": obs, "state": state, "TP": tp}, "stats": self.stats, "info": self.info},
                               self.batch_size)
         obs = {"state_self": b["obs_self"].unsqueeze(2), "cylinders": b["obs_cylinders"]}
@@ -318,7 +331,32 @@ class HideAndSeek:
         """hideandseek.py:871-886: state_self with the UNMASKED relative position of the evader."""
         b = self._bufs
         rpos = b["drone_state"][..., 0:3] - b["target_pos"].unsqueeze(1)
-        return torch.cat([rpos, b["obs_self"][..., 3:]], dim=-1)
+        rest = self._tp_bufs["obs_self"] if self.use_TP_net else b["obs_self"]       # :873-880 / :881-886
+        return torch.cat([rpos, rest[..., 3:]], dim=-1)
+
+    def _tp_observe(self):
+        """The TP branch of `_compute_state_and_obs` (hideandseek.py:805-854) on the device: frame
+        append, TP_net forward on the matrix cores, 35-value rows (hns_tp_observe).  `self.TP`'s
+        parameters are read in place; a re-bind happens only if the learner swapped the tensors."""
+        sd = self.TP.state_dict(keep_vars=True)
+        ptrs = tuple(sd[abi.TP_STATE_DICT_KEYS[f]].data_ptr() for f in abi.TP_WEIGHT_FIELDS)
+        if ptrs != self._tp_weight_ptrs:
+            tb = abi.HnsTpBuffers()
+            for f, ptr in zip(abi.TP_WEIGHT_FIELDS, ptrs):
+                w = sd[abi.TP_STATE_DICT_KEYS[f]]
+                if w.dtype != torch.float32 or not w.is_contiguous() or w.device != self.device:
+                    raise HnsError(f"TP_net parameter {abi.TP_STATE_DICT_KEYS[f]} must be a contiguous fp32 tensor on {self.device}")
+                setattr(tb, f, ptr)
+            for name, t in self._tp_bufs.items():
+                setattr(tb, name, t.data_ptr())
+            if not self.write_critic_state:
+                tb.state_drones = None
+            self._check(self._lib.hns_tp_bind(self._env, C.byref(tb), self.tp_history_step, self.tp_future_step), "hns_tp_bind")
+            self._tp_weight_ptrs = ptrs
+        rc = self._lib.hns_tp_observe(self._env, 0 if self._tp_filled else 1, self._stream())
+        if rc != 0:
+            self._check(rc, "hns_tp_observe")
+        self._tp_filled = True                      # the window is never reset per env (hideandseek.py:825-830)
 
     # ---- schedule hooks -------------------------------------------------------------------------------------------
     def set_update_epoch(self, epoch):
@@ -365,7 +403,10 @@ class HideAndSeek:
         """Snapshot every bound buffer + the host-side counters to an .npz file."""
         import numpy as np
         meta = np.array([self.seed & 0x7FFFFFFFFFFFFFFF, self.reset_epoch, self._since_full_reset, self.update_epoch], dtype=np.int64)
-        np.savez_compressed(path, _meta=meta, _v_prey=np.float64(self.v_prey), **self.export_state())
+        extra = {}
+        if self.use_TP_net:                         # the predictor's window is state too
+            extra = {"_tp_history": self._tp_bufs["history"].cpu().numpy(), "_tp_filled": np.int64(self._tp_filled)}
+        np.savez_compressed(path, _meta=meta, _v_prey=np.float64(self.v_prey), **extra, **self.export_state())
 
     def load_state(self, path):
         import numpy as np
@@ -379,6 +420,9 @@ class HideAndSeek:
         self.v_prey = float(z["_v_prey"])
         self._check(self._lib.hns_set_v_prey(self._env, C.c_float(self.v_prey)), "hns_set_v_prey")
         self.set_update_epoch(self.update_epoch)
+        if self.use_TP_net and "_tp_history" in z.files:
+            self._tp_bufs["history"].copy_(torch.from_numpy(z["_tp_history"]))
+            self._tp_filled = bool(int(z["_tp_filled"]))
 
     def check_finite(self):
         """Failure detection: True iff every state/output buffer is finite (one device reduction per buffer)."""

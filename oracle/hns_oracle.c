@@ -1044,3 +1044,104 @@ void hns_oracle_raycast(const hns_cfg *c, const hns_buffers *b, int N, float max
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Trajectory predictor in the observation: the `use_TP_net` branch of
+ * HideAndSeek._compute_state_and_obs (hideandseek.py:805-854, 871-880) with
+ * TP_net.forward (learning/mappo.py:572-589): LSTM(I->64, zero initial state) over the T-frame
+ * window, last hidden state -> Linear(64->3F) -> tanh.  torch.nn.LSTM gate order i,f,g,o:
+ *   z = W_ih x + b_ih + W_hh h + b_hh;  c' = sig(z_f) c + sig(z_i) tanh(z_g);  h' = sig(z_o) tanh(c')
+ * The accumulation order of z is the HIP kernel's (an fmaf chain from b_ih+b_hh over the k-pairs
+ * of the f32 matrix-core product, hns_tp.hip), so pre-activations agree bit for bit; the
+ * nonlinearities here are libm's, the kernel's the hardware's — compared at 1e-5.
+ * ---------------------------------------------------------------------------------------- */
+static inline int o_tp_unit(int s, int hb) { return 32 * (s >> 4) + 8 * ((s & 15) >> 2) + 4 * hb + (s & 3); }
+static inline float o_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_buffers *tp, int T, int F, int fill) {
+    const int E = c->num_envs, A = c->num_agents, I = 7 + 3 * A, H = HNS_TP_HIDDEN, R = 3 * F, D = HNS_SELF_DIM + R;
+    const int SX = 4 * (((I + 1) / 2 + 3) / 4);          /* input k-steps; k-step s pairs x[s] with x[SX+s] */
+    if (T < 1 || T > 16 || R > 32 || !b->detect) return HNS_ERR_INVALID_ARG;
+    float *frame = (float *)malloc(sizeof(float) * (size_t)I);
+    for (int e = 0; e < E; ++e) {
+        /* frame (:815-820) and window (:825-831) */
+        const int det = b->detect[e] != 0;
+        frame[0] = b->progress[e];
+        for (int j = 0; j < 3; ++j) {
+            frame[1 + j] = det ? b->target_pos[(size_t)e * 3 + j] : c->mask_value;
+            frame[4 + j] = det ? b->target_vel[(size_t)e * 3 + j] : c->mask_value;
+        }
+        for (int a = 0; a < A; ++a)
+            for (int j = 0; j < 3; ++j) frame[7 + 3 * a + j] = b->drone_state[((size_t)e * A + a) * 13 + j];
+        float *hist = tp->history + (size_t)e * T * I;
+        if (fill) {
+            for (int t = 0; t < T; ++t) memcpy(hist + (size_t)t * I, frame, sizeof(float) * (size_t)I);
+        } else {
+            memmove(hist, hist + I, sizeof(float) * (size_t)(T - 1) * I);
+            memcpy(hist + (size_t)(T - 1) * I, frame, sizeof(float) * (size_t)I);
+        }
+        /* LSTM */
+        float h[HNS_TP_HIDDEN], cs[HNS_TP_HIDDEN], hn[HNS_TP_HIDDEN];
+        for (int u = 0; u < H; ++u) { h[u] = 0.0f; cs[u] = 0.0f; }
+        for (int t = 0; t < T; ++t) {
+            const float *x = hist + (size_t)t * I;
+            for (int u = 0; u < H; ++u) {
+                float z[4];
+                for (int q = 0; q < 4; ++q) {
+                    const int g = q * H + u;
+                    float acc = tp->b_ih[g] + tp->b_hh[g];
+                    for (int s = 0; s < SX; ++s) {
+                        if (s < I) acc = O_FMA(tp->w_ih[(size_t)g * I + s], x[s], acc);
+                        if (SX + s < I) acc = O_FMA(tp->w_ih[(size_t)g * I + SX + s], x[SX + s], acc);
+                    }
+                    if (t > 0)
+                        for (int s = 0; s < 32; ++s) {
+                            const int u0 = o_tp_unit(s, 0), u1 = o_tp_unit(s, 1);
+                            acc = O_FMA(tp->w_hh[(size_t)g * H + u0], h[u0], acc);
+                            acc = O_FMA(tp->w_hh[(size_t)g * H + u1], h[u1], acc);
+                        }
+                    z[q] = acc;
+                }
+                const float ig = o_sigmoid(z[0]), fg = o_sigmoid(z[1]), gg = tanhf(z[2]), og = o_sigmoid(z[3]);
+                const float cn = O_FMA(fg, cs[u], ig * gg);
+                cs[u] = cn;
+                hn[u] = og * tanhf(cn);
+            }
+            memcpy(h, hn, sizeof(h));
+        }
+        /* output layer + rescale (:834-836) */
+        float *pr = tp->pred + (size_t)e * R;
+        for (int r = 0; r < R; ++r) {
+            float acc = tp->b_fc[r];
+            for (int s = 0; s < 32; ++s) {
+                const int u0 = o_tp_unit(s, 0), u1 = o_tp_unit(s, 1);
+                acc = O_FMA(tp->w_fc[(size_t)r * H + u0], h[u0], acc);
+                acc = O_FMA(tp->w_fc[(size_t)r * H + u1], h[u1], acc);
+            }
+            const float v = tanhf(acc);
+            pr[r] = (r % 3 < 2) ? (v * 0.5f) * c->arena_size : ((v + 1.0f) * 0.5f) * c->max_height;
+        }
+        /* TP_groundtruth / TP_done (:838-842) */
+        const float *tpos = b->target_pos + (size_t)e * 3;
+        tp->groundtruth[(size_t)e * 3] = tpos[0] * (1.0f / (0.5f * c->arena_size));
+        tp->groundtruth[(size_t)e * 3 + 1] = tpos[1] * (1.0f / (0.5f * c->arena_size));
+        tp->groundtruth[(size_t)e * 3 + 2] = (tpos[2] * (1.0f / c->max_height)) * 2.0f - 1.0f;
+        tp->tp_done[e] = (uint8_t)(b->progress[e] <= (float)(c->max_episode_length - F));
+        /* rows (:844-854, :873-880) */
+        for (int a = 0; a < A; ++a) {
+            const size_t ia = (size_t)e * A + a;
+            const float *o20 = b->obs_self + ia * HNS_SELF_DIM, *ds = b->drone_state + ia * 13;
+            for (int pass = 0; pass < 2; ++pass) {
+                float *dst = pass == 0 ? tp->obs_self : tp->state_drones;
+                if (!dst) continue;
+                float *row = dst + ia * D;
+                for (int j = 0; j < 3; ++j) row[j] = pass == 0 ? o20[j] : ds[j] - tpos[j];
+                for (int f = 0; f < F; ++f)
+                    for (int j = 0; j < 3; ++j) row[3 + 3 * f + j] = ds[j] - pr[3 * f + j];
+                for (int j = 3; j < HNS_SELF_DIM; ++j) row[R + j] = o20[j];
+            }
+        }
+    }
+    free(frame);
+    return 0;
+}

@@ -207,3 +207,23 @@ def raycast(cfg, arrs, num_rays, max_range):
     out = np.empty((cfg.num_envs, cfg.num_agents, num_rays), np.float32)
     lib().hns_oracle_raycast(C.byref(cfg), C.byref(b), int(num_rays), C.c_float(max_range), _p(out))
     return out
+
+
+def alloc_tp_buffers(cfg, T=10, F=5):
+    """Zero-initialised host arrays for every hns_tp_buffers field (weights included)."""
+    return {k: np.zeros(shape, dtype=dt) for k, (shape, dt) in abi.tp_buffer_shapes(cfg.num_envs, cfg.num_agents, T, F).items()}
+
+
+def tp_observe(cfg, arrs, tp_arrs, fill, with_state=True):
+    """hns_tp_observe on host arrays: frame append / window shift, TP_net forward, 20+3F-value rows."""
+    b = as_struct(arrs)
+    t = abi.HnsTpBuffers()
+    for k in abi.TP_BUFFER_FIELDS:
+        a = tp_arrs[k]
+        assert a.flags["C_CONTIGUOUS"] and a.dtype in (np.float32, np.uint8)
+        setattr(t, k, a.ctypes.data)
+    if not with_state:
+        t.state_drones = None
+    T, F = tp_arrs["history"].shape[1], tp_arrs["pred"].shape[1]
+    rc = lib().hns_oracle_tp_observe(C.byref(cfg), C.byref(b), C.byref(t), int(T), int(F), int(bool(fill)))
+    assert rc == 0, rc

@@ -1,0 +1,152 @@
+"""GPU parity of the trajectory-predictor path (hns_tp_observe) through the C ABI.
+
+HIP vs the C oracle: the window (TP_input), TP_groundtruth and TP_done bit for bit; the predicted
+positions and the 35-value rows within 1e-5 (north-star tolerance: the gate pre-activations are
+bit-identical fmaf chains, the kernel's sigmoid/tanh run on the transcendental unit, the oracle's
+are libm's).  HIP vs the reference golden (its own TP_net, 14 consecutive calls) within 1e-5, and
+the env class against a plain-torch fp32 LSTM."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import hns_oracle as O
+from hns_amd import abi, config
+from hns_amd.env import HideAndSeek
+from hns_amd.tp_net import TPObservation
+
+TOL = 1e-5
+
+
+def _env(E, A, Cn=5, max_len=40, **kw):
+    cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": Cn, "min_num": min(3, Cn)},
+                           "env": {"num_envs": E, "max_episode_length": max_len}}, algo={"use_TP_net": 1, **kw})
+    env = HideAndSeek(cfg)
+    env.set_seed(3)
+    return env
+
+
+def _host_tp(env):
+    """Host copies of the predictor's buffers + weights, for the oracle."""
+    tpa = {k: v.cpu().numpy().copy() for k, v in env._tp_bufs.items()}
+    sd = env.TP.state_dict()
+    for f, key in abi.TP_STATE_DICT_KEYS.items():
+        tpa[f] = sd[key].detach().cpu().numpy().copy()
+    return tpa
+
+
+@pytest.mark.parametrize("E,A", [(48, 3), (300, 1), (257, 2), (1000, 4), (130, 6)])
+def test_tp_observe_matches_oracle(E, A):
+    env = _env(E, A, critic_input="state")
+    torch.manual_seed(E + A)
+    with torch.no_grad():
+        for prm in env.TP.parameters():                     # larger than the default init: gates leave the linear range
+            prm.mul_(3.0)
+    env.reset()
+    host = env.export_state()
+    tpa = _host_tp(env)
+    tpa["history"][:] = 0
+    O.tp_observe(env.hcfg, host, tpa, fill=True)
+    for t in range(14):
+        dev = {k: v.cpu().numpy() for k, v in env._tp_bufs.items()}
+        assert np.array_equal(dev["history"], tpa["history"]), f"window differs at call {t}"
+        assert np.array_equal(dev["groundtruth"], tpa["groundtruth"])
+        assert np.array_equal(dev["tp_done"], tpa["tp_done"])
+        np.testing.assert_allclose(dev["pred"], tpa["pred"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(dev["obs_self"], tpa["obs_self"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(dev["state_drones"], tpa["state_drones"], rtol=0, atol=TOL)
+        act = torch.randn(E, A, 4, device=env.device)
+        env.step(env.rand_step_input(act))
+        host = env.export_state()                           # the step itself is covered by test_hip_parity
+        O.tp_observe(env.hcfg, host, tpa, fill=False)
+    assert np.abs(tpa["pred"]).max() > 0.05
+
+
+def test_tp_rows_without_critic_state_and_lazy_state():
+    env = _env(200, 3)                                       # critic_input: obs -> state_drones pointer is NULL
+    env.reset()
+    td = env.step(env.rand_step_input())
+    nxt = td["next"]
+    ss = nxt[("agents", "observation", "state_self")]
+    sd = nxt[("agents", "state")]["state_drones"]
+    assert ss.shape == (200, 3, 1, 35) and sd.shape == (200, 3, 35)
+    rpos = env._bufs["drone_state"][..., :3] - env._bufs["target_pos"].unsqueeze(1)
+    assert torch.equal(sd[..., :3], rpos) and torch.equal(sd[..., 3:], ss[:, :, 0, 3:])
+    assert nxt[("agents", "TP", "TP_input")].shape == (200, 10, 16)
+    assert nxt[("agents", "TP", "TP_done")].dtype == torch.bool
+
+
+def test_tp_env_matches_torch_lstm():
+    """The env's rows against the plain-torch composition (torch.nn.LSTM fp32 on the same device)."""
+    E, A = 512, 3
+    env = _env(E, A, critic_input="state")
+    ref = TPObservation(env.TP, A, float(env.hcfg.arena_size), float(env.hcfg.max_height), env.max_episode_length)
+    env.reset()
+    b = env._bufs
+    for t in range(13):
+        ss, sd, tp = ref(b["obs_self"], b["drone_state"][..., :3], b["target_pos"], b["target_vel"], env.progress_buf, b["detect"])
+        tb = env._tp_bufs
+        assert torch.equal(tp["TP_input"], tb["history"])
+        torch.testing.assert_close(ss, tb["obs_self"], rtol=0, atol=TOL)
+        torch.testing.assert_close(sd, tb["state_drones"], rtol=0, atol=TOL)
+        torch.testing.assert_close(tp["TP_groundtruth"], tb["groundtruth"], rtol=0, atol=1e-6)
+        assert torch.equal(tp["TP_done"][:, 0], tb["tp_done"].bool())
+        env.step(env.rand_step_input(torch.randn(E, A, 4, device=env.device)))
+
+
+def test_tp_matches_reference_golden(golden):
+    """hns_tp_observe fed with the golden's states (obs rows from the oracle's observation pass) against
+    the reference's own `_compute_state_and_obs` + TP_net outputs."""
+    g = golden("g_tp_obs")
+    E, A, Cn, T, max_len = (int(x) for x in g["meta"])
+    cfg = config.make_cfg({"num_agents": A, "drone_detect_radius": 0.9, "cylinder": {"max_num": Cn, "min_num": 4},
+                           "env": {"num_envs": E, "max_episode_length": max_len}}, algo={"use_TP_net": 1, "critic_input": "state"})
+    env = HideAndSeek(cfg)
+    env.TP.load_state_dict({k: torch.from_numpy(g["w_" + k.replace(".", "_")]) for k in env.TP.state_dict()})
+    c = env.hcfg
+    arrs = O.alloc_buffers(c)
+    arrs["cylinders"][:] = g["cyl"]
+    for t in range(T):
+        arrs["drone_state"][..., 0:3], arrs["drone_state"][..., 3:7], arrs["drone_state"][..., 7:13] = g["pos"][t], g["rot"][t], g["vel"][t]
+        arrs["throttle"][:] = g["throttle"][t]
+        arrs["target_pos"][:] = g["tpos"][t][:, 0]
+        arrs["target_vel"][:] = g["tvel"][t][:, 0]
+        arrs["progress"][:] = g["progress"][t]
+        _, bdet, _ = O.obs_reward(c, arrs)
+        arrs["detect"][:] = bdet
+        env.import_state(arrs)
+        env._tp_observe()
+        tb = {k: v.cpu().numpy() for k, v in env._tp_bufs.items()}
+        np.testing.assert_allclose(tb["history"], g["TP_input"][t], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(tb["obs_self"], g["state_self"][t][:, :, 0], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(tb["state_drones"], g["state_drones"][t], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(tb["groundtruth"], g["TP_groundtruth"][t], rtol=1e-6, atol=1e-6)
+        assert (tb["tp_done"].astype(bool) == g["TP_done"][t][:, 0]).all()
+
+
+def test_tp_sees_in_place_weight_updates_and_rebinds():
+    env = _env(64, 3)
+    env.reset()
+    p0 = env._tp_bufs["pred"].clone()
+    with torch.no_grad():
+        env.TP.fc.bias.add_(0.5)                             # in-place optimiser-style update: same storage
+    env._tp_observe()
+    assert not torch.equal(p0, env._tp_bufs["pred"])
+    ptrs = env._tp_weight_ptrs
+    env.TP.fc.bias = torch.nn.Parameter(env.TP.fc.bias.detach().clone())   # swapped tensor -> re-bind
+    env._tp_observe()
+    assert env._tp_weight_ptrs != ptrs
+
+
+def test_tp_bind_errors():
+    env = _env(64, 3)
+    lib = env._lib
+    tb = abi.HnsTpBuffers()
+    assert lib.hns_tp_bind(env._env, C.byref(tb), 10, 5) == abi.HNS_ERR_INVALID_ARG
+    assert lib.hns_tp_bind(env._env, None, 10, 5) == abi.HNS_ERR_INVALID_ARG
+    env2 = HideAndSeek(config.make_cfg({"env": {"num_envs": 64}}))
+    assert lib.hns_tp_observe(env2._env, 1, None) == abi.HNS_ERR_NOT_BOUND
+    assert b"hns_tp_bind" in lib.hns_last_error()

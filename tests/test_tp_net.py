@@ -48,3 +48,33 @@ def test_tp_net_state_dict_is_reference_compatible():
     tp = TPNet(16, 15, 5, 1)
     assert set(tp.state_dict()) == {"lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0", "fc.weight", "fc.bias"}
     assert tp(torch.zeros(4, 10, 16)).shape == (4, 15)
+
+
+def test_oracle_tp_observe_matches_reference(golden):
+    """The C restatement of the whole TP branch (window, LSTM in the matrix-core accumulation order,
+    output layer, rows) against the reference's `_compute_state_and_obs` + its own TP_net."""
+    g = golden("g_tp_obs")
+    E, A, C, T, max_len = (int(x) for x in g["meta"])
+    cfg = config.make_cfg({"num_agents": A, "drone_detect_radius": 0.9, "cylinder": {"max_num": C, "min_num": 4},
+                           "env": {"num_envs": E, "max_episode_length": max_len}})
+    c = config.resolve_hns_cfg(cfg)
+    arrs = O.alloc_buffers(c)
+    tpa = O.alloc_tp_buffers(c, 10, 5)
+    from hns_amd import abi
+    for f, key in abi.TP_STATE_DICT_KEYS.items():
+        tpa[f][...] = g["w_" + key.replace(".", "_")]
+    arrs["cylinders"][:] = g["cyl"]
+    for t in range(T):
+        arrs["drone_state"][..., 0:3], arrs["drone_state"][..., 3:7], arrs["drone_state"][..., 7:13] = g["pos"][t], g["rot"][t], g["vel"][t]
+        arrs["throttle"][:] = g["throttle"][t]
+        arrs["target_pos"][:] = g["tpos"][t][:, 0]
+        arrs["target_vel"][:] = g["tvel"][t][:, 0]
+        arrs["progress"][:] = g["progress"][t]
+        _, bdet, _ = O.obs_reward(c, arrs)
+        arrs["detect"][:] = bdet
+        O.tp_observe(c, arrs, tpa, fill=(t == 0))
+        np.testing.assert_allclose(tpa["history"], g["TP_input"][t], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(tpa["obs_self"], g["state_self"][t][:, :, 0], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(tpa["state_drones"], g["state_drones"][t], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(tpa["groundtruth"], g["TP_groundtruth"][t], rtol=1e-6, atol=1e-6)
+        assert (tpa["tp_done"].astype(bool) == g["TP_done"][t][:, 0]).all()
