@@ -236,7 +236,8 @@ int hns_raycast(hns_env *env, int num_rays, float max_range, float *out, void *s
  * + Linear(64 -> 3F) + tanh) evaluated on a T-frame history, I = 7 + 3A:
  *   frame = [progress, evader pos (masked), evader vel (masked), pursuer positions]   (:815-820)
  * The parameters are the caller's tensors in PyTorch layouts (the learner trains them,
- * scripts/train.py:180); they are read on every call, so in-place optimiser updates are seen.
+ * scripts/train.py:180).  They are converted into a matrix-core operand image (`packed`) by
+ * hns_tp_refresh: call it after every parameter update (hns_tp_bind schedules one).
  */
 #define HNS_TP_HIDDEN 64           /* TP_net.hidden_dim, mappo.py:576 */
 typedef struct hns_tp_buffers {
@@ -246,6 +247,7 @@ typedef struct hns_tp_buffers {
     const float *b_hh;        /* [4*64]      lstm.bias_hh_l0 */
     const float *w_fc;        /* [3F, 64]    fc.weight */
     const float *b_fc;        /* [3F]        fc.bias */
+    void *packed;             /* [hns_tp_packed_bytes()] scratch, 16-byte aligned: operand image of the parameters */
     float *history;           /* [E,T,I]  state: the sliding window == agents.TP.TP_input, oldest frame first */
     float *pred;              /* [E,F,3]  out: predicted evader positions, arena units (hideandseek.py:834-836) */
     float *obs_self;          /* [E,A,20+3F] out: agents.observation.state_self rows (:846-854) */
@@ -253,8 +255,11 @@ typedef struct hns_tp_buffers {
     float *groundtruth;       /* [E,3]    out: agents.TP.TP_groundtruth (:839-842) */
     uint8_t *tp_done;         /* [E]      out: agents.TP.TP_done (:838) */
 } hns_tp_buffers;
-/* history_step T in [1,16], future_step F in [1,10]. */
+size_t hns_tp_packed_bytes(void);
+/* history_step T in [1,16], future_step F in [1,10]; max_episode_length <= 60000 (fp16-split operands). */
 int hns_tp_bind(hns_env *env, const hns_tp_buffers *buffers, int32_t history_step, int32_t future_step);
+/* Re-read the parameters (after an optimiser step / load_state_dict): one small launch on `stream`. */
+int hns_tp_refresh(hns_env *env, void *stream);
 /* Run after hns_step / hns_reset on the same stream: appends the frame of the bound step buffers to
  * the window (fill_history != 0: the window is filled with this frame, as the reference does on its
  * first call, hideandseek.py:825-828), evaluates TP_net, writes the 20+3F-value rows. */

@@ -129,8 +129,9 @@ HNS_OK, HNS_ERR_INVALID_ARG, HNS_ERR_NOT_BOUND, HNS_ERR_DEVICE, HNS_ERR_NO_DEVIC
 
 # ---- trajectory predictor (include/hns.h: hns_tp_buffers) ------------------------------------------------
 HNS_TP_HIDDEN = 64
+TP_PACKED_BYTES = 16 * (2 * 8 * 4 * 64 + 2 * 8 * 2 * 64 + 2 * 4 * 64 + 8 * 2 * 16 // 4 + 2 * 16 // 4)   # hns_tp_packed_bytes()
 TP_WEIGHT_FIELDS = ["w_ih", "w_hh", "b_ih", "b_hh", "w_fc", "b_fc"]
-TP_BUFFER_FIELDS = TP_WEIGHT_FIELDS + ["history", "pred", "obs_self", "state_drones", "groundtruth", "tp_done"]
+TP_BUFFER_FIELDS = TP_WEIGHT_FIELDS + ["packed", "history", "pred", "obs_self", "state_drones", "groundtruth", "tp_done"]
 # hns_tp_buffers weight field -> TP_net.state_dict() key (learning/mappo.py:572-589)
 TP_STATE_DICT_KEYS = {"w_ih": "lstm.weight_ih_l0", "w_hh": "lstm.weight_hh_l0", "b_ih": "lstm.bias_ih_l0",
                       "b_hh": "lstm.bias_hh_l0", "w_fc": "fc.weight", "b_fc": "fc.bias"}
@@ -145,7 +146,7 @@ def tp_buffer_shapes(E, A, T, F):
     return {"w_ih": ((4 * HNS_TP_HIDDEN, I), "float32"), "w_hh": ((4 * HNS_TP_HIDDEN, HNS_TP_HIDDEN), "float32"),
             "b_ih": ((4 * HNS_TP_HIDDEN,), "float32"), "b_hh": ((4 * HNS_TP_HIDDEN,), "float32"),
             "w_fc": ((3 * F, HNS_TP_HIDDEN), "float32"), "b_fc": ((3 * F,), "float32"),
-            "history": ((E, T, I), "float32"), "pred": ((E, F, 3), "float32"), "obs_self": ((E, A, D), "float32"),
+            "packed": ((TP_PACKED_BYTES,), "uint8"), "history": ((E, T, I), "float32"), "pred": ((E, F, 3), "float32"), "obs_self": ((E, A, D), "float32"),
             "state_drones": ((E, A, D), "float32"), "groundtruth": ((E, 3), "float32"), "tp_done": ((E,), "uint8")}
 
 
@@ -204,6 +205,10 @@ def load_library():
     lib.hns_hover_reset.restype = C.c_int
     lib.hns_tp_bind.argtypes = [C.c_void_p, C.POINTER(HnsTpBuffers), C.c_int32, C.c_int32]
     lib.hns_tp_bind.restype = C.c_int
+    lib.hns_tp_refresh.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hns_tp_refresh.restype = C.c_int
+    lib.hns_tp_packed_bytes.argtypes = []
+    lib.hns_tp_packed_bytes.restype = C.c_size_t
     lib.hns_tp_observe.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.hns_tp_observe.restype = C.c_int
     lib.hns_abi_version.argtypes = []
@@ -214,6 +219,8 @@ def load_library():
     lib.hns_last_error.restype = C.c_char_p
     if lib.hns_abi_version() != HNS_ABI_VERSION:
         raise RuntimeError("libhns.so ABI version mismatch")
+    if lib.hns_tp_packed_bytes() != TP_PACKED_BYTES:
+        raise RuntimeError("hns_tp_packed_bytes() differs from abi.TP_PACKED_BYTES")
     if lib.hns_cfg_size() != C.sizeof(HnsCfg):
         raise RuntimeError("hns_cfg layout mismatch between include/hns.h and abi.py")
     _LIB = lib
@@ -223,5 +230,5 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "hns_create", "hns_destroy", "hns_bind", "hns_step", "hns_reset", "hns_reset_tasks", "hns_raycast", "hns_set_v_prey",
     "hns_set_smoothness_coef", "hns_set_reset_epoch", "hns_get_reset_epoch", "hns_enable_timing",
-    "hns_step_kernel_ms", "hns_set_phase_profile", "hns_tp_bind", "hns_tp_observe", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
+    "hns_step_kernel_ms", "hns_set_phase_profile", "hns_tp_bind", "hns_tp_refresh", "hns_tp_packed_bytes", "hns_tp_observe", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
 ]

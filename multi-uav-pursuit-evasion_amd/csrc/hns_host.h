@@ -20,6 +20,7 @@ struct hns_tp_state {
     hns_tp_buffers buf;
     int history_step = 0, future_step = 0;
     bool bound = false;
+    bool dirty = true;     // operand image out of date (parameters changed)
 };
 
 struct hns_env {

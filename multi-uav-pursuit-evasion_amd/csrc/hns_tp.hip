@@ -5,22 +5,35 @@
 // LSTM(I -> 64, 1 layer, zero initial state) + Linear(64 -> 3F) + tanh
 // (omni_drones/learning/mappo.py:572-589), I = 7 + 3A, evaluated every step on a T-frame window.
 // In the reference this is a cuDNN LSTM over [E,T,I] plus ~25 elementwise launches; here it is
-//   hns_tp_lstm_kernel : frame append + window shift + LSTM + FC + tanh + rescale   (MFMA-bound)
+//   hns_tp_pack_kernel : parameters -> matrix-core operand image (only when they changed)
+//   hns_tp_lstm_kernel : frame append + window shift + LSTM + FC + tanh + rescale
 //   hns_tp_rows_kernel : the 20+3F-value observation rows                           (HBM-bound)
 //
 // This is the one dense contraction near the hot path: per env and timestep z[256] = W[256 x (I+64)]·[x;h].
-// Mapping onto the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 — bit-for-bit a k-ordered
-// fmaf chain, so the CPU oracle reproduces every gate pre-activation exactly):
+// It runs on the matrix cores at fp32-class accuracy with TWO-TERM fp16 SPLITS:
+//     w = w1 + 2^-11 w2,  v = v1 + 2^-11 v2   (w1 = fp16(w), w2 = fp16((w - w1) 2^11), same for v)
+//     w·v ~= w1 v1 + 2^-11 (w1 v2 + w2 v1)            (dropped: 2^-22 w2 v2)
+// i.e. three v_mfma_f32_32x32x16_f16 per product tile: the two cross terms accumulate first, are
+// scaled by 2^-11 (with the bias added) and the leading term accumulates on top, all in fp32.
+// Measured against fp64 the split is as accurate as a plain fp32 evaluation (<= 3e-7 on the
+// outputs; tools/tp_split_error.py), and it is 5.3x fewer matrix-pipe cycles than
+// v_mfma_f32_32x32x2_f32 — which on gfx950 moreover shares the VALU's fp32 lanes: measured here,
+// a partner wave's gate nonlinearities took 12.6k cycles beside it instead of 2.3k, so nothing
+// overlapped (the fp32-MFMA version of this kernel ran 228 us, this one see DESIGN.md §8).
+// The scaling keeps the low parts out of fp16's subnormal range; |x| must stay below 65 504
+// (the frame holds `progress` <= max_episode_length, checked at bind time).
+//
+// Mapping:
 //   * one wave owns 32 envs for the whole window; gates are the M dimension (8 tiles of 32 rows),
-//     envs the N dimension, [x;h] the K dimension;
-//   * the weights sit in LDS in A-operand order (lane l: row l&31, k-slot l>>5), staged once per
-//     workgroup; x_t and h_{t-1} are B operands held in registers;
+//     envs the N dimension, [x;h] the K dimension (16 per MFMA);
+//   * the operand image sits in LDS in A-operand order (lane l: row l&31, k-slots 8(l>>5)..+7: one
+//     ds_read_b128 per lane is one MFMA's A operand); x_t and h_{t-1} are B operands in registers;
 //   * D tile layout: lane (env n = l&31, half hb = l>>5), register i  <->  row 8(i>>2)+4hb+(i&3).
 //     Gate q of hidden unit u lives in tile 2q + u/32, row u%32: the four gates of a unit land in
 //     the SAME lane and register index, so the cell update is lane-local;
-//   * the K order of the recurrent product is free, so k-step s is DEFINED to pair the units
-//     that the lower and the upper half-wave hold in register s: h_t leaves the cell update in
-//     exactly the registers the next timestep's B operand reads — no shuffle, no LDS round trip.
+//   * the K order of the recurrent product is free, so its k-slots are DEFINED as the units each
+//     half-wave holds: h_t leaves the cell update in exactly the lanes whose B operand needs it —
+//     no shuffle, no LDS round trip, just the fp16 split.
 // 8 waves per workgroup (2 per SIMD: one wave's gate nonlinearities overlap the other's MFMAs),
 // 256 envs per workgroup => 256 workgroups = one per CU at 65 536 envs.
 #include <hip/hip_runtime.h>
@@ -34,12 +47,15 @@
 namespace hns {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int kTpH = HNS_TP_HIDDEN;
 constexpr int kTpWaves = 8;
 constexpr int kTpThreads = kTpWaves * 64;
 constexpr int kTpEnvs = kTpWaves * 32;      // envs per workgroup
 constexpr int kTpMaxRows = 32;              // 3F <= 32: one M tile for the output layer
+constexpr float kTpLoScale = 2048.0f;       // 2^11: the low split term, kept in fp16's normal range
+constexpr float kTpLoInv = 1.0f / 2048.0f;
 
 struct TpParams {
     hns_tp_buffers tp;
@@ -47,27 +63,89 @@ struct TpParams {
     const uint8_t *detect;
     int E, A, I, T, F, fill, max_len;
     float mask_value, arena_size, max_height;
+    unsigned long long *prof;   // diagnostics (hns_set_phase_profile): per-wave stamps of the 100 MHz clock
 };
 
-// LDS image (floats).  W_hh / W_ih / W_fc as [tile][k-step/4][lane][4]: one ds_read_b128 per lane
-// yields the A operands of 4 consecutive k-steps; biases as [tile][half][16] (broadcast reads).
-struct TpLds {
-    int whh, wih, wfc, bias, bfc, total;
+// Operand image (16-byte slots = one lane's A operand of one MFMA; then the fp32 biases).
+// Slot index within a matrix: ((term * tiles + tile) * chunks + chunk) * 64 + lane, term 0 = w1, 1 = w2.
+struct TpImage {
+    int whh, wih, wfc, bias, bfc, slots, bytes;    // slot offsets; bias/bfc in slots too (16 B = 4 floats)
 };
-__host__ __device__ inline TpLds tp_lds_layout(int sxq) {
-    TpLds L;
+__host__ __device__ inline TpImage tp_image(int nxc) {
+    TpImage L;
     int o = 0;
-    L.whh = o;  o += 8 * 8 * 64 * 4;
-    L.wih = o;  o += 8 * sxq * 64 * 4;
-    L.wfc = o;  o += 8 * 64 * 4;
-    L.bias = o; o += 8 * 2 * 16;
-    L.bfc = o;  o += 2 * 16;
-    L.total = o;
+    L.whh = o;  o += 2 * 8 * 4 * 64;
+    L.wih = o;  o += 2 * 8 * nxc * 64;
+    L.wfc = o;  o += 2 * 1 * 4 * 64;
+    L.slots = o;                                   // operand slots; biases follow
+    L.bias = o; o += 8 * 2 * 16 / 4;
+    L.bfc = o;  o += 2 * 16 / 4;
+    L.bytes = o * 16;
     return L;
 }
 
 // hidden unit that half-wave `hb` holds in register s (s = 16*tile_pair + i): D row 8(i>>2)+4hb+(i&3)
 __host__ __device__ inline int tp_unit(int s, int hb) { return 32 * (s >> 4) + 8 * ((s & 15) >> 2) + 4 * hb + (s & 3); }
+
+HNS_DEV void tp_split(float w, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)w;
+    lo = (_Float16)((w - (float)hi) * kTpLoScale);
+}
+
+// ---- parameters -> operand image (run when the parameters changed) ------------------------------
+__global__ __launch_bounds__(256) void hns_tp_pack_kernel(const TpParams p, int nxc) {
+    const TpImage L = tp_image(nxc);
+    const int I = p.I, R = 3 * p.F;
+    const int n_hh = 8 * 4 * 64, n_ih = 8 * nxc * 64, n_fc = 4 * 64;
+    uint4 *img = reinterpret_cast<uint4 *>(p.tp.packed);
+    for (int sidx = blockIdx.x * blockDim.x + threadIdx.x; sidx < n_hh + n_ih + n_fc; sidx += gridDim.x * blockDim.x) {
+        float w[8];
+        int slot_hi, slot_lo;
+        if (sidx < n_hh) {                                  // [tile][chunk][lane]
+            const int ln = sidx & 63, c = (sidx >> 6) & 3, m = sidx >> 8;
+            const int row = 32 * m + (ln & 31), hb = ln >> 5;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = p.tp.w_hh[row * kTpH + tp_unit(8 * c + j, hb)];
+            slot_hi = L.whh + sidx; slot_lo = L.whh + n_hh + sidx;
+        } else if (sidx < n_hh + n_ih) {
+            const int u = sidx - n_hh, ln = u & 63, g = u >> 6, m = g / nxc, cx = g - m * nxc;
+            const int row = 32 * m + (ln & 31), hb = ln >> 5;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * cx + 8 * hb + j;
+                w[j] = k < I ? p.tp.w_ih[row * I + k] : 0.0f;
+            }
+            slot_hi = L.wih + u; slot_lo = L.wih + n_ih + u;
+        } else {
+            const int u = sidx - n_hh - n_ih, ln = u & 63, c = u >> 6;
+            const int row = ln & 31, hb = ln >> 5;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = row < R ? p.tp.w_fc[row * kTpH + tp_unit(8 * c + j, hb)] : 0.0f;
+            slot_hi = L.wfc + u; slot_lo = L.wfc + n_fc + u;
+        }
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 a, b;
+            tp_split(w[j], a, b);
+            hi[j] = a; lo[j] = b;
+        }
+        img[slot_hi] = *reinterpret_cast<uint4 *>(&hi);
+        img[slot_lo] = *reinterpret_cast<uint4 *>(&lo);
+    }
+    float *bias = reinterpret_cast<float *>(img + L.bias), *bfc = reinterpret_cast<float *>(img + L.bfc);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 8 * 2 * 16 + 2 * 16; idx += gridDim.x * blockDim.x) {
+        if (idx < 256) {                                    // [tile][half][16]
+            const int i = idx & 15, hb = (idx >> 4) & 1, m = idx >> 5;
+            const int g = 32 * m + 8 * (i >> 2) + 4 * hb + (i & 3);
+            bias[idx] = p.tp.b_ih[g] + p.tp.b_hh[g];
+        } else {
+            const int i = idx & 15, hb = (idx - 256) >> 4;
+            const int row = 8 * (i >> 2) + 4 * hb + (i & 3);
+            bfc[idx - 256] = row < R ? p.tp.b_fc[row] : 0.0f;
+        }
+    }
+}
 
 // gate nonlinearities on the transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp each); the oracle
 // uses libm, the parity tolerance is the north star's 1e-5
@@ -86,122 +164,139 @@ HNS_DEV float tp_frame_val(const TpParams &p, int e, int k, bool det) {
     return p.drone_state[((size_t)e * p.A + a) * 13 + (j - 3 * a)];
 }
 
-template <int SXQ>
-__global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams p) {
-    constexpr int SX = 4 * SXQ;                 // k-steps of the input product; half-wave hb takes x[hb*SX + s]
-    extern __shared__ __align__(16) float smem[];
-    const TpLds L = tp_lds_layout(SXQ);
-    float *sWhh = smem + L.whh, *sWih = smem + L.wih, *sWfc = smem + L.wfc, *sB = smem + L.bias, *sBfc = smem + L.bfc;
-    const int tid = threadIdx.x, I = p.I, T = p.T, R = 3 * p.F;
+#define TP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
-    // ---- stage the parameters in A-operand order (80-100 KB, L2-resident source) -----------------
-    for (int idx = tid; idx < 8 * 8 * 64 * 4; idx += kTpThreads) {
-        const int r = idx & 3, ln = (idx >> 2) & 63, sq = (idx >> 8) & 7, m = idx >> 11;
-        const int row = 32 * m + (ln & 31);
-        sWhh[idx] = p.tp.w_hh[row * kTpH + tp_unit(4 * sq + r, ln >> 5)];
-    }
-    for (int idx = tid; idx < 8 * SXQ * 64 * 4; idx += kTpThreads) {
-        const int r = idx & 3, ln = (idx >> 2) & 63, g = idx >> 8, m = g / SXQ, sq = g - m * SXQ;
-        const int row = 32 * m + (ln & 31), k = (ln >> 5) * SX + 4 * sq + r;
-        sWih[idx] = k < I ? p.tp.w_ih[row * I + k] : 0.0f;
-    }
-    for (int idx = tid; idx < 8 * 64 * 4; idx += kTpThreads) {
-        const int r = idx & 3, ln = (idx >> 2) & 63, sq = idx >> 8;
-        const int row = ln & 31;
-        sWfc[idx] = row < R ? p.tp.w_fc[row * kTpH + tp_unit(4 * sq + r, ln >> 5)] : 0.0f;
-    }
-    for (int idx = tid; idx < 8 * 2 * 16; idx += kTpThreads) {
-        const int i = idx & 15, hbb = (idx >> 4) & 1, m = idx >> 5;
-        const int g = 32 * m + 8 * (i >> 2) + 4 * hbb + (i & 3);
-        sB[idx] = p.tp.b_ih[g] + p.tp.b_hh[g];
-    }
-    for (int idx = tid; idx < 2 * 16; idx += kTpThreads) {
-        const int i = idx & 15, hbb = idx >> 4;
-        const int row = 8 * (i >> 2) + 4 * hbb + (i & 3);
-        sBfc[idx] = row < R ? p.tp.b_fc[row] : 0.0f;
+// NXC = 16-wide k-chunks of the frame (1: I <= 16, i.e. up to 3 pursuers; 2: I <= 32)
+template <int NXC>
+__global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams p) {
+    extern __shared__ __align__(16) uint4 simg[];
+    const TpImage L = tp_image(NXC);
+    const int tid = threadIdx.x, I = p.I, T = p.T, R = 3 * p.F;
+    unsigned long long *prof = p.prof ? p.prof + (size_t)(blockIdx.x * kTpWaves + (tid >> 6)) * 16 : nullptr;
+    if (prof && (tid & 63) == 0) prof[0] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- stage the operand image (88-104 KB, L2-resident, contiguous) ------------------------------
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.tp.packed);
+        const int n = L.bytes / 16;
+        for (int i = tid; i < n; i += kTpThreads) simg[i] = src[i];
     }
     __syncthreads();
+    if (prof && (tid & 63) == 0) prof[1] = __builtin_amdgcn_s_memrealtime();
 
     const int wave = tid >> 6, lane = tid & 63, hb = lane >> 5;
     const int e = blockIdx.x * kTpEnvs + wave * 32 + (lane & 31);
     if (blockIdx.x * kTpEnvs + wave * 32 >= p.E) return;          // whole wave out of range
     const bool valid = e < p.E;
     const int ec = valid ? e : p.E - 1;                           // clamped: loads stay in bounds, stores are guarded
-    const int k0 = hb * SX;
+    const float *sBias = reinterpret_cast<const float *>(simg + L.bias), *sBfc = reinterpret_cast<const float *>(simg + L.bfc);
+    constexpr int N_HH = 8 * 4 * 64, N_IH = 8 * NXC * 64, N_FC = 4 * 64;
 
-    // the new frame, this lane's half
-    float xn[SX];
+    // this lane's part of a frame: k = 16 cx + 8 hb + j
+    float xn[8 * NXC];
     {
         const bool det = p.detect[ec] != 0;
 #pragma unroll
-        for (int s = 0; s < SX; ++s) xn[s] = (k0 + s < I) ? tp_frame_val(p, ec, k0 + s, det) : 0.0f;
+        for (int cx = 0; cx < NXC; ++cx)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * cx + 8 * hb + j;
+                xn[8 * cx + j] = k < I ? tp_frame_val(p, ec, k, det) : 0.0f;
+            }
     }
-    float *hist = p.tp.history + (size_t)ec * T * I + k0;
+    float *hist = p.tp.history + (size_t)ec * T * I + 8 * hb;
     // x_t = old frame t+1 for t <= T-2, the new frame for t = T-1 (or for every t when filling)
-    float xb[SX];
-    if (T == 1 || p.fill) {
+    float xc[8 * NXC];
 #pragma unroll
-        for (int s = 0; s < SX; ++s) xb[s] = xn[s];
-    } else {
+    for (int cx = 0; cx < NXC; ++cx)
 #pragma unroll
-        for (int s = 0; s < SX; ++s) xb[s] = (k0 + s < I) ? hist[I + s] : 0.0f;
-    }
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * cx + 8 * hb + j;
+            xc[8 * cx + j] = (T == 1 || p.fill) ? xn[8 * cx + j] : (k < I ? hist[I + 16 * cx + j] : 0.0f);
+        }
 
-    float h[32], c[32];
+    half8 hh[4], hl[4];                     // h_{t-1}: leading and low split terms, k-slot j of chunk c = own register 8c + j
+    float c[32];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { h[i] = 0.0f; c[i] = 0.0f; }
+    for (int i = 0; i < 4; ++i) { hh[i] = (half8)(_Float16)0.0f; hl[i] = (half8)(_Float16)0.0f; }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) c[i] = 0.0f;
+    float hn[32];
 
     for (int t = 0; t < T; ++t) {
-        // prefetch x_{t+1} (slot t+2 of the old window, untouched so far), then shift x_t into slot t
-        float xnext[SX];
+        // shift x_t into slot t and split it; prefetch x_{t+1} (slot t+2 of the old window, untouched so far)
+        half8 xh[NXC], xl[NXC];
+#pragma unroll
+        for (int cx = 0; cx < NXC; ++cx)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * cx + 8 * hb + j;
+                const float v = xc[8 * cx + j];
+                if (valid && k < I) hist[t * I + 16 * cx + j] = v;
+                _Float16 a, b;
+                tp_split(v, a, b);
+                xh[cx][j] = a; xl[cx][j] = b;
+            }
         const bool from_hist = !p.fill && (t + 1 <= T - 2);
 #pragma unroll
-        for (int s = 0; s < SX; ++s) xnext[s] = (from_hist && k0 + s < I) ? hist[(t + 2) * I + s] : xn[s];
-        if (valid) {
+        for (int cx = 0; cx < NXC; ++cx)
 #pragma unroll
-            for (int s = 0; s < SX; ++s)
-                if (k0 + s < I) hist[t * I + s] = xb[s];
-        }
-        float hn[32];
-        // the weight image is loop-invariant; an opaque lane offset keeps the compiler from hoisting
-        // every A operand of the window (hundreds of registers) out of the timestep loop
-        int lo = lane * 4;
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * cx + 8 * hb + j;
+                xc[8 * cx + j] = (from_hist && k < I) ? hist[(t + 2) * I + 16 * cx + j] : xn[8 * cx + j];
+            }
+        // the operand image is loop-invariant; an opaque lane offset keeps the compiler from hoisting
+        // the A operands of the whole window (hundreds of registers) out of the timestep loop
+        int lo = lane;
         asm volatile("" : "+v"(lo));
+        const uint4 *aw = simg + lo;
+#define TP_A(base, idx) (*reinterpret_cast<const half8 *>(aw + (base) + (idx) * 64))
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {                 // units 32tj..32tj+31: gate tiles m = 2q + tj
             f32x16 acc[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 *b4 = reinterpret_cast<const float4 *>(sB + ((2 * q + tj) * 2 + hb) * 16);
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float4 bv = b4[v];
-                    acc[q][4 * v] = bv.x; acc[q][4 * v + 1] = bv.y; acc[q][4 * v + 2] = bv.z; acc[q][4 * v + 3] = bv.w;
-                }
-            }
+                for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+            // cross terms w1 v2 + w2 v1 (scaled by 2^11)
 #pragma unroll
-            for (int sq = 0; sq < SXQ; ++sq) {
+            for (int cx = 0; cx < NXC; ++cx) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 a = *reinterpret_cast<const float4 *>(sWih + ((2 * q + tj) * SXQ + sq) * 256 + lo);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xb[4 * sq], acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xb[4 * sq + 1], acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xb[4 * sq + 2], acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xb[4 * sq + 3], acc[q], 0, 0, 0);
-                }
+                for (int q = 0; q < 4; ++q) acc[q] = TP_MFMA(TP_A(L.wih, (2 * q + tj) * NXC + cx), xl[cx], acc[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = TP_MFMA(TP_A(L.wih + N_IH, (2 * q + tj) * NXC + cx), xh[cx], acc[q]);
             }
             if (t > 0) {                                   // h_0 = 0: the recurrent product vanishes
 #pragma unroll
-                for (int sq = 0; sq < 8; ++sq) {
+                for (int ch = 0; ch < 4; ++ch) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 a = *reinterpret_cast<const float4 *>(sWhh + ((2 * q + tj) * 8 + sq) * 256 + lo);
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, h[4 * sq], acc[q], 0, 0, 0);
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, h[4 * sq + 1], acc[q], 0, 0, 0);
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, h[4 * sq + 2], acc[q], 0, 0, 0);
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, h[4 * sq + 3], acc[q], 0, 0, 0);
-                    }
+                    for (int q = 0; q < 4; ++q) acc[q] = TP_MFMA(TP_A(L.whh, (2 * q + tj) * 4 + ch), hl[ch], acc[q]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = TP_MFMA(TP_A(L.whh + N_HH, (2 * q + tj) * 4 + ch), hh[ch], acc[q]);
                 }
+            }
+            // 2^-11 (cross terms) + bias, then the leading term w1 v1 on top
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 *b4 = reinterpret_cast<const float4 *>(sBias + ((2 * q + tj) * 2 + hb) * 16);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float4 bv = b4[v];
+                    acc[q][4 * v] = HNS_FMA(acc[q][4 * v], kTpLoInv, bv.x);
+                    acc[q][4 * v + 1] = HNS_FMA(acc[q][4 * v + 1], kTpLoInv, bv.y);
+                    acc[q][4 * v + 2] = HNS_FMA(acc[q][4 * v + 2], kTpLoInv, bv.z);
+                    acc[q][4 * v + 3] = HNS_FMA(acc[q][4 * v + 3], kTpLoInv, bv.w);
+                }
+            }
+#pragma unroll
+            for (int cx = 0; cx < NXC; ++cx)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = TP_MFMA(TP_A(L.wih, (2 * q + tj) * NXC + cx), xh[cx], acc[q]);
+            if (t > 0) {
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = TP_MFMA(TP_A(L.whh, (2 * q + tj) * 4 + ch), hh[ch], acc[q]);
             }
             // cell update (torch.nn.LSTM: i, f, g, o), lane-local
 #pragma unroll
@@ -213,30 +308,44 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
                 hn[16 * tj + i] = og * tp_tanh(cn);
             }
         }
+        // h_t -> B operands of the next timestep
 #pragma unroll
-        for (int i = 0; i < 32; ++i) h[i] = hn[i];
+        for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
-        for (int s = 0; s < SX; ++s) xb[s] = xnext[s];
+            for (int j = 0; j < 8; ++j) {
+                _Float16 a, b;
+                tp_split(hn[8 * ch + j], a, b);
+                hh[ch][j] = a; hl[ch][j] = b;
+            }
     }
 
+    if (prof && lane == 0) prof[2] = __builtin_amdgcn_s_memrealtime();
     // ---- output layer on h_T: tanh(W_fc h + b), rescaled to arena units (hideandseek.py:834-836) ----
     f32x16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.0f;
     {
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const uint4 *aw = simg + lo;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            o = TP_MFMA(TP_A(L.wfc, ch), hl[ch], o);
+            o = TP_MFMA(TP_A(L.wfc + N_FC, ch), hh[ch], o);
+        }
         const float4 *b4 = reinterpret_cast<const float4 *>(sBfc + hb * 16);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const float4 bv = b4[v];
-            o[4 * v] = bv.x; o[4 * v + 1] = bv.y; o[4 * v + 2] = bv.z; o[4 * v + 3] = bv.w;
+            o[4 * v] = HNS_FMA(o[4 * v], kTpLoInv, bv.x);
+            o[4 * v + 1] = HNS_FMA(o[4 * v + 1], kTpLoInv, bv.y);
+            o[4 * v + 2] = HNS_FMA(o[4 * v + 2], kTpLoInv, bv.z);
+            o[4 * v + 3] = HNS_FMA(o[4 * v + 3], kTpLoInv, bv.w);
         }
-    }
 #pragma unroll
-    for (int sq = 0; sq < 8; ++sq) {
-        const float4 a = *reinterpret_cast<const float4 *>(sWfc + (sq * 64 + lane) * 4);
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, h[4 * sq], o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, h[4 * sq + 1], o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, h[4 * sq + 2], o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, h[4 * sq + 3], o, 0, 0, 0);
+        for (int ch = 0; ch < 4; ++ch) o = TP_MFMA(TP_A(L.wfc, ch), hh[ch], o);
     }
+#undef TP_A
     if (valid) {
         float *pr = p.tp.pred + (size_t)e * R;
 #pragma unroll
@@ -249,6 +358,7 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
             }
         }
     }
+    if (prof && lane == 0) prof[3] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---- observation rows: [rpos_evader(3) | drone - predicted (3F) | quat4 linvel3 heading3 up3 t x4 (17)] -------------
@@ -323,9 +433,28 @@ __global__ __launch_bounds__(kRowThreads) void hns_tp_rows_kernel(const TpParams
 // =================================================================================================
 using hns::TpParams;
 
-static int tp_sxq(int I) { return ((I + 1) / 2 + 3) / 4; }
+static int tp_nxc(int I) { return (I + 15) / 16; }
+
+static void tp_fill_params(const hns_env *env, TpParams &p) {
+    const hns_cfg &c = env->cfg;
+    p.tp = env->tp.buf;
+    p.drone_state = env->buf.drone_state;
+    p.target_pos = env->buf.target_pos;
+    p.target_vel = env->buf.target_vel;
+    p.progress = env->buf.progress;
+    p.obs_self20 = env->buf.obs_self;
+    p.detect = env->buf.detect;
+    p.E = c.num_envs; p.A = c.num_agents; p.I = 7 + 3 * c.num_agents;
+    p.T = env->tp.history_step; p.F = env->tp.future_step;
+    p.fill = 0;
+    p.max_len = c.max_episode_length;
+    p.prof = env->prof;
+    p.mask_value = c.mask_value; p.arena_size = c.arena_size; p.max_height = c.max_height;
+}
 
 extern "C" {
+
+size_t hns_tp_packed_bytes(void) { return (size_t)hns::tp_image(2).bytes; }
 
 int hns_tp_bind(hns_env *env, const hns_tp_buffers *b, int32_t history_step, int32_t future_step) {
     if (!env || !b) { hns_set_error("hns_tp_bind: null argument"); return HNS_ERR_INVALID_ARG; }
@@ -337,44 +466,54 @@ int hns_tp_bind(hns_env *env, const hns_tp_buffers *b, int32_t history_step, int
         hns_set_error("hns_tp_bind: history_step must be in [1,16], future_step in [1,10]");
         return HNS_ERR_INVALID_ARG;
     }
-    if (!b->w_ih || !b->w_hh || !b->b_ih || !b->b_hh || !b->w_fc || !b->b_fc || !b->history || !b->pred || !b->obs_self ||
-        !b->groundtruth || !b->tp_done) {
+    if (!b->w_ih || !b->w_hh || !b->b_ih || !b->b_hh || !b->w_fc || !b->b_fc || !b->packed || !b->history || !b->pred ||
+        !b->obs_self || !b->groundtruth || !b->tp_done) {
         hns_set_error("hns_tp_bind: null buffer (only state_drones may be null)");
         return HNS_ERR_INVALID_ARG;
     }
-    const int sxq = tp_sxq(7 + 3 * env->cfg.num_agents);
-    if (sxq < 2 || sxq > 4) { hns_set_error("hns_tp_bind: unsupported frame width"); return HNS_ERR_CONFIG; }
+    if ((reinterpret_cast<uintptr_t>(b->packed) & 15) != 0) { hns_set_error("hns_tp_bind: packed must be 16-byte aligned"); return HNS_ERR_INVALID_ARG; }
+    if (tp_nxc(7 + 3 * env->cfg.num_agents) > 2) { hns_set_error("hns_tp_bind: unsupported frame width"); return HNS_ERR_CONFIG; }
+    if (env->cfg.max_episode_length > 60000) {
+        // the frame holds `progress`; the matrix-core operands are fp16 splits (|x| < 65 504)
+        hns_set_error("hns_tp_bind: max_episode_length > 60000 does not fit the fp16-split operands of the predictor");
+        return HNS_ERR_CONFIG;
+    }
     env->tp.buf = *b;
     env->tp.history_step = history_step;
     env->tp.future_step = future_step;
     env->tp.bound = true;
+    env->tp.dirty = true;
+    return HNS_OK;
+}
+
+int hns_tp_refresh(hns_env *env, void *stream) {
+    if (!env) { hns_set_error("hns_tp_refresh: null env"); return HNS_ERR_INVALID_ARG; }
+    if (!env->tp.bound) { hns_set_error("hns_tp_refresh: hns_tp_bind first"); return HNS_ERR_NOT_BOUND; }
+    TpParams p;
+    tp_fill_params(env, p);
+    hipLaunchKernelGGL(hns::hns_tp_pack_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, p, tp_nxc(p.I));
+    HNS_CHECK_HIP(hipGetLastError());
+    env->tp.dirty = false;
     return HNS_OK;
 }
 
 int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
     if (!env) { hns_set_error("hns_tp_observe: null env"); return HNS_ERR_INVALID_ARG; }
     if (!env->tp.bound) { hns_set_error("hns_tp_observe: hns_tp_bind first"); return HNS_ERR_NOT_BOUND; }
-    const hns_cfg &c = env->cfg;
+    if (env->tp.dirty) {
+        const int rc = hns_tp_refresh(env, stream);
+        if (rc != HNS_OK) return rc;
+    }
     TpParams p;
-    p.tp = env->tp.buf;
-    p.drone_state = env->buf.drone_state;
-    p.target_pos = env->buf.target_pos;
-    p.target_vel = env->buf.target_vel;
-    p.progress = env->buf.progress;
-    p.obs_self20 = env->buf.obs_self;
-    p.detect = env->buf.detect;
-    p.E = c.num_envs; p.A = c.num_agents; p.I = 7 + 3 * c.num_agents;
-    p.T = env->tp.history_step; p.F = env->tp.future_step;
+    tp_fill_params(env, p);
     p.fill = fill_history ? 1 : 0;
-    p.max_len = c.max_episode_length;
-    p.mask_value = c.mask_value; p.arena_size = c.arena_size; p.max_height = c.max_height;
-    const int sxq = tp_sxq(p.I);
-    void (*fn)(const TpParams) = sxq == 2 ? hns::hns_tp_lstm_kernel<2> : (sxq == 3 ? hns::hns_tp_lstm_kernel<3> : hns::hns_tp_lstm_kernel<4>);
-    const size_t lds = (size_t)hns::tp_lds_layout(sxq).total * sizeof(float);
-    static thread_local const void *attr_set[3] = {nullptr, nullptr, nullptr};
-    if (attr_set[sxq - 2] != (const void *)fn) {
+    const int nxc = tp_nxc(p.I);
+    void (*fn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_kernel<1> : hns::hns_tp_lstm_kernel<2>;
+    const size_t lds = (size_t)hns::tp_image(nxc).bytes;
+    static thread_local const void *attr_set[2] = {nullptr, nullptr};
+    if (attr_set[nxc - 1] != (const void *)fn) {
         HNS_CHECK_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[sxq - 2] = (const void *)fn;
+        attr_set[nxc - 1] = (const void *)fn;
     }
     hipStream_t s = (hipStream_t)stream;
     const int grid = (p.E + hns::kTpEnvs - 1) / hns::kTpEnvs;

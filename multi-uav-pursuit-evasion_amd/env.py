@@ -151,6 +151,7 @@ class HideAndSeek:
                 if name not in abi.TP_WEIGHT_FIELDS:
                     self._tp_bufs[name] = torch.zeros(shape, dtype=getattr(torch, dt), device=self.device)
             self._tp_weight_ptrs = None
+            self._tp_weight_versions = None
             self._tp_filled = False
         self._set_specs()
         self._since_full_reset = 0
@@ -337,22 +338,27 @@ class HideAndSeek:
     def _tp_observe(self):
         """The TP branch of `_compute_state_and_obs` (hideandseek.py:805-854) on the device: frame
         append, TP_net forward on the matrix cores, 35-value rows (hns_tp_observe).  `self.TP`'s
-        parameters are read in place; a re-bind happens only if the learner swapped the tensors."""
+        parameters are re-packed into the operand image only when their version counters moved
+        (optimiser step / load_state_dict), re-bound only if the learner swapped the tensors."""
         sd = self.TP.state_dict(keep_vars=True)
-        ptrs = tuple(sd[abi.TP_STATE_DICT_KEYS[f]].data_ptr() for f in abi.TP_WEIGHT_FIELDS)
+        ws = [sd[abi.TP_STATE_DICT_KEYS[f]] for f in abi.TP_WEIGHT_FIELDS]
+        ptrs = tuple(w.data_ptr() for w in ws)
+        versions = tuple(w._version for w in ws)         # bumped by every in-place update (optimiser step, copy_)
         if ptrs != self._tp_weight_ptrs:
             tb = abi.HnsTpBuffers()
-            for f, ptr in zip(abi.TP_WEIGHT_FIELDS, ptrs):
-                w = sd[abi.TP_STATE_DICT_KEYS[f]]
+            for f, w in zip(abi.TP_WEIGHT_FIELDS, ws):
                 if w.dtype != torch.float32 or not w.is_contiguous() or w.device != self.device:
                     raise HnsError(f"TP_net parameter {abi.TP_STATE_DICT_KEYS[f]} must be a contiguous fp32 tensor on {self.device}")
-                setattr(tb, f, ptr)
+                setattr(tb, f, w.data_ptr())
             for name, t in self._tp_bufs.items():
                 setattr(tb, name, t.data_ptr())
             if not self.write_critic_state:
                 tb.state_drones = None
             self._check(self._lib.hns_tp_bind(self._env, C.byref(tb), self.tp_history_step, self.tp_future_step), "hns_tp_bind")
-            self._tp_weight_ptrs = ptrs
+            self._tp_weight_ptrs, self._tp_weight_versions = ptrs, versions
+        elif versions != self._tp_weight_versions:
+            self._check(self._lib.hns_tp_refresh(self._env, self._stream()), "hns_tp_refresh")
+            self._tp_weight_versions = versions
         rc = self._lib.hns_tp_observe(self._env, 0 if self._tp_filled else 1, self._stream())
         if rc != 0:
             self._check(rc, "hns_tp_observe")

@@ -1051,16 +1051,14 @@ void hns_oracle_raycast(const hns_cfg *c, const hns_buffers *b, int N, float max
  * TP_net.forward (learning/mappo.py:572-589): LSTM(I->64, zero initial state) over the T-frame
  * window, last hidden state -> Linear(64->3F) -> tanh.  torch.nn.LSTM gate order i,f,g,o:
  *   z = W_ih x + b_ih + W_hh h + b_hh;  c' = sig(z_f) c + sig(z_i) tanh(z_g);  h' = sig(z_o) tanh(c')
- * The accumulation order of z is the HIP kernel's (an fmaf chain from b_ih+b_hh over the k-pairs
- * of the f32 matrix-core product, hns_tp.hip), so pre-activations agree bit for bit; the
- * nonlinearities here are libm's, the kernel's the hardware's — compared at 1e-5.
+ * Plain fp32 with libm nonlinearities.  The HIP kernel evaluates the same products on the matrix
+ * cores with two-term fp16 splits (fp32-class accuracy, hns_tp.hip) and hardware exp/rcp — compared
+ * at the north star's 1e-5.
  * ---------------------------------------------------------------------------------------- */
-static inline int o_tp_unit(int s, int hb) { return 32 * (s >> 4) + 8 * ((s & 15) >> 2) + 4 * hb + (s & 3); }
 static inline float o_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_buffers *tp, int T, int F, int fill) {
     const int E = c->num_envs, A = c->num_agents, I = 7 + 3 * A, H = HNS_TP_HIDDEN, R = 3 * F, D = HNS_SELF_DIM + R;
-    const int SX = 4 * (((I + 1) / 2 + 3) / 4);          /* input k-steps; k-step s pairs x[s] with x[SX+s] */
     if (T < 1 || T > 16 || R > 32 || !b->detect) return HNS_ERR_INVALID_ARG;
     float *frame = (float *)malloc(sizeof(float) * (size_t)I);
     for (int e = 0; e < E; ++e) {
@@ -1090,16 +1088,8 @@ int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_b
                 for (int q = 0; q < 4; ++q) {
                     const int g = q * H + u;
                     float acc = tp->b_ih[g] + tp->b_hh[g];
-                    for (int s = 0; s < SX; ++s) {
-                        if (s < I) acc = O_FMA(tp->w_ih[(size_t)g * I + s], x[s], acc);
-                        if (SX + s < I) acc = O_FMA(tp->w_ih[(size_t)g * I + SX + s], x[SX + s], acc);
-                    }
-                    if (t > 0)
-                        for (int s = 0; s < 32; ++s) {
-                            const int u0 = o_tp_unit(s, 0), u1 = o_tp_unit(s, 1);
-                            acc = O_FMA(tp->w_hh[(size_t)g * H + u0], h[u0], acc);
-                            acc = O_FMA(tp->w_hh[(size_t)g * H + u1], h[u1], acc);
-                        }
+                    for (int k = 0; k < I; ++k) acc = O_FMA(tp->w_ih[(size_t)g * I + k], x[k], acc);
+                    for (int k = 0; k < H; ++k) acc = O_FMA(tp->w_hh[(size_t)g * H + k], h[k], acc);
                     z[q] = acc;
                 }
                 const float ig = o_sigmoid(z[0]), fg = o_sigmoid(z[1]), gg = tanhf(z[2]), og = o_sigmoid(z[3]);
@@ -1113,11 +1103,7 @@ int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_b
         float *pr = tp->pred + (size_t)e * R;
         for (int r = 0; r < R; ++r) {
             float acc = tp->b_fc[r];
-            for (int s = 0; s < 32; ++s) {
-                const int u0 = o_tp_unit(s, 0), u1 = o_tp_unit(s, 1);
-                acc = O_FMA(tp->w_fc[(size_t)r * H + u0], h[u0], acc);
-                acc = O_FMA(tp->w_fc[(size_t)r * H + u1], h[u1], acc);
-            }
+            for (int k = 0; k < H; ++k) acc = O_FMA(tp->w_fc[(size_t)r * H + k], h[k], acc);
             const float v = tanhf(acc);
             pr[r] = (r % 3 < 2) ? (v * 0.5f) * c->arena_size : ((v + 1.0f) * 0.5f) * c->max_height;
         }

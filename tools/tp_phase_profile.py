@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Per-wave start / staged / loop-end / end stamps of hns_tp_lstm_kernel (100 MHz chip-wide clock)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import numpy as np, torch, hns_amd
+from hns_amd import config
+from hns_amd.env import HideAndSeek
+E, A = 65536, 3
+env = HideAndSeek(config.make_cfg({"num_agents": A, "cylinder": {"max_num": 8, "min_num": 8}, "env": {"num_envs": E, "max_episode_length": 50000}},
+                                  algo={"use_TP_net": 1}))
+env.reset()
+td = env.rand_step_input()
+for _ in range(10): env.step(td)
+buf = torch.zeros((E // 64) * (A + 1), 16, dtype=torch.int64, device=env.device)
+env._lib.hns_set_phase_profile(env._env, C.c_void_p(buf.data_ptr()))
+env._tp_observe(); torch.cuda.synchronize()
+env._lib.hns_set_phase_profile(env._env, None)
+nw = (E // 256) * 8
+t = buf.cpu().numpy()[:nw, :4].astype(np.float64) * 10.0      # ns
+z = t[:, 0].min()
+t -= z
+print("waves", nw)
+for i, n in enumerate(["start", "staged", "loop end", "end"]):
+    print("%-9s min %8.0f  p10 %8.0f  median %8.0f  p90 %8.0f  max %8.0f ns" % ((n,) + tuple(np.percentile(t[:, i], [0, 10, 50, 90, 100]))))
+d = t[:, 3] - t[:, 0]
+print("wave lifetime: min %.0f median %.0f max %.0f ns; staging median %.0f ns" % (d.min(), np.median(d), d.max(), np.median(t[:, 1] - t[:, 0])))
+wg = t.reshape(-1, 8, 4)
+print("per-workgroup end (max over waves): p10 %.0f median %.0f p90 %.0f max %.0f" % tuple(np.percentile(wg[:, :, 3].max(1), [10, 50, 90, 100])))
+order = np.argsort(wg[:, :, 3].max(1))
+print("slowest workgroups:", order[-8:], "fastest:", order[:8])
