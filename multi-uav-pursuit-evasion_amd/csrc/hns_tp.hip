@@ -40,6 +40,7 @@
 
 #include <new>
 #include <string>
+#include <utility>
 
 #include "hns_device.h"
 #include "hns_host.h"
@@ -71,8 +72,8 @@ struct TpParams {
 struct TpImage {
     int whh, wih, wfc, bias, bfc, slots, bytes;    // slot offsets; bias/bfc in slots too (16 B = 4 floats)
 };
-__host__ __device__ inline TpImage tp_image(int nxc) {
-    TpImage L;
+__host__ __device__ constexpr TpImage tp_image(int nxc) {
+    TpImage L{};
     int o = 0;
     L.whh = o;  o += 2 * 8 * 4 * 64;
     L.wih = o;  o += 2 * 8 * nxc * 64;
@@ -166,6 +167,110 @@ HNS_DEV float tp_frame_val(const TpParams &p, int e, int k, bool det) {
 
 #define TP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
+// ---- the gate pre-activations of 32 hidden units (4 gate tiles) for one timestep ------------------
+// Op list (n ascending): cross terms  — per k-chunk (frame chunks, then the 4 recurrent chunks):
+//                                        4 tiles x {w1·v_lo, w2·v_hi}
+//                        scale + bias — acc = 2^-11 acc + b
+//                        leading term — per k-chunk: 4 tiles x w1·v_hi
+// One ds_read_b128 per MFMA; the reads run kTpDepth ops ahead of the matrix pipe through a register
+// ring, and every index below is a template constant (a plain unrolled loop over the op list ended
+// up with dynamically indexed register arrays in scratch memory for some shapes: 20x slower).
+// The kernel as a whole is bound by the gate nonlinearities (10 transcendental ops per unit and
+// timestep), not by this block.
+constexpr int kTpDepth = 2;
+template <int NXC, bool WITH_H>
+struct TpGate {
+    static constexpr int NC = NXC + (WITH_H ? 4 : 0), NLO = 8 * NC, NHI = 4 * NC, N = NLO + NHI;
+    static constexpr int D = kTpDepth < N ? kTpDepth : N;
+    // A slot is refilled only after a LATER MFMA ON THE SAME ACCUMULATOR has issued (ops n and n+4 share
+    // a tile): that one cannot issue before the slot's last reader has completed.  Refilling a source
+    // register right behind its MFMA corrupts the operand on gfx950 when the matrix pipe is shared with
+    // a partner wave (measured: 2e-5 errors = cross terms picking up the next op's low split term).
+    static constexpr int RING = D + 4;
+    static constexpr int chunk(int n) { return n < NLO ? n / 8 : (n - NLO) / 4; }
+    static constexpr int tile(int n) { return n < NLO ? (n % 8) % 4 : (n - NLO) % 4; }
+    static constexpr bool w2(int n) { return n < NLO && (n % 8) / 4 == 1; }       // A = low split term of W
+    static constexpr bool vlo(int n) { return n < NLO && (n % 8) / 4 == 0; }      // B = low split term of v
+    // slot(n) = base + tj * stride (in 16-byte slots, before the lane offset)
+    static constexpr int slot_base(const TpImage &L, int n) {
+        const int ci = chunk(n), q = tile(n);
+        return ci < NXC ? L.wih + (w2(n) ? 8 * NXC * 64 : 0) + (2 * q * NXC + ci) * 64
+                        : L.whh + (w2(n) ? 8 * 4 * 64 : 0) + (2 * q * 4 + (ci - NXC)) * 64;
+    }
+    static constexpr int slot_stride(int n) { return (chunk(n) < NXC ? NXC : 4) * 64; }
+
+    struct Ctx {
+        f32x16 (&acc)[4];
+        half8 (&a)[RING];
+        const uint4 *aw;          // image + lane
+        const float *bias;        // sBias + hb * 16
+        int tj;
+        const half8 (&xh)[NXC];
+        const half8 (&xl)[NXC];
+        const half8 (&hh)[4];
+        const half8 (&hl)[4];
+    };
+
+    template <int n>
+    static __device__ __forceinline__ half8 load(const Ctx &c) {
+        constexpr TpImage L = tp_image(NXC);
+        return *reinterpret_cast<const half8 *>(c.aw + slot_base(L, n) + c.tj * slot_stride(n));
+    }
+    template <int n>
+    static __device__ __forceinline__ void prologue(const Ctx &c) {
+        c.a[n % RING] = load<n>(c);
+        __builtin_amdgcn_sched_barrier(0x6);
+    }
+
+    static __device__ __forceinline__ void scale_bias(const Ctx &c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 *b4 = reinterpret_cast<const float4 *>(c.bias + (2 * q + c.tj) * 32);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 bv = b4[v];
+                c.acc[q][4 * v] = HNS_FMA(c.acc[q][4 * v], kTpLoInv, bv.x);
+                c.acc[q][4 * v + 1] = HNS_FMA(c.acc[q][4 * v + 1], kTpLoInv, bv.y);
+                c.acc[q][4 * v + 2] = HNS_FMA(c.acc[q][4 * v + 2], kTpLoInv, bv.z);
+                c.acc[q][4 * v + 3] = HNS_FMA(c.acc[q][4 * v + 3], kTpLoInv, bv.w);
+            }
+        }
+    }
+
+    template <int n>
+    static __device__ __forceinline__ void step(const Ctx &c) {
+        if constexpr (n == NLO) scale_bias(c);
+        constexpr int ci = chunk(n), q = tile(n);
+        if constexpr (ci < NXC) {
+            if constexpr (vlo(n)) c.acc[q] = TP_MFMA(c.a[n % RING], c.xl[ci], c.acc[q]);
+            else c.acc[q] = TP_MFMA(c.a[n % RING], c.xh[ci], c.acc[q]);
+        } else {
+            if constexpr (vlo(n)) c.acc[q] = TP_MFMA(c.a[n % RING], c.hl[ci - NXC], c.acc[q]);
+            else c.acc[q] = TP_MFMA(c.a[n % RING], c.hh[ci - NXC], c.acc[q]);
+        }
+        if constexpr (n + D < N) c.a[(n + D) % RING] = load<n + D>(c);
+        __builtin_amdgcn_sched_barrier(0x6);     // keep the hand-placed MFMA / LDS-read order (VALU and SALU may move)
+    }
+    template <int... Ns>
+    static __device__ __forceinline__ void run_prologue(const Ctx &c, std::integer_sequence<int, Ns...>) { (prologue<Ns>(c), ...); }
+    template <int... Ns>
+    static __device__ __forceinline__ void run_steps(const Ctx &c, std::integer_sequence<int, Ns...>) { (step<Ns>(c), ...); }
+};
+
+template <int NXC, bool WITH_H>
+HNS_DEV void tp_gate_tiles(f32x16 (&acc)[4], const uint4 *aw, int tj, int hb, const float *sBias,
+                           const half8 (&xh)[NXC], const half8 (&xl)[NXC], const half8 (&hh)[4], const half8 (&hl)[4]) {
+    using G = TpGate<NXC, WITH_H>;
+    half8 a[G::RING];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+    const typename G::Ctx c{acc, a, aw, sBias + hb * 16, tj, xh, xl, hh, hl};
+    G::run_prologue(c, std::make_integer_sequence<int, G::D>{});
+    G::run_steps(c, std::make_integer_sequence<int, G::N>{});
+}
+
 // NXC = 16-wide k-chunks of the frame (1: I <= 16, i.e. up to 3 pursuers; 2: I <= 32)
 template <int NXC>
 __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams p) {
@@ -221,7 +326,7 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
     for (int i = 0; i < 4; ++i) { hh[i] = (half8)(_Float16)0.0f; hl[i] = (half8)(_Float16)0.0f; }
 #pragma unroll
     for (int i = 0; i < 32; ++i) c[i] = 0.0f;
-    float hn[32];
+    float hn0[16];                          // h_t of units 0..15 (tile pair 0), parked while tile pair 1 still reads h_{t-1}
 
     for (int t = 0; t < T; ++t) {
         // shift x_t into slot t and split it; prefetch x_{t+1} (slot t+2 of the old window, untouched so far)
@@ -250,54 +355,11 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
         int lo = lane;
         asm volatile("" : "+v"(lo));
         const uint4 *aw = simg + lo;
-#define TP_A(base, idx) (*reinterpret_cast<const half8 *>(aw + (base) + (idx) * 64))
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {                 // units 32tj..32tj+31: gate tiles m = 2q + tj
             f32x16 acc[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
-            // cross terms w1 v2 + w2 v1 (scaled by 2^11)
-#pragma unroll
-            for (int cx = 0; cx < NXC; ++cx) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = TP_MFMA(TP_A(L.wih, (2 * q + tj) * NXC + cx), xl[cx], acc[q]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = TP_MFMA(TP_A(L.wih + N_IH, (2 * q + tj) * NXC + cx), xh[cx], acc[q]);
-            }
-            if (t > 0) {                                   // h_0 = 0: the recurrent product vanishes
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = TP_MFMA(TP_A(L.whh, (2 * q + tj) * 4 + ch), hl[ch], acc[q]);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = TP_MFMA(TP_A(L.whh + N_HH, (2 * q + tj) * 4 + ch), hh[ch], acc[q]);
-                }
-            }
-            // 2^-11 (cross terms) + bias, then the leading term w1 v1 on top
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 *b4 = reinterpret_cast<const float4 *>(sBias + ((2 * q + tj) * 2 + hb) * 16);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float4 bv = b4[v];
-                    acc[q][4 * v] = HNS_FMA(acc[q][4 * v], kTpLoInv, bv.x);
-                    acc[q][4 * v + 1] = HNS_FMA(acc[q][4 * v + 1], kTpLoInv, bv.y);
-                    acc[q][4 * v + 2] = HNS_FMA(acc[q][4 * v + 2], kTpLoInv, bv.z);
-                    acc[q][4 * v + 3] = HNS_FMA(acc[q][4 * v + 3], kTpLoInv, bv.w);
-                }
-            }
-#pragma unroll
-            for (int cx = 0; cx < NXC; ++cx)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = TP_MFMA(TP_A(L.wih, (2 * q + tj) * NXC + cx), xh[cx], acc[q]);
-            if (t > 0) {
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = TP_MFMA(TP_A(L.whh, (2 * q + tj) * 4 + ch), hh[ch], acc[q]);
-            }
+            if (t > 0) tp_gate_tiles<NXC, true>(acc, aw, tj, hb, sBias, xh, xl, hh, hl);
+            else tp_gate_tiles<NXC, false>(acc, aw, tj, hb, sBias, xh, xl, hh, hl);   // h_0 = 0: no recurrent product
             // cell update (torch.nn.LSTM: i, f, g, o), lane-local
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -305,18 +367,22 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
                 const float gg = tp_tanh(acc[2][i]), og = tp_sigmoid(acc[3][i]);
                 const float cn = HNS_FMA(fg, c[16 * tj + i], ig * gg);
                 c[16 * tj + i] = cn;
-                hn[16 * tj + i] = og * tp_tanh(cn);
+                const float hv = og * tp_tanh(cn);
+                if (tj == 0) {
+                    hn0[i] = hv;
+                } else {                                   // h_{t-1} is dead now: h_t -> B operands of the next timestep
+                    _Float16 a, b;
+                    tp_split(hv, a, b);
+                    hh[2 + (i >> 3)][i & 7] = a; hl[2 + (i >> 3)][i & 7] = b;
+                }
             }
         }
-        // h_t -> B operands of the next timestep
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                _Float16 a, b;
-                tp_split(hn[8 * ch + j], a, b);
-                hh[ch][j] = a; hl[ch][j] = b;
-            }
+        for (int i = 0; i < 16; ++i) {
+            _Float16 a, b;
+            tp_split(hn0[i], a, b);
+            hh[i >> 3][i & 7] = a; hl[i >> 3][i & 7] = b;
+        }
     }
 
     if (prof && lane == 0) prof[2] = __builtin_amdgcn_s_memrealtime();
@@ -328,6 +394,7 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
         int lo = lane;
         asm volatile("" : "+v"(lo));
         const uint4 *aw = simg + lo;
+#define TP_A(base, idx) (*reinterpret_cast<const half8 *>(aw + (base) + (idx) * 64))
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             o = TP_MFMA(TP_A(L.wfc, ch), hl[ch], o);

@@ -340,8 +340,8 @@ class HideAndSeek:
         append, TP_net forward on the matrix cores, 35-value rows (hns_tp_observe).  `self.TP`'s
         parameters are re-packed into the operand image only when their version counters moved
         (optimiser step / load_state_dict), re-bound only if the learner swapped the tensors."""
-        sd = self.TP.state_dict(keep_vars=True)
-        ws = [sd[abi.TP_STATE_DICT_KEYS[f]] for f in abi.TP_WEIGHT_FIELDS]
+        tp = self.TP            # attribute lookups, not state_dict(): this runs every step
+        ws = (tp.lstm.weight_ih_l0, tp.lstm.weight_hh_l0, tp.lstm.bias_ih_l0, tp.lstm.bias_hh_l0, tp.fc.weight, tp.fc.bias)
         ptrs = tuple(w.data_ptr() for w in ws)
         versions = tuple(w._version for w in ws)         # bumped by every in-place update (optimiser step, copy_)
         if ptrs != self._tp_weight_ptrs:

@@ -31,7 +31,7 @@ class _ShimTensorDict(dict):
         if isinstance(key, tuple) and key and all(isinstance(k, str) for k in key):
             cur = self
             for k in key:
-                cur = dict.__getitem__(cur, k)
+                cur = cur[k]                 # through __getitem__: nested lazy entries (env._LazyState) resolve
             return cur
         if isinstance(key, str):
             return dict.__getitem__(self, key)
@@ -179,7 +179,7 @@ class CompositeSpec(dict):
         if isinstance(key, tuple):
             cur = self
             for k in key:
-                cur = dict.__getitem__(cur, k)
+                cur = cur[k]                 # through __getitem__: nested lazy entries (env._LazyState) resolve
             return cur
         return dict.__getitem__(self, key)
 

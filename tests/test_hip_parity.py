@@ -180,7 +180,8 @@ def test_error_paths():
 
 
 def test_tp_net_observation_on_gpu(golden):
-    """algo.use_TP_net=1 (the reference's default): 35-dim rows and the TP TensorDict on the GPU path."""
+    """algo.use_TP_net=1 (the reference's default): 35-dim rows and the TP TensorDict on the GPU path
+    (values against the oracle and the reference golden: tests/test_hip_tp.py)."""
     from hns_amd.env import HideAndSeek
     g = golden("g_tp_obs")
     E, A, C, T, max_len = (int(x) for x in g["meta"])
@@ -202,28 +203,7 @@ def test_tp_net_observation_on_gpu(golden):
     pred = env.export_state()["drone_state"][..., None, :3] - ss[..., 3:18].reshape(E, A, 5, 3).cpu().numpy()
     assert np.allclose(pred[:, 0], pred[:, 1], atol=1e-5)            # every pursuer sees the same predicted evader path
     assert (np.abs(pred[..., :2]) <= 0.45 + 1e-5).all() and (pred[..., 2] >= -1e-5).all() and (pred[..., 2] <= 1.2 + 1e-5).all()
-    # replay the golden call sequence through the GPU path (kernel obs + MIOpen LSTM)
-    env2 = HideAndSeek(cfg, headless=True)
-    env2.TP.load_state_dict(sd)
-    env2.reset()
-    env2._tp_obs.history.clear()
-    st = env2.export_state()
-    st["cylinders"][:] = g["cyl"]
-    for t in range(T):
-        st["drone_state"][..., 0:3], st["drone_state"][..., 3:7], st["drone_state"][..., 7:13] = g["pos"][t], g["rot"][t], g["vel"][t]
-        st["target_pos"][:] = g["tpos"][t][:, 0]
-        st["target_vel"][:] = g["tvel"][t][:, 0]
-        st["progress"][:] = g["progress"][t]
-        env2.import_state(st)
-        host = {k: v.copy() for k, v in st.items()}
-        O.obs_reward(env2.hcfg, host)                                   # oracle obs on the same state -> device buffers
-        env2._bufs["obs_self"].copy_(torch.from_numpy(host["obs_self"]))
-        _, bdet, _ = O.obs_reward(env2.hcfg, host)
-        env2._bufs["detect"].copy_(torch.from_numpy(bdet.astype(np.uint8)))
-        o = env2._obs_tensordict()
-        np.testing.assert_allclose(o[("agents", "observation", "state_self")][:, :, 0].cpu().numpy(), g["state_self"][t][:, :, 0],
-                                   rtol=1e-4, atol=1e-4)
-        np.testing.assert_allclose(o[("agents", "TP", "TP_input")].cpu().numpy(), g["TP_input"][t], rtol=1e-6, atol=1e-6)
+
 
 
 def test_snapshot_resume_is_bit_exact(tmp_path):

@@ -29,3 +29,10 @@ wg = t.reshape(-1, 8, 4)
 print("per-workgroup end (max over waves): p10 %.0f median %.0f p90 %.0f max %.0f" % tuple(np.percentile(wg[:, :, 3].max(1), [10, 50, 90, 100])))
 order = np.argsort(wg[:, :, 3].max(1))
 print("slowest workgroups:", order[-8:], "fastest:", order[:8])
+if "--stamps" in sys.argv:
+    c = buf.cpu().numpy()[:nw, :16].astype(np.float64).reshape(-1, 8, 16)
+    for grp, name in ((slice(0, 4), "waves 0-3"), (slice(4, 8), "waves 4-7")):
+        g = c[:, grp]
+        print("%s t=5: M0 %.0f  E0 %.0f  gap %.0f  M1 %.0f  E1 %.0f cyc; timestep 5 %.0f cyc, timestep 6 %.0f cyc" % (
+            name, (g[..., 5] - g[..., 4]).mean(), (g[..., 6] - g[..., 5]).mean(), (g[..., 7] - g[..., 6]).mean(), (g[..., 8] - g[..., 7]).mean(),
+            (g[..., 9] - g[..., 8]).mean(), (g[..., 11] - g[..., 10]).mean(), (g[..., 12] - g[..., 11]).mean()))
