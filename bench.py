@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--time-every", type=int, default=32)
+    ap.add_argument("--tp-steps", type=int, default=300,
+                    help="extra untimed-in-`value` leg: steps with the trajectory predictor in the observation "
+                         "(algo.use_TP_net: 1, the reference's default config), reported as `tp_mode`; 0 = skip")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,6 +149,32 @@ def main():
                     "kernel": f"hns_step_kernel<{A}>", "kernel_us": round(kernel_ms * 1e3, 2), "samples": n_samples,
                     "bytes_per_launch": b_env * E}
 
+    # secondary leg ("use_TP_net=1 reported separately"): step + hns_tp_observe
+    tp_mode = None
+    if args.tp_steps > 0 and world == 1:
+        cfg_tp = config.make_cfg({"num_agents": A, "cylinder": {"max_num": C, "min_num": C, "obs_max_cylinder": K},
+                                  "env": {"num_envs": E, "max_episode_length": args.episode},
+                                  "sim": {"device": f"cuda:{local_rank}"}}, algo={"use_TP_net": 1})
+        env_tp = HideAndSeek(cfg_tp, headless=True, write_critic_state=args.critic_state)
+        env_tp.set_seed(0)
+        env_tp.reset()                              # binds + packs the predictor's parameters
+        h2 = env_tp._env
+
+        def run_tp(n):
+            for i in range(n):
+                assert lib.hns_step(h2, aptr[i % R], sptr) == 0, lib.hns_last_error()
+                assert lib.hns_tp_observe(h2, 0, sptr) == 0, lib.hns_last_error()
+        run_tp(20)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        run_tp(args.tp_steps)
+        torch.cuda.synchronize(device)
+        dt_tp = time.perf_counter() - t1
+        tp_mode = {"value": round(E * A * args.tp_steps / dt_tp, 1), "unit": "agent-steps/s", "steps": args.tp_steps,
+                   "ms_per_step": round(dt_tp / args.tp_steps * 1e3, 5),
+                   "what": "hns_step + hns_tp_observe (window shift, LSTM(16->64)x10 + FC on the matrix cores, 35-value rows)"}
+        del env_tp
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import numpy as np
@@ -176,7 +205,7 @@ def main():
                        "sharding": f"contiguous env slices x{world}",
                        "collective": "1 all-gather of 5 fp64 per 64-step rollout" if world > 1 else "none"},
             "env_frames_per_s": round(value / A, 1),
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "tp_mode": tp_mode,
         }
         print(json.dumps(out))
     if world > 1:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats + a PMC pass of the TP-mode step.
+# Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats + one PMC pass of the TP-mode step.
 # usage: tools/profile_tp.sh <tag>
 set -u
 TAG=${1:-run}
@@ -7,13 +7,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/tp_$TAG
 mkdir -p $OUT
 B="python tools/tp_step_cost.py 65536 --tp-only"
-rocprofv3 --kernel-trace --stats -d $OUT/stats -- $B > $OUT/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc1 -- $B > $OUT/pmc1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 FETCH_SIZE WRITE_SIZE -d $OUT/pmc2 -- $B > $OUT/pmc2.log 2>&1
-for d in stats pmc1 pmc2; do
+timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/stats -- $B > $OUT/stats.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc1 -- $B --short > $OUT/pmc1.log 2>&1
+for d in stats pmc1; do
   db=$(ls $OUT/$d/*/*.db 2>/dev/null | head -1)
   [ -n "$db" ] && python tools/rocpd_summary.py "$db" hns_ > $OUT/$d.csv && rm -rf $OUT/$d
 done
-tail -3 $OUT/stats.log
+grep -h "us/step" $OUT/stats.log
 cat $OUT/*.csv
-tail -5 $OUT/pmc1.log $OUT/pmc2.log | grep -i "error\|invalid\|not" | head

@@ -13,7 +13,7 @@ for tp in ((1,) if "--tp-only" in sys.argv else (0, 1)):
     td = env.rand_step_input()
     for _ in range(20): env.step(td)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    n = 200
+    n = 40 if "--short" in sys.argv else 200
     for _ in range(n): env.step(td)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"use_TP_net={tp}: {dt / n * 1e6:.1f} us/step  ({E * 3 * n / dt:.3e} agent-steps/s)")
