@@ -265,6 +265,24 @@ int hns_tp_refresh(hns_env *env, void *stream);
  * first call, hideandseek.py:825-828), evaluates TP_net, writes the 20+3F-value rows. */
 int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream);
 
+/*
+ * Adaptive Environment Generator, device side (reference GenBuffer,
+ * omni_drones/envs/hide_and_seek/hideandseek_envgen.py:209-377).
+ */
+/* Farthest-point sampling (replaces dgl.geometry.farthest_point_sampler, :291-304): out_idx[0] = start,
+ * out_idx[r] = arg-max over all points of the minimum squared distance to out_idx[0..r-1] (ties -> lower
+ * index).  points [n,d] fp32, out_idx [k] int32, scratch [hns_fps_scratch_bytes()] — device pointers.
+ * One persistent launch (<= one workgroup per CU).  If a workgroup never shows up the kernel gives up
+ * instead of hanging: the first 8 bytes of scratch are then non-zero (check after synchronising). */
+size_t hns_fps_scratch_bytes(void);
+int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start, int32_t *out_idx, void *scratch, void *stream);
+/* samplenearby (:316-370) with the grid sanity check (:187-207): tasks_out[t] = a random history entry,
+ * pursuers / evader jittered by U(-1,1)*expand_step per coordinate (cylinders by {-1,0,1} cells when
+ * expand_cylinders), clipped to the task bounds (:320-333); up to 10 attempts, then the entry itself.
+ * history [n_hist, 3(A+1+C)], tasks_out [n_tasks, 3(A+1+C)]: device pointers; Philox stream (seed, task). */
+int hns_perturb_tasks(hns_env *env, const float *history, int32_t n_hist, float *tasks_out, int32_t n_tasks,
+                      int32_t expand_cylinders, float expand_step, uint64_t seed, void *stream);
+
 /* Curriculum hook (hideandseek.py:1012-1015): change the evader speed. */
 int hns_set_v_prey(hns_env *env, float v_prey);
 /* Smoothness schedule hook (hideandseek.py:988-991). */

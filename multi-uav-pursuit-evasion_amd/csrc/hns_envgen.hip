@@ -1,0 +1,289 @@
+// hns_envgen.hip — device side of the Adaptive Environment Generator, gfx950.
+//
+// Reference: GenBuffer in omni_drones/envs/hide_and_seek/hideandseek_envgen.py:209-377 — host numpy
+// with a Python loop per task (`samplenearby`, :316-370) and DGL's farthest_point_sampler for
+// trimming the history to 5000 entries (:291-304).  At 65 536 envs that is seconds per task batch;
+// the step kernel runs a whole 800-step episode in 23 ms.  Two kernels replace it:
+//
+//   hns_fps_kernel     : farthest-point sampling of k of n points.  FPS is k strictly sequential
+//                        rounds (update min-distance to the newest sample, take the arg-max), so the
+//                        cost is the per-round latency.  One persistent launch, one workgroup per
+//                        CU, points partitioned over ALL threads of the chip with their running
+//                        min-distances in registers; per round every workgroup publishes its
+//                        candidate as two tagged 8-byte granules (agent-scope stores), every workgroup
+//                        sweeps all candidates and computes the same global arg-max — one fabric hop
+//                        per round, no grid barrier, no atomics (MI355X_MICROARCH "R2": the data is
+//                        the flag; slots are double-buffered by round parity).  Every spin is bounded.
+//   hns_perturb_kernel : one thread per task: draw a history entry, perturb, clip, grid sanity check,
+//                        retry (Philox4x32 stream per task; the oracle reproduces it bit for bit).
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "hns_device.h"
+#include "hns_host.h"
+
+namespace hns {
+
+constexpr int kFpsThreads = 256;
+constexpr int kFpsMaxGroups = 256;          // one workgroup per CU
+constexpr int kFpsMaxPerThread = 8;         // points per thread (registers): n <= 256*256*8
+constexpr unsigned kFpsSpinLimit = 1u << 20;     // ~1 s of polling before a workgroup gives up
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+struct FpsParams {
+    const float *points;   // [n, d]
+    int n, d, k, start, groups;
+    int in_lds;            // the workgroup's points are staged in LDS (rows of d+1 floats: conflict-free)
+    int32_t *out_idx;      // [k]
+    unsigned long long *scratch;   // [0]: error word; [8 ..): granules [2 parity][2 (dist, idx)][groups]
+};
+
+// order: larger distance first, ties -> lower index (torch.argmax picks the first maximum)
+HNS_DEV bool fps_better(float d, int i, float bd, int bi) { return d > bd || (d == bd && i < bi); }
+
+__global__ __launch_bounds__(kFpsThreads) void hns_fps_kernel(const FpsParams p) {
+    extern __shared__ __align__(16) float s_dyn[];     // [d] the newest sample, then the staged points
+    __shared__ float s_d[kFpsThreads / 64];
+    __shared__ int s_i[kFpsThreads / 64];
+    __shared__ int s_cur;
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = p.groups, gtid = blockIdx.x * kFpsThreads + tid, stride = G * kFpsThreads;
+    gu64 *gran = (gu64 *)(p.scratch + 8);
+    float dist[kFpsMaxPerThread];
+#pragma unroll
+    for (int j = 0; j < kFpsMaxPerThread; ++j) dist[j] = kInf;
+    if (tid == 0) s_fail = 0;
+    const int d = p.d, ld = d + 1;
+    float *sQ = s_dyn, *sPts = s_dyn + ((d + 3) & ~3);
+    if (p.in_lds) {                                     // this thread's points, row (j*256 + tid)
+#pragma unroll
+        for (int j = 0; j < kFpsMaxPerThread; ++j) {
+            const int i = gtid + j * stride;
+            if (i < p.n)
+                for (int c = 0; c < d; ++c) sPts[(j * kFpsThreads + tid) * ld + c] = p.points[(size_t)i * d + c];
+        }
+    }
+    int cur = p.start;
+    for (int c = tid; c < d; c += kFpsThreads) sQ[c] = p.points[(size_t)cur * d + c];
+    __syncthreads();
+    for (int r = 0; r < p.k; ++r) {
+        if (blockIdx.x == 0 && tid == 0) p.out_idx[r] = cur;
+        if (r == p.k - 1) break;
+        // ---- distances to the newest sample (in sQ), running minimum, local arg-max -----------------
+        float bd = -1.0f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < kFpsMaxPerThread; ++j) {
+            const int i = gtid + j * stride;
+            if (i < p.n) {
+                const float *x = p.in_lds ? sPts + (j * kFpsThreads + tid) * ld : p.points + (size_t)i * d;
+                float acc = 0.0f;                     // one sequential fmaf chain over the coordinates (= the oracle)
+                int c = 0;
+                for (; c + 4 <= d; c += 4) {
+                    const float x0 = x[c], x1 = x[c + 1], x2 = x[c + 2], x3 = x[c + 3];
+                    const float d0 = x0 - sQ[c], d1 = x1 - sQ[c + 1], d2 = x2 - sQ[c + 2], d3 = x3 - sQ[c + 3];
+                    acc = HNS_FMA(d0, d0, acc); acc = HNS_FMA(d1, d1, acc); acc = HNS_FMA(d2, d2, acc); acc = HNS_FMA(d3, d3, acc);
+                }
+                for (; c < d; ++c) {
+                    const float df = x[c] - sQ[c];
+                    acc = HNS_FMA(df, df, acc);
+                }
+                // a chosen point leaves the pool (-1 never wins), so the k indices are distinct even among duplicates
+                const float m = (i == cur) ? -1.0f : (acc < dist[j] ? acc : dist[j]);
+                dist[j] = m;
+                if (fps_better(m, i, bd, bi)) { bd = m; bi = i; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float od = __shfl_xor(bd, off);
+            const int oi = __shfl_xor(bi, off);
+            if (fps_better(od, oi, bd, bi)) { bd = od; bi = oi; }
+        }
+        if (lane == 0) { s_d[wave] = bd; s_i[wave] = bi; }
+        __syncthreads();
+        // ---- publish this workgroup's candidate: two {tag = round + 1, value} granules ---------------
+        const unsigned tag = (unsigned)(r + 1);
+        gu64 *slot = gran + (size_t)(r & 1) * 2 * G;
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 1; w < kFpsThreads / 64; ++w)
+                if (fps_better(s_d[w], s_i[w], bd, bi)) { bd = s_d[w]; bi = s_i[w]; }
+            __hip_atomic_store(slot + blockIdx.x, ((unsigned long long)tag << 32) | __float_as_uint(bd), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + G + blockIdx.x, ((unsigned long long)tag << 32) | (unsigned)bi, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- sweep every workgroup's candidate (wave 0), same arg-max everywhere ----------------------
+        if (wave == 0) {
+            float gd = -1.0f;
+            int gi = 0x7fffffff;
+            bool fail = false;
+            for (int base = 0; base < G; base += 64) {
+                const int g = base + lane;
+                unsigned long long vd = 0, vi = 0;
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+                    if (g < G) {
+                        vd = __hip_atomic_load(slot + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vi = __hip_atomic_load(slot + G + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = (unsigned)(vd >> 32) == tag && (unsigned)(vi >> 32) == tag;
+                    }
+                    if (__all(ok)) break;
+                    if (++spins > kFpsSpinLimit) { fail = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (fail) break;
+                if (g < G) {
+                    const float d2 = __uint_as_float((unsigned)vd);
+                    const int i2 = (int)(unsigned)vi;
+                    if (fps_better(d2, i2, gd, gi)) { gd = d2; gi = i2; }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float od = __shfl_xor(gd, off);
+                const int oi = __shfl_xor(gi, off);
+                if (fps_better(od, oi, gd, gi)) { gd = od; gi = oi; }
+            }
+            if (lane == 0) { s_cur = gi; if (fail) s_fail = 1; }
+            // the winner's coordinates for the next round (immutable input: plain loads)
+            if (!fail)
+                for (int c = lane; c < d; c += 64) sQ[c] = p.points[(size_t)gi * d + c];
+        }
+        __syncthreads();
+        if (s_fail) {                                   // a workgroup never showed up: give up loudly, never hang
+            if (tid == 0) __hip_atomic_store((gu64 *)p.scratch, 1ull + (unsigned long long)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        cur = s_cur;
+    }
+}
+
+// ---- samplenearby (hideandseek_envgen.py:316-370, grid check :187-207) -----------------------------
+struct PerturbParams {
+    hns_cfg cfg;
+    const float *history;   // [n_hist, task_dim]
+    float *out;             // [n_tasks, task_dim]
+    int n_hist, n_tasks, expand_cylinders;
+    float expand_step;
+    uint32_t seed_lo, seed_hi;
+};
+
+// continuous -> grid cell exactly as the host GenBuffer does it (float64 rint, clip)
+HNS_DEV int envgen_cell(double x, double grid_size, int num_grid) {
+    int g = (int)__builtin_rint(x / grid_size) + num_grid / 2;
+    return g < 0 ? 0 : (g > num_grid - 1 ? num_grid - 1 : g);
+}
+
+constexpr int kMaxBodies = HNS_MAX_AGENTS + 1 + HNS_MAX_CYLINDERS;
+
+__global__ __launch_bounds__(256) void hns_perturb_kernel(const PerturbParams p) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.n_tasks) return;
+    const hns_cfg &c = p.cfg;
+    const int A = c.num_agents, Cn = c.num_cylinders, nb = A + 1 + Cn, TD = 3 * nb, GN = c.grid_num, half = GN / 2;
+    const double gs = (double)c.grid_size;
+    // bounds, :320-333 (incl. the reference's z window around max_height for drones / evader)
+    const float cb = (float)((int)(c.arena_size / c.grid_size)) * c.grid_size;
+    const float bxy = c.arena_size / 1.41421356237309515f - 0.1f;
+    Rng rng{p.seed_lo, p.seed_hi, (uint32_t)t, 0x9E3779B9u, 0u, {0, 0, 0, 0}, 0};
+    float *out = p.out + (size_t)t * TD;
+    const float *origin = nullptr;
+    for (int attempt = 0; attempt < 10; ++attempt) {
+        // a fresh history entry per attempt keeps every task independent of the others
+        // (the reference re-perturbs the same origin and, failing that, copies another task's result)
+        int h = (int)(rng.uniform() * (float)p.n_hist);
+        if (h > p.n_hist - 1) h = p.n_hist - 1;
+        origin = p.history + (size_t)h * TD;
+        int cells[kMaxBodies];
+        bool ok = true;
+        for (int b = 0; b < nb; ++b) {
+            float v[3] = {origin[3 * b], origin[3 * b + 1], origin[3 * b + 2]};
+            if (b <= A) {
+                for (int j = 0; j < 3; ++j) v[j] += (rng.uniform() * 2.0f - 1.0f) * p.expand_step;
+                v[0] = d_clamp(v[0], -bxy, bxy); v[1] = d_clamp(v[1], -bxy, bxy);
+                v[2] = d_clamp(v[2], c.max_height - 0.1f, c.max_height + 0.1f);
+            } else {
+                if (p.expand_cylinders) {
+                    for (int j = 0; j < 2; ++j) {
+                        int s = (int)(rng.uniform() * 3.0f);
+                        v[j] += (float)((s > 2 ? 2 : s) - 1) * c.grid_size;
+                    }
+                }
+                v[0] = d_clamp(v[0], -cb, cb); v[1] = d_clamp(v[1], -cb, cb);
+                v[2] = d_clamp(v[2], -20.0f, c.max_height * 0.5f);
+            }
+            out[3 * b] = v[0]; out[3 * b + 1] = v[1]; out[3 * b + 2] = v[2];
+            const int gx = envgen_cell((double)v[0], gs, GN), gy = envgen_cell((double)v[1], gs, GN);
+            const int dx = gx - half, dy = gy - half;
+            if (dx * dx + dy * dy >= half * half) ok = false;           // outside the disc of free cells (:168-181)
+            cells[b] = gx * GN + gy;
+        }
+        for (int b = 1; b < nb && ok; ++b)
+            for (int b2 = 0; b2 < b; ++b2)
+                if (cells[b] == cells[b2]) { ok = false; break; }
+        if (ok) return;
+    }
+    // every attempt failed the grid check: fall back to the last origin unperturbed (a stored task)
+    for (int j = 0; j < TD; ++j) out[j] = origin[j];
+}
+
+}  // namespace hns
+
+extern "C" {
+
+size_t hns_fps_scratch_bytes(void) { return (size_t)(8 + 2 * 2 * hns::kFpsMaxGroups) * sizeof(unsigned long long); }
+
+int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start, int32_t *out_idx, void *scratch, void *stream) {
+    if (!points || !out_idx || !scratch || n < 1 || d < 1 || k < 1 || k > n || start < 0 || start >= n) {
+        hns_set_error("hns_fps: bad argument (need 1 <= k <= n, 0 <= start < n, non-null device pointers)");
+        return HNS_ERR_INVALID_ARG;
+    }
+    const long cap = (long)hns::kFpsMaxGroups * hns::kFpsThreads * hns::kFpsMaxPerThread;
+    if (n > cap) { hns_set_error("hns_fps: more than 524288 points"); return HNS_ERR_INVALID_ARG; }
+    int dev = 0, cus = 0;
+    HNS_CHECK_HIP(hipGetDevice(&dev));
+    HNS_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int groups = (n + hns::kFpsThreads - 1) / hns::kFpsThreads;        // every workgroup must be resident: <= one per CU
+    const int max_groups = cus < hns::kFpsMaxGroups ? cus : hns::kFpsMaxGroups;
+    if (groups > max_groups) groups = max_groups;
+    if ((long)groups * hns::kFpsThreads * hns::kFpsMaxPerThread < n) { hns_set_error("hns_fps: too many points for this device"); return HNS_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    HNS_CHECK_HIP(hipMemsetAsync(scratch, 0, hns_fps_scratch_bytes(), s));
+    hns::FpsParams p;
+    p.points = points; p.n = n; p.d = d; p.k = k; p.start = start; p.groups = groups;
+    p.out_idx = out_idx; p.scratch = (unsigned long long *)scratch;
+    const int per_thread = (n + groups * hns::kFpsThreads - 1) / (groups * hns::kFpsThreads);
+    const size_t q_floats = (size_t)((d + 3) & ~3), pts_floats = (size_t)per_thread * hns::kFpsThreads * (d + 1);
+    p.in_lds = (q_floats + pts_floats) * sizeof(float) <= 144 * 1024 ? 1 : 0;
+    const size_t lds = (q_floats + (p.in_lds ? pts_floats : 0)) * sizeof(float);
+    static thread_local size_t lds_attr = 0;
+    if (lds > lds_attr) {
+        HNS_CHECK_HIP(hipFuncSetAttribute((const void *)hns::hns_fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 1024));
+        lds_attr = 145 * 1024;
+    }
+    hipLaunchKernelGGL(hns::hns_fps_kernel, dim3(groups), dim3(hns::kFpsThreads), lds, s, p);
+    HNS_CHECK_HIP(hipGetLastError());
+    return HNS_OK;
+}
+
+int hns_perturb_tasks(hns_env *env, const float *history, int32_t n_hist, float *tasks_out, int32_t n_tasks, int32_t expand_cylinders,
+                      float expand_step, uint64_t seed, void *stream) {
+    if (!env || !history || !tasks_out || n_hist < 1 || n_tasks < 0) { hns_set_error("hns_perturb_tasks: bad argument"); return HNS_ERR_INVALID_ARG; }
+    if (n_tasks == 0) return HNS_OK;
+    hns::PerturbParams p;
+    p.cfg = env->cfg;
+    p.history = history; p.out = tasks_out; p.n_hist = n_hist; p.n_tasks = n_tasks;
+    p.expand_cylinders = expand_cylinders; p.expand_step = expand_step;
+    p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+    hipLaunchKernelGGL(hns::hns_perturb_kernel, dim3((n_tasks + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
+    HNS_CHECK_HIP(hipGetLastError());
+    return HNS_OK;
+}
+
+}  // extern "C"

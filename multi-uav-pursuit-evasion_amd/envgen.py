@@ -42,6 +42,7 @@ def farthest_point_sampling(points, k, start=0):
         idx[i] = cur
         d = ((points - points[cur]) ** 2).sum(-1)
         dist = torch.minimum(dist, d)
+        dist[cur] = -1.0                            # chosen points leave the pool (distinct indices among duplicates)
         cur = torch.argmax(dist)
     return idx
 

@@ -1131,3 +1131,91 @@ int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_b
     free(frame);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Adaptive Environment Generator: farthest-point sampling as GenBuffer uses it
+ * (hideandseek_envgen.py:291-304; DGL's sampler is not vendored and its start point / tie order are
+ * unpinned — this is the build's definition: start given, ties -> lower index) and samplenearby
+ * (:316-370) with the grid sanity check (:187-207), on the Philox stream of hns_perturb_tasks.
+ * ---------------------------------------------------------------------------------------- */
+int hns_oracle_fps(const float *points, int n, int d, int k, int start, int32_t *out_idx) {
+    if (n < 1 || k < 1 || k > n || start < 0 || start >= n) return HNS_ERR_INVALID_ARG;
+    float *dist = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int i = 0; i < n; ++i) dist[i] = INFINITY;
+    int cur = start;
+    for (int r = 0; r < k; ++r) {
+        out_idx[r] = cur;
+        if (r == k - 1) break;
+        const float *q = points + (size_t)cur * d;
+        float bd = -1.0f;
+        int bi = 0x7fffffff;
+        for (int i = 0; i < n; ++i) {
+            const float *x = points + (size_t)i * d;
+            float acc = 0.0f;
+            for (int c = 0; c < d; ++c) {
+                const float df = x[c] - q[c];
+                acc = O_FMA(df, df, acc);
+            }
+            if (acc < dist[i]) dist[i] = acc;
+            if (i == cur) dist[i] = -1.0f;                   /* chosen points leave the pool */
+            if (dist[i] > bd) { bd = dist[i]; bi = i; }       /* ascending i: ties keep the lower index */
+        }
+        cur = bi;
+    }
+    free(dist);
+    return 0;
+}
+
+static int o_envgen_cell(double x, double grid_size, int num_grid) {
+    int g = (int)rint(x / grid_size) + num_grid / 2;
+    return g < 0 ? 0 : (g > num_grid - 1 ? num_grid - 1 : g);
+}
+
+int hns_oracle_perturb_tasks(const hns_cfg *c, const float *history, int n_hist, float *tasks_out, int n_tasks,
+                             int expand_cylinders, float expand_step, uint64_t seed) {
+    const int A = c->num_agents, Cn = c->num_cylinders, nb = A + 1 + Cn, TD = 3 * nb, GN = c->grid_num, half = GN / 2;
+    const double gs = (double)c->grid_size;
+    const float cb = (float)((int)(c->arena_size / c->grid_size)) * c->grid_size;
+    const float bxy = c->arena_size / 1.41421356237309515f - 0.1f;
+    int cells[HNS_MAX_AGENTS + 1 + HNS_MAX_CYLINDERS];
+    for (int t = 0; t < n_tasks; ++t) {
+        o_rng rng = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)t, 0x9E3779B9u, 0u, {0, 0, 0, 0}, 0};
+        float *out = tasks_out + (size_t)t * TD;
+        const float *origin = NULL;
+        int done = 0;
+        for (int attempt = 0; attempt < 10 && !done; ++attempt) {
+            int h = (int)(o_uniform(&rng) * (float)n_hist);
+            if (h > n_hist - 1) h = n_hist - 1;
+            origin = history + (size_t)h * TD;
+            int ok = 1;
+            for (int b = 0; b < nb; ++b) {
+                float v[3] = {origin[3 * b], origin[3 * b + 1], origin[3 * b + 2]};
+                if (b <= A) {
+                    for (int j = 0; j < 3; ++j) v[j] += (o_uniform(&rng) * 2.0f - 1.0f) * expand_step;
+                    v[0] = o_clamp(v[0], -bxy, bxy); v[1] = o_clamp(v[1], -bxy, bxy);
+                    v[2] = o_clamp(v[2], c->max_height - 0.1f, c->max_height + 0.1f);
+                } else {
+                    if (expand_cylinders)
+                        for (int j = 0; j < 2; ++j) {
+                            int s = (int)(o_uniform(&rng) * 3.0f);
+                            v[j] += (float)((s > 2 ? 2 : s) - 1) * c->grid_size;
+                        }
+                    v[0] = o_clamp(v[0], -cb, cb); v[1] = o_clamp(v[1], -cb, cb);
+                    v[2] = o_clamp(v[2], -20.0f, c->max_height * 0.5f);
+                }
+                out[3 * b] = v[0]; out[3 * b + 1] = v[1]; out[3 * b + 2] = v[2];
+                const int gx = o_envgen_cell((double)v[0], gs, GN), gy = o_envgen_cell((double)v[1], gs, GN);
+                const int dx = gx - half, dy = gy - half;
+                if (dx * dx + dy * dy >= half * half) ok = 0;
+                cells[b] = gx * GN + gy;
+            }
+            for (int b = 1; b < nb && ok; ++b)
+                for (int b2 = 0; b2 < b; ++b2)
+                    if (cells[b] == cells[b2]) { ok = 0; break; }
+            done = ok;
+        }
+        if (!done)
+            for (int j = 0; j < TD; ++j) out[j] = origin[j];
+    }
+    return 0;
+}

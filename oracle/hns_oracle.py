@@ -228,3 +228,21 @@ def tp_observe(cfg, arrs, tp_arrs, fill, with_state=True):
     T, F = tp_arrs["history"].shape[1], tp_arrs["pred"].shape[1]
     rc = lib().hns_oracle_tp_observe(C.byref(cfg), C.byref(b), C.byref(t), int(T), int(F), int(bool(fill)))
     assert rc == 0, rc
+
+
+def fps(points, k, start=0):
+    """Farthest-point sampling indices (int32 [k]) of points [n,d]."""
+    pts = f32(points)
+    out = np.empty(int(k), np.int32)
+    rc = lib().hns_oracle_fps(_p(pts), int(pts.shape[0]), int(pts.shape[1]), int(k), int(start), _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def perturb_tasks(cfg, history, n_tasks, expand_cylinders, expand_step, seed):
+    hist = f32(history)
+    out = np.zeros((int(n_tasks), hist.shape[1]), np.float32)
+    rc = lib().hns_oracle_perturb_tasks(C.byref(cfg), _p(hist), int(hist.shape[0]), _p(out), int(n_tasks), int(bool(expand_cylinders)),
+                                        C.c_float(expand_step), C.c_uint64(seed))
+    assert rc == 0, rc
+    return out

@@ -129,3 +129,49 @@ def test_envgen_env_on_gpu():
     assert float(env.stats["ratio_unif"][0]) == pytest.approx(0.3)
     assert sum(float(env.stats[f"ratio_cylinders_{i}"][0]) for i in range(6)) == pytest.approx(1.0)
     assert env.generator_seconds > 0
+
+
+# ---- device-side generator pieces: oracle restatements -----------------------------------
+def test_oracle_fps_matches_torch_reference():
+    """Integer coordinates: squared distances are exact in fp32 whatever the summation order, so the
+    oracle's index sequence must equal the plain-torch FPS (ties -> lower index in both)."""
+    import hns_oracle as O
+    from hns_amd.envgen import farthest_point_sampling
+    rng = np.random.default_rng(5)
+    for n, d, k in ((50, 3, 49), (700, 36, 120), (2000, 7, 64)):
+        pts = rng.integers(-20, 21, size=(n, d)).astype(np.float32)
+        pts[n // 2] = pts[3]                                   # duplicates: zero distances and ties
+        ref = farthest_point_sampling(torch.from_numpy(pts), k, start=7).numpy()
+        got = O.fps(pts, k, start=7)
+        assert (got == ref).all()
+        assert len(set(got.tolist())) == k
+
+
+def test_oracle_perturb_tasks_properties():
+    import hns_oracle as O
+    A, Cn = 3, 5
+    cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": Cn, "min_num": 2}, "env": {"num_envs": 64}})
+    c = config.resolve_hns_cfg(cfg)
+    gb = GenBuffer(A, Cn)
+    # history = valid tasks: placements produced by the oracle's own reset
+    arrs = O.alloc_buffers(c)
+    O.reset(c, arrs, None, 3, 0)
+    hist = np.concatenate([arrs["drone_state"][..., :3].reshape(64, -1), arrs["target_pos"], arrs["cylinders"].reshape(64, -1)], axis=1)
+    hist[:, 2:3 * (A + 1):3] = 1.2                              # the reference's z window sits around max_height (:320-333)
+    hist = hist[gb.sanity_ok(hist)]                             # uniform resets may put two pursuers into one cell
+    assert len(hist) > 20
+    out = O.perturb_tasks(c, hist, 500, 0, 0.1, seed=11)
+    assert out.shape == (500, 3 * (A + 1 + Cn)) and gb.sanity_ok(out).all()
+    b = gb.task_bounds()
+    assert (out >= b[:, 0] - 1e-6).all() and (out <= b[:, 1] + 1e-6).all()
+    # every task is a jittered copy of SOME history entry: cylinders untouched, bodies within expand_step
+    cyl_match = (np.abs(out[:, None, 3 * (A + 1):] - hist[None, :, 3 * (A + 1):]).max(-1) == 0)
+    body_close = (np.abs(out[:, None, :3 * (A + 1)] - hist[None, :, :3 * (A + 1)]).max(-1) <= 0.1 + 1e-6)
+    assert (cyl_match & body_close).any(1).all()
+    assert (np.abs(out[:, None, :] - hist[None]).max(-1).min(1) > 0).mean() > 0.9      # and most really moved
+    assert np.array_equal(out, O.perturb_tasks(c, hist, 500, 0, 0.1, seed=11))
+    assert not np.array_equal(out, O.perturb_tasks(c, hist, 500, 0, 0.1, seed=12))
+    moved = O.perturb_tasks(c, hist, 500, 1, 0.1, seed=11)                               # cylinders hop by whole cells
+    dxy = (moved[:, None, 3 * (A + 1):] - hist[None, :, 3 * (A + 1):]).reshape(500, len(hist), Cn, 3)[..., :2]
+    cells = np.abs(dxy / 0.2 - np.rint(dxy / 0.2)).max((-1, -2)).min(1)
+    assert (cells < 1e-4).all() and gb.sanity_ok(moved).all()
