@@ -9,14 +9,21 @@ bookkeeping on the host (reference omni_drones/envs/hide_and_seek/hideandseek_en
     + perturbed buffer tasks, replayed for `eval_iter` episodes;
   * the curriculum block at episode end (:1302-1333) and the extra statistics (:617-651, :1241-1246).
 
+In the env the buffer lives on the device (`DeviceGenBuffer`): the history, the task batch and the
+success weights never leave HBM; `samplenearby` is `hns_perturb_tasks` (one thread per task) and the
+FPS trim is `hns_fps` (one persistent launch, ~30 ms for 5000 of 50 000 tasks) — csrc/hns_envgen.hip.
+`GenBuffer` below is the same logic on the host in numpy (the reference's class surface; used by the
+CPU tests and as the plain restatement of the device path).
+
 Differences from the reference, all distribution-preserving (the generator's RNG streams
 and DGL's FPS start point are unpinned):
-  * `samplenearby` is vectorised (all tasks perturbed at once, failed ones retried up to 10 times)
-    instead of a Python loop per task — needed at 65 536 envs;
-  * FPS is an iterative torch implementation (runs on the env's GPU) instead of
+  * `samplenearby` perturbs every task independently (Philox stream per task, a fresh history entry
+    per attempt, the entry itself after 10 failed attempts) instead of a Python loop per task that
+    pads failures with copies of other tasks' results — needed at 65 536 envs;
+  * FPS is the build's own (`hns_fps`; start index random, ties -> lower index) instead of
     `dgl.geometry.farthest_point_sampler` (not installed; its version is unpinned in the reference);
   * task placement on the device goes through `hns_reset_tasks`; uniform tasks are sampled by the
-    reset kernel itself and read back once per task batch;
+    reset kernel itself and copied into the task batch on the device;
   * `success_buffer` / `success_unif` are refreshed at episode end (where `EpisodeStats` reads them)
     rather than every step, which would need a cross-env reduction per step.
 """
@@ -189,6 +196,86 @@ class GenBuffer:
         np.save("{}/history_{}.npy".format(model_dir, episode), self._history_buffer)
 
 
+class DeviceGenBuffer:
+    """GenBuffer (hideandseek_envgen.py:209-377) with every array resident on the env's GPU."""
+
+    def __init__(self, env, buffer_length=5000, seed=0):
+        self.env, self.lib, self.device = env, env._lib, env.device
+        self.num_agents, self.num_cylinders = env.num_agents, env.num_cylinders
+        self.task_dim = 3 * self.num_agents + 3 + 3 * self.num_cylinders
+        self.buffer_length, self.eps, self.update_method = buffer_length, 1e-5, "fps"
+        self._history = torch.zeros(0, self.task_dim, device=self.device)
+        self._state_buffer = torch.zeros(0, self.task_dim, device=self.device)
+        self._weight_buffer = torch.zeros(0, device=self.device)
+        self._temp_state, self._temp_weights = None, []
+        self._fps_scratch = torch.zeros(int(self.lib.hns_fps_scratch_bytes()), dtype=torch.uint8, device=self.device)
+        self._fps_idx = torch.zeros(buffer_length, dtype=torch.int32, device=self.device)
+        self.rng = np.random.default_rng(seed)
+        self._draws = 0
+
+    # numpy views for callers that want the reference's attributes (statistics, save_task, tests)
+    @property
+    def _history_buffer(self):
+        return self._history.cpu().numpy()
+
+    def __len__(self):
+        return int(self._history.shape[0])
+
+    def init_history(self, init_tasks):
+        self._history = torch.as_tensor(np.asarray(init_tasks, dtype=np.float32).reshape(-1, self.task_dim), device=self.device)
+
+    def insert(self, states):
+        self._temp_state = states.detach().clone()
+
+    def insert_weights(self, weights):
+        self._temp_weights.append(weights.detach().reshape(-1).clone())
+
+    def update(self):
+        self._state_buffer = self._temp_state
+        self._weight_buffer = torch.stack(self._temp_weights, dim=-1).mean(-1)
+        self._temp_state, self._temp_weights = None, []
+
+    def insert_history(self, states):
+        if states.shape[0] == 0:
+            return
+        all_states = torch.cat([self._history, states.reshape(-1, self.task_dim)]).contiguous()
+        n = int(all_states.shape[0])
+        if self.update_method == "fifo":
+            self._history = all_states[-self.buffer_length:].contiguous()
+        elif n > self.buffer_length:
+            lo, hi = all_states.min(0).values, all_states.max(0).values
+            normed = ((all_states - lo) / (hi - lo + self.eps)).contiguous()
+            rc = self.lib.hns_fps(normed.data_ptr(), n, self.task_dim, self.buffer_length, int(self.rng.integers(n)),
+                                  self._fps_idx.data_ptr(), self._fps_scratch.data_ptr(), self.env._stream())
+            self.env._check(rc, "hns_fps")
+            self._history = all_states.index_select(0, self._fps_idx.long())
+            if int(self._fps_scratch[:8].view(torch.int64)[0]) != 0:          # also the sync that ends the launch
+                raise HnsError("hns_fps gave up: a workgroup of the persistent launch never became resident")
+        else:
+            self._history = all_states
+
+    def samplenearby_into(self, out, expand_cylinders, expand_step):
+        """Fill `out` ([n, task_dim], a device tensor or a contiguous slice of one) with perturbed history tasks."""
+        assert out.is_contiguous() and out.shape[1] == self.task_dim
+        self._draws += 1
+        seed = (int(self.env.seed) * 0x9E3779B97F4A7C15 + self._draws) & 0xFFFFFFFFFFFFFFFF
+        rc = self.lib.hns_perturb_tasks(self.env._env, self._history.data_ptr(), len(self), out.data_ptr(), int(out.shape[0]),
+                                        int(bool(expand_cylinders)), C.c_float(expand_step), C.c_uint64(seed), self.env._stream())
+        self.env._check(rc, "hns_perturb_tasks")
+
+    def samplenearby(self, num_tasks, expand_cylinders, expand_step):
+        out = torch.zeros(num_tasks, self.task_dim, device=self.device)
+        self.samplenearby_into(out, expand_cylinders, expand_step)
+        return out.cpu().numpy()
+
+    def sample(self, num_tasks):
+        idx = torch.as_tensor(self.rng.integers(len(self), size=num_tasks), device=self.device)
+        return self._history.index_select(0, idx).cpu().numpy()
+
+    def save_task(self, model_dir, episode):
+        np.save("{}/history_{}.npy".format(model_dir, episode), self._history_buffer)
+
+
 class HideAndSeek_envgen(HideAndSeek):
     def __init__(self, cfg, headless=True, env_index_offset=0, write_critic_state=None):
         super().__init__(cfg, headless, env_index_offset, write_critic_state)
@@ -203,15 +290,14 @@ class HideAndSeek_envgen(HideAndSeek):
         self.update_iter = 0
         self.num_unif = self.num_envs
         A, Cn, E = self.num_agents, self.num_cylinders, self.num_envs
-        self.gen_buffer = GenBuffer(A, Cn, device=self.device, arena_size=float(t.arena_size), cylinder_size=float(t.cylinder.size),
-                                    max_height=float(t.max_height), seed=int(cfg.get("seed", 0)))
+        self.gen_buffer = DeviceGenBuffer(self, seed=int(cfg.get("seed", 0)))
         if self.use_init_easy:                                                # :485-495
-            easy = self.gen_buffer.init_easy_cases()
+            easy = GenBuffer(A, Cn, arena_size=float(t.arena_size), cylinder_size=float(t.cylinder.size),
+                             max_height=float(t.max_height), seed=int(cfg.get("seed", 0))).init_easy_cases()
             cyl = np.tile(np.array([0.0, 0.0, -20.0], np.float32), (easy.shape[0], Cn, 1))
             self.gen_buffer.init_history(np.concatenate([easy.reshape(easy.shape[0], -1), cyl.reshape(easy.shape[0], -1)], axis=1))
         self.task_dim = self.gen_buffer.task_dim
         self._tasks_dev = torch.zeros(E, self.task_dim, device=self.device)
-        self.all_tasks = None
         self.active_cylinders = torch.zeros(E, 1, device=self.device)
         extra = ["success_buffer", "success_unif", "history_buffer", "add_history", "ratio_unif"]
         extra += [f"ratio_cylinders_{i}" for i in range(Cn + 1)] + [f"success_cylinders_{i}" for i in range(Cn + 1)]
@@ -219,6 +305,11 @@ class HideAndSeek_envgen(HideAndSeek):
         for k, v in self._extra.items():
             self.stats.set(k, v)
         self.generator_seconds = 0.0
+
+    @property
+    def all_tasks(self):
+        """The current task batch [E, task_dim] as numpy (hideandseek_envgen.py:886-899 keeps it on the host)."""
+        return self._tasks_dev.cpu().numpy()
 
     # ---- hideandseek_envgen.py:875-902 ------------------------------------------------------------------
     def _reset(self, tensordict=None, **kwargs):
@@ -233,20 +324,18 @@ class HideAndSeek_envgen(HideAndSeek):
         t0 = time.perf_counter()
         mptr = C.c_void_p(mask_t.data_ptr()) if mask_t is not None else None
         if self.update_iter == 0:
-            hist = self.gen_buffer._history_buffer.shape[0]
+            hist = len(self.gen_buffer)
             num_buffer = min(hist, int(E * (1 - self.ratio_unif)))
             self.num_unif = E - num_buffer
             if num_buffer > 0:
-                tasks_buffer = self.gen_buffer.samplenearby(num_buffer, self.expand_cylinders, self.expand_step)
-                self._tasks_dev[self.num_unif:].copy_(torch.from_numpy(tasks_buffer))
+                self.gen_buffer.samplenearby_into(self._tasks_dev[self.num_unif:], self.expand_cylinders, self.expand_step)
             self._check(self._lib.hns_reset_tasks(self._env, mptr, C.c_void_p(self._tasks_dev.data_ptr()),
                                                   C.c_int32(self.num_unif), C.c_uint64(self.seed), self._stream()), "hns_reset_tasks")
             # the uniform tasks were sampled on the device: read the placement back as task vectors
             b = self._bufs
             placed = torch.cat([b["drone_state"][..., :3].reshape(E, -1), b["target_pos"], b["cylinders"].reshape(E, -1)], dim=1)
             self._tasks_dev[:self.num_unif].copy_(placed[:self.num_unif])
-            self.all_tasks = self._tasks_dev.cpu().numpy().copy()
-            self.gen_buffer.insert(self.all_tasks)
+            self.gen_buffer.insert(self._tasks_dev)
         else:
             self._check(self._lib.hns_reset_tasks(self._env, mptr, C.c_void_p(self._tasks_dev.data_ptr()),
                                                   C.c_int32(0), C.c_uint64(self.seed), self._stream()), "hns_reset_tasks")
@@ -284,21 +373,24 @@ class HideAndSeek_envgen(HideAndSeek):
             ex["success_unif"].copy_(success)
         if float(success.mean()) > self.success_threshold:
             self.ratio_unif = 1.0
-        self.gen_buffer.insert_weights(success.cpu().numpy())
+        self.gen_buffer.insert_weights(success)
         self.update_iter += 1
         if self.update_iter >= self.eval_iter:
             self.update_iter = 0
             self.gen_buffer.update()
-            act = self.active_cylinders.reshape(-1).cpu().numpy()
-            w = self.gen_buffer._weight_buffer.reshape(-1)
+            w = self.gen_buffer._weight_buffer
+            act = self.active_cylinders.reshape(-1).long()
+            counts = torch.bincount(act, minlength=Cn + 1).double()
+            sums = torch.bincount(act, weights=w.double(), minlength=Cn + 1)
+            both = torch.stack([counts, sums]).cpu().numpy()                  # one read-back for the 2(C+1) statistics
             for i in range(Cn + 1):
-                sel = act == i
-                ex[f"ratio_cylinders_{i}"].fill_(float(sel.mean()))
-                ex[f"success_cylinders_{i}"].fill_(float(w[sel].mean()) if sel.any() else 0.0)
+                ex[f"ratio_cylinders_{i}"].fill_(float(both[0, i] / E))
+                ex[f"success_cylinders_{i}"].fill_(float(both[1, i] / both[0, i]) if both[0, i] > 0 else 0.0)
             keep = (w <= self.R_max) & (w >= self.R_min)
-            self.gen_buffer.insert_history(self.gen_buffer._state_buffer[keep])
-            ex["add_history"].fill_(float(keep.sum()))
-        ex["history_buffer"].fill_(float(len(self.gen_buffer._history_buffer)))
+            kept = self.gen_buffer._state_buffer[keep]
+            self.gen_buffer.insert_history(kept)
+            ex["add_history"].fill_(float(kept.shape[0]))
+        ex["history_buffer"].fill_(float(len(self.gen_buffer)))
         ex["ratio_unif"].fill_(self.ratio_unif)
         self.generator_seconds += time.perf_counter() - t0
 

@@ -131,6 +131,41 @@ def test_envgen_env_on_gpu():
     assert env.generator_seconds > 0
 
 
+@pytest.mark.gpu
+def test_envgen_history_trim_on_gpu():
+    """More kept tasks than the buffer holds: the history is trimmed to 5000 by hns_fps, every kept row
+    is one of the inserted tasks, and the next batch is drawn around them by hns_perturb_tasks."""
+    from hns_amd.envgen import HideAndSeek_envgen, GenBuffer
+    E, L = 8192, 3
+    cfg = config.make_cfg({"name": "HideAndSeek_envgen", "num_agents": 3, "ratio_unif": 0.3, "eval_iter": 1, "R_min": 0.0, "R_max": 1.0,
+                           "use_particle_generator": 1, "cylinder": {"max_num": 8, "min_num": 8}, "env": {"num_envs": E, "max_episode_length": L}})
+    env = HideAndSeek_envgen(cfg)
+    env.set_seed(1)
+    env.reset()
+    batch0 = env.all_tasks.copy()
+    for ep in range(2):
+        for t in range(L):
+            td = env.step(env.rand_step_input())
+        rtd = env.rand_step_input()
+        rtd.set("_reset", td[("next", "done")].squeeze(-1))
+        env.reset(rtd)
+        hist = env.gen_buffer._history_buffer
+        assert hist.shape == (5000, 36) and len(np.unique(hist, axis=0)) == 5000
+        if ep == 0:
+            rows = {r.tobytes() for r in batch0}
+            assert all(r.tobytes() in rows for r in hist)                 # FPS selects, it does not alter
+            # the trim equals the oracle's FPS on the same normalised points with the same start index
+            lo, hi = batch0.min(0), batch0.max(0)
+            normed = ((batch0 - lo) / (hi - lo + np.float32(1e-5))).astype(np.float32)
+            start = int(np.flatnonzero((batch0 == hist[0]).all(1))[0])
+            ref = O.fps(normed, 5000, start)
+            np.testing.assert_array_equal(hist, batch0[ref])
+    assert env.num_unif == E - min(5000, int(E * 0.7))
+    new = env.all_tasks[env.num_unif:]
+    gb = GenBuffer(3, 8)
+    assert gb.sanity_ok(new).mean() > 0.95                                # perturbed tasks pass the grid check (fallbacks may not)
+
+
 # ---- device-side generator pieces (SURVEY §8 N3): oracle restatements -----------------------------------
 def test_oracle_fps_matches_torch_reference():
     """Integer coordinates: squared distances are exact in fp32 whatever the summation order, so the

@@ -26,6 +26,6 @@ for ep in range(EPISODES):
     rtd.set("_reset", td[("next", "done")].squeeze(-1))
     env.reset(rtd)
     torch.cuda.synchronize()
-    print(f"episode {ep}: generator {1e3 * (env.generator_seconds - g0):8.1f} ms  history {len(env.gen_buffer._history_buffer):5d}  num_unif {env.num_unif}")
+    print(f"episode {ep}: generator {1e3 * (env.generator_seconds - g0):8.1f} ms  history {len(env.gen_buffer):5d}  num_unif {env.num_unif}")
 dt = time.perf_counter() - t0
 print(f"total {dt:.2f} s for {EPISODES} episodes x {L} steps: {E * 3 * L * EPISODES / dt:.3e} agent-steps/s incl. generator")
