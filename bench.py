@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--episode", type=int, default=800)
     ap.add_argument("--critic-state", action="store_true", help="also write the [E,A,20] centralised-critic state (critic_input: state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=200)
+    ap.add_argument("--cpu-steps", type=int, default=150)
     ap.add_argument("--time-every", type=int, default=32)
     ap.add_argument("--tp-steps", type=int, default=300,
                     help="extra untimed-in-`value` leg: steps with the trajectory predictor in the observation "
@@ -142,12 +142,30 @@ def main():
         traffic = tj.get(key, {}).get("traffic_bytes_per_launch")
     except Exception:  # noqa: BLE001
         pass
+    # achievable HBM bandwidth on this box ("measure achievable with a device copy kernel and report both")
+    copy_gbs = None
+    try:
+        src = torch.empty(256 * 1024 * 1024 // 4, dtype=torch.float32, device=device).normal_()
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize(device)
+        copy_gbs = round(20 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del src, dst
+    except Exception:  # noqa: BLE001
+        pass
     if kernel_ms > 0:
         achieved = b_env * E / (kernel_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": f"hns_step_kernel<{A}>", "kernel_us": round(kernel_ms * 1e3, 2), "samples": n_samples,
-                    "bytes_per_launch": b_env * E}
+                    "bytes_per_launch": b_env * E, "device_copy_GBs": copy_gbs,
+                    "frac_of_device_copy": round(achieved / copy_gbs, 4) if copy_gbs else None}
 
     # secondary leg ("use_TP_net=1 reported separately"): step + hns_tp_observe
     tp_mode = None
@@ -187,10 +205,20 @@ def main():
         for _ in range(args.cpu_steps):
             O.step(env.hcfg, host, act)
         cdt = time.perf_counter() - c0
-        cpu_baseline = {"value": round(E * A * args.cpu_steps / cdt, 1), "unit": "agent-steps/s", "cores": 1,
-                        "kind": "port",
-                        "sample": f"{args.cpu_steps} steps of the same {E}-env workload with the scalar C oracle "
-                                  f"(oracle/hns_oracle.c), 1 thread, {cdt:.1f} s"}
+        one_core = E * A * args.cpu_steps / cdt
+        # the same sample on every host core (envs are independent: OpenMP over the env loop)
+        ncores = os.cpu_count() or 1
+        O.set_threads(ncores)
+        O.step(env.hcfg, host, act)
+        m0 = time.perf_counter()
+        for _ in range(args.cpu_steps):
+            O.step(env.hcfg, host, act)
+        mdt = time.perf_counter() - m0
+        O.set_threads(1)
+        cpu_baseline = {"value": round(E * A * args.cpu_steps / mdt, 1), "unit": "agent-steps/s", "cores": ncores,
+                        "kind": "port", "one_core_value": round(one_core, 1),
+                        "sample": f"{args.cpu_steps} steps of the same {E}-env workload with the C oracle "
+                                  f"(oracle/hns_oracle.c): {ncores} threads {mdt:.1f} s, 1 thread {cdt:.1f} s"}
 
     if rank == 0:
         out = {

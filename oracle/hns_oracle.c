@@ -560,9 +560,15 @@ static void o_reward(const hns_cfg *c, int A, int C, int K, const float *drone_s
 /* ------------------------------------------------------------------------------------------
  * Full step over all envs, on the ABI's buffers (host pointers here).  Order = SURVEY App. C.
  * ---------------------------------------------------------------------------------------- */
+static int g_step_threads = 1;
+/* envs are independent: the step may be spread over host threads (bench.py's multi-core cpu_baseline leg);
+ * the results do not depend on the thread count */
+void hns_oracle_set_threads(int n) { g_step_threads = n < 1 ? 1 : n; }
+
 int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action) {
     const int E = c->num_envs, A = c->num_agents, C = c->num_cylinders, K = c->obs_max_cylinder;
     if (A < 1 || A > HNS_MAX_AGENTS || C > HNS_MAX_CYLINDERS || K > C) return HNS_ERR_INVALID_ARG;
+#pragma omp parallel for schedule(static) num_threads(g_step_threads)
     for (int e = 0; e < E; ++e) {
         float *ds = b->drone_state + (size_t)e * A * 13;
         float *tp = b->target_pos + (size_t)e * 3;

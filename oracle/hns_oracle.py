@@ -58,6 +58,11 @@ def as_struct(arrs):
     return b
 
 
+def set_threads(n):
+    """Host threads for step() (envs are independent; results identical for any count)."""
+    lib().hns_oracle_set_threads(int(n))
+
+
 def step(cfg, arrs, action):
     action = f32(action)
     b = as_struct(arrs)
