@@ -30,9 +30,12 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measu
 NUM_STATS = 24
 
 
-def algorithmic_bytes_per_env(A, C, k, S=NUM_STATS):
-    """mandatory fp32 traffic of one env-step, one read + one write, no temporaries."""
-    return A * (232 + 4 * (20 + 3 * (A - 1) + 5 * k) + 4) + 4 * (3 + 3 * C + 1 + S) + 4 * (7 + S) + 1
+def algorithmic_bytes_per_env(A, C, k, S=NUM_STATS, NT=1):
+    """mandatory fp32 traffic of one env-step, one read + one write, no temporaries.
+    Two-evader extension (NT=2): + the second evader's position read (12 B), position + velocity written (24 B)
+    and 4 more values in every state_self row (16 B per pursuer)."""
+    base = A * (232 + 4 * (20 + 3 * (A - 1) + 5 * k) + 4) + 4 * (3 + 3 * C + 1 + S) + 4 * (7 + S) + 1
+    return base + (NT - 1) * (12 + 24 + 16 * A)
 
 
 def main():
@@ -43,6 +46,7 @@ def main():
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=3)
     ap.add_argument("--cylinders", type=int, default=8)
+    ap.add_argument("--targets", type=int, default=1, help="evaders per env: 1 = the reference, 2 = BASELINE config 5's extension")
     ap.add_argument("--episode", type=int, default=800)
     ap.add_argument("--critic-state", action="store_true", help="also write the [E,A,20] centralised-critic state (critic_input: state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -72,7 +76,7 @@ def main():
     from hns_amd.env import HideAndSeek
 
     E, A, C, K = args.envs, args.agents, args.cylinders, 3
-    cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": C, "min_num": C, "obs_max_cylinder": K},
+    cfg = config.make_cfg({"num_agents": A, "num_targets": args.targets, "cylinder": {"max_num": C, "min_num": C, "obs_max_cylinder": K},
                            "env": {"num_envs": E, "max_episode_length": args.episode},
                            "sim": {"device": f"cuda:{local_rank}"}})
     env = HideAndSeek(cfg, headless=True, env_index_offset=rank * E, write_critic_state=args.critic_state)
@@ -133,7 +137,7 @@ def main():
     assert torch.isfinite(env._bufs["reward"]).all(), "non-finite reward"
     total_agent_steps = world * E * A * args.steps
     value = total_agent_steps / elapsed
-    b_env = algorithmic_bytes_per_env(A, C, K)
+    b_env = algorithmic_bytes_per_env(A, C, K, NT=args.targets)
     roofline = None
     traffic = None
     try:   # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), see profiles/
@@ -169,7 +173,7 @@ def main():
 
     # secondary leg ("use_TP_net=1 reported separately"): step + hns_tp_observe
     tp_mode = None
-    if args.tp_steps > 0 and world == 1:
+    if args.tp_steps > 0 and world == 1 and args.targets == 1:
         cfg_tp = config.make_cfg({"num_agents": A, "cylinder": {"max_num": C, "min_num": C, "obs_max_cylinder": K},
                                   "env": {"num_envs": E, "max_episode_length": args.episode},
                                   "sim": {"device": f"cuda:{local_rank}"}}, algo={"use_TP_net": 1})
@@ -226,9 +230,9 @@ def main():
             "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"HideAndSeek {A}v1, {C} random cylinders + LOS/k-nearest sensing, "
+            "config": {"workload": f"HideAndSeek {A}v{args.targets}, {C} random cylinders + LOS/k-nearest sensing, "
                                    f"{E} envs per GPU (BASELINE configs[2])",
-                       "num_envs_per_gpu": E, "num_agents": A, "num_cylinders": C, "obs_max_cylinder": K,
+                       "num_envs_per_gpu": E, "num_agents": A, "num_targets": args.targets, "num_cylinders": C, "obs_max_cylinder": K,
                        "episode_length": args.episode, "critic_state_output": args.critic_state,
                        "sharding": f"contiguous env slices x{world}",
                        "collective": "1 all-gather of 5 fp64 per 64-step rollout" if world > 1 else "none"},

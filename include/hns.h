@@ -88,7 +88,7 @@ typedef struct hns_cfg {
     int32_t cyl_fixed_num;     /* cylinder.fixed_num, -1 = null */
     int32_t grid_num;          /* int(arena*2/(2*size)) = 9, hideandseek.py:579 */
     int32_t env_index_offset;  /* global index of local env 0 (multi-GPU shard); keys the reset RNG */
-    int32_t reserved0;
+    int32_t num_targets;       /* evaders per env: 0 or 1 = the reference (one evader); 2 = two-evader extension (below) */
 
     float dt;                  /* cfg.sim.dt */
     float gravity;             /* 9.81 */
@@ -139,6 +139,16 @@ typedef struct hns_cfg {
     int32_t reserved1;
 } hns_cfg;
 
+/*
+ * Two-evader extension (num_targets = 2; NOT in the reference — BASELINE config 5 "6-pursuer/2-evader"):
+ * each evader runs the reference's potential-field policy (hideandseek.py:1067-1141) on its own against all
+ * pursuers, the arena and the cylinders (evaders ignore each other); line of sight, detection and masking
+ * are evaluated per evader; the distance reward refers to the NEAREST evader, the catch reward to ANY
+ * evader captured by any pursuer; `blocked` counts steps in which no pursuer sees either evader.  Shapes:
+ * target_pos / target_vel [E,2,3]; obs_self / state_drones rows have 24 values = the reference's 20, the
+ * relative position of evader 1, one zero; detect[e] is a bit mask (bit k = evader k detected); task vectors
+ * are [drones | evader 0 | evader 1 | cylinders].  hns_tp_* (one evader in the frame) is not available.
+ */
 /* Device buffers, caller-owned.  Shapes in brackets; E,A,C,k as in hns_cfg. */
 typedef struct hns_buffers {
     /* persistent state, updated in place */
@@ -147,7 +157,7 @@ typedef struct hns_buffers {
     float *pid_integ;      /* [E,A,4]  xyz + pad, lee_position_controller.py:497-502 */
     float *pid_last_rate;  /* [E,A,4]  xyz + pad */
     float *prev_action;    /* [E,A,4]  == info.prev_action (ctbr of the last step) */
-    float *target_pos;     /* [E,3]    evader position */
+    float *target_pos;     /* [E,3]    evader position ([E,2,3] with num_targets = 2) */
     float *target_vel;     /* [E,3]    evader linear velocity set this step (hideandseek.py:741) */
     float *cylinders;      /* [E,C,3]  z<0 => inactive */
     float *progress;       /* [E]      float step counter, isaac_env.py:142-147 */

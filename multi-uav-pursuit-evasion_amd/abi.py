@@ -35,7 +35,7 @@ class HnsCfg(C.Structure):
         ("obs_max_cylinder", _i), ("max_episode_length", _i), ("use_deployment", _i),
         ("fixed_yaw", _i), ("ground_clamp", _i), ("write_critic_state", _i), ("init_mode", _i),
         ("cyl_min_num", _i), ("cyl_fixed_num", _i), ("grid_num", _i), ("env_index_offset", _i),
-        ("reserved0", _i),
+        ("num_targets", _i),
         ("dt", _f), ("gravity", _f),
         ("arena_size", _f), ("max_height", _f), ("cylinder_size", _f), ("cylinder_height", _f),
         ("catch_radius", _f), ("drone_detect_radius", _f), ("target_detect_radius", _f),
@@ -76,16 +76,23 @@ class HnsBuffers(C.Structure):
     _fields_ = [(name, _fp) for name in BUFFER_FIELDS]
 
 
-def buffer_shapes(E, A, Cn, K):
+def self_dim(num_targets=1):
+    """Values per state_self / state_drones row: the reference's 20; 24 with the two-evader extension."""
+    return 24 if num_targets == 2 else HNS_SELF_DIM
+
+
+def buffer_shapes(E, A, Cn, K, num_targets=1):
     """Shape (and dtype name) of every hns_buffers field."""
+    tgt = (E, 2, 3) if num_targets == 2 else (E, 3)
+    D = self_dim(num_targets)
     return {
         "drone_state": ((E, A, 13), "float32"), "throttle": ((E, A, 4), "float32"),
         "pid_integ": ((E, A, 4), "float32"), "pid_last_rate": ((E, A, 4), "float32"),
-        "prev_action": ((E, A, 4), "float32"), "target_pos": ((E, 3), "float32"),
-        "target_vel": ((E, 3), "float32"), "cylinders": ((E, Cn, 3), "float32"),
+        "prev_action": ((E, A, 4), "float32"), "target_pos": (tgt, "float32"),
+        "target_vel": (tgt, "float32"), "cylinders": ((E, Cn, 3), "float32"),
         "progress": ((E,), "float32"), "stats": ((HNS_NUM_STATS, E), "float32"),
-        "obs_self": ((E, A, HNS_SELF_DIM), "float32"), "obs_others": ((E, A, max(A - 1, 0), 3), "float32"),
-        "obs_cylinders": ((E, A, K, 5), "float32"), "state_drones": ((E, A, HNS_SELF_DIM), "float32"),
+        "obs_self": ((E, A, D), "float32"), "obs_others": ((E, A, max(A - 1, 0), 3), "float32"),
+        "obs_cylinders": ((E, A, K, 5), "float32"), "state_drones": ((E, A, D), "float32"),
         "reward": ((E, A), "float32"), "action_error": ((E, A), "float32"), "done": ((E,), "uint8"),
         "detect": ((E,), "uint8"),
     }

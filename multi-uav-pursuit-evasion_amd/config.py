@@ -250,6 +250,13 @@ def resolve_hns_cfg(cfg, num_envs=None, env_index_offset=0, drone_params=None, w
     if not (1 <= K <= Cn):
         raise ValueError("cylinder.obs_max_cylinder must be in [1, cylinder.max_num]")
     c.num_envs, c.num_agents, c.num_cylinders, c.obs_max_cylinder = E, A, Cn, K
+    # two-evader extension (BASELINE config 5, not in the reference): task.num_targets: 2
+    NT = int(t.get("num_targets", 1))
+    if NT not in (1, 2):
+        raise ValueError("task.num_targets must be 1 (the reference) or 2 (extension)")
+    if NT == 2 and int(cfg.algo.get("use_TP_net", 0)):
+        raise NotImplementedError("num_targets=2 with algo.use_TP_net=1: the predictor's frame holds one evader")
+    c.num_targets = NT
     c.max_episode_length = int(cfg.env.max_episode_length)
     c.use_deployment = int(t.use_deployment)
     c.fixed_yaw = int(p["fixed_yaw"])

@@ -37,8 +37,11 @@ enum { R_AERR = 0, R_TD, R_DIST, R_SPEED, R_CC, R_CD, R_CW, R_COLL, R_SMOOTH, R_
        // the pursuer's push on the evader is consumed before phase 3 writes the reward terms: same slots
        R_FX = R_DIST, R_FY = R_SPEED, R_FZ = R_CC,
        // so is the thrust vector handed to the downwash partners (3 consecutive slots)
-       R_TWX = R_CD };
-enum { F_CAP = 1, F_BLOCKED = 2, F_DET = 4 };
+       R_TWX = R_CD,
+       // two-evader extension: the push on the second evader (slots 8..10, free before phase 3)
+       R_F1X = R_SMOOTH };
+enum { F_CAP = 1, F_BLOCKED = 2, F_DET = 4, F_DET1 = 8 };
+constexpr int kMaxT = 2;   // evaders per env (1 = the reference; 2 = BASELINE config 5's extension)
 
 template <int A>
 struct Geo {
@@ -73,13 +76,13 @@ struct Lds {
     int ds, cyl, cyl_stride, tp, red, ocyl, total;
 };
 __host__ __device__ inline int r4(int n) { return (n + 3) & ~3; }
-__host__ __device__ inline Lds lds_layout(int A, int C, int K) {
+__host__ __device__ inline Lds lds_layout(int A, int C, int K, int NT = 1) {
     Lds L;
     int o = 0;
     L.ds = o;    o += r4(kEPB * A * 13);
     L.cyl_stride = (3 * C) | 1;                 // odd per-env stride: env-wave reads are conflict-free
     L.cyl = o;   o += r4(kEPB * L.cyl_stride);
-    L.tp = o;    o += r4(kEPB * 3);
+    L.tp = o;    o += r4(kEPB * 3 * NT);
     L.red = o;   o += r4(kEPB * A * kRed);
     L.ocyl = o;  o += r4(kEPB * A * K * 5);
     L.total = o;
@@ -150,10 +153,12 @@ HNS_DEV void store_rigid(float *r, const Rigid &s) {
 // global memory (5 float4 per thread, thread-contiguous); the relative position of the evader is
 // written UNMASKED and the env wave re-masks it in the rare case that no pursuer detects the
 // evader (:791-794).  Returns the flags and the k-nearest selection the reward pass needs.
-template <int A>
-HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigid &s, const V3 &tp, float progress,
+// Two-evader extension (NT = 2, not in the reference): rows grow to 24 values = the reference's 20 +
+// the relative position of the second evader + one zero; line of sight / detection per evader.
+template <int A, int NT>
+HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigid &s, const V3 &tp, const V3 &tpB, float progress,
                        const float *cyl, const float *sDS, float *gOth, float *sOCyl, float *gSelf, float *gState,
-                       bool &blocked, bool &det, int knn_idx[kMaxK], bool knn_masked[kMaxK]) {
+                       bool &blocked, bool &det, bool &blockedB, bool &detB, int knn_idx[kMaxK], bool knn_masked[kMaxK]) {
     float rtx = s.pos.x - tp.x, rty = s.pos.y - tp.y, rtz = s.pos.z - tp.z;
     float dist = d_norm3(rtx, rty, rtz);
     const float t = progress * c.inv_max_episode_length;              // :796 (CUDA scalar-division form)
@@ -169,6 +174,14 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
     if (gState) {                                                      // :871-886 (never masked)
         float4 *ss = reinterpret_cast<float4 *>(gState);
         ss[0] = v0; ss[1] = v1; ss[2] = v2; ss[3] = v3; ss[4] = v4;
+    }
+    float dist1 = 0.0f;
+    if constexpr (NT == 2) {
+        const float r1x = s.pos.x - tpB.x, r1y = s.pos.y - tpB.y, r1z = s.pos.z - tpB.z;
+        dist1 = d_norm3(r1x, r1y, r1z);
+        const float4 v5 = make_float4(r1x, r1y, r1z, 0.0f);
+        so[5] = v5;
+        if (gState) reinterpret_cast<float4 *>(gState)[5] = v5;
     }
     // state_others: p_i - p_j, j != i ascending (:750-751, utils/torch.py:41-53); (A-1)*3 floats per
     // thread, thread-contiguous in global memory
@@ -203,10 +216,14 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
     for (int i = 0; i < kTrack; ++i) key[i] = 0x7F80000Fu;             // +inf | 15
     const LosLine los = d_los_setup(c, s.pos, tp);
     bool any_block = false, los_uncertain = false;
+    LosLine los1 = los;
+    bool any_block1 = false, los_uncertain1 = false;
+    if constexpr (NT == 2) los1 = d_los_setup(c, s.pos, tpB);
 #pragma unroll 4
     for (int k = 0; k < C; ++k) {
         const float ccx = cyl[3 * k], ccy = cyl[3 * k + 1], ccz = cyl[3 * k + 2];
         any_block = d_los_cylinder_fast(los, ccx, ccy, ccz, los_uncertain) || any_block;
+        if constexpr (NT == 2) any_block1 = d_los_cylinder_fast(los1, ccx, ccy, ccz, los_uncertain1) || any_block1;
         const float ex = s.pos.x - ccx, ey = s.pos.y - ccy, ez = s.pos.z - ccz;
         const float d2 = HNS_FMA(ez, ez, HNS_FMA(ey, ey, ex * ex));          // the radicand of d_norm3
         uint32_t nk = (__float_as_uint(d2) & 0xFFFFFFF0u) | (uint32_t)k;
@@ -218,6 +235,7 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
         }
     }
     if (los_uncertain) any_block = d_blocked_exact(c, C, los, cyl);
+    if (NT == 2 && los_uncertain1) any_block1 = d_blocked_exact(c, C, los1, cyl);
     float bd[kTrack];
     int bi[kTrack];
 #pragma unroll
@@ -245,6 +263,10 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
     }
     blocked = any_block;
     det = (dist < c.drone_detect_radius) && !blocked;                 // :787-789
+    if constexpr (NT == 2) {
+        blockedB = any_block1;
+        detB = (dist1 < c.drone_detect_radius) && !any_block1;
+    }
     float *oc = sOCyl + (le * A + a) * K * 5;
 #pragma unroll
     for (int sidx = 0; sidx < kMaxK; ++sidx) {
@@ -266,15 +288,16 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
 // =================================================================================================
 // The fused step kernel
 // =================================================================================================
-template <int A>
+template <int A, int NT>
 __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
     constexpr int T = Geo<A>::T, NA = Geo<A>::NA;
+    constexpr int SD = NT == 2 ? 24 : HNS_SELF_DIM;      // floats per state_self / state_drones row
     extern __shared__ __align__(16) float smem[];
     const hns_cfg &c = p.cfg;
     const hns_buffers &b = p.buf;
     const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.num_envs;
     const bool with_state = c.write_critic_state && b.state_drones != nullptr;
-    const Lds L = lds_layout(A, C, K);
+    const Lds L = lds_layout(A, C, K, NT);
     float *sDS = smem + L.ds, *sCyl = smem + L.cyl, *sTp = smem + L.tp;
     float *sRed = smem + L.red, *sOCyl = smem + L.ocyl;
 
@@ -306,10 +329,10 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
     const bool full = nenv == kEPB;
     if (full) {
         coop_copy_full<T, kEPB * A * 13>(sDS, b.drone_state + (size_t)e0 * A * 13);
-        coop_copy_full<T, kEPB * 3>(sTp, b.target_pos + (size_t)e0 * 3);
+        coop_copy_full<T, kEPB * 3 * NT>(sTp, b.target_pos + (size_t)e0 * 3 * NT);
     } else {
         coop_g2s<T>(sDS, b.drone_state + (size_t)e0 * A * 13, nenv * A * 13);
-        coop_g2s<T>(sTp, b.target_pos + (size_t)e0 * 3, nenv * 3);
+        coop_g2s<T>(sTp, b.target_pos + (size_t)e0 * 3 * NT, nenv * 3 * NT);
     }
     coop_cyl<T, true>(sCyl, b.cylinders + (size_t)e0 * C * 3, nenv, 3 * C, L.cyl_stride, p.cyl_magic, nullptr);
     // the env wave keeps its env's statistics in registers: row-major [S][E] makes every row a
@@ -329,13 +352,15 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
     s.q.w = 1.0f;
     float thrust[4] = {0, 0, 0, 0}, moment[4] = {0, 0, 0, 0};
     V3 tw = {0.f, 0.f, 0.f}, tvel = {0.f, 0.f, 0.f}, tpn = {0.f, 0.f, 0.f};
+    V3 Fenv1 = {0.f, 0.f, 0.f}, tvel1 = {0.f, 0.f, 0.f}, tpn1 = {0.f, 0.f, 0.f}, tp1 = {0.f, 0.f, 0.f};   // second evader (NT == 2)
     bool out_of_arena = false;
     float aerr = 0.f;
 
     // ================= phase 1: pre-physics on S_t =================================================
     V3 Fenv = {0.f, 0.f, 0.f};
     V3 tp0 = {0.f, 0.f, 0.f};
-    if (valid) tp0 = {sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]};
+    if (valid) tp0 = {sTp[le * 3 * NT], sTp[le * 3 * NT + 1], sTp[le * 3 * NT + 2]};
+    if (NT == 2 && valid) tp1 = {sTp[le * 3 * NT + 3], sTp[le * 3 * NT + 4], sTp[le * 3 * NT + 5]};
     if (!env_wave) {
         if (valid) {
             load_rigid(sDS + tid * 13, s);
@@ -353,6 +378,11 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             red[R_AERR] = aerr; red[R_TD] = thr_diff;
             red[R_FX] = fp.x; red[R_FY] = fp.y; red[R_FZ] = fp.z;
             red[R_TWX] = tw.x; red[R_TWX + 1] = tw.y; red[R_TWX + 2] = tw.z;
+            if constexpr (NT == 2) {                                                        // the same pursuer's push on the second evader
+                const bool blocked1 = d_blocked(c, C, s.pos, tp1, cyl);
+                const V3 f1 = d_prey_pursuer_term(c, s.pos, tp1, blocked1);
+                red[R_F1X] = f1.x; red[R_F1X + 1] = f1.y; red[R_F1X + 2] = f1.z;
+            }
         }
     } else if (valid) {
         // A6: arena + cylinder terms of the evader's potential field (hideandseek.py:1090-1136)
@@ -366,6 +396,20 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             fcy += ty;
         }
         tvel = {fcx, fcy, 0.0f};     // parked until the pursuer terms arrive
+        if constexpr (NT == 2) {               // each evader runs the potential field on its own (they ignore each other)
+            bool out1 = false;
+            Fenv1 = d_prey_arena_term(c, tp1, out1);
+            out_of_arena = out_of_arena || out1;
+            float gx = 0.f, gy = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < C; ++k) {
+                float tx, ty;
+                d_prey_cylinder_term(c, tp1, cyl[3 * k], cyl[3 * k + 1], cyl[3 * k + 2], tx, ty);
+                gx += tx;
+                gy += ty;
+            }
+            tvel1 = {gx, gy, 0.0f};
+        }
     }
     __syncthreads();
     if (env_wave && valid) {
@@ -383,6 +427,21 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
         tvel = {(c.v_prey * F.x) / (__builtin_fabsf(F.x) + 1e-5f), (c.v_prey * F.y) / (__builtin_fabsf(F.y) + 1e-5f),
                 (c.v_prey * F.z) / (__builtin_fabsf(F.z) + 1e-5f)};
         tpn = {tp0.x + tvel.x * c.dt, tp0.y + tvel.y * c.dt, tp0.z + tvel.z * c.dt};   // evader: p += v dt
+        if constexpr (NT == 2) {
+            V3 G = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                const float *red = sRed + (le * A + j) * kRed;
+                G.x = (j == 0) ? red[R_F1X] : G.x + red[R_F1X];
+                G.y = (j == 0) ? red[R_F1X + 1] : G.y + red[R_F1X + 1];
+                G.z = (j == 0) ? red[R_F1X + 2] : G.z + red[R_F1X + 2];
+            }
+            G.x = G.x + Fenv1.x; G.y = G.y + Fenv1.y; G.z = G.z + Fenv1.z;
+            G.x = G.x + tvel1.x; G.y = G.y + tvel1.y; G.z = G.z + 0.0f;
+            tvel1 = {(c.v_prey * G.x) / (__builtin_fabsf(G.x) + 1e-5f), (c.v_prey * G.y) / (__builtin_fabsf(G.y) + 1e-5f),
+                     (c.v_prey * G.z) / (__builtin_fabsf(G.z) + 1e-5f)};
+            tpn1 = {tp1.x + tvel1.x * c.dt, tp1.y + tvel1.y * c.dt, tp1.z + tvel1.z * c.dt};
+        }
         // statistics that only need phase-1 data are folded in now, while the agent waves integrate
         // (A10 hideandseek.py:731-733, :1097-1098, :996-997)
         float sum_ae = 0.f, sum_td = 0.f, max_td = 0.f;
@@ -441,7 +500,8 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
     if (!env_wave) {
         if (valid) store_rigid(sDS + tid * 13, s);
     } else if (valid) {
-        sTp[le * 3] = tpn.x; sTp[le * 3 + 1] = tpn.y; sTp[le * 3 + 2] = tpn.z;
+        sTp[le * 3 * NT] = tpn.x; sTp[le * 3 * NT + 1] = tpn.y; sTp[le * 3 * NT + 2] = tpn.z;
+        if constexpr (NT == 2) { sTp[le * 3 * NT + 3] = tpn1.x; sTp[le * 3 * NT + 4] = tpn1.y; sTp[le * 3 * NT + 5] = tpn1.z; }
     }
     __syncthreads();
     prof_mark(p.prof, 8);
@@ -459,26 +519,41 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             for (int i = lane; i < nenv * A * 13; i += 64) g[i] = sDS[i];
         }
         if (valid) {
-            float *gp = b.target_pos + (size_t)e * 3, *gv = b.target_vel + (size_t)e * 3;
+            float *gp = b.target_pos + (size_t)e * 3 * NT, *gv = b.target_vel + (size_t)e * 3 * NT;
             gp[0] = tpn.x; gp[1] = tpn.y; gp[2] = tpn.z;
             gv[0] = tvel.x; gv[1] = tvel.y; gv[2] = tvel.z;
+            if constexpr (NT == 2) {
+                gp[3] = tpn1.x; gp[4] = tpn1.y; gp[5] = tpn1.z;
+                gv[3] = tvel1.x; gv[4] = tvel1.y; gv[5] = tvel1.z;
+            }
         }
     }
 
     // ================= phase 3a: observation + per-agent reward terms on S_{t+1} =====================
     if (!env_wave && valid) {
-        V3 tp = {sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]};
-        bool blocked, det;
+        V3 tp = {sTp[le * 3 * NT], sTp[le * 3 * NT + 1], sTp[le * 3 * NT + 2]};
+        V3 tpB = tp;
+        if constexpr (NT == 2) tpB = {sTp[le * 3 * NT + 3], sTp[le * 3 * NT + 4], sTp[le * 3 * NT + 5]};
+        bool blocked, det, blockedB = false, detB = false;
         int knn_idx[kMaxK];
         bool knn_masked[kMaxK];
-        agent_obs<A>(c, C, K, le, a, s, tp, progress, cyl, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * HNS_SELF_DIM,
-                     with_state ? b.state_drones + ia * HNS_SELF_DIM : nullptr, blocked, det, knn_idx, knn_masked);
+        agent_obs<A, NT>(c, C, K, le, a, s, tp, tpB, progress, cyl, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * SD,
+                         with_state ? b.state_drones + ia * SD : nullptr, blocked, det, blockedB, detB, knn_idx, knn_masked);
         prof_mark(p.prof, 9);
         // hideandseek.py:919-995
         float d = d_norm3(tp.x - s.pos.x, tp.y - s.pos.y, tp.z - s.pos.z);
         float act = (d > c.catch_radius) ? 1.0f : 0.0f;
         float dist_rew = (-c.dist_reward_coef * d) * act;
         bool cap_ok = (d < c.catch_radius) && !blocked;
+        if constexpr (NT == 2) {
+            // extension: distance term to the NEAREST evader, capture of ANY evader, `blocked` = no line of sight to either
+            const float d1 = d_norm3(tpB.x - s.pos.x, tpB.y - s.pos.y, tpB.z - s.pos.z);
+            cap_ok = cap_ok || ((d1 < c.catch_radius) && !blockedB);
+            blocked = blocked && blockedB;
+            d = d1 < d ? d1 : d;
+            act = (d > c.catch_radius) ? 1.0f : 0.0f;
+            dist_rew = (-c.dist_reward_coef * d) * act;
+        }
         float sp = d_norm3(s.lin.x, s.lin.y, s.lin.z);
         float speed_rew = -c.speed_coef * ((sp > c.v_drone) ? 1.0f : 0.0f);
         float cc = 0.f, cd = 0.f;
@@ -510,7 +585,10 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
         float *red = sRed + tid * kRed;
         red[R_DIST] = dist_rew; red[R_SPEED] = speed_rew; red[R_CC] = cc; red[R_CD] = cd; red[R_CW] = cw;
         red[R_COLL] = cr; red[R_SMOOTH] = sm;
-        red[R_FLAGS] = __int_as_float((cap_ok ? F_CAP : 0) | (blocked ? F_BLOCKED : 0) | (det ? F_DET : 0));
+        if constexpr (NT == 2)
+            red[R_FLAGS] = __int_as_float((cap_ok ? F_CAP : 0) | (blocked ? F_BLOCKED : 0) | (det ? F_DET : 0) | (detB ? F_DET1 : 0));
+        else
+            red[R_FLAGS] = __int_as_float((cap_ok ? F_CAP : 0) | (blocked ? F_BLOCKED : 0) | (det ? F_DET : 0));
     }
     prof_mark(p.prof, 4);
     __syncthreads();
@@ -519,7 +597,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
     // ================= phase 3b: per-env reductions, reward, done, stats (env wave) ===================
     if (env_wave && valid) {
         const float iA = c.inv_num_agents;             // mean over agents = sum * (1/A), as torch's CUDA mean
-        bool any_cap = false, all_blocked = true, any_coll = false, det_any = false;
+        bool any_cap = false, all_blocked = true, any_coll = false, det_any = false, det_any1 = false;
         float sum_dist = 0, sum_speed = 0, sum_cc = 0, sum_cd = 0, sum_cw = 0, sum_coll = 0, sum_smooth = 0;
 #pragma unroll
         for (int j = 0; j < A; ++j) {
@@ -528,6 +606,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
             any_cap |= (fl & F_CAP) != 0;
             all_blocked &= (fl & F_BLOCKED) != 0;
             det_any |= (fl & F_DET) != 0;
+            det_any1 |= (fl & F_DET1) != 0;
             any_coll |= red[R_COLL] < 0.0f;
             if (j == 0) {
                 sum_dist = red[R_DIST]; sum_speed = red[R_SPEED]; sum_cc = red[R_CC]; sum_cd = red[R_CD]; sum_cw = red[R_CW];
@@ -537,7 +616,8 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
                 sum_coll += red[R_COLL]; sum_smooth += red[R_SMOOTH];
             }
         }
-        const float detf = det_any ? 1.0f : 0.0f;
+        float detf = det_any ? 1.0f : 0.0f;
+        if constexpr (NT == 2) detf = (det_any || det_any1) ? 1.0f : 0.0f;
         const float detect_rew = c.detect_reward_coef * detf;
         const float catch_rew = c.catch_reward_coef * (any_cap ? 1.0f : 0.0f);
         float sum_rew = 0.f;
@@ -551,7 +631,14 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
         if (!det_any) {                                        // hideandseek.py:791-794: mask the evader's rpos
 #pragma unroll
             for (int j = 0; j < A; ++j) {
-                float *o = b.obs_self + ((size_t)e * A + j) * HNS_SELF_DIM;
+                float *o = b.obs_self + ((size_t)e * A + j) * SD;
+                o[0] = c.mask_value; o[1] = c.mask_value; o[2] = c.mask_value;
+            }
+        }
+        if (NT == 2 && !det_any1) {
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                float *o = b.obs_self + ((size_t)e * A + j) * SD + HNS_SELF_DIM;
                 o[0] = c.mask_value; o[1] = c.mask_value; o[2] = c.mask_value;
             }
         }
@@ -594,7 +681,8 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
         ST(HNS_ST_RETURN) += sum_rew * iA;
 #undef ST
         b.done[e] = (uint8_t)done;
-        if (b.detect) b.detect[e] = (uint8_t)det_any;
+        if constexpr (NT == 2) { if (b.detect) b.detect[e] = (uint8_t)((det_any ? 1 : 0) | (det_any1 ? 2 : 0)); }   // bit k: evader k detected
+        else { if (b.detect) b.detect[e] = (uint8_t)det_any; }
         b.progress[e] = progress;
 #pragma unroll
         for (int i = 0; i < HNS_NUM_STATS; ++i) b.stats[(size_t)i * E + e] = st[i];
@@ -613,17 +701,19 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
 // (isaac_env.py:221).  The env wave regenerates the state of the masked envs into LDS with a
 // Philox stream, then the agent waves run the same agent_obs as the step kernel.
 // =================================================================================================
-template <int A>
+template <int A, int NT>
 __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
     constexpr int T = Geo<A>::T, NA = Geo<A>::NA;
+    constexpr int SD = NT == 2 ? 24 : HNS_SELF_DIM;
     extern __shared__ __align__(16) float smem[];
     __shared__ uint8_t sMask[kEPB];
     __shared__ uint8_t sDet[kEPB];
+    __shared__ uint8_t sDet1[kEPB];
     const hns_cfg &c = p.cfg;
     const hns_buffers &b = p.buf;
     const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.num_envs, GN = c.grid_num;
     const bool with_state = c.write_critic_state && b.state_drones != nullptr;
-    const Lds L = lds_layout(A, C, K);
+    const Lds L = lds_layout(A, C, K, NT);
     float *sDS = smem + L.ds, *sCyl = smem + L.cyl, *sTp = smem + L.tp;
     float *sOCyl = smem + L.ocyl;
     uint8_t *sGrid = reinterpret_cast<uint8_t *>(smem + L.total);   // 64 x 512 B of grid scratch after the step layout
@@ -639,6 +729,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
     if (tid < kEPB) {
         sMask[tid] = (tid < nenv) ? (p.reset_mask ? (p.reset_mask[e0 + tid] != 0) : 1) : 0;
         sDet[tid] = 0;
+        sDet1[tid] = 0;
     }
     __syncthreads();
     const bool masked = valid && sMask[le];
@@ -650,10 +741,10 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
     if (env_wave && masked) {
         Rng rng = {p.seed_lo, p.seed_hi, (uint32_t)(e + c.env_index_offset), p.epoch, 0u, {0u, 0u, 0u, 0u}, 0};
         float *ds = sDS + le * A * 13;
-        float *tp = sTp + le * 3;
+        float *tp = sTp + le * 3 * NT;
         float *cyl = sCyl + le * L.cyl_stride;
-        // envgen (hideandseek_envgen.py:896-898): placement given by a task vector [drones | evader | cylinders]
-        const float *task = (p.tasks && e >= p.task_first) ? p.tasks + (size_t)e * (3 * A + 3 + 3 * C) : nullptr;
+        // envgen (hideandseek_envgen.py:896-898): placement given by a task vector [drones | evader(s) | cylinders]
+        const float *task = (p.tasks && e >= p.task_first) ? p.tasks + (size_t)e * (3 * A + 3 * NT + 3 * C) : nullptr;
         for (int j = 0; j < A; ++j) {
             float *d = ds + 13 * j;
             if (task) {
@@ -694,8 +785,22 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
             if (c.init_mode == HNS_INIT_SCENARIO) tp[2] = c.fixed_target_pos[2];
             else tp[2] = c.z_lo + rng.uniform() * (c.z_hi - c.z_lo);
         }
+        if constexpr (NT == 2) {               // second evader: same box as the first (its draws follow the first evader's)
+            if (task) {
+                tp[3] = task[3 * A + 3]; tp[4] = task[3 * A + 4]; tp[5] = task[3 * A + 5];
+            } else {
+                if (c.init_mode == HNS_INIT_RANDOM) {
+                    tp[3] = c.target_xy_lo[0] + rng.uniform() * (c.target_xy_hi[0] - c.target_xy_lo[0]);
+                    tp[4] = c.target_xy_lo[1] + rng.uniform() * (c.target_xy_hi[1] - c.target_xy_lo[1]);
+                } else {             // fixed scenarios name one evader: the second mirrors it in y
+                    tp[3] = c.fixed_target_pos[0]; tp[4] = -c.fixed_target_pos[1];
+                }
+                if (c.init_mode == HNS_INIT_SCENARIO) tp[5] = c.fixed_target_pos[2];
+                else tp[5] = c.z_lo + rng.uniform() * (c.z_hi - c.z_lo);
+            }
+        }
         if (task) {
-            for (int k = 0; k < 3 * C; ++k) cyl[k] = task[3 * A + 3 + k];
+            for (int k = 0; k < 3 * C; ++k) cyl[k] = task[3 * A + 3 * NT + k];
         } else if (c.init_mode == HNS_INIT_SCENARIO) {
             for (int k = 0; k < C; ++k) {
                 cyl[3 * k] = c.fixed_cyl_pos[k][0]; cyl[3 * k + 1] = c.fixed_cyl_pos[k][1];
@@ -712,6 +817,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
                 }
             for (int j = 0; j < A; ++j) occ[d_cell(c, ds[13 * j]) * GN + d_cell(c, ds[13 * j + 1])] = 1;
             occ[d_cell(c, tp[0]) * GN + d_cell(c, tp[1])] = 1;
+            if constexpr (NT == 2) occ[d_cell(c, tp[3]) * GN + d_cell(c, tp[4])] = 1;
             int n_active;
             if (c.cyl_fixed_num >= 0) n_active = c.cyl_fixed_num;
             else {
@@ -744,26 +850,35 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
     if (!env_wave && masked) {
         Rigid s;
         load_rigid(sDS + tid * 13, s);
-        V3 tp = {sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]};
+        V3 tp = {sTp[le * 3 * NT], sTp[le * 3 * NT + 1], sTp[le * 3 * NT + 2]};
+        V3 tpB = tp;
+        if constexpr (NT == 2) tpB = {sTp[le * 3 * NT + 3], sTp[le * 3 * NT + 4], sTp[le * 3 * NT + 5]};
         const size_t ia = (size_t)e0 * A + tid;
-        bool blocked, det;
+        bool blocked, det, blockedB = false, detB = false;
         int knn_idx[kMaxK];
         bool knn_masked[kMaxK];
-        agent_obs<A>(c, C, K, le, a, s, tp, 0.0f, sCyl + le * L.cyl_stride, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * HNS_SELF_DIM,
-                     with_state ? b.state_drones + ia * HNS_SELF_DIM : nullptr, blocked, det, knn_idx, knn_masked);
+        agent_obs<A, NT>(c, C, K, le, a, s, tp, tpB, 0.0f, sCyl + le * L.cyl_stride, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * SD,
+                         with_state ? b.state_drones + ia * SD : nullptr, blocked, det, blockedB, detB, knn_idx, knn_masked);
         if (det) sDet[le] = 1;
+        if (NT == 2 && detB) sDet1[le] = 1;
     }
     __syncthreads();
     if (env_wave && masked && !sDet[le]) {                     // hideandseek.py:791-794
         for (int j = 0; j < A; ++j) {
-            float *o = b.obs_self + ((size_t)e * A + j) * HNS_SELF_DIM;
+            float *o = b.obs_self + ((size_t)e * A + j) * SD;
             o[0] = c.mask_value; o[1] = c.mask_value; o[2] = c.mask_value;
         }
     }
-    if (env_wave && masked && b.detect) b.detect[e] = sDet[le];
+    if (NT == 2 && env_wave && masked && !sDet1[le]) {
+        for (int j = 0; j < A; ++j) {
+            float *o = b.obs_self + ((size_t)e * A + j) * SD + HNS_SELF_DIM;
+            o[0] = c.mask_value; o[1] = c.mask_value; o[2] = c.mask_value;
+        }
+    }
+    if (env_wave && masked && b.detect) b.detect[e] = (uint8_t)(sDet[le] | (NT == 2 ? (sDet1[le] << 1) : 0));
     coop_s2g_masked<T>(b.drone_state + (size_t)e0 * A * 13, sDS, nenv * A * 13, A * 13, sMask);
     coop_cyl<T, false>(sCyl, b.cylinders + (size_t)e0 * C * 3, nenv, 3 * C, L.cyl_stride, p.cyl_magic, sMask);
-    coop_s2g_masked<T>(b.target_pos + (size_t)e0 * 3, sTp, nenv * 3, 3, sMask);
+    coop_s2g_masked<T>(b.target_pos + (size_t)e0 * 3 * NT, sTp, nenv * 3 * NT, 3 * NT, sMask);
     coop_s2g_masked<T>(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5, A * K * 5, sMask);
 }
 
@@ -1008,13 +1123,18 @@ static void set_error(const std::string &m) { g_last_error = m; }
 
 template <int A>
 static void select_kernels(hns_env *env) {
-    env->step_fn = hns::hns_step_kernel<A>;
-    env->reset_fn = hns::hns_reset_kernel<A>;
     const hns_cfg &c = env->cfg;
+    if (c.num_targets == 2) {
+        env->step_fn = hns::hns_step_kernel<A, 2>;
+        env->reset_fn = hns::hns_reset_kernel<A, 2>;
+    } else {
+        env->step_fn = hns::hns_step_kernel<A, 1>;
+        env->reset_fn = hns::hns_reset_kernel<A, 1>;
+    }
     env->threads = hns::Geo<A>::T;
     env->cyl_magic = (uint32_t)(0xFFFFFFFFull / (uint32_t)(3 * c.num_cylinders) + 1ull);
     env->grid = (c.num_envs + hns::kEPB - 1) / hns::kEPB;
-    hns::Lds L = hns::lds_layout(A, c.num_cylinders, c.obs_max_cylinder);
+    hns::Lds L = hns::lds_layout(A, c.num_cylinders, c.obs_max_cylinder, c.num_targets == 2 ? 2 : 1);
     env->lds_step = (size_t)L.total * sizeof(float);
     env->lds_reset = env->lds_step + (size_t)hns::kEPB * 512;   // + per-env occupancy grid / free-cell list
 }
@@ -1035,6 +1155,7 @@ int hns_create(const hns_cfg *cfg, hns_env **out) {
         set_error("hns_create: num_envs/num_agents/num_cylinders/obs_max_cylinder out of range");
         return HNS_ERR_INVALID_ARG;
     }
+    if (cfg->num_targets < 0 || cfg->num_targets > hns::kMaxT) { set_error("hns_create: num_targets must be 0, 1 or 2"); return HNS_ERR_INVALID_ARG; }
     if (cfg->obs_max_cylinder > hns::kMaxK) {
         set_error("hns_create: obs_max_cylinder > 4 is not supported by the HIP kernels");
         return HNS_ERR_INVALID_ARG;

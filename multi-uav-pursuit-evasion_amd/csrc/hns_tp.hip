@@ -539,6 +539,7 @@ int hns_tp_bind(hns_env *env, const hns_tp_buffers *b, int32_t history_step, int
         return HNS_ERR_INVALID_ARG;
     }
     if ((reinterpret_cast<uintptr_t>(b->packed) & 15) != 0) { hns_set_error("hns_tp_bind: packed must be 16-byte aligned"); return HNS_ERR_INVALID_ARG; }
+    if (env->cfg.num_targets == 2) { hns_set_error("hns_tp_bind: the predictor's frame holds one evader (num_targets = 2 is not supported)"); return HNS_ERR_CONFIG; }
     if (tp_nxc(7 + 3 * env->cfg.num_agents) > 2) { hns_set_error("hns_tp_bind: unsupported frame width"); return HNS_ERR_CONFIG; }
     if (env->cfg.max_episode_length > 60000) {
         // the frame holds `progress`; the matrix-core operands are fp16 splits (|x| < 65 504)

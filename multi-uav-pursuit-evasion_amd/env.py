@@ -112,7 +112,8 @@ class HideAndSeek:
 
         torch.cuda.set_device(self.device)
         self._bufs = {}
-        for name, (shape, dt) in abi.buffer_shapes(E, A, Cn, K).items():
+        self.num_targets = 2 if int(self.hcfg.num_targets) == 2 else 1
+        for name, (shape, dt) in abi.buffer_shapes(E, A, Cn, K, self.num_targets).items():
             n = 1
             for s in shape:
                 n *= s
@@ -172,7 +173,7 @@ class HideAndSeek:
     # ---- specs (hideandseek.py:327-433, use_TP_net=0 branch) ------------------------------------------
     def _set_specs(self):
         A, K, E, dev = self.num_agents, self.obs_max_cylinder, self.num_envs, self.device
-        D = abi.HNS_SELF_DIM + (3 * self.tp_future_step if self.use_TP_net else 0)      # 20 or 35
+        D = abi.self_dim(self.num_targets) + (3 * self.tp_future_step if self.use_TP_net else 0)      # 20 or 35 (24: two evaders)
         obs = {"state_self": TensorSpec((1, D)), "cylinders": TensorSpec((K, 5))}
         if A > 1:
             obs["state_others"] = TensorSpec((A - 1, 3))
@@ -331,8 +332,11 @@ class HideAndSeek:
     def _lazy_state_drones(self):
         """hideandseek.py:871-886: state_self with the UNMASKED relative position of the evader."""
         b = self._bufs
-        rpos = b["drone_state"][..., 0:3] - b["target_pos"].unsqueeze(1)
         rest = self._tp_bufs["obs_self"] if self.use_TP_net else b["obs_self"]       # :873-880 / :881-886
+        if self.num_targets == 2:                                                    # extension: both relative positions unmasked
+            rpos = b["drone_state"][..., None, 0:3] - b["target_pos"].unsqueeze(1)   # [E,A,2,3]
+            return torch.cat([rpos[:, :, 0], rest[..., 3:20], rpos[:, :, 1], rest[..., 23:]], dim=-1)
+        rpos = b["drone_state"][..., 0:3] - b["target_pos"].unsqueeze(1)
         return torch.cat([rpos, rest[..., 3:]], dim=-1)
 
     def _tp_observe(self):

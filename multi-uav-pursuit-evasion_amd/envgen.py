@@ -279,6 +279,8 @@ class DeviceGenBuffer:
 class HideAndSeek_envgen(HideAndSeek):
     def __init__(self, cfg, headless=True, env_index_offset=0, write_critic_state=None):
         super().__init__(cfg, headless, env_index_offset, write_critic_state)
+        if self.num_targets != 1:
+            raise NotImplementedError("HideAndSeek_envgen with num_targets=2 is not built (task vectors hold one evader)")
         t = cfg.task
         self.use_particle_generator = int(t.get("use_particle_generator", 1))
         self.ratio_unif = float(t.get("ratio_unif", 0.3))

@@ -369,18 +369,26 @@ static void o_integrate(const hns_cfg *c, float ds[13], const float force_w[3], 
  * A8: observation pass for one env   multirotor.py:599-633, hideandseek.py:746-917
  * Side products kept for the reward pass: blocked[A], bdetect, knn index/mask.
  * ---------------------------------------------------------------------------------------- */
+/* Two-evader extension (hns_cfg.num_targets = 2, NOT in the reference; include/hns.h): `tp` then points to
+ * [2][3], rows have 24 values, line of sight / detection per evader. */
+static inline int o_nt(const hns_cfg *c) { return c->num_targets == 2 ? 2 : 1; }
+static inline int o_self_dim(const hns_cfg *c) { return c->num_targets == 2 ? 24 : HNS_SELF_DIM; }
+
 typedef struct o_obs_side {
     int blocked[HNS_MAX_AGENTS];
     int bdetect;
+    int blocked1[HNS_MAX_AGENTS];   /* second evader */
+    int bdetect1;
     int knn_idx[HNS_MAX_AGENTS][HNS_MAX_CYLINDERS];
     int knn_masked[HNS_MAX_AGENTS][HNS_MAX_CYLINDERS];
 } o_obs_side;
 
-static void o_obs(const hns_cfg *c, int A, int C, int K, const float *drone_state /*[A,13]*/, const float tp[3],
+static void o_obs(const hns_cfg *c, int A, int C, int K, const float *drone_state /*[A,13]*/, const float *tp /*[NT,3]*/,
                   const float *cyl, float progress, float *obs_self /*[A,20]*/, float *obs_others /*[A,A-1,3]*/,
                   float *obs_cyl /*[A,K,5]*/, float *state_drones /*[A,20] or NULL*/, o_obs_side *side) {
-    int det_any = 0;
-    float rt[HNS_MAX_AGENTS][3];
+    int det_any = 0, det_any1 = 0;
+    const int NT = o_nt(c), SD = o_self_dim(c);
+    float rt[HNS_MAX_AGENTS][3], rt1[HNS_MAX_AGENTS][3];
     for (int a = 0; a < A; ++a) {
         const float *ds = drone_state + 13 * a;
         for (int i = 0; i < 3; ++i) rt[a][i] = ds[i] - tp[i];
@@ -388,23 +396,36 @@ static void o_obs(const hns_cfg *c, int A, int C, int K, const float *drone_stat
         side->blocked[a] = o_blocked(c, C, ds, tp, cyl);
         int det = (dist < c->drone_detect_radius) && !side->blocked[a];
         det_any |= det;
+        side->blocked1[a] = 0;
+        if (NT == 2) {
+            for (int i = 0; i < 3; ++i) rt1[a][i] = ds[i] - tp[3 + i];
+            float dist1 = o_norm3(rt1[a][0], rt1[a][1], rt1[a][2]);
+            side->blocked1[a] = o_blocked(c, C, ds, tp + 3, cyl);
+            det_any1 |= (dist1 < c->drone_detect_radius) && !side->blocked1[a];
+        }
     }
     side->bdetect = det_any;
+    side->bdetect1 = det_any1;
     float t = progress * c->inv_max_episode_length;   /* :796, CUDA scalar-division form */
     for (int a = 0; a < A; ++a) {
         const float *ds = drone_state + 13 * a;
         float heading[3], up[3];
         o_quat_rot_x(ds + 3, heading);
         o_quat_rot_z(ds + 3, 1.0f, up);
-        float *o = obs_self + HNS_SELF_DIM * a;
+        float *o = obs_self + SD * a;
         for (int i = 0; i < 3; ++i) o[i] = det_any ? rt[a][i] : c->mask_value;
+        if (NT == 2) {
+            for (int i = 0; i < 3; ++i) o[HNS_SELF_DIM + i] = det_any1 ? rt1[a][i] : c->mask_value;
+            o[HNS_SELF_DIM + 3] = 0.0f;
+        }
         for (int i = 0; i < 7; ++i) o[3 + i] = ds[3 + i];
         for (int i = 0; i < 3; ++i) { o[10 + i] = heading[i]; o[13 + i] = up[i]; }
         for (int i = 0; i < 4; ++i) o[16 + i] = t;
         if (state_drones) {
-            float *s = state_drones + HNS_SELF_DIM * a;
-            for (int i = 0; i < HNS_SELF_DIM; ++i) s[i] = o[i];
+            float *s = state_drones + SD * a;
+            for (int i = 0; i < SD; ++i) s[i] = o[i];
             for (int i = 0; i < 3; ++i) s[i] = rt[a][i];
+            if (NT == 2) for (int i = 0; i < 3; ++i) s[HNS_SELF_DIM + i] = rt1[a][i];
         }
         /* state_others: p_i - p_j, j != i ascending (utils/torch.py:41-53) */
         int w = 0;
@@ -449,7 +470,7 @@ static void o_obs(const hns_cfg *c, int A, int C, int K, const float *drone_stat
  * A9: reward / done / stats for one env   hideandseek.py:919-1065
  * stats: pointer to this env's column, stride = E floats between rows
  * ---------------------------------------------------------------------------------------- */
-static void o_reward(const hns_cfg *c, int A, int C, int K, const float *drone_state, const float tp[3],
+static void o_reward(const hns_cfg *c, int A, int C, int K, const float *drone_state, const float *tp /*[NT,3]*/,
                      const float *cyl, float progress, const o_obs_side *side, const float *action_error,
                      const float *thr_diff, float *stats, size_t sstride, float *reward, uint8_t *done_out) {
     (void)C;
@@ -462,11 +483,18 @@ static void o_reward(const hns_cfg *c, int A, int C, int K, const float *drone_s
     for (int a = 0; a < A; ++a) {
         const float *ds = drone_state + 13 * a;
         float d = o_norm3(tp[0] - ds[0], tp[1] - ds[1], tp[2] - ds[2]);
+        int cap_ok = (d < c->catch_radius) && !side->blocked[a];
+        int blk = side->blocked[a];
+        if (o_nt(c) == 2) {   /* nearest evader for the distance term, any evader for the capture */
+            float d1 = o_norm3(tp[3] - ds[0], tp[4] - ds[1], tp[5] - ds[2]);
+            cap_ok = cap_ok || ((d1 < c->catch_radius) && !side->blocked1[a]);
+            blk = blk && side->blocked1[a];
+            d = d1 < d ? d1 : d;
+        }
         float act = (d > c->catch_radius) ? 1.0f : 0.0f;
         dist_rew[a] = (-c->dist_reward_coef * d) * act;
-        int cap = d < c->catch_radius;
-        any_cap |= (cap && !side->blocked[a]);
-        all_blocked &= side->blocked[a];
+        any_cap |= cap_ok;
+        all_blocked &= blk;
         float sp = o_norm3(ds[7], ds[8], ds[9]);
         speed_rew[a] = -c->speed_coef * ((sp > c->v_drone) ? 1.0f : 0.0f);
         float cc = 0.0f;
@@ -507,7 +535,7 @@ static void o_reward(const hns_cfg *c, int A, int C, int K, const float *drone_s
             if (thr_diff[a] > max_td) max_td = thr_diff[a];
         }
     }
-    float detf = side->bdetect ? 1.0f : 0.0f;
+    float detf = (side->bdetect || side->bdetect1) ? 1.0f : 0.0f;
     float detect_rew = c->detect_reward_coef * detf;
     float catch_rew = c->catch_reward_coef * (any_cap ? 1.0f : 0.0f);
     int capture_flag = catch_rew != 0.0f;             /* torch.any(catch_reward, dim=1) :945 */
@@ -571,7 +599,8 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
 #pragma omp parallel for schedule(static) num_threads(g_step_threads)
     for (int e = 0; e < E; ++e) {
         float *ds = b->drone_state + (size_t)e * A * 13;
-        float *tp = b->target_pos + (size_t)e * 3;
+        const int NT = o_nt(c), SD = o_self_dim(c);
+        float *tp = b->target_pos + (size_t)e * 3 * NT;
         const float *cyl = b->cylinders + (size_t)e * C * 3;
         float *stats = b->stats + e;
         float thrust[HNS_MAX_AGENTS][4], moment[HNS_MAX_AGENTS][4], thr_diff[HNS_MAX_AGENTS];
@@ -596,6 +625,8 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
         for (int a = 0; a < A; ++a) for (int i = 0; i < 3; ++i) dpos[3 * a + i] = ds[13 * a + i];
         float force[3], tvel[3];
         o_prey(c, A, C, dpos, tp, cyl, force, tvel, &stats[(size_t)HNS_ST_OUT_OF_ARENA * E]);
+        float force1[3], tvel1[3] = {0.0f, 0.0f, 0.0f};
+        if (NT == 2) o_prey(c, A, C, dpos, tp + 3, cyl, force1, tvel1, &stats[(size_t)HNS_ST_OUT_OF_ARENA * E]);
         /* A4 forces/torques on S_t, then A5 */
         float fw[HNS_MAX_AGENTS][3], tb[HNS_MAX_AGENTS][3];
         for (int a = 0; a < A; ++a) {
@@ -616,17 +647,21 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
         }
         for (int a = 0; a < A; ++a) o_integrate(c, ds + 13 * a, fw[a], tb[a]);
         for (int i = 0; i < 3; ++i) {
-            b->target_vel[(size_t)e * 3 + i] = tvel[i];
+            b->target_vel[(size_t)e * 3 * NT + i] = tvel[i];
             tp[i] = tp[i] + tvel[i] * c->dt;
+            if (NT == 2) {
+                b->target_vel[(size_t)e * 3 * NT + 3 + i] = tvel1[i];
+                tp[3 + i] = tp[3 + i] + tvel1[i] * c->dt;
+            }
         }
         b->progress[e] += 1.0f;
         o_obs_side side;
-        o_obs(c, A, C, K, ds, tp, cyl, b->progress[e], b->obs_self + (size_t)e * A * HNS_SELF_DIM,
+        o_obs(c, A, C, K, ds, tp, cyl, b->progress[e], b->obs_self + (size_t)e * A * SD,
               b->obs_others + (size_t)e * A * (A - 1) * 3, b->obs_cylinders + (size_t)e * A * K * 5,
-              (c->write_critic_state && b->state_drones) ? b->state_drones + (size_t)e * A * HNS_SELF_DIM : NULL, &side);
+              (c->write_critic_state && b->state_drones) ? b->state_drones + (size_t)e * A * SD : NULL, &side);
         o_reward(c, A, C, K, ds, tp, cyl, b->progress[e], &side, b->action_error + (size_t)e * A, thr_diff,
                  stats, (size_t)E, b->reward + (size_t)e * A, b->done + e);
-        if (b->detect) b->detect[e] = (uint8_t)side.bdetect;
+        if (b->detect) b->detect[e] = (uint8_t)(side.bdetect | (side.bdetect1 << 1));
     }
     return HNS_OK;
 }
@@ -682,9 +717,10 @@ static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *m
         if (mask && !mask[e]) continue;
         o_rng rng = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(e + c->env_index_offset), epoch, 0u, {0, 0, 0, 0}, 0};
         float *ds = b->drone_state + (size_t)e * A * 13;
-        float *tp = b->target_pos + (size_t)e * 3;
+        const int NT = o_nt(c), SD = o_self_dim(c);
+        float *tp = b->target_pos + (size_t)e * 3 * NT;
         float *cyl = b->cylinders + (size_t)e * C * 3;
-        const float *task = (tasks && e >= task_first) ? tasks + (size_t)e * (3 * A + 3 + 3 * C) : NULL;
+        const float *task = (tasks && e >= task_first) ? tasks + (size_t)e * (3 * A + 3 * NT + 3 * C) : NULL;
         for (int a = 0; a < A; ++a) {
             float *d = ds + 13 * a;
             if (task) {
@@ -726,8 +762,22 @@ static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *m
             if (c->init_mode == HNS_INIT_SCENARIO) tp[2] = c->fixed_target_pos[2];
             else tp[2] = c->z_lo + o_uniform(&rng) * (c->z_hi - c->z_lo);
         }
+        if (NT == 2) {   /* second evader: same box, its draws follow the first evader's */
+            if (task) {
+                for (int i = 0; i < 3; ++i) tp[3 + i] = task[3 * A + 3 + i];
+            } else {
+                if (c->init_mode == HNS_INIT_RANDOM) {
+                    tp[3] = c->target_xy_lo[0] + o_uniform(&rng) * (c->target_xy_hi[0] - c->target_xy_lo[0]);
+                    tp[4] = c->target_xy_lo[1] + o_uniform(&rng) * (c->target_xy_hi[1] - c->target_xy_lo[1]);
+                } else {
+                    tp[3] = c->fixed_target_pos[0]; tp[4] = -c->fixed_target_pos[1];
+                }
+                if (c->init_mode == HNS_INIT_SCENARIO) tp[5] = c->fixed_target_pos[2];
+                else tp[5] = c->z_lo + o_uniform(&rng) * (c->z_hi - c->z_lo);
+            }
+        }
         if (task) {
-            for (int k = 0; k < 3 * C; ++k) cyl[k] = task[3 * A + 3 + k];
+            for (int k = 0; k < 3 * C; ++k) cyl[k] = task[3 * A + 3 * NT + k];
         } else if (c->init_mode == HNS_INIT_SCENARIO) {
             for (int k = 0; k < C; ++k) {
                 for (int i = 0; i < 3; ++i) cyl[3 * k + i] = c->fixed_cyl_pos[k][i];
@@ -744,6 +794,7 @@ static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *m
                 }
             for (int a = 0; a < A; ++a) occ[o_cell(c, ds[13 * a]) * G + o_cell(c, ds[13 * a + 1])] = 1;
             occ[o_cell(c, tp[0]) * G + o_cell(c, tp[1])] = 1;
+            if (NT == 2) occ[o_cell(c, tp[3]) * G + o_cell(c, tp[4])] = 1;
             int n_active;
             if (c->cyl_fixed_num >= 0) n_active = c->cyl_fixed_num;
             else {
@@ -774,10 +825,10 @@ static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *m
         b->progress[e] = 0.0f;
         b->done[e] = 0;
         o_obs_side side;
-        o_obs(c, A, C, K, ds, tp, cyl, 0.0f, b->obs_self + (size_t)e * A * HNS_SELF_DIM,
+        o_obs(c, A, C, K, ds, tp, cyl, 0.0f, b->obs_self + (size_t)e * A * SD,
               b->obs_others + (size_t)e * A * (A - 1) * 3, b->obs_cylinders + (size_t)e * A * K * 5,
-              (c->write_critic_state && b->state_drones) ? b->state_drones + (size_t)e * A * HNS_SELF_DIM : NULL, &side);
-        if (b->detect) b->detect[e] = (uint8_t)side.bdetect;
+              (c->write_critic_state && b->state_drones) ? b->state_drones + (size_t)e * A * SD : NULL, &side);
+        if (b->detect) b->detect[e] = (uint8_t)(side.bdetect | (side.bdetect1 << 1));
     }
     return HNS_OK;
 }

@@ -45,7 +45,7 @@ def f32(a):
 
 def alloc_buffers(cfg):
     """Zero-initialised host arrays for every hns_buffers field."""
-    shapes = abi.buffer_shapes(cfg.num_envs, cfg.num_agents, cfg.num_cylinders, cfg.obs_max_cylinder)
+    shapes = abi.buffer_shapes(cfg.num_envs, cfg.num_agents, cfg.num_cylinders, cfg.obs_max_cylinder, cfg.num_targets)
     return {k: np.zeros(shape, dtype=dt) for k, (shape, dt) in shapes.items()}
 
 
