@@ -288,8 +288,10 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
 // =================================================================================================
 // The fused step kernel
 // =================================================================================================
+// (the second evader costs ~15 registers: without the cap of 128 the 7-wave workgroups of the 6-pursuer
+//  shape drop from two per CU to one)
 template <int A, int NT>
-__global__ __launch_bounds__(Geo<A>::T) void hns_step_kernel(const Params p) {
+__global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(const Params p) {
     constexpr int T = Geo<A>::T, NA = Geo<A>::NA;
     constexpr int SD = NT == 2 ? 24 : HNS_SELF_DIM;      // floats per state_self / state_drones row
     extern __shared__ __align__(16) float smem[];
