@@ -88,6 +88,12 @@ __host__ __device__ constexpr TpImage tp_image(int nxc) {
 // hidden unit that half-wave `hb` holds in register s (s = 16*tile_pair + i): D row 8(i>>2)+4hb+(i&3)
 __host__ __device__ inline int tp_unit(int s, int hb) { return 32 * (s >> 4) + 8 * ((s & 15) >> 2) + 4 * hb + (s & 3); }
 
+// The operand image holds the gate rows pre-multiplied by the constant their nonlinearity needs:
+// sigmoid(z) = 1 / (1 + 2^(-z log2 e)), tanh(z) = 2 / (1 + 2^(-2 z log2 e)) - 1, so the matrix product
+// delivers the exponent directly (one multiply less per gate and unit on the VALU-bound side).
+constexpr float kNegLog2e = -1.4426950408889634f;
+HNS_DEV float tp_gate_scale(int row) { return (row >= 2 * kTpH && row < 3 * kTpH) ? 2.0f * kNegLog2e : kNegLog2e; }   // i,f,o | g
+
 HNS_DEV void tp_split(float w, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)w;
     lo = (_Float16)((w - (float)hi) * kTpLoScale);
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void hns_tp_pack_kernel(const TpParams p, int 
             const int ln = sidx & 63, c = (sidx >> 6) & 3, m = sidx >> 8;
             const int row = 32 * m + (ln & 31), hb = ln >> 5;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = p.tp.w_hh[row * kTpH + tp_unit(8 * c + j, hb)];
+            for (int j = 0; j < 8; ++j) w[j] = p.tp.w_hh[row * kTpH + tp_unit(8 * c + j, hb)] * tp_gate_scale(row);
             slot_hi = L.whh + sidx; slot_lo = L.whh + n_hh + sidx;
         } else if (sidx < n_hh + n_ih) {
             const int u = sidx - n_hh, ln = u & 63, g = u >> 6, m = g / nxc, cx = g - m * nxc;
@@ -114,14 +120,14 @@ __global__ __launch_bounds__(256) void hns_tp_pack_kernel(const TpParams p, int 
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = 16 * cx + 8 * hb + j;
-                w[j] = k < I ? p.tp.w_ih[row * I + k] : 0.0f;
+                w[j] = k < I ? p.tp.w_ih[row * I + k] * tp_gate_scale(row) : 0.0f;
             }
             slot_hi = L.wih + u; slot_lo = L.wih + n_ih + u;
         } else {
             const int u = sidx - n_hh - n_ih, ln = u & 63, c = u >> 6;
             const int row = ln & 31, hb = ln >> 5;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = row < R ? p.tp.w_fc[row * kTpH + tp_unit(8 * c + j, hb)] : 0.0f;
+            for (int j = 0; j < 8; ++j) w[j] = row < R ? p.tp.w_fc[row * kTpH + tp_unit(8 * c + j, hb)] * (2.0f * kNegLog2e) : 0.0f;
             slot_hi = L.wfc + u; slot_lo = L.wfc + n_fc + u;
         }
         half8 hi, lo;
@@ -139,21 +145,21 @@ __global__ __launch_bounds__(256) void hns_tp_pack_kernel(const TpParams p, int 
         if (idx < 256) {                                    // [tile][half][16]
             const int i = idx & 15, hb = (idx >> 4) & 1, m = idx >> 5;
             const int g = 32 * m + 8 * (i >> 2) + 4 * hb + (i & 3);
-            bias[idx] = p.tp.b_ih[g] + p.tp.b_hh[g];
+            bias[idx] = (p.tp.b_ih[g] + p.tp.b_hh[g]) * tp_gate_scale(g);
         } else {
             const int i = idx & 15, hb = (idx - 256) >> 4;
             const int row = 8 * (i >> 2) + 4 * hb + (i & 3);
-            bfc[idx - 256] = row < R ? p.tp.b_fc[row] : 0.0f;
+            bfc[idx - 256] = row < R ? p.tp.b_fc[row] * (2.0f * kNegLog2e) : 0.0f;
         }
     }
 }
 
 // gate nonlinearities on the transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp each); the oracle
 // uses libm, the parity tolerance is the north star's 1e-5
-HNS_DEV float tp_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
-HNS_DEV float tp_tanh(float x) {
-    return HNS_FMA(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.8853900817779268f)), -1.0f);
-}
+// arguments come pre-scaled from the matrix product: zs = -z log2 e (sigmoid), zt = -2 z log2 e (tanh)
+HNS_DEV float tp_sigmoid_s(float zs) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zs)); }
+HNS_DEV float tp_tanh_s(float zt) { return HNS_FMA(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zt)), -1.0f); }
+HNS_DEV float tp_tanh(float x) { return tp_tanh_s(x * (2.0f * kNegLog2e)); }
 
 // component k of the frame [progress, evader pos (masked), evader vel (masked), pursuer positions]
 // (hideandseek.py:815-820; the mask is broadcast_detect, :791-803)
@@ -219,7 +225,7 @@ struct TpGate {
     template <int n>
     static __device__ __forceinline__ void prologue(const Ctx &c) {
         c.a[n % RING] = load<n>(c);
-        __builtin_amdgcn_sched_barrier(0x6);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     static __device__ __forceinline__ void scale_bias(const Ctx &c) {
@@ -249,7 +255,7 @@ struct TpGate {
             else c.acc[q] = TP_MFMA(c.a[n % RING], c.hh[ci - NXC], c.acc[q]);
         }
         if constexpr (n + D < N) c.a[(n + D) % RING] = load<n + D>(c);
-        __builtin_amdgcn_sched_barrier(0x6);     // keep the hand-placed MFMA / LDS-read order (VALU and SALU may move)
+        __builtin_amdgcn_sched_barrier(0);       // keep the hand-placed MFMA / LDS-read order (a 0x6 mask lets MFMAs move: they count as VALU)
     }
     template <int... Ns>
     static __device__ __forceinline__ void run_prologue(const Ctx &c, std::integer_sequence<int, Ns...>) { (prologue<Ns>(c), ...); }
@@ -309,16 +315,59 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
                 xn[8 * cx + j] = k < I ? tp_frame_val(p, ec, k, det) : 0.0f;
             }
     }
-    float *hist = p.tp.history + (size_t)ec * T * I + 8 * hb;
+    float *hist = p.tp.history + (size_t)ec * T * I;       // this env's window, [T][I]
+    // Window rows are read with unconditional loads (one wait for all of them): 16-byte loads when the frame
+    // fills its chunks exactly (I = 16 NXC, e.g. 3 pursuers), else per-element loads with the column clamped
+    // into the row (padding lanes are zeroed afterwards).  Per-element predicated loads cost the timestep
+    // loop ~4 000 cycles of serialised memory latency per iteration.
+    const bool vec = (I == 16 * NXC);
+    auto load_row = [&](int slot, float (&dst)[8 * NXC]) {
+        const float *row = hist + (size_t)slot * I;
+        if (vec) {
+#pragma unroll
+            for (int cx = 0; cx < NXC; ++cx) {
+                const float4 a = *reinterpret_cast<const float4 *>(row + 16 * cx + 8 * hb);
+                const float4 b = *reinterpret_cast<const float4 *>(row + 16 * cx + 8 * hb + 4);
+                dst[8 * cx] = a.x; dst[8 * cx + 1] = a.y; dst[8 * cx + 2] = a.z; dst[8 * cx + 3] = a.w;
+                dst[8 * cx + 4] = b.x; dst[8 * cx + 5] = b.y; dst[8 * cx + 6] = b.z; dst[8 * cx + 7] = b.w;
+            }
+        } else {
+#pragma unroll
+            for (int cx = 0; cx < NXC; ++cx)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * cx + 8 * hb + j;
+                    const float v = row[k < I ? k : I - 1];
+                    dst[8 * cx + j] = k < I ? v : 0.0f;
+                }
+        }
+    };
+    auto store_row = [&](int slot, const float (&src)[8 * NXC]) {
+        float *row = hist + (size_t)slot * I;
+        if (vec) {
+#pragma unroll
+            for (int cx = 0; cx < NXC; ++cx) {
+                *reinterpret_cast<float4 *>(row + 16 * cx + 8 * hb) = make_float4(src[8 * cx], src[8 * cx + 1], src[8 * cx + 2], src[8 * cx + 3]);
+                *reinterpret_cast<float4 *>(row + 16 * cx + 8 * hb + 4) = make_float4(src[8 * cx + 4], src[8 * cx + 5], src[8 * cx + 6], src[8 * cx + 7]);
+            }
+        } else {
+#pragma unroll
+            for (int cx = 0; cx < NXC; ++cx)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * cx + 8 * hb + j;
+                    if (k < I) row[k] = src[8 * cx + j];
+                }
+        }
+    };
     // x_t = old frame t+1 for t <= T-2, the new frame for t = T-1 (or for every t when filling)
     float xc[8 * NXC];
+    if (T == 1 || p.fill) {
 #pragma unroll
-    for (int cx = 0; cx < NXC; ++cx)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 16 * cx + 8 * hb + j;
-            xc[8 * cx + j] = (T == 1 || p.fill) ? xn[8 * cx + j] : (k < I ? hist[I + 16 * cx + j] : 0.0f);
-        }
+        for (int i = 0; i < 8 * NXC; ++i) xc[i] = xn[i];
+    } else {
+        load_row(1, xc);
+    }
 
     half8 hh[4], hl[4];                     // h_{t-1}: leading and low split terms, k-slot j of chunk c = own register 8c + j
     float c[32];
@@ -335,21 +384,17 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
         for (int cx = 0; cx < NXC; ++cx)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int k = 16 * cx + 8 * hb + j;
-                const float v = xc[8 * cx + j];
-                if (valid && k < I) hist[t * I + 16 * cx + j] = v;
                 _Float16 a, b;
-                tp_split(v, a, b);
+                tp_split(xc[8 * cx + j], a, b);
                 xh[cx][j] = a; xl[cx][j] = b;
             }
-        const bool from_hist = !p.fill && (t + 1 <= T - 2);
+        if (valid) store_row(t, xc);
+        if (!p.fill && t + 1 <= T - 2) {            // consumed one timestep later: the latency is off the critical path
+            load_row(t + 2, xc);
+        } else {
 #pragma unroll
-        for (int cx = 0; cx < NXC; ++cx)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 16 * cx + 8 * hb + j;
-                xc[8 * cx + j] = (from_hist && k < I) ? hist[(t + 2) * I + 16 * cx + j] : xn[8 * cx + j];
-            }
+            for (int i = 0; i < 8 * NXC; ++i) xc[i] = xn[i];
+        }
         // the operand image is loop-invariant; an opaque lane offset keeps the compiler from hoisting
         // the A operands of the whole window (hundreds of registers) out of the timestep loop
         int lo = lane;
@@ -363,8 +408,8 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
             // cell update (torch.nn.LSTM: i, f, g, o), lane-local
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float ig = tp_sigmoid(acc[0][i]), fg = tp_sigmoid(acc[1][i]);
-                const float gg = tp_tanh(acc[2][i]), og = tp_sigmoid(acc[3][i]);
+                const float ig = tp_sigmoid_s(acc[0][i]), fg = tp_sigmoid_s(acc[1][i]);
+                const float gg = tp_tanh_s(acc[2][i]), og = tp_sigmoid_s(acc[3][i]);
                 const float cn = HNS_FMA(fg, c[16 * tj + i], ig * gg);
                 c[16 * tj + i] = cn;
                 const float hv = og * tp_tanh(cn);
@@ -419,7 +464,7 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
         for (int i = 0; i < 16; ++i) {
             const int row = 8 * (i >> 2) + 4 * hb + (i & 3);
             if (row < R) {
-                const float v = tp_tanh(o[i]);
+                const float v = tp_tanh_s(o[i]);
                 const int comp = row % 3;
                 pr[row] = (comp < 2) ? (v * 0.5f) * p.arena_size : ((v + 1.0f) * 0.5f) * p.max_height;
             }

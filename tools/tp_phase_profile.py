@@ -36,3 +36,10 @@ if "--stamps" in sys.argv:
         print("%s t=5: M0 %.0f  E0 %.0f  gap %.0f  M1 %.0f  E1 %.0f cyc; timestep 5 %.0f cyc, timestep 6 %.0f cyc" % (
             name, (g[..., 5] - g[..., 4]).mean(), (g[..., 6] - g[..., 5]).mean(), (g[..., 7] - g[..., 6]).mean(), (g[..., 8] - g[..., 7]).mean(),
             (g[..., 9] - g[..., 8]).mean(), (g[..., 11] - g[..., 10]).mean(), (g[..., 12] - g[..., 11]).mean()))
+if "--pp" in sys.argv:        # ping-pong stamps (instrumented build only)
+    c = buf.cpu().numpy()[:nw, :11].astype(np.float64).reshape(-1, 8, 11)
+    for grp, name in ((slice(0, 4), "group 0"), (slice(4, 8), "group 1")):
+        g = c[:, grp]
+        print("%s (t=5, tj=0): M block %.0f cyc, wait %.0f, E block %.0f, wait %.0f; full cycle %.0f cyc = %.0f ns -> clock %.2f GHz" % (
+            name, (g[..., 5] - g[..., 4]).mean(), (g[..., 6] - g[..., 5]).mean(), (g[..., 7] - g[..., 6]).mean(), (g[..., 8] - g[..., 7]).mean(),
+            (g[..., 8] - g[..., 4]).mean(), (g[..., 10] - g[..., 9]).mean() * 10, (g[..., 8] - g[..., 4]).mean() / ((g[..., 10] - g[..., 9]).mean() * 10)))
