@@ -342,12 +342,14 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
     float st[HNS_NUM_STATS];
 #pragma unroll
     for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = 0.0f;
+    __syncthreads();
+    prof_mark(p.prof, 1);
+    // issued after the barrier: the statistics are first needed behind phase 1, so their 6 MB stay out of the
+    // bandwidth-bound load burst at the head of the launch and stream in under the phase-1 arithmetic
     if (env_wave && valid) {
 #pragma unroll
         for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = b.stats[(size_t)i * E + e];
     }
-    __syncthreads();
-    prof_mark(p.prof, 1);
 
     const float *cyl = sCyl + le * L.cyl_stride;
     Rigid s = {};
