@@ -301,6 +301,12 @@ int hns_set_smoothness_coef(hns_env *env, float coef);
 int hns_set_reset_epoch(hns_env *env, uint32_t epoch);
 uint32_t hns_get_reset_epoch(const hns_env *env);
 
+/* Fixture injection / read-back for parity tests and checkpoints: `host` holds HOST pointers with the
+ * shapes of hns_buffers; null fields are skipped; copies are asynchronous on `stream` (synchronise before
+ * reading what hns_get_state wrote).  Equivalent to the caller copying into / out of its own bound buffers. */
+int hns_set_state(hns_env *env, const hns_buffers *host, void *stream);
+int hns_get_state(hns_env *env, const hns_buffers *host, void *stream);
+
 /* Kernel timing: hns_enable_timing(env, n) brackets every n-th hns_step launch with hipEvents on
  * the launch stream (n = 0 disables).  hns_step_kernel_ms returns the average device time (ms)
  * of the sampled launches since the last call (synchronises on the last sample); <0 if none. */

@@ -1404,6 +1404,34 @@ int hns_set_reset_epoch(hns_env *env, uint32_t epoch) {
 }
 uint32_t hns_get_reset_epoch(const hns_env *env) { return env ? env->epoch : 0u; }
 
+// Fixture injection / read-back: copies between HOST arrays and the bound device buffers, field
+// by field (null host fields are skipped), asynchronously on `stream`.
+static int copy_state(hns_env *env, const hns_buffers *host, void *stream, bool to_device) {
+    if (!env || !host) { set_error("hns_set_state/hns_get_state: null argument"); return HNS_ERR_INVALID_ARG; }
+    if (!env->bound) { set_error("hns_set_state/hns_get_state: hns_bind first"); return HNS_ERR_NOT_BOUND; }
+    const hns_cfg &c = env->cfg;
+    const size_t E = (size_t)c.num_envs, A = (size_t)c.num_agents, C = (size_t)c.num_cylinders, K = (size_t)c.obs_max_cylinder;
+    const size_t NT = c.num_targets == 2 ? 2 : 1, SD = c.num_targets == 2 ? 24 : HNS_SELF_DIM;
+    const hns_buffers &d = env->buf;
+    struct Field { const void *host; void *dev; size_t bytes; };
+    const Field f[] = {
+        {host->drone_state, d.drone_state, E * A * 13 * 4}, {host->throttle, d.throttle, E * A * 16}, {host->pid_integ, d.pid_integ, E * A * 16},
+        {host->pid_last_rate, d.pid_last_rate, E * A * 16}, {host->prev_action, d.prev_action, E * A * 16},
+        {host->target_pos, d.target_pos, E * NT * 12}, {host->target_vel, d.target_vel, E * NT * 12}, {host->cylinders, d.cylinders, E * C * 12},
+        {host->progress, d.progress, E * 4}, {host->stats, d.stats, (size_t)HNS_NUM_STATS * E * 4}, {host->obs_self, d.obs_self, E * A * SD * 4},
+        {host->obs_others, d.obs_others, E * A * (A - 1) * 12}, {host->obs_cylinders, d.obs_cylinders, E * A * K * 20},
+        {host->state_drones, d.state_drones, E * A * SD * 4}, {host->reward, d.reward, E * A * 4}, {host->action_error, d.action_error, E * A * 4},
+        {host->done, d.done, E}, {host->detect, d.detect, E}};
+    for (const Field &x : f) {
+        if (!x.host || !x.dev || x.bytes == 0) continue;
+        if (to_device) HNS_CHECK_HIP(hipMemcpyAsync(x.dev, x.host, x.bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+        else HNS_CHECK_HIP(hipMemcpyAsync(const_cast<void *>(x.host), x.dev, x.bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    }
+    return HNS_OK;
+}
+int hns_set_state(hns_env *env, const hns_buffers *host, void *stream) { return copy_state(env, host, stream, true); }
+int hns_get_state(hns_env *env, const hns_buffers *host, void *stream) { return copy_state(env, host, stream, false); }
+
 int hns_set_phase_profile(hns_env *env, unsigned long long *device_buf) {
     if (!env) return HNS_ERR_INVALID_ARG;
     env->prof = device_buf;

@@ -231,3 +231,39 @@ def test_snapshot_resume_is_bit_exact(tmp_path):
     st["drone_state"][0, 0, 0] = np.nan
     a.import_state(st)
     assert not a.check_finite()
+
+
+def test_set_state_get_state_round_trip():
+    """hns_set_state / hns_get_state (SURVEY §8b fixture injection): host arrays -> bound buffers -> host arrays."""
+    import ctypes as C
+    from hns_amd import abi
+    from hns_amd.env import HideAndSeek
+    cfg = config.make_cfg({"num_agents": 3, "cylinder": {"max_num": 5, "min_num": 3}, "env": {"num_envs": 300}})
+    env = HideAndSeek(cfg, headless=True)
+    env.reset()
+    c = env.hcfg
+    src = O.alloc_buffers(c)
+    O.reset(c, src, None, 11, 0)
+    rng = np.random.default_rng(0)
+    src["stats"][:] = rng.random(src["stats"].shape, dtype=np.float32)
+    hb = O.as_struct(src)
+    hb.obs_others = None                                       # a skipped field keeps its device contents
+    before = env._bufs["obs_others"].clone()
+    assert env._lib.hns_set_state(env._env, C.byref(hb), env._stream()) == 0, env._lib.hns_last_error()
+    torch.cuda.synchronize()
+    for k in ("drone_state", "throttle", "target_pos", "cylinders", "stats", "progress", "obs_self"):
+        assert np.array_equal(env._bufs[k].cpu().numpy(), src[k]), k
+    assert torch.equal(env._bufs["obs_others"], before)
+    dst = O.alloc_buffers(c)
+    assert env._lib.hns_get_state(env._env, C.byref(O.as_struct(dst)), env._stream()) == 0
+    torch.cuda.synchronize()
+    for k in src:
+        if k != "obs_others":
+            assert np.array_equal(dst[k], src[k]), k
+    # a step from the injected state equals the oracle's step from the same state
+    act = rng.standard_normal((300, 3, 4)).astype(np.float32)
+    env.step(env.rand_step_input(torch.from_numpy(act).to(env.device)))
+    O.step(c, src, act)
+    dev = env.export_state()
+    for k in ("drone_state", "target_pos", "reward", "stats", "obs_self", "obs_cylinders", "done"):
+        assert np.array_equal(dev[k], src[k], equal_nan=True), k
