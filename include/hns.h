@@ -301,7 +301,8 @@ int hns_set_smoothness_coef(hns_env *env, float coef);
 int hns_set_reset_epoch(hns_env *env, uint32_t epoch);
 uint32_t hns_get_reset_epoch(const hns_env *env);
 
-/* Fixture injection / read-back for parity tests and checkpoints: `host` holds HOST pointers with the
+/* Fixture injection / read-back for parity tests and checkpoints (the reference's counterpart is the
+ * PhysX tensor view API, omni_drones/views/rigid_prim_view.py:61-118): `host` holds HOST pointers with the
  * shapes of hns_buffers; null fields are skipped; copies are asynchronous on `stream` (synchronise before
  * reading what hns_get_state wrote).  Equivalent to the caller copying into / out of its own bound buffers. */
 int hns_set_state(hns_env *env, const hns_buffers *host, void *stream);
