@@ -304,7 +304,8 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
     constexpr int N_HH = 8 * 4 * 64, N_IH = 8 * NXC * 64, N_FC = 4 * 64;
 
     // this lane's part of a frame: k = 16 cx + 8 hb + j
-    float xn[8 * NXC];
+    // parked in LDS (read once, as x_{T-1}): [wave][value][lane], conflict-free
+    float *sXn = reinterpret_cast<float *>(simg + L.bytes / 16) + (wave * 8 * NXC) * 64 + lane;
     {
         const bool det = p.detect[ec] != 0;
 #pragma unroll
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = 16 * cx + 8 * hb + j;
-                xn[8 * cx + j] = k < I ? tp_frame_val(p, ec, k, det) : 0.0f;
+                sXn[(8 * cx + j) * 64] = k < I ? tp_frame_val(p, ec, k, det) : 0.0f;
             }
     }
     float *hist = p.tp.history + (size_t)ec * T * I;       // this env's window, [T][I]
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
     float xc[8 * NXC];
     if (T == 1 || p.fill) {
 #pragma unroll
-        for (int i = 0; i < 8 * NXC; ++i) xc[i] = xn[i];
+        for (int i = 0; i < 8 * NXC; ++i) xc[i] = sXn[i * 64];
     } else {
         load_row(1, xc);
     }
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
             load_row(t + 2, xc);
         } else {
 #pragma unroll
-            for (int i = 0; i < 8 * NXC; ++i) xc[i] = xn[i];
+            for (int i = 0; i < 8 * NXC; ++i) xc[i] = sXn[i * 64];
         }
         // the operand image is loop-invariant; an opaque lane offset keeps the compiler from hoisting
         // the A operands of the whole window (hundreds of registers) out of the timestep loop
@@ -622,7 +623,7 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
     p.fill = fill_history ? 1 : 0;
     const int nxc = tp_nxc(p.I);
     void (*fn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_kernel<1> : hns::hns_tp_lstm_kernel<2>;
-    const size_t lds = (size_t)hns::tp_image(nxc).bytes;
+    const size_t lds = (size_t)hns::tp_image(nxc).bytes + (size_t)hns::kTpWaves * 8 * nxc * 64 * sizeof(float);   // image + parked new frame
     static thread_local const void *attr_set[2] = {nullptr, nullptr};
     if (attr_set[nxc - 1] != (const void *)fn) {
         HNS_CHECK_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
