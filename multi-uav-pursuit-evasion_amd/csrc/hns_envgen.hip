@@ -10,8 +10,8 @@
 //                        cost is the per-round latency.  One persistent launch, one workgroup per
 //                        CU, points partitioned over ALL threads of the chip with their running
 //                        min-distances in registers; per round every workgroup publishes its
-//                        candidate as two tagged 8-byte granules (agent-scope stores), every workgroup
-//                        sweeps all candidates and computes the same global arg-max — one fabric hop
+//                        candidate as one tagged 8-byte granule (agent-scope store), every workgroup
+//                        sweeps all candidates (all loads in flight at once) and computes the same global arg-max — one fabric hop
 //                        per round, no grid barrier, no atomics (MI355X_MICROARCH "R2": the data is
 //                        the flag; slots are double-buffered by round parity).  Every spin is bounded.
 //   hns_perturb_kernel : one thread per task: draw a history entry, perturb, clip, grid sanity check,
@@ -37,16 +37,13 @@ struct FpsParams {
     int n, d, k, start, groups;
     int in_lds;            // the workgroup's points are staged in LDS (rows of d+1 floats: conflict-free)
     int32_t *out_idx;      // [k]
-    unsigned long long *scratch;   // [0]: error word; [8 ..): granules [2 parity][2 (dist, idx)][groups]
+    unsigned long long *scratch;   // [0]: error word; [8 ..): granules [2 parity][groups]
 };
 
-// order: larger distance first, ties -> lower index (torch.argmax picks the first maximum)
-HNS_DEV bool fps_better(float d, int i, float bd, int bi) { return d > bd || (d == bd && i < bi); }
 
 __global__ __launch_bounds__(kFpsThreads) void hns_fps_kernel(const FpsParams p) {
     extern __shared__ __align__(16) float s_dyn[];     // [d] the newest sample, then the staged points
-    __shared__ float s_d[kFpsThreads / 64];
-    __shared__ int s_i[kFpsThreads / 64];
+    __shared__ unsigned long long s_best[kFpsThreads / 64];
     __shared__ int s_cur;
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,8 +70,10 @@ __global__ __launch_bounds__(kFpsThreads) void hns_fps_kernel(const FpsParams p)
         if (blockIdx.x == 0 && tid == 0) p.out_idx[r] = cur;
         if (r == p.k - 1) break;
         // ---- distances to the newest sample (in sQ), running minimum, local arg-max -----------------
-        float bd = -1.0f;
-        int bi = 0x7fffffff;
+        // candidates travel as ONE 64-bit word: [tag 12 | key 32 | 0xFFFFF - index 20]; key = 0 for a chosen point,
+        // else bits(distance) + 1 (non-negative floats order like their bit patterns), so the arg-max with
+        // ties -> lower index is an integer max
+        unsigned long long best = 0;
 #pragma unroll
         for (int j = 0; j < kFpsMaxPerThread; ++j) {
             const int i = gtid + j * stride;
@@ -94,62 +93,56 @@ __global__ __launch_bounds__(kFpsThreads) void hns_fps_kernel(const FpsParams p)
                 // a chosen point leaves the pool (-1 never wins), so the k indices are distinct even among duplicates
                 const float m = (i == cur) ? -1.0f : (acc < dist[j] ? acc : dist[j]);
                 dist[j] = m;
-                if (fps_better(m, i, bd, bi)) { bd = m; bi = i; }
+                const unsigned long long key = m < 0.0f ? 0ull : (unsigned long long)__float_as_uint(m) + 1ull;
+                const unsigned long long cand = (key << 20) | (unsigned long long)(0xFFFFFu - (unsigned)i);
+                best = cand > best ? cand : best;
             }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
-            const float od = __shfl_xor(bd, off);
-            const int oi = __shfl_xor(bi, off);
-            if (fps_better(od, oi, bd, bi)) { bd = od; bi = oi; }
+            const unsigned long long o = __shfl_xor(best, off);
+            best = o > best ? o : best;
         }
-        if (lane == 0) { s_d[wave] = bd; s_i[wave] = bi; }
+        if (lane == 0) s_best[wave] = best;
         __syncthreads();
-        // ---- publish this workgroup's candidate: two {tag = round + 1, value} granules ---------------
-        const unsigned tag = (unsigned)(r + 1);
-        gu64 *slot = gran + (size_t)(r & 1) * 2 * G;
+        // ---- publish this workgroup's candidate as one tagged granule (slots double-buffered by round parity) ----
+        const unsigned long long tag = (unsigned long long)(r % 4095 + 1) << 52;
+        gu64 *slot = gran + (size_t)(r & 1) * G;
         if (tid == 0) {
 #pragma unroll
-            for (int w = 1; w < kFpsThreads / 64; ++w)
-                if (fps_better(s_d[w], s_i[w], bd, bi)) { bd = s_d[w]; bi = s_i[w]; }
-            __hip_atomic_store(slot + blockIdx.x, ((unsigned long long)tag << 32) | __float_as_uint(bd), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(slot + G + blockIdx.x, ((unsigned long long)tag << 32) | (unsigned)bi, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            for (int w = 1; w < kFpsThreads / 64; ++w) best = s_best[w] > best ? s_best[w] : best;
+            __hip_atomic_store(slot + blockIdx.x, tag | best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // ---- sweep every workgroup's candidate (wave 0), same arg-max everywhere ----------------------
+        // ---- sweep every workgroup's candidate (wave 0): all loads in flight at once, same arg-max everywhere ----
         if (wave == 0) {
-            float gd = -1.0f;
-            int gi = 0x7fffffff;
+            unsigned long long v[kFpsMaxGroups / 64];
             bool fail = false;
-            for (int base = 0; base < G; base += 64) {
-                const int g = base + lane;
-                unsigned long long vd = 0, vi = 0;
-                unsigned spins = 0;
-                for (;;) {
-                    bool ok = true;
-                    if (g < G) {
-                        vd = __hip_atomic_load(slot + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vi = __hip_atomic_load(slot + G + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = (unsigned)(vd >> 32) == tag && (unsigned)(vi >> 32) == tag;
-                    }
-                    if (__all(ok)) break;
-                    if (++spins > kFpsSpinLimit) { fail = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < kFpsMaxGroups / 64; ++u) {
+                    const int g = u * 64 + lane;
+                    v[u] = g < G ? __hip_atomic_load(slot + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
                 }
-                if (fail) break;
-                if (g < G) {
-                    const float d2 = __uint_as_float((unsigned)vd);
-                    const int i2 = (int)(unsigned)vi;
-                    if (fps_better(d2, i2, gd, gi)) { gd = d2; gi = i2; }
-                }
+#pragma unroll
+                for (int u = 0; u < kFpsMaxGroups / 64; ++u) ok = ok && ((v[u] >> 52) == (tag >> 52));
+                if (__all(ok)) break;
+                if (++spins > kFpsSpinLimit) { fail = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            unsigned long long gb = 0;
+#pragma unroll
+            for (int u = 0; u < kFpsMaxGroups / 64; ++u) {
+                const unsigned long long c52 = v[u] & 0xFFFFFFFFFFFFFull;
+                gb = c52 > gb ? c52 : gb;
             }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
-                const float od = __shfl_xor(gd, off);
-                const int oi = __shfl_xor(gi, off);
-                if (fps_better(od, oi, gd, gi)) { gd = od; gi = oi; }
+                const unsigned long long o = __shfl_xor(gb, off);
+                gb = o > gb ? o : gb;
             }
+            const int gi = (int)(0xFFFFFu - (unsigned)(gb & 0xFFFFFu));
             if (lane == 0) { s_cur = gi; if (fail) s_fail = 1; }
             // the winner's coordinates for the next round (immutable input: plain loads)
             if (!fail)
