@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 import hns_oracle as O
 from hns_amd import abi, config
 from hns_amd.env import HideAndSeek
-from hns_amd.tp_net import TPObservation
+from tp_reference import TPObservation
 
 TOL = 1e-5
 

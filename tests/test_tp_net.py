@@ -6,7 +6,8 @@ import torch
 
 import hns_oracle as O
 from hns_amd import config
-from hns_amd.tp_net import TPNet, TPObservation
+from hns_amd.tp_net import TPNet
+from tp_reference import TPObservation
 
 
 def _load_weights(tp, g):
