@@ -41,3 +41,16 @@ def test_reference_form_constants():
     assert abs(c.drone_xy_hi[0] - (0.9 / 2 ** 0.5 - 0.1)) < 1e-6
     e = config.resolve_hns_cfg(config.make_cfg({"use_eval": 1}))
     assert e.init_mode == 1 and list(e.rpy_hi) == [0.0, 0.0, 0.0]
+
+
+def test_bench_algorithmic_bytes_match_the_survey_figures():
+    """B_env(A,C,k,S) — 1 533 B (3v1, 8 cylinders), 1 497 B (5 slots), 3 045 B (6 pursuers, 16 cylinders)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.algorithmic_bytes_per_env(3, 8, 3) == 1533
+    assert bench.algorithmic_bytes_per_env(3, 5, 3) == 1497
+    assert bench.algorithmic_bytes_per_env(6, 16, 3) == 3045
+    assert bench.algorithmic_bytes_per_env(6, 16, 3, NT=2) == 3045 + 12 + 24 + 16 * 6
