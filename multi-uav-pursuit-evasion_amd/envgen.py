@@ -347,6 +347,8 @@ class HideAndSeek_envgen(HideAndSeek):
         if mask_t is None:
             self._since_full_reset = 0
         self._needs_reset = False
+        if self.use_TP_net:
+            self._tp_observe()
         td = self._obs_tensordict()
         td.set("stats", last_stats)
         td.set("truncated", (self.progress_buf > self.max_episode_length).unsqueeze(1))

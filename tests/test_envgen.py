@@ -166,6 +166,34 @@ def test_envgen_history_trim_on_gpu():
     assert gb.sanity_ok(new).mean() > 0.95                                # perturbed tasks pass the grid check (fallbacks may not)
 
 
+@pytest.mark.gpu
+def test_envgen_with_trajectory_predictor_on_gpu():
+    """Both reference defaults together (use_particle_generator + use_TP_net): the reset's observation pass runs
+    the predictor too, so the 35-value rows handed out by reset() belong to the NEW placement."""
+    from hns_amd.envgen import HideAndSeek_envgen
+    E, L = 256, 4
+    cfg = config.make_cfg({"name": "HideAndSeek_envgen", "num_agents": 3, "eval_iter": 1, "R_min": 0.0, "R_max": 1.0,
+                           "use_particle_generator": 1, "cylinder": {"max_num": 5, "min_num": 3}, "env": {"num_envs": E, "max_episode_length": L}},
+                          algo={"use_TP_net": 1})
+    env = HideAndSeek_envgen(cfg)
+    env.set_seed(2)
+    td = env.reset()
+    for ep in range(2):
+        for t in range(L):
+            td = env.step(env.rand_step_input())
+        rtd = env.rand_step_input()
+        rtd.set("_reset", td[("next", "done")].squeeze(-1))
+        td = env.reset(rtd)
+        ss = td[("agents", "observation", "state_self")][:, :, 0]
+        assert ss.shape == (E, 3, 35)
+        b = env._bufs
+        pred = env._tp_bufs["pred"]                                   # [E,5,3]
+        rpos_pred = (b["drone_state"][..., None, :3] - pred[:, None]).reshape(E, 3, 15)
+        assert torch.equal(ss[..., 3:18], rpos_pred)                  # rows were rebuilt on the reset state
+        assert torch.equal(ss[..., 18:], b["obs_self"][..., 3:])
+        assert torch.equal(td[("agents", "TP", "TP_input")][:, -1, 7:], b["drone_state"][..., :3].reshape(E, -1))
+
+
 # ---- device-side generator pieces (SURVEY §8 N3): oracle restatements -----------------------------------
 def test_oracle_fps_matches_torch_reference():
     """Integer coordinates: squared distances are exact in fp32 whatever the summation order, so the
