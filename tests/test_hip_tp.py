@@ -159,3 +159,29 @@ def test_tp_bind_errors():
     long_env = HideAndSeek(config.make_cfg({"env": {"num_envs": 64, "max_episode_length": 100000}}, algo={"use_TP_net": 1}))
     with pytest.raises(Exception, match="max_episode_length"):
         long_env.reset()
+
+
+def test_tp_snapshot_resume(tmp_path):
+    """save_state / load_state carry the predictor's window: a resumed run reproduces the rows bit for bit."""
+    E, A = 200, 3
+    env = _env(E, A)
+    env.reset()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    acts = [torch.randn(E, A, 4, generator=g).to(env.device) for _ in range(8)]
+    for a in acts[:5]:
+        env.step(env.rand_step_input(a))
+    path = str(tmp_path / "snap.npz")
+    env.save_state(path)
+    for a in acts[5:]:
+        env.step(env.rand_step_input(a))
+    want = {k: v.clone() for k, v in env._tp_bufs.items() if k != "packed"}
+    want_obs = env._bufs["obs_self"].clone()
+    env2 = _env(E, A)
+    env2.TP.load_state_dict(env.TP.state_dict())
+    env2.reset()
+    env2.load_state(path)
+    for a in acts[5:]:
+        env2.step(env2.rand_step_input(a))
+    assert torch.equal(env2._bufs["obs_self"], want_obs)
+    for k, v in want.items():
+        assert torch.equal(env2._tp_bufs[k], v), k
