@@ -267,3 +267,36 @@ def test_set_state_get_state_round_trip():
     dev = env.export_state()
     for k in ("drone_state", "target_pos", "reward", "stats", "obs_self", "obs_cylinders", "done"):
         assert np.array_equal(dev[k], src[k], equal_nan=True), k
+
+
+def test_steps_captured_in_a_hip_graph_replay_identically():
+    """hns_step never allocates, never synchronises and launches on the caller's stream, so a rollout segment can be
+    captured into a hipGraph (torch.cuda.CUDAGraph) and replayed; the result equals eager stepping bit for bit."""
+    import ctypes as C
+    from hns_amd.env import HideAndSeek
+    E, A, steps, replays = 4096, 3, 4, 3
+    cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": 8, "min_num": 4}, "env": {"num_envs": E, "max_episode_length": 1000}})
+    envs = [HideAndSeek(cfg, headless=True) for _ in range(2)]
+    for env in envs:
+        env.set_seed(5)
+        env.reset()
+    act = torch.randn(E, A, 4, device=envs[0].device)
+    eager, graphed = envs
+    for _ in range(steps * replays):
+        assert eager._lib.hns_step(eager._env, act.data_ptr(), eager._stream()) == 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(steps):
+                assert graphed._lib.hns_step(graphed._env, act.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert float(graphed._bufs["progress"][0]) == 0.0            # capture did not execute anything
+    for _ in range(replays):
+        graph.replay()
+    torch.cuda.synchronize()
+    a, b = eager.export_state(), graphed.export_state()
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
