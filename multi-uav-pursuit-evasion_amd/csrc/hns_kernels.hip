@@ -41,6 +41,7 @@ enum { R_AERR = 0, R_TD, R_DIST, R_SPEED, R_CC, R_CD, R_CW, R_COLL, R_SMOOTH, R_
        // two-evader extension: the push on the second evader (slots 8..10, free before phase 3)
        R_F1X = R_SMOOTH };
 enum { F_CAP = 1, F_BLOCKED = 2, F_DET = 4, F_DET1 = 8 };
+constexpr int kGridStride = 516;   // bytes of reset scratch per env: 2 x 256 + 4 (an odd dword stride: lanes = envs hit different LDS banks)
 constexpr int kMaxT = 2;   // evaders per env (1 = the reference; 2 = BASELINE config 5's extension)
 
 template <int A>
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
     const Lds L = lds_layout(A, C, K, NT);
     float *sDS = smem + L.ds, *sCyl = smem + L.cyl, *sTp = smem + L.tp;
     float *sOCyl = smem + L.ocyl;
-    uint8_t *sGrid = reinterpret_cast<uint8_t *>(smem + L.total);   // 64 x 512 B of grid scratch after the step layout
+    uint8_t *sGrid = reinterpret_cast<uint8_t *>(smem + L.total);   // 64 x kGridStride B of grid scratch after the step layout
 
     const int tid = threadIdx.x;
     const int e0 = blockIdx.x * kEPB;
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
                 cyl[3 * k + 2] = (k >= c.fixed_cyl_active) ? c.invalid_z : c.fixed_cyl_pos[k][2];
             }
         } else {                                                                  // hideandseek.py:576-607
-            uint8_t *occ = sGrid + le * 512;        // [GN*GN] occupancy, then [GN*GN] free-cell list
+            uint8_t *occ = sGrid + le * kGridStride;   // [GN*GN] occupancy, then [GN*GN] free-cell list
             uint8_t *freec = occ + 256;
             const int half = GN / 2;
             for (int i = 0; i < GN; ++i)
@@ -1140,7 +1141,7 @@ static void select_kernels(hns_env *env) {
     env->grid = (c.num_envs + hns::kEPB - 1) / hns::kEPB;
     hns::Lds L = hns::lds_layout(A, c.num_cylinders, c.obs_max_cylinder, c.num_targets == 2 ? 2 : 1);
     env->lds_step = (size_t)L.total * sizeof(float);
-    env->lds_reset = env->lds_step + (size_t)hns::kEPB * 512;   // + per-env occupancy grid / free-cell list
+    env->lds_reset = env->lds_step + (size_t)hns::kEPB * hns::kGridStride;   // + per-env occupancy grid / free-cell list
 }
 
 
