@@ -944,10 +944,10 @@ def _tp_class():
     return tp_cls
 
 
-def gen_tp_obs():
+def gen_tp_obs(tag="g_tp_obs", E=48, A=3, C=5, seed=20241020):
     import collections
-    g = torch.Generator().manual_seed(20241020)
-    E, A, C, T = 48, 3, 5, 14
+    g = torch.Generator().manual_seed(seed)
+    T = 14
     env = ShimEnv(E, A, C, {"drone_detect_radius": 0.9}, max_len=20)
     env.use_TP_net = 1
     env.future_predcition_step, env.history_step, env.window_step = 5, 10, 1
@@ -975,10 +975,11 @@ def gen_tp_obs():
                          state_drones=td[("agents", "state")]["state_drones"], TP_input=tp["TP_input"],
                          TP_groundtruth=tp["TP_groundtruth"], TP_done=tp["TP_done"], broadcast_detect=env.broadcast_detect).items():
             rec[k].append(v.clone())
-    save("g_tp_obs", cyl=cyl, **{k: torch.stack(v) for k, v in rec.items()},
+    save(tag, cyl=cyl, **{k: torch.stack(v) for k, v in rec.items()},
          **{"w_" + k.replace(".", "_"): v for k, v in weights.items()}, meta=np.array([E, A, C, T, 20], dtype=np.int64))
 
 
 if __name__ == "__main__":
     gen_hover()
     gen_tp_obs()
+    gen_tp_obs("g_tp_obs_a6", E=10, A=6, C=8, seed=20241021)      # 25-value frames: the two-chunk path of the HIP kernel

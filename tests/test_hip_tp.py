@@ -101,10 +101,11 @@ def test_tp_env_matches_torch_lstm():
         env.step(env.rand_step_input(torch.randn(E, A, 4, device=env.device)))
 
 
-def test_tp_matches_reference_golden(golden):
+@pytest.mark.parametrize("name", ["g_tp_obs", "g_tp_obs_a6"])
+def test_tp_matches_reference_golden(golden, name):
     """hns_tp_observe fed with the golden's states (obs rows from the oracle's observation pass) against
     the reference's own `_compute_state_and_obs` + TP_net outputs."""
-    g = golden("g_tp_obs")
+    g = golden(name)
     E, A, Cn, T, max_len = (int(x) for x in g["meta"])
     cfg = config.make_cfg({"num_agents": A, "drone_detect_radius": 0.9, "cylinder": {"max_num": Cn, "min_num": 4},
                            "env": {"num_envs": E, "max_episode_length": max_len}}, algo={"use_TP_net": 1, "critic_input": "state"})

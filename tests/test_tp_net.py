@@ -15,8 +15,12 @@ def _load_weights(tp, g):
     tp.load_state_dict(sd)
 
 
-def test_tp_observation_matches_reference(golden):
-    g = golden("g_tp_obs")
+import pytest
+
+
+@pytest.mark.parametrize("name", ["g_tp_obs", "g_tp_obs_a6"])
+def test_tp_observation_matches_reference(golden, name):
+    g = golden(name)
     E, A, C, T, max_len = (int(x) for x in g["meta"])
     cfg = config.make_cfg({"num_agents": A, "drone_detect_radius": 0.9, "cylinder": {"max_num": C, "min_num": 4},
                            "env": {"num_envs": E, "max_episode_length": max_len}})
@@ -51,10 +55,11 @@ def test_tp_net_state_dict_is_reference_compatible():
     assert tp(torch.zeros(4, 10, 16)).shape == (4, 15)
 
 
-def test_oracle_tp_observe_matches_reference(golden):
-    """The C restatement of the whole TP branch (window, LSTM in the matrix-core accumulation order,
-    output layer, rows) against the reference's `_compute_state_and_obs` + its own TP_net."""
-    g = golden("g_tp_obs")
+@pytest.mark.parametrize("name", ["g_tp_obs", "g_tp_obs_a6"])
+def test_oracle_tp_observe_matches_reference(golden, name):
+    """The C restatement of the whole TP branch (window, LSTM, output layer, rows) against the reference's
+    `_compute_state_and_obs` + its own TP_net, for 3 pursuers (16-value frames) and 6 (25-value frames)."""
+    g = golden(name)
     E, A, C, T, max_len = (int(x) for x in g["meta"])
     cfg = config.make_cfg({"num_agents": A, "drone_detect_radius": 0.9, "cylinder": {"max_num": C, "min_num": 4},
                            "env": {"num_envs": E, "max_episode_length": max_len}})
