@@ -180,7 +180,9 @@ __global__ __launch_bounds__(256) void hns_perturb_kernel(const PerturbParams p)
     if (t >= p.n_tasks) return;
     const hns_cfg &c = p.cfg;
     const int A = c.num_agents, Cn = c.num_cylinders, nb = A + 1 + Cn, TD = 3 * nb, GN = c.grid_num, half = GN / 2;
-    const double gs = (double)c.grid_size;
+    // the reference divides by the Python double 2*cylinder_size (0.2), not by its fp32 rounding: recover the
+    // decimal the YAML holds (6 places) so that bodies exactly on a cell edge fall into the same cell
+    const double gs = __builtin_rint((double)c.grid_size * 1e6) / 1e6;
     // bounds, :320-333 (incl. the reference's z window around max_height for drones / evader)
     const float cb = (float)((int)(c.arena_size / c.grid_size)) * c.grid_size;
     const float bxy = c.arena_size / 1.41421356237309515f - 0.1f;

@@ -1223,15 +1223,38 @@ int hns_oracle_fps(const float *points, int n, int d, int k, int start, int32_t 
     return 0;
 }
 
+/* the reference divides by the Python double 2*cylinder_size (0.2), not by its fp32 rounding: recover the decimal
+ * the YAML holds (6 places) so that bodies sitting exactly on a cell edge fall into the same cell */
+static double o_envgen_grid_size(const hns_cfg *c) { return rint((double)c->grid_size * 1e6) / 1e6; }
 static int o_envgen_cell(double x, double grid_size, int num_grid) {
     int g = (int)rint(x / grid_size) + num_grid / 2;
     return g < 0 ? 0 : (g > num_grid - 1 ? num_grid - 1 : g);
 }
 
+/* the grid sanity check alone (hideandseek_envgen.py:187-207): every body in its own free cell of the disc */
+void hns_oracle_tasks_sane(const hns_cfg *c, const float *tasks, int n, uint8_t *out) {
+    const int A = c->num_agents, Cn = c->num_cylinders, nb = A + 1 + Cn, TD = 3 * nb, GN = c->grid_num, half = GN / 2;
+    int cells[HNS_MAX_AGENTS + 1 + HNS_MAX_CYLINDERS];
+    for (int t = 0; t < n; ++t) {
+        const float *v = tasks + (size_t)t * TD;
+        int ok = 1;
+        for (int b = 0; b < nb; ++b) {
+            const int gx = o_envgen_cell((double)v[3 * b], o_envgen_grid_size(c), GN), gy = o_envgen_cell((double)v[3 * b + 1], o_envgen_grid_size(c), GN);
+            const int dx = gx - half, dy = gy - half;
+            if (dx * dx + dy * dy >= half * half) ok = 0;
+            cells[b] = gx * GN + gy;
+        }
+        for (int b = 1; b < nb && ok; ++b)
+            for (int b2 = 0; b2 < b; ++b2)
+                if (cells[b] == cells[b2]) { ok = 0; break; }
+        out[t] = (uint8_t)ok;
+    }
+}
+
 int hns_oracle_perturb_tasks(const hns_cfg *c, const float *history, int n_hist, float *tasks_out, int n_tasks,
                              int expand_cylinders, float expand_step, uint64_t seed) {
     const int A = c->num_agents, Cn = c->num_cylinders, nb = A + 1 + Cn, TD = 3 * nb, GN = c->grid_num, half = GN / 2;
-    const double gs = (double)c->grid_size;
+    const double gs = o_envgen_grid_size(c);
     const float cb = (float)((int)(c->arena_size / c->grid_size)) * c->grid_size;
     const float bxy = c->arena_size / 1.41421356237309515f - 0.1f;
     int cells[HNS_MAX_AGENTS + 1 + HNS_MAX_CYLINDERS];

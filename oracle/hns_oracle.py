@@ -251,3 +251,10 @@ def perturb_tasks(cfg, history, n_tasks, expand_cylinders, expand_step, seed):
                                         C.c_float(expand_step), C.c_uint64(seed))
     assert rc == 0, rc
     return out
+
+
+def tasks_sane(cfg, tasks):
+    t = f32(tasks)
+    out = np.zeros(t.shape[0], np.uint8)
+    lib().hns_oracle_tasks_sane(C.byref(cfg), _p(t), int(t.shape[0]), _p(out))
+    return out.astype(bool)

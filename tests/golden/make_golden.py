@@ -983,3 +983,37 @@ if __name__ == "__main__":
     gen_hover()
     gen_tp_obs()
     gen_tp_obs("g_tp_obs_a6", E=10, A=6, C=8, seed=20241021)      # 25-value frames: the two-chunk path of the HIP kernel
+
+
+# ---- envgen grid sanity check (hideandseek_envgen.py:145-207), module-level functions executed as they are ----
+def gen_envgen_sanity():
+    ENVGEN = "omni_drones/envs/hide_and_seek/hideandseek_envgen.py"
+    ns = dict(torch=torch, np=np)
+    fn = exec_functions(extract_source(ENVGEN, ["continuous_to_grid", "set_outside_circle_to_one", "sanity_check"]), ns)
+    rng = np.random.default_rng(20241022)
+    A, C, N = 3, 5, 3000
+    grid_size, num_grid = 0.2, 9
+    grid_map = fn["set_outside_circle_to_one"](np.zeros((1, num_grid, num_grid), dtype=int))
+    center_pos, center_grid = np.zeros((1, 2)), np.ones((1, 2), dtype=int) * (num_grid // 2)
+    tasks = np.zeros((N, 3 * (A + 1 + C)), dtype=np.float32)
+    xy = rng.uniform(-0.75, 0.75, size=(N, A + 1 + C, 2))
+    snap = rng.random((N, A + 1 + C, 1)) < 0.5                     # half of the bodies sit exactly on cell centres / edges
+    xy = np.where(snap, np.round(xy / 0.1) * 0.1, xy)
+    tasks.reshape(N, -1, 3)[..., :2] = xy
+    tasks.reshape(N, -1, 3)[..., 2] = rng.uniform(-20, 1.3, size=(N, A + 1 + C))
+    tasks[: N // 3, 3 * (A + 1):] = np.tile(np.array([[0.0, 0.0, -20.0], [0.2, 0.0, 0.6], [0.0, 0.2, 0.6], [-0.2, 0.0, 0.6], [0.0, -0.2, 0.6]],
+                                                   np.float32).reshape(-1), (N // 3, 1))   # a sane cylinder set: the bodies decide
+    ok = np.zeros(N, dtype=bool)
+    t64 = tasks.astype(np.float64)
+    for i in range(N):
+        d = t64[i, :3 * A].reshape(-1, 3)
+        t = t64[i, 3 * A:3 * A + 3].reshape(-1, 3)
+        c = t64[i, 3 * A + 3:].reshape(-1, 3)
+        g = [fn["continuous_to_grid"](torch.from_numpy(x[..., :2]), num_grid, grid_size, torch.from_numpy(center_pos), torch.from_numpy(center_grid)).numpy()
+             for x in (d, t, c)]
+        ok[i] = bool(fn["sanity_check"](grid_map[0], *g))
+    save("g_envgen_sanity", tasks=tasks, ok=ok, disc=grid_map[0], meta=np.array([A, C, N], dtype=np.int64))
+
+
+if __name__ == "__main__":
+    gen_envgen_sanity()

@@ -194,6 +194,21 @@ def test_envgen_with_trajectory_predictor_on_gpu():
         assert torch.equal(td[("agents", "TP", "TP_input")][:, -1, 7:], b["drone_state"][..., :3].reshape(E, -1))
 
 
+def test_grid_sanity_check_matches_reference(golden):
+    """The reference's own `sanity_check` + `continuous_to_grid` (hideandseek_envgen.py:145-207, executed as they
+    are) on 3000 task vectors, half of the bodies exactly on cell centres / edges: the host GenBuffer and the C
+    oracle (whose perturbation kernel the HIP one matches bit for bit) agree on every one."""
+    import hns_oracle as O
+    g = golden("g_envgen_sanity")
+    A, Cn, N = (int(x) for x in g["meta"])
+    gb = GenBuffer(A, Cn)
+    assert np.array_equal(gb.grid_map, g["disc"])
+    assert np.array_equal(gb.sanity_ok(g["tasks"]), g["ok"])
+    c = config.resolve_hns_cfg(config.make_cfg({"num_agents": A, "cylinder": {"max_num": Cn, "min_num": 2}, "env": {"num_envs": 8}}))
+    assert np.array_equal(O.tasks_sane(c, g["tasks"]), g["ok"])
+    assert 0.05 < g["ok"].mean() < 0.95
+
+
 # ---- device-side generator pieces (SURVEY §8 N3): oracle restatements -----------------------------------
 def test_oracle_fps_matches_torch_reference():
     """Integer coordinates: squared distances are exact in fp32 whatever the summation order, so the
