@@ -37,6 +37,8 @@ CASES = [
     dict(E=64, A=4, C=6, K=4, drone_detect_radius=0.7, target_detect_radius=0.8, use_deployment=1, init_smoothness_coef=2.0),
     dict(E=128, A=3, C=6, use_random_cylinder=0, scenario_flag="narrow_gap"),
     dict(E=64, A=3, C=5, use_eval=1),
+    dict(E=100, A=5, C=9, K=3),
+    dict(E=65, A=7, C=12, K=4),                              # the widest workgroup: 512 threads
 ]
 
 
