@@ -1117,9 +1117,11 @@ static inline float o_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_buffers *tp, int T, int F, int fill) {
     const int E = c->num_envs, A = c->num_agents, I = 7 + 3 * A, H = HNS_TP_HIDDEN, R = 3 * F, D = HNS_SELF_DIM + R;
     if (T < 1 || T > 16 || R > 32 || !b->detect) return HNS_ERR_INVALID_ARG;
-    float *frame = (float *)malloc(sizeof(float) * (size_t)I);
+    if (I > 7 + 3 * HNS_MAX_AGENTS) return HNS_ERR_INVALID_ARG;
+#pragma omp parallel for schedule(static) num_threads(g_step_threads)
     for (int e = 0; e < E; ++e) {
         /* frame (:815-820) and window (:825-831) */
+        float frame[7 + 3 * HNS_MAX_AGENTS];
         const int det = b->detect[e] != 0;
         frame[0] = b->progress[e];
         for (int j = 0; j < 3; ++j) {
@@ -1185,7 +1187,6 @@ int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_b
             }
         }
     }
-    free(frame);
     return 0;
 }
 

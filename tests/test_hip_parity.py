@@ -39,12 +39,14 @@ CASES = [
     dict(E=64, A=3, C=5, use_eval=1),
     dict(E=100, A=5, C=9, K=3),
     dict(E=65, A=7, C=12, K=4),                              # the widest workgroup: 512 threads
+    dict(E=65536, A=3, C=8, cylinder={"min_num": 8}),        # BASELINE config 3 at full size, every buffer bit for bit
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"E{c['E']}A{c['A']}C{c['C']}")
 def test_step_and_reset_bit_exact(case):
     case = dict(case)
+    O.set_threads(8 if case["E"] > 4096 else 1)
     env = make_env(max_len=12, **case)
     env.set_seed(1234)
     env.reset()

@@ -101,9 +101,10 @@ def test_capture_of_either_evader_counts():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("E,A,Cn", [(100, 3, 8), (64, 6, 16), (257, 1, 3), (130, 2, 5)])
+@pytest.mark.parametrize("E,A,Cn", [(100, 3, 8), (64, 6, 16), (257, 1, 3), (130, 2, 5), (16384, 6, 16)])
 def test_hip_two_evaders_matches_oracle(E, A, Cn):
     from hns_amd.env import HideAndSeek
+    O.set_threads(8 if E > 4096 else 1)
     cfg = config.make_cfg({"num_agents": A, "num_targets": 2, "cylinder": {"max_num": Cn, "min_num": min(3, Cn)},
                            "env": {"num_envs": E, "max_episode_length": 12}}, algo={"critic_input": "state"})
     env = HideAndSeek(cfg)
