@@ -34,12 +34,14 @@
 //   * the K order of the recurrent product is free, so its k-slots are DEFINED as the units each
 //     half-wave holds: h_t leaves the cell update in exactly the lanes whose B operand needs it —
 //     no shuffle, no LDS round trip, just the fp16 split.
-// 8 waves per workgroup (2 per SIMD: one wave's gate nonlinearities overlap the other's MFMAs),
-// 256 envs per workgroup => 256 workgroups = one per CU at 65 536 envs.
+// 8 waves per workgroup (2 per SIMD), 256 envs per workgroup => 256 workgroups = one per CU at
+// 65 536 envs.  The two waves of a SIMD run in phase, so each wave overlaps its own work instead:
+// the cell update of units 0..31 is issued between the MFMAs of units 32..63 (TpCell / TpGate SIDE).
 #include <hip/hip_runtime.h>
 
 #include <new>
 #include <string>
+#include <type_traits>
 #include <utility>
 
 #include "hns_device.h"
@@ -184,7 +186,63 @@ HNS_DEV float tp_frame_val(const TpParams &p, int e, int k, bool det) {
 // The kernel as a whole is bound by the gate nonlinearities (10 transcendental ops per unit and
 // timestep), not by this block.
 constexpr int kTpDepth = 2;
-template <int NXC, bool WITH_H>
+
+// ---- cell update of the 16 units of one tile pair (torch.nn.LSTM gate order i, f, g, o), lane-local ----
+// Cut into 40 slices (8 unit pairs x 5 stages of <= 8 VALU ops) so that the update of tile pair 0 can be
+// issued BETWEEN the MFMAs of tile pair 1 (same wave, independent registers): left to themselves the two
+// waves of a SIMD run in phase — both in their MFMA block, then both in their nonlinearities — and the
+// matrix pipe and the VALU alternate instead of overlapping (counters: 36 % + 53 % of the kernel).
+struct TpCellCtx {
+    const f32x16 (&z)[4];     // pre-activations, already scaled to the exponents the nonlinearities need
+    float (&c)[32];           // cell state, units 16 TJ + i
+    float (&h)[16];           // TJ = 0: h_t of these units, parked while tile pair 1 still reads h_{t-1}
+    half8 (&hh)[4];           // TJ = 1: h_{t-1} is dead by then, h_t goes straight into the next B operands
+    half8 (&hl)[4];
+    float t[10];
+};
+template <int TJ>
+struct TpCell {
+    static constexpr int N = 40;
+    template <int K>
+    static __device__ __forceinline__ void slice(TpCellCtx &x) {
+        constexpr int S = K % 5, u0 = 2 * (K / 5), u1 = u0 + 1;
+        float *t = x.t;
+        if constexpr (S == 0) {            // 1 + e_i, 1 + e_f
+            t[0] = 1.0f + __builtin_amdgcn_exp2f(x.z[0][u0]); t[1] = 1.0f + __builtin_amdgcn_exp2f(x.z[0][u1]);
+            t[2] = 1.0f + __builtin_amdgcn_exp2f(x.z[1][u0]); t[3] = 1.0f + __builtin_amdgcn_exp2f(x.z[1][u1]);
+        } else if constexpr (S == 1) {     // 1 + e_g; i, f
+            t[4] = 1.0f + __builtin_amdgcn_exp2f(x.z[2][u0]); t[5] = 1.0f + __builtin_amdgcn_exp2f(x.z[2][u1]);
+            t[0] = __builtin_amdgcn_rcpf(t[0]); t[1] = __builtin_amdgcn_rcpf(t[1]);
+            t[2] = __builtin_amdgcn_rcpf(t[2]); t[3] = __builtin_amdgcn_rcpf(t[3]);
+        } else if constexpr (S == 2) {     // g = tanh; c' = f c + i g; e_c
+            const float g0 = HNS_FMA(2.0f, __builtin_amdgcn_rcpf(t[4]), -1.0f), g1 = HNS_FMA(2.0f, __builtin_amdgcn_rcpf(t[5]), -1.0f);
+            const float c0 = HNS_FMA(t[2], x.c[16 * TJ + u0], t[0] * g0), c1 = HNS_FMA(t[3], x.c[16 * TJ + u1], t[1] * g1);
+            x.c[16 * TJ + u0] = c0; x.c[16 * TJ + u1] = c1;
+            t[6] = __builtin_amdgcn_exp2f(c0 * (2.0f * kNegLog2e)); t[7] = __builtin_amdgcn_exp2f(c1 * (2.0f * kNegLog2e));
+        } else if constexpr (S == 3) {     // o; 1 + e_c
+            t[8] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x.z[3][u0]));
+            t[9] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x.z[3][u1]));
+            t[6] = 1.0f + t[6]; t[7] = 1.0f + t[7];
+        } else {                           // h' = o tanh(c')
+            const float h0 = t[8] * HNS_FMA(2.0f, __builtin_amdgcn_rcpf(t[6]), -1.0f);
+            const float h1 = t[9] * HNS_FMA(2.0f, __builtin_amdgcn_rcpf(t[7]), -1.0f);
+            if constexpr (TJ == 0) {
+                x.h[u0] = h0; x.h[u1] = h1;
+            } else {
+                _Float16 a0, b0, a1, b1;
+                tp_split(h0, a0, b0);
+                tp_split(h1, a1, b1);
+                x.hh[2 + (u0 >> 3)][u0 & 7] = a0; x.hl[2 + (u0 >> 3)][u0 & 7] = b0;
+                x.hh[2 + (u1 >> 3)][u1 & 7] = a1; x.hl[2 + (u1 >> 3)][u1 & 7] = b1;
+            }
+        }
+    }
+    template <int... Ks>
+    static __device__ __forceinline__ void run(TpCellCtx &x, std::integer_sequence<int, Ks...>) { (slice<Ks>(x), ...); }
+    static __device__ __forceinline__ void run_all(TpCellCtx &x) { run(x, std::make_integer_sequence<int, N>{}); }
+};
+
+template <int NXC, bool WITH_H, bool SIDE = false>
 struct TpGate {
     static constexpr int NC = NXC + (WITH_H ? 4 : 0), NLO = 8 * NC, NHI = 4 * NC, N = NLO + NHI;
     static constexpr int D = kTpDepth < N ? kTpDepth : N;
@@ -215,6 +273,7 @@ struct TpGate {
         const half8 (&xl)[NXC];
         const half8 (&hh)[4];
         const half8 (&hl)[4];
+        TpCellCtx *side;          // SIDE: the other tile pair's cell update, one slice per MFMA
     };
 
     template <int n>
@@ -255,6 +314,7 @@ struct TpGate {
             else c.acc[q] = TP_MFMA(c.a[n % RING], c.hh[ci - NXC], c.acc[q]);
         }
         if constexpr (n + D < N) c.a[(n + D) % RING] = load<n + D>(c);
+        if constexpr (SIDE && n < TpCell<0>::N) TpCell<0>::slice<n>(*c.side);
         __builtin_amdgcn_sched_barrier(0);       // keep the hand-placed MFMA / LDS-read order (a 0x6 mask lets MFMAs move: they count as VALU)
     }
     template <int... Ns>
@@ -263,16 +323,18 @@ struct TpGate {
     static __device__ __forceinline__ void run_steps(const Ctx &c, std::integer_sequence<int, Ns...>) { (step<Ns>(c), ...); }
 };
 
-template <int NXC, bool WITH_H>
+template <int NXC, bool WITH_H, bool SIDE = false>
 HNS_DEV void tp_gate_tiles(f32x16 (&acc)[4], const uint4 *aw, int tj, int hb, const float *sBias,
-                           const half8 (&xh)[NXC], const half8 (&xl)[NXC], const half8 (&hh)[4], const half8 (&hl)[4]) {
-    using G = TpGate<NXC, WITH_H>;
+                           const half8 (&xh)[NXC], const half8 (&xl)[NXC], const half8 (&hh)[4], const half8 (&hl)[4],
+                           TpCellCtx *side = nullptr) {
+    using G = TpGate<NXC, WITH_H, SIDE>;
+    static_assert(!SIDE || G::N >= TpCell<0>::N, "not enough MFMAs to carry the cell update");
     half8 a[G::RING];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
-    const typename G::Ctx c{acc, a, aw, sBias + hb * 16, tj, xh, xl, hh, hl};
+    const typename G::Ctx c{acc, a, aw, sBias + hb * 16, tj, xh, xl, hh, hl, side};
     G::run_prologue(c, std::make_integer_sequence<int, G::D>{});
     G::run_steps(c, std::make_integer_sequence<int, G::N>{});
 }
@@ -376,9 +438,11 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
     for (int i = 0; i < 4; ++i) { hh[i] = (half8)(_Float16)0.0f; hl[i] = (half8)(_Float16)0.0f; }
 #pragma unroll
     for (int i = 0; i < 32; ++i) c[i] = 0.0f;
-    float hn0[16];                          // h_t of units 0..15 (tile pair 0), parked while tile pair 1 still reads h_{t-1}
+    float hn0[16];                          // h_t of tile pair 0's units, parked while tile pair 1 still reads h_{t-1}
 
-    for (int t = 0; t < T; ++t) {
+    // one timestep; t = 0 (h_0 = 0: no recurrent product) is peeled so that the loop body is straight-line code
+    auto timestep = [&](int t, auto with_h) {
+        constexpr bool WITH_H = decltype(with_h)::value;
         // shift x_t into slot t and split it; prefetch x_{t+1} (slot t+2 of the old window, untouched so far)
         half8 xh[NXC], xl[NXC];
 #pragma unroll
@@ -401,35 +465,32 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
         int lo = lane;
         asm volatile("" : "+v"(lo));
         const uint4 *aw = simg + lo;
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {                 // units 32tj..32tj+31: gate tiles m = 2q + tj
-            f32x16 acc[4];
-            if (t > 0) tp_gate_tiles<NXC, true>(acc, aw, tj, hb, sBias, xh, xl, hh, hl);
-            else tp_gate_tiles<NXC, false>(acc, aw, tj, hb, sBias, xh, xl, hh, hl);   // h_0 = 0: no recurrent product
-            // cell update (torch.nn.LSTM: i, f, g, o), lane-local
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float ig = tp_sigmoid_s(acc[0][i]), fg = tp_sigmoid_s(acc[1][i]);
-                const float gg = tp_tanh_s(acc[2][i]), og = tp_sigmoid_s(acc[3][i]);
-                const float cn = HNS_FMA(fg, c[16 * tj + i], ig * gg);
-                c[16 * tj + i] = cn;
-                const float hv = og * tp_tanh(cn);
-                if (tj == 0) {
-                    hn0[i] = hv;
-                } else {                                   // h_{t-1} is dead now: h_t -> B operands of the next timestep
-                    _Float16 a, b;
-                    tp_split(hv, a, b);
-                    hh[2 + (i >> 3)][i & 7] = a; hl[2 + (i >> 3)][i & 7] = b;
-                }
-            }
+        // units 0..31 (gate tiles m = 2q) then 32..63 (m = 2q + 1); where the registers allow it the cell update
+        // of the first half rides between the MFMAs of the second
+        f32x16 acc0[4], acc1[4];
+        TpCellCtx cell0{acc0, c, hn0, hh, hl, {}}, cell1{acc1, c, hn0, hh, hl, {}};
+        tp_gate_tiles<NXC, WITH_H>(acc0, aw, 0, hb, sBias, xh, xl, hh, hl);
+        // (the two-chunk frame of 4..7 pursuers has no registers left for it: both accumulator sets live = spills)
+        constexpr bool SIDE = WITH_H && NXC == 1;
+        if constexpr (SIDE) {
+            tp_gate_tiles<NXC, WITH_H, true>(acc1, aw, 1, hb, sBias, xh, xl, hh, hl, &cell0);
+        } else {
+            TpCell<0>::run_all(cell0);
+            __builtin_amdgcn_sched_barrier(0);            // acc0 is dead before acc1 goes live
+            tp_gate_tiles<NXC, WITH_H>(acc1, aw, 1, hb, sBias, xh, xl, hh, hl);
         }
+        TpCell<1>::run_all(cell1);
+        __builtin_amdgcn_sched_barrier(0);
+        // h_{t-1} is dead now: h_t -> B operands of the next timestep
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             _Float16 a, b;
             tp_split(hn0[i], a, b);
             hh[i >> 3][i & 7] = a; hl[i >> 3][i & 7] = b;
         }
-    }
+    };
+    timestep(0, std::false_type{});
+    for (int t = 1; t < T; ++t) timestep(t, std::true_type{});
 
     if (prof && lane == 0) prof[2] = __builtin_amdgcn_s_memrealtime();
     // ---- output layer on h_T: tanh(W_fc h + b), rescaled to arena units (hideandseek.py:834-836) ----
