@@ -39,6 +39,8 @@ CASES = [
     dict(E=64, A=3, C=5, use_eval=1),
     dict(E=100, A=5, C=9, K=3),
     dict(E=65, A=7, C=12, K=4),                              # the widest workgroup: 512 threads
+    dict(E=1, A=3, C=5),                                     # a single env
+    dict(E=33, A=7, C=16, K=4, cylinder={"min_num": 16}),    # every limit of the ABI at once (HNS_MAX_AGENTS / _CYLINDERS, k = 4)
     dict(E=65536, A=3, C=8, cylinder={"min_num": 8}),        # BASELINE config 3 at full size, every buffer bit for bit
 ]
 
@@ -60,7 +62,7 @@ def test_step_and_reset_bit_exact(case):
         action = torch.randn(E, A, 4, generator=g) * 0.7
         if t == 3:
             action[0] = float("nan")                         # NaN policy output -> nan_to_num path
-            action[1] = 50.0
+            action[E - 1] = 50.0
         env.step(env.rand_step_input(action.to(env.device)))
         O.step(env.hcfg, host, action.numpy())
         if t in (0, 5, 11, 29):
