@@ -136,7 +136,8 @@ typedef struct hns_cfg {
     float fixed_target_pos[3];
     float fixed_cyl_pos[HNS_MAX_CYLINDERS][3];
     int32_t fixed_cyl_active;  /* HNS_INIT_SCENARIO: number of active cylinders */
-    int32_t reserved1;
+    int32_t tp_use_obstacles;  /* task.use_obstacles: the predictor's frame also holds [x, y, cylinder_size] of every cylinder slot
+                                  (hideandseek.py:808-816); 0 = the reference's default */
 } hns_cfg;
 
 /*
@@ -243,8 +244,10 @@ int hns_raycast(hns_env *env, int num_rays, float max_range, float *out, void *s
  * Trajectory predictor in the observation (reference default `algo.use_TP_net: 1`).
  * Replaces the TP branch of HideAndSeek._compute_state_and_obs (hideandseek.py:805-854,871-880)
  * incl. the TP_net forward (learning/mappo.py:572-589: LSTM(I -> 64, 1 layer, zero initial state)
- * + Linear(64 -> 3F) + tanh) evaluated on a T-frame history, I = 7 + 3A:
+ * + Linear(64 -> 3F) + tanh) evaluated on a T-frame history, I = 7 + 3A (+ 3C with cfg.tp_use_obstacles):
  *   frame = [progress, evader pos (masked), evader vel (masked), pursuer positions]   (:815-820)
+ *           + [x, y, cylinder_size] of every cylinder slot with task.use_obstacles     (:808-816)
+ * I <= 32 (two 16-wide operand chunks): up to 7 pursuers, or e.g. 3 pursuers + 5 cylinder slots.
  * The parameters are the caller's tensors in PyTorch layouts (the learner trains them,
  * scripts/train.py:180).  They are converted into a matrix-core operand image (`packed`) by
  * hns_tp_refresh: call it after every parameter update (hns_tp_bind schedules one).

@@ -54,7 +54,7 @@ class HnsCfg(C.Structure):
         ("drone_xy_lo", _f * 2), ("drone_xy_hi", _f * 2), ("target_xy_lo", _f * 2),
         ("target_xy_hi", _f * 2), ("z_lo", _f), ("z_hi", _f), ("rpy_lo", _f * 3), ("rpy_hi", _f * 3),
         ("fixed_drone_pos", (_f * 3) * (HNS_MAX_AGENTS + 1)), ("fixed_target_pos", _f * 3),
-        ("fixed_cyl_pos", (_f * 3) * HNS_MAX_CYLINDERS), ("fixed_cyl_active", _i), ("reserved1", _i),
+        ("fixed_cyl_pos", (_f * 3) * HNS_MAX_CYLINDERS), ("fixed_cyl_active", _i), ("tp_use_obstacles", _i),
     ]
 
     def copy(self):
@@ -148,8 +148,13 @@ class HnsTpBuffers(C.Structure):
     _fields_ = [(name, _fp) for name in TP_BUFFER_FIELDS]
 
 
-def tp_buffer_shapes(E, A, T, F):
-    I, D = 7 + 3 * A, HNS_SELF_DIM + 3 * F
+def tp_frame_dim(A, C=0, use_obstacles=False):
+    """Width of one predictor frame (hideandseek.py:808-820)."""
+    return 7 + 3 * A + (3 * C if use_obstacles else 0)
+
+
+def tp_buffer_shapes(E, A, T, F, I=None):
+    I, D = (7 + 3 * A if I is None else I), HNS_SELF_DIM + 3 * F
     return {"w_ih": ((4 * HNS_TP_HIDDEN, I), "float32"), "w_hh": ((4 * HNS_TP_HIDDEN, HNS_TP_HIDDEN), "float32"),
             "b_ih": ((4 * HNS_TP_HIDDEN,), "float32"), "b_hh": ((4 * HNS_TP_HIDDEN,), "float32"),
             "w_fc": ((3 * F, HNS_TP_HIDDEN), "float32"), "b_fc": ((3 * F,), "float32"),

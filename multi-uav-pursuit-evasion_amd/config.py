@@ -229,8 +229,10 @@ def _f32(x):
 
 def resolve_hns_cfg(cfg, num_envs=None, env_index_offset=0, drone_params=None, write_critic_state=True):
     t = cfg.task
-    if int(cfg.algo.get("use_TP_net", 0)) and int(t.get("use_obstacles", 0)):
-        raise NotImplementedError("task.use_obstacles=1 (cylinders in the TP_net input, hideandseek.py:806-814) is not built")
+    use_obst = int(cfg.algo.get("use_TP_net", 0)) and int(t.get("use_obstacles", 0))
+    if int(cfg.algo.get("use_TP_net", 0)) and abi.tp_frame_dim(int(t.num_agents), int(t.cylinder.max_num), use_obst) > 32:
+        raise NotImplementedError("TP_net frame wider than 32 values (7 + 3 num_agents + 3 cylinder.max_num with "
+                                  "task.use_obstacles=1) is not built: the HIP predictor holds two 16-wide operand chunks")
     if t.get("drone_model", "Crazyflie").lower() != "crazyflie":
         raise NotImplementedError("only drone_model=Crazyflie is on the hot path")
     if not t.get("time_encoding", True):
@@ -257,6 +259,7 @@ def resolve_hns_cfg(cfg, num_envs=None, env_index_offset=0, drone_params=None, w
     if NT == 2 and int(cfg.algo.get("use_TP_net", 0)):
         raise NotImplementedError("num_targets=2 with algo.use_TP_net=1: the predictor's frame holds one evader")
     c.num_targets = NT
+    c.tp_use_obstacles = 1 if use_obst else 0
     c.max_episode_length = int(cfg.env.max_episode_length)
     c.use_deployment = int(t.use_deployment)
     c.fixed_yaw = int(p["fixed_yaw"])

@@ -62,10 +62,10 @@ constexpr float kTpLoInv = 1.0f / 2048.0f;
 
 struct TpParams {
     hns_tp_buffers tp;
-    const float *drone_state, *target_pos, *target_vel, *progress, *obs_self20;
+    const float *drone_state, *target_pos, *target_vel, *progress, *obs_self20, *cylinders;
     const uint8_t *detect;
-    int E, A, I, T, F, fill, max_len;
-    float mask_value, arena_size, max_height;
+    int E, A, C, I, T, F, fill, max_len;
+    float mask_value, arena_size, max_height, cylinder_size;
     unsigned long long *prof;   // diagnostics (hns_set_phase_profile): per-wave stamps of the 100 MHz clock
 };
 
@@ -164,13 +164,16 @@ HNS_DEV float tp_tanh_s(float zt) { return HNS_FMA(2.0f, __builtin_amdgcn_rcpf(1
 HNS_DEV float tp_tanh(float x) { return tp_tanh_s(x * (2.0f * kNegLog2e)); }
 
 // component k of the frame [progress, evader pos (masked), evader vel (masked), pursuer positions]
-// (hideandseek.py:815-820; the mask is broadcast_detect, :791-803)
+// (hideandseek.py:815-820; the mask is broadcast_detect, :791-803), followed with task.use_obstacles by
+// [x, y, cylinder_size] of every cylinder slot (:808-816; I = 7 + 3A + 3C then)
 HNS_DEV float tp_frame_val(const TpParams &p, int e, int k, bool det) {
     if (k == 0) return p.progress[e];
     if (k < 4) return det ? p.target_pos[(size_t)e * 3 + (k - 1)] : p.mask_value;
     if (k < 7) return det ? p.target_vel[(size_t)e * 3 + (k - 4)] : p.mask_value;
     const int j = k - 7, a = j / 3;
-    return p.drone_state[((size_t)e * p.A + a) * 13 + (j - 3 * a)];
+    if (a < p.A) return p.drone_state[((size_t)e * p.A + a) * 13 + (j - 3 * a)];
+    const int jc = j - 3 * p.A, cy = jc / 3, comp = jc - 3 * cy;
+    return comp == 2 ? p.cylinder_size : p.cylinders[((size_t)e * p.C + cy) * 3 + comp];
 }
 
 #define TP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
@@ -608,6 +611,7 @@ __global__ __launch_bounds__(kRowThreads) void hns_tp_rows_kernel(const TpParams
 using hns::TpParams;
 
 static int tp_nxc(int I) { return (I + 15) / 16; }
+static int tp_frame_dim(const hns_cfg &c) { return 7 + 3 * c.num_agents + (c.tp_use_obstacles ? 3 * c.num_cylinders : 0); }
 
 static void tp_fill_params(const hns_env *env, TpParams &p) {
     const hns_cfg &c = env->cfg;
@@ -618,7 +622,10 @@ static void tp_fill_params(const hns_env *env, TpParams &p) {
     p.progress = env->buf.progress;
     p.obs_self20 = env->buf.obs_self;
     p.detect = env->buf.detect;
-    p.E = c.num_envs; p.A = c.num_agents; p.I = 7 + 3 * c.num_agents;
+    p.cylinders = env->buf.cylinders;
+    p.E = c.num_envs; p.A = c.num_agents; p.C = c.num_cylinders;
+    p.I = tp_frame_dim(c);
+    p.cylinder_size = c.cylinder_size;
     p.T = env->tp.history_step; p.F = env->tp.future_step;
     p.fill = 0;
     p.max_len = c.max_episode_length;
@@ -647,7 +654,10 @@ int hns_tp_bind(hns_env *env, const hns_tp_buffers *b, int32_t history_step, int
     }
     if ((reinterpret_cast<uintptr_t>(b->packed) & 15) != 0) { hns_set_error("hns_tp_bind: packed must be 16-byte aligned"); return HNS_ERR_INVALID_ARG; }
     if (env->cfg.num_targets == 2) { hns_set_error("hns_tp_bind: the predictor's frame holds one evader (num_targets = 2 is not supported)"); return HNS_ERR_CONFIG; }
-    if (tp_nxc(7 + 3 * env->cfg.num_agents) > 2) { hns_set_error("hns_tp_bind: unsupported frame width"); return HNS_ERR_CONFIG; }
+    if (tp_nxc(tp_frame_dim(env->cfg)) > 2) {
+        hns_set_error("hns_tp_bind: frame wider than 32 values (7 + 3 num_agents + 3 num_cylinders with tp_use_obstacles)");
+        return HNS_ERR_CONFIG;
+    }
     if (env->cfg.max_episode_length > 60000) {
         // the frame holds `progress`; the matrix-core operands are fp16 splits (|x| < 65 504)
         hns_set_error("hns_tp_bind: max_episode_length > 60000 does not fit the fp16-split operands of the predictor");

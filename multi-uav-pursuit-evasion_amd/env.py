@@ -145,10 +145,12 @@ class HideAndSeek:
             t = cfg.task
             self.tp_future_step = int(t.get("future_predcition_step", 5))
             self.tp_history_step = int(t.get("history_step", 10))
-            self.TP = TPNet(1 + 3 + 3 + 3 * A, 3 * self.tp_future_step, self.tp_future_step,
-                            int(t.get("window_step", 1))).to(self.device)                       # hideandseek.py:317
+            self.use_obstacles = int(self.hcfg.tp_use_obstacles)                                # the frame also holds the cylinders
+            self.tp_frame_dim = abi.tp_frame_dim(A, self.hcfg.num_cylinders, self.use_obstacles)
+            self.TP = TPNet(self.tp_frame_dim, 3 * self.tp_future_step, self.tp_future_step,
+                            int(t.get("window_step", 1))).to(self.device)                       # hideandseek.py:315-318
             self._tp_bufs = {}
-            for name, (shape, dt) in abi.tp_buffer_shapes(E, A, self.tp_history_step, self.tp_future_step).items():
+            for name, (shape, dt) in abi.tp_buffer_shapes(E, A, self.tp_history_step, self.tp_future_step, self.tp_frame_dim).items():
                 if name not in abi.TP_WEIGHT_FIELDS:
                     self._tp_bufs[name] = torch.zeros(shape, dtype=getattr(torch, dt), device=self.device)
             self._tp_weight_ptrs = None
@@ -183,7 +185,7 @@ class HideAndSeek:
         info_spec = CompositeSpec({"drone_state": TensorSpec((A, 13)), "prev_action": TensorSpec((A, 4), low=-1.0, high=1.0)})
         agents = {"observation": observation_spec.expand(A), "state": state_spec}
         if self.use_TP_net:                                              # hideandseek.py:368-374
-            agents["TP"] = CompositeSpec({"TP_input": TensorSpec((self.tp_history_step, 7 + 3 * A)),
+            agents["TP"] = CompositeSpec({"TP_input": TensorSpec((self.tp_history_step, self.tp_frame_dim)),
                                           "TP_groundtruth": TensorSpec((1, 3)), "TP_done": TensorSpec((1, 3))})
         self.observation_spec = CompositeSpec({
             "agents": CompositeSpec(agents), "stats": stats_spec, "info": info_spec}).expand(E).to(dev)

@@ -1115,13 +1115,14 @@ void hns_oracle_raycast(const hns_cfg *c, const hns_buffers *b, int N, float max
 static inline float o_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_buffers *tp, int T, int F, int fill) {
-    const int E = c->num_envs, A = c->num_agents, I = 7 + 3 * A, H = HNS_TP_HIDDEN, R = 3 * F, D = HNS_SELF_DIM + R;
+    const int E = c->num_envs, A = c->num_agents, Cn = c->tp_use_obstacles ? c->num_cylinders : 0;
+    const int I = 7 + 3 * A + 3 * Cn, H = HNS_TP_HIDDEN, R = 3 * F, D = HNS_SELF_DIM + R;
     if (T < 1 || T > 16 || R > 32 || !b->detect) return HNS_ERR_INVALID_ARG;
-    if (I > 7 + 3 * HNS_MAX_AGENTS) return HNS_ERR_INVALID_ARG;
+    if (A > HNS_MAX_AGENTS || Cn > HNS_MAX_CYLINDERS) return HNS_ERR_INVALID_ARG;
 #pragma omp parallel for schedule(static) num_threads(g_step_threads)
     for (int e = 0; e < E; ++e) {
         /* frame (:815-820) and window (:825-831) */
-        float frame[7 + 3 * HNS_MAX_AGENTS];
+        float frame[7 + 3 * HNS_MAX_AGENTS + 3 * HNS_MAX_CYLINDERS];
         const int det = b->detect[e] != 0;
         frame[0] = b->progress[e];
         for (int j = 0; j < 3; ++j) {
@@ -1130,6 +1131,11 @@ int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_b
         }
         for (int a = 0; a < A; ++a)
             for (int j = 0; j < 3; ++j) frame[7 + 3 * a + j] = b->drone_state[((size_t)e * A + a) * 13 + j];
+        for (int k = 0; k < Cn; ++k) {          /* task.use_obstacles (:808-816): [x, y, cylinder_size] of every slot */
+            frame[7 + 3 * A + 3 * k] = b->cylinders[((size_t)e * c->num_cylinders + k) * 3];
+            frame[7 + 3 * A + 3 * k + 1] = b->cylinders[((size_t)e * c->num_cylinders + k) * 3 + 1];
+            frame[7 + 3 * A + 3 * k + 2] = c->cylinder_size;
+        }
         float *hist = tp->history + (size_t)e * T * I;
         if (fill) {
             for (int t = 0; t < T; ++t) memcpy(hist + (size_t)t * I, frame, sizeof(float) * (size_t)I);

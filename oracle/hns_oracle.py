@@ -217,7 +217,8 @@ def raycast(cfg, arrs, num_rays, max_range):
 def alloc_tp_buffers(cfg, T=10, F=5):
     """Zero-initialised host arrays for every hns_tp_buffers field (weights included)."""
     return {k: np.zeros(shape if k != "packed" else (16,), dtype=dt)       # `packed` is the HIP kernel's scratch
-            for k, (shape, dt) in abi.tp_buffer_shapes(cfg.num_envs, cfg.num_agents, T, F).items()}
+            for k, (shape, dt) in abi.tp_buffer_shapes(cfg.num_envs, cfg.num_agents, T, F,
+                                                       abi.tp_frame_dim(cfg.num_agents, cfg.num_cylinders, cfg.tp_use_obstacles)).items()}
 
 
 def tp_observe(cfg, arrs, tp_arrs, fill, with_state=True):

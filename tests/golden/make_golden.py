@@ -944,15 +944,16 @@ def _tp_class():
     return tp_cls
 
 
-def gen_tp_obs(tag="g_tp_obs", E=48, A=3, C=5, seed=20241020):
+def gen_tp_obs(tag="g_tp_obs", E=48, A=3, C=5, seed=20241020, use_obstacles=0):
     import collections
     g = torch.Generator().manual_seed(seed)
     T = 14
     env = ShimEnv(E, A, C, {"drone_detect_radius": 0.9}, max_len=20)
     env.use_TP_net = 1
+    env.use_obstacles = use_obstacles                 # hideandseek.py:808-816: the frame also holds the cylinders
     env.future_predcition_step, env.history_step, env.window_step = 5, 10, 1
     torch.manual_seed(123)
-    env.TP = _tp_class()(input_dim=1 + 3 + 3 + 3 * A, output_dim=15, future_predcition_step=5, window_step=1)
+    env.TP = _tp_class()(input_dim=1 + 3 + 3 + 3 * A + (3 * C if use_obstacles else 0), output_dim=15, future_predcition_step=5, window_step=1)
     env.history_data = collections.deque(maxlen=10)
     weights = {k: v.detach().clone() for k, v in env.TP.state_dict().items()}
     rec = {k: [] for k in ["pos", "rot", "vel", "throttle", "tpos", "tvel", "progress", "state_self", "state_drones",
@@ -976,13 +977,15 @@ def gen_tp_obs(tag="g_tp_obs", E=48, A=3, C=5, seed=20241020):
                          TP_groundtruth=tp["TP_groundtruth"], TP_done=tp["TP_done"], broadcast_detect=env.broadcast_detect).items():
             rec[k].append(v.clone())
     save(tag, cyl=cyl, **{k: torch.stack(v) for k, v in rec.items()},
-         **{"w_" + k.replace(".", "_"): v for k, v in weights.items()}, meta=np.array([E, A, C, T, 20], dtype=np.int64))
+         **{"w_" + k.replace(".", "_"): v for k, v in weights.items()}, meta=np.array([E, A, C, T, 20], dtype=np.int64),
+         use_obstacles=np.array(use_obstacles, dtype=np.int64))
 
 
 if __name__ == "__main__":
     gen_hover()
     gen_tp_obs()
     gen_tp_obs("g_tp_obs_a6", E=10, A=6, C=8, seed=20241021)      # 25-value frames: the two-chunk path of the HIP kernel
+    gen_tp_obs("g_tp_obs_obst", E=12, A=3, C=5, seed=20241023, use_obstacles=1)   # task.use_obstacles: 31-value frames
 
 
 # ---- envgen grid sanity check (hideandseek_envgen.py:145-207), module-level functions executed as they are ----

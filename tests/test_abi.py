@@ -71,8 +71,10 @@ def test_config_schema_and_validation(tmp_path):
     assert (c.num_envs, c.num_agents, c.num_cylinders, c.cyl_fixed_num, c.max_episode_length) == (128, 4, 6, 2, 100)
     assert abs(c.v_prey - 1.3) < 1e-6 and c.grid_num == 9
     config.resolve_hns_cfg(config.make_cfg(algo={"use_TP_net": 1}))          # TP_net runs above the kernel (tp_net.py)
-    with pytest.raises(NotImplementedError):
-        config.resolve_hns_cfg(config.make_cfg({"use_obstacles": 1}, algo={"use_TP_net": 1}))
+    assert config.resolve_hns_cfg(config.make_cfg({"use_obstacles": 1}, algo={"use_TP_net": 1})).tp_use_obstacles == 1   # 7+9+15 = 31 values
+    assert config.resolve_hns_cfg(config.make_cfg({"use_obstacles": 1})).tp_use_obstacles == 0                           # only read with TP_net
+    with pytest.raises(NotImplementedError):                                 # 7 + 9 + 24 = 40 > 32 values per frame
+        config.resolve_hns_cfg(config.make_cfg({"use_obstacles": 1, "cylinder": {"max_num": 8}}, algo={"use_TP_net": 1}))
     with pytest.raises(ValueError):
         config.resolve_hns_cfg(config.make_cfg({"cylinder": {"max_num": 40}}))
     sc = config.resolve_hns_cfg(config.make_cfg({"use_random_cylinder": 0, "scenario_flag": "wall"}))

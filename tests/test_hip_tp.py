@@ -21,8 +21,8 @@ from tp_reference import TPObservation
 TOL = 1e-5
 
 
-def _env(E, A, Cn=5, max_len=40, **kw):
-    cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": Cn, "min_num": min(3, Cn)},
+def _env(E, A, Cn=5, max_len=40, use_obstacles=0, **kw):
+    cfg = config.make_cfg({"num_agents": A, "use_obstacles": use_obstacles, "cylinder": {"max_num": Cn, "min_num": min(3, Cn)},
                            "env": {"num_envs": E, "max_episode_length": max_len}}, algo={"use_TP_net": 1, **kw})
     env = HideAndSeek(cfg)
     env.set_seed(3)
@@ -39,10 +39,12 @@ def _host_tp(env):
     return tpa
 
 
-@pytest.mark.parametrize("E,A", [(48, 3), (300, 1), (257, 2), (1000, 4), (130, 6), (65536, 3)])
-def test_tp_observe_matches_oracle(E, A):
+@pytest.mark.parametrize("E,A,obst", [(48, 3, 0), (300, 1, 0), (257, 2, 0), (1000, 4, 0), (130, 6, 0), (65536, 3, 0),
+                                      (200, 3, 1), (70, 1, 1)])     # obst: task.use_obstacles, cylinders in the frame
+def test_tp_observe_matches_oracle(E, A, obst):
     O.set_threads(16 if E > 4096 else 1)                    # (65536, 3): BASELINE config 3 at full size
-    env = _env(E, A, critic_input="state")
+    env = _env(E, A, critic_input="state", use_obstacles=obst)
+    assert env._tp_bufs["history"].shape == (E, 10, 7 + 3 * A + 15 * obst)
     torch.manual_seed(E + A)
     with torch.no_grad():
         for prm in env.TP.parameters():                     # larger than the default init: gates leave the linear range
@@ -102,13 +104,14 @@ def test_tp_env_matches_torch_lstm():
         env.step(env.rand_step_input(torch.randn(E, A, 4, device=env.device)))
 
 
-@pytest.mark.parametrize("name", ["g_tp_obs", "g_tp_obs_a6"])
+@pytest.mark.parametrize("name", ["g_tp_obs", "g_tp_obs_a6", "g_tp_obs_obst"])
 def test_tp_matches_reference_golden(golden, name):
     """hns_tp_observe fed with the golden's states (obs rows from the oracle's observation pass) against
     the reference's own `_compute_state_and_obs` + TP_net outputs."""
     g = golden(name)
     E, A, Cn, T, max_len = (int(x) for x in g["meta"])
-    cfg = config.make_cfg({"num_agents": A, "drone_detect_radius": 0.9, "cylinder": {"max_num": Cn, "min_num": 4},
+    obst = int(g["use_obstacles"]) if "use_obstacles" in g else 0          # task.use_obstacles: cylinders in the frame
+    cfg = config.make_cfg({"num_agents": A, "drone_detect_radius": 0.9, "use_obstacles": obst, "cylinder": {"max_num": Cn, "min_num": 4},
                            "env": {"num_envs": E, "max_episode_length": max_len}}, algo={"use_TP_net": 1, "critic_input": "state"})
     env = HideAndSeek(cfg)
     env.TP.load_state_dict({k: torch.from_numpy(g["w_" + k.replace(".", "_")]) for k in env.TP.state_dict()})

@@ -17,17 +17,26 @@ def _load_weights(tp, g):
 
 import pytest
 
+GOLDENS = ["g_tp_obs", "g_tp_obs_a6", "g_tp_obs_obst"]     # 3 pursuers, 6 pursuers, 3 pursuers + task.use_obstacles
 
-@pytest.mark.parametrize("name", ["g_tp_obs", "g_tp_obs_a6"])
+
+def _golden_cfg(g):
+    E, A, C, T, max_len = (int(x) for x in g["meta"])
+    obst = int(g["use_obstacles"]) if "use_obstacles" in g else 0
+    cfg = config.make_cfg({"num_agents": A, "drone_detect_radius": 0.9, "use_obstacles": obst, "cylinder": {"max_num": C, "min_num": 4},
+                           "env": {"num_envs": E, "max_episode_length": max_len}}, algo={"use_TP_net": 1})
+    return cfg, obst
+
+
+@pytest.mark.parametrize("name", GOLDENS)
 def test_tp_observation_matches_reference(golden, name):
     g = golden(name)
     E, A, C, T, max_len = (int(x) for x in g["meta"])
-    cfg = config.make_cfg({"num_agents": A, "drone_detect_radius": 0.9, "cylinder": {"max_num": C, "min_num": 4},
-                           "env": {"num_envs": E, "max_episode_length": max_len}})
+    cfg, obst = _golden_cfg(g)
     c = config.resolve_hns_cfg(cfg)
-    tp = TPNet(7 + 3 * A, 15, 5, 1)
+    tp = TPNet(7 + 3 * A + (3 * C if obst else 0), 15, 5, 1)
     _load_weights(tp, g)
-    helper = TPObservation(tp, A, 0.9, 1.2, max_len)
+    helper = TPObservation(tp, A, 0.9, 1.2, max_len, cylinder_size=float(c.cylinder_size) if obst else None)
     arrs = O.alloc_buffers(c)
     arrs["cylinders"][:] = g["cyl"]
     saw_masked = False
@@ -40,7 +49,8 @@ def test_tp_observation_matches_reference(golden, name):
         assert (bdet == g["broadcast_detect"][t][:, 0]).all()
         saw_masked |= bool((~bdet).any())
         ss, sd, tpd = helper(torch.from_numpy(arrs["obs_self"]), torch.from_numpy(g["pos"][t]), torch.from_numpy(g["tpos"][t][:, 0]),
-                             torch.from_numpy(g["tvel"][t][:, 0]), torch.from_numpy(g["progress"][t]), torch.from_numpy(bdet))
+                             torch.from_numpy(g["tvel"][t][:, 0]), torch.from_numpy(g["progress"][t]), torch.from_numpy(bdet),
+                             cylinders=torch.from_numpy(g["cyl"]))
         np.testing.assert_allclose(tpd["TP_input"].numpy(), g["TP_input"][t], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(ss.numpy(), g["state_self"][t][:, :, 0], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(sd.numpy(), g["state_drones"][t], rtol=1e-5, atol=1e-5)
@@ -55,15 +65,16 @@ def test_tp_net_state_dict_is_reference_compatible():
     assert tp(torch.zeros(4, 10, 16)).shape == (4, 15)
 
 
-@pytest.mark.parametrize("name", ["g_tp_obs", "g_tp_obs_a6"])
+@pytest.mark.parametrize("name", GOLDENS)
 def test_oracle_tp_observe_matches_reference(golden, name):
     """The C restatement of the whole TP branch (window, LSTM, output layer, rows) against the reference's
-    `_compute_state_and_obs` + its own TP_net, for 3 pursuers (16-value frames) and 6 (25-value frames)."""
+    `_compute_state_and_obs` + its own TP_net, for 3 pursuers (16-value frames), 6 (25-value frames) and
+    3 with task.use_obstacles (31-value frames: the cylinders ride in the frame)."""
     g = golden(name)
     E, A, C, T, max_len = (int(x) for x in g["meta"])
-    cfg = config.make_cfg({"num_agents": A, "drone_detect_radius": 0.9, "cylinder": {"max_num": C, "min_num": 4},
-                           "env": {"num_envs": E, "max_episode_length": max_len}})
+    cfg, obst = _golden_cfg(g)
     c = config.resolve_hns_cfg(cfg)
+    assert int(c.tp_use_obstacles) == obst
     arrs = O.alloc_buffers(c)
     tpa = O.alloc_tp_buffers(c, 10, 5)
     from hns_amd import abi

@@ -10,20 +10,24 @@ class TPObservation:
     (tests only; the env never calls it)."""
 
     def __init__(self, tp, num_agents, arena_size, max_height, max_episode_length, history_step=10, future_step=5,
-                 mask_value=-5.0):
+                 mask_value=-5.0, cylinder_size=None):
         self.tp, self.A = tp, num_agents
         self.arena_size, self.max_height, self.max_len = arena_size, max_height, max_episode_length
         self.history_step, self.future_step, self.mask_value = history_step, future_step, mask_value
+        self.cylinder_size = cylinder_size                      # not None: task.use_obstacles (hideandseek.py:808-816)
         self.history = collections.deque(maxlen=history_step)   # never reset per env (hideandseek.py:825-830)
 
     @torch.no_grad()
-    def __call__(self, obs_self20, drone_pos, target_pos, target_vel, progress, detect):
+    def __call__(self, obs_self20, drone_pos, target_pos, target_vel, progress, detect, cylinders=None):
         """obs_self20 [E,A,20] (kernel), drone_pos [E,A,3], target_pos/vel [E,3], progress [E], detect [E] bool."""
         E, A = drone_pos.shape[:2]
         det = detect.reshape(E, 1).bool()
         mv = torch.full_like(target_pos, self.mask_value)
         frame = torch.cat([progress.reshape(E, 1), torch.where(det, target_pos, mv), torch.where(det, target_vel, mv),
                            drone_pos.reshape(E, -1)], dim=-1)                                   # :815-820
+        if self.cylinder_size is not None:
+            frame = torch.cat([frame, torch.cat([cylinders[..., :2], torch.full_like(cylinders[..., :1], self.cylinder_size)],
+                                                dim=-1).reshape(E, -1)], dim=-1)                   # :808-816
         if len(self.history) < self.history_step:
             for _ in range(self.history_step):
                 self.history.append(frame)
