@@ -6,7 +6,8 @@ import torch, hns_amd
 from hns_amd import config
 from hns_amd.env import HideAndSeek
 E, L, STEPS = 65536, 400, int(sys.argv[1]) if len(sys.argv) > 1 else 4000
-modes = {"3v1": ({}, {}), "3v1 + predictor": ({}, {"use_TP_net": 1}), "6v2 (extension)": ({"num_agents": 6, "num_targets": 2, "cylinder": {"max_num": 16, "min_num": 8}}, {})}
+modes = {"3v1": ({}, {}), "3v1 + predictor": ({}, {"use_TP_net": 1}),
+         "3v1 + predictor + obstacles in the frame": ({"use_obstacles": 1, "cylinder": {"max_num": 5, "min_num": 4}}, {"use_TP_net": 1}), "6v2 (extension)": ({"num_agents": 6, "num_targets": 2, "cylinder": {"max_num": 16, "min_num": 8}}, {})}
 for name, (task, algo) in modes.items():
     t = {"cylinder": {"max_num": 8, "min_num": 4}, "env": {"num_envs": E, "max_episode_length": L}}
     t.update(task)
