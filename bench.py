@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=100)
     ap.add_argument("--time-every", type=int, default=32)
+    ap.add_argument("--stream-groups", type=int, default=2, help="secondary leg: shards of the env batch on separate HIP streams of one GPU (0/1 = skip)")
+    ap.add_argument("--group-steps", type=int, default=1000)
     ap.add_argument("--tp-steps", type=int, default=300,
                     help="extra untimed-in-`value` leg: steps with the trajectory predictor in the observation "
                          "(algo.use_TP_net: 1, the reference's default config), reported as `tp_mode`; 0 = skip")
@@ -197,6 +199,43 @@ def main():
                    "what": "hns_step + hns_tp_observe (window shift, LSTM(16->64)x10 + FC on the matrix cores, 35-value rows)"}
         del env_tp
 
+    # secondary leg: the same 65 536 envs as G shards on G HIP streams of this GPU (the multi-GPU sharding applied
+    # inside one GPU).  Shards are independent, so the tail of one shard's launch — workgroups draining their stores —
+    # overlaps the load burst and the arithmetic of the others; an asynchronous (double-buffered) collector gets this
+    # rate.  Not the headline: the per-launch roofline above needs serial launches to mean anything.
+    streams_mode = None
+    if args.stream_groups > 1 and world == 1 and args.targets == 1 and E % args.stream_groups == 0:
+        G, Eg = args.stream_groups, E // args.stream_groups
+        cfg_g = config.make_cfg({"num_agents": A, "cylinder": {"max_num": C, "min_num": C, "obs_max_cylinder": K},
+                                 "env": {"num_envs": Eg, "max_episode_length": args.episode},
+                                 "sim": {"device": f"cuda:{local_rank}"}})
+        shards = []
+        for gidx in range(G):
+            sh = HideAndSeek(cfg_g, headless=True, env_index_offset=gidx * Eg, write_critic_state=args.critic_state)
+            sh.set_seed(0)
+            sh.reset()
+            shards.append(sh)
+        gstreams = [torch.cuda.Stream(device) for _ in range(G)]
+        gptr = [Cx.c_void_p(st.cuda_stream) for st in gstreams]
+        gact = [[Cx.c_void_p(a[gidx * Eg:(gidx + 1) * Eg].data_ptr()) for a in actions] for gidx in range(G)]
+        torch.cuda.synchronize(device)
+
+        def run_groups(n):
+            for i in range(n):
+                for gidx in range(G):
+                    assert lib.hns_step(shards[gidx]._env, gact[gidx][i % R], gptr[gidx]) == 0, lib.hns_last_error()
+        run_groups(100)
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        run_groups(args.group_steps)
+        torch.cuda.synchronize(device)
+        dt_g = time.perf_counter() - t2
+        ms_g = dt_g / args.group_steps * 1e3
+        streams_mode = {"groups": G, "value": round(E * A * args.group_steps / dt_g, 1), "unit": "agent-steps/s", "steps": args.group_steps,
+                        "ms_per_step": round(ms_g, 5), "hbm_frac": round(b_env * E / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "what": f"the same {E} envs as {G} shards of {Eg} on {G} HIP streams (no join between steps)"}
+        del shards
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import numpy as np
@@ -253,7 +292,7 @@ def main():
                        "sharding": f"contiguous env slices x{world}",
                        "collective": "1 all-gather of 5 fp64 per 64-step rollout" if world > 1 else "none"},
             "env_frames_per_s": round(value / A, 1),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "tp_mode": tp_mode,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "tp_mode": tp_mode, "stream_shards": streams_mode,
         }
         print(json.dumps(out))
     if world > 1:
