@@ -382,14 +382,23 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
             }
     }
     float *hist = p.tp.history + (size_t)ec * T * I;       // this env's window, [T][I]
-    // Window rows are read with unconditional loads (one wait for all of them): 16-byte loads when the frame
-    // fills its chunks exactly (I = 16 NXC, e.g. 3 pursuers), else per-element loads with the column clamped
-    // into the row (padding lanes are zeroed afterwards).  Per-element predicated loads cost the timestep
-    // loop ~4 000 cycles of serialised memory latency per iteration.
+    // Window rows are read with unconditional loads (one wait for all of them; per-element predicated loads cost
+    // the timestep loop ~4 000 cycles of serialised memory latency per iteration): 16-byte global loads when the
+    // frame fills its chunks exactly (I = 16 NXC, e.g. 3 pursuers).  Otherwise rows are only 4-byte aligned and
+    // shorter than their chunks: raw BUFFER loads/stores through a descriptor over this workgroup's part of the
+    // window — one lane offset + immediates instead of 16 clamped 64-bit addresses (that version spilled 15-39
+    // registers), the hardware range check returns 0 past the end of the buffer, and values past the end of
+    // the ROW (they belong to the next row) are zeroed / not stored by the k < I selects below.
     const bool vec = (I == 16 * NXC);
+    const int e_wg = blockIdx.x * kTpEnvs;
+    const long long wg_bytes = (long long)(p.E - e_wg) * T * I * 4;
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.tp.history + (size_t)e_wg * T * I), 0, (int)(wg_bytes < (long long)kTpEnvs * T * I * 4 ? wg_bytes : (long long)kTpEnvs * T * I * 4),
+        0x00020000);
+    const int lane_off = (((ec - e_wg) * T) * I + 8 * hb) * 4;            // bytes from the descriptor's base
     auto load_row = [&](int slot, float (&dst)[8 * NXC]) {
-        const float *row = hist + (size_t)slot * I;
         if (vec) {
+            const float *row = hist + (size_t)slot * I;
 #pragma unroll
             for (int cx = 0; cx < NXC; ++cx) {
                 const float4 a = *reinterpret_cast<const float4 *>(row + 16 * cx + 8 * hb);
@@ -398,32 +407,39 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
                 dst[8 * cx + 4] = b.x; dst[8 * cx + 5] = b.y; dst[8 * cx + 6] = b.z; dst[8 * cx + 7] = b.w;
             }
         } else {
+            const int off = lane_off + slot * I * 4;
 #pragma unroll
             for (int cx = 0; cx < NXC; ++cx)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int k = 16 * cx + 8 * hb + j;
-                    const float v = row[k < I ? k : I - 1];
-                    dst[8 * cx + j] = k < I ? v : 0.0f;
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hrsrc, off + (16 * cx + j) * 4, 0, 0));
+                    dst[8 * cx + j] = (16 * cx + 8 * hb + j) < I ? v : 0.0f;
                 }
         }
     };
     auto store_row = [&](int slot, const float (&src)[8 * NXC]) {
-        float *row = hist + (size_t)slot * I;
         if (vec) {
+            float *row = hist + (size_t)slot * I;
 #pragma unroll
             for (int cx = 0; cx < NXC; ++cx) {
                 *reinterpret_cast<float4 *>(row + 16 * cx + 8 * hb) = make_float4(src[8 * cx], src[8 * cx + 1], src[8 * cx + 2], src[8 * cx + 3]);
                 *reinterpret_cast<float4 *>(row + 16 * cx + 8 * hb + 4) = make_float4(src[8 * cx + 4], src[8 * cx + 5], src[8 * cx + 6], src[8 * cx + 7]);
             }
         } else {
+            const int off = lane_off + slot * I * 4;
 #pragma unroll
-            for (int cx = 0; cx < NXC; ++cx)
+            for (int cx = 0; cx < NXC; ++cx) {
+                if (16 * cx + 16 <= I) {                  // both half-waves' groups lie inside the row (uniform)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = 16 * cx + 8 * hb + j;
-                    if (k < I) row[k] = src[8 * cx + j];
+                    for (int j = 0; j < 8; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, src[8 * cx + j]), hrsrc, off + (16 * cx + j) * 4, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (16 * cx + 8 * hb + j < I)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, src[8 * cx + j]), hrsrc, off + (16 * cx + j) * 4, 0, 0);
                 }
+            }
         }
     };
     // x_t = old frame t+1 for t <= T-2, the new frame for t = T-1 (or for every t when filling)
@@ -468,13 +484,12 @@ __global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams 
         int lo = lane;
         asm volatile("" : "+v"(lo));
         const uint4 *aw = simg + lo;
-        // units 0..31 (gate tiles m = 2q) then 32..63 (m = 2q + 1); where the registers allow it the cell update
-        // of the first half rides between the MFMAs of the second
+        // units 0..31 (gate tiles m = 2q) then 32..63 (m = 2q + 1); the cell update of the first half rides between
+        // the MFMAs of the second (not at t = 0: too few MFMAs without the recurrent product)
         f32x16 acc0[4], acc1[4];
         TpCellCtx cell0{acc0, c, hn0, hh, hl, {}}, cell1{acc1, c, hn0, hh, hl, {}};
         tp_gate_tiles<NXC, WITH_H>(acc0, aw, 0, hb, sBias, xh, xl, hh, hl);
-        // (the two-chunk frame of 4..7 pursuers has no registers left for it: both accumulator sets live = spills)
-        constexpr bool SIDE = WITH_H && NXC == 1;
+        constexpr bool SIDE = WITH_H;
         if constexpr (SIDE) {
             tp_gate_tiles<NXC, WITH_H, true>(acc1, aw, 1, hb, sBias, xh, xl, hh, hl, &cell0);
         } else {
