@@ -51,6 +51,7 @@ namespace hns {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kTpH = HNS_TP_HIDDEN;
 constexpr int kTpWaves = 8;
@@ -201,40 +202,42 @@ struct TpCellCtx {
     float (&h)[16];           // TJ = 0: h_t of these units, parked while tile pair 1 still reads h_{t-1}
     half8 (&hh)[4];           // TJ = 1: h_{t-1} is dead by then, h_t goes straight into the next B operands
     half8 (&hl)[4];
-    float t[10];
+    f32x2 t[5];               // the unit pair in flight: two values per register pair, so the adds / fmas / muls are v_pk_*
 };
+// v_exp_f32 / v_rcp_f32 on both halves of a pair (transcendentals have no packed form; measured 8 cycles each)
+HNS_DEV f32x2 tp_exp2_2(f32x2 v) { return (f32x2){__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])}; }
+HNS_DEV f32x2 tp_fma_2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+HNS_DEV f32x2 tp_rcp_2(f32x2 v) { return (f32x2){__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; }
 template <int TJ>
 struct TpCell {
     static constexpr int N = 40;
     template <int K>
     static __device__ __forceinline__ void slice(TpCellCtx &x) {
         constexpr int S = K % 5, u0 = 2 * (K / 5), u1 = u0 + 1;
-        float *t = x.t;
+        f32x2 *t = x.t;
         if constexpr (S == 0) {            // 1 + e_i, 1 + e_f
-            t[0] = 1.0f + __builtin_amdgcn_exp2f(x.z[0][u0]); t[1] = 1.0f + __builtin_amdgcn_exp2f(x.z[0][u1]);
-            t[2] = 1.0f + __builtin_amdgcn_exp2f(x.z[1][u0]); t[3] = 1.0f + __builtin_amdgcn_exp2f(x.z[1][u1]);
+            t[0] = tp_exp2_2((f32x2){x.z[0][u0], x.z[0][u1]}) + 1.0f;
+            t[1] = tp_exp2_2((f32x2){x.z[1][u0], x.z[1][u1]}) + 1.0f;
         } else if constexpr (S == 1) {     // 1 + e_g; i, f
-            t[4] = 1.0f + __builtin_amdgcn_exp2f(x.z[2][u0]); t[5] = 1.0f + __builtin_amdgcn_exp2f(x.z[2][u1]);
-            t[0] = __builtin_amdgcn_rcpf(t[0]); t[1] = __builtin_amdgcn_rcpf(t[1]);
-            t[2] = __builtin_amdgcn_rcpf(t[2]); t[3] = __builtin_amdgcn_rcpf(t[3]);
+            t[2] = tp_exp2_2((f32x2){x.z[2][u0], x.z[2][u1]}) + 1.0f;
+            t[0] = tp_rcp_2(t[0]);
+            t[1] = tp_rcp_2(t[1]);
         } else if constexpr (S == 2) {     // g = tanh; c' = f c + i g; e_c
-            const float g0 = HNS_FMA(2.0f, __builtin_amdgcn_rcpf(t[4]), -1.0f), g1 = HNS_FMA(2.0f, __builtin_amdgcn_rcpf(t[5]), -1.0f);
-            const float c0 = HNS_FMA(t[2], x.c[16 * TJ + u0], t[0] * g0), c1 = HNS_FMA(t[3], x.c[16 * TJ + u1], t[1] * g1);
-            x.c[16 * TJ + u0] = c0; x.c[16 * TJ + u1] = c1;
-            t[6] = __builtin_amdgcn_exp2f(c0 * (2.0f * kNegLog2e)); t[7] = __builtin_amdgcn_exp2f(c1 * (2.0f * kNegLog2e));
+            const f32x2 g = tp_fma_2(tp_rcp_2(t[2]), (f32x2)2.0f, (f32x2)-1.0f);
+            const f32x2 cn = tp_fma_2(t[1], (f32x2){x.c[16 * TJ + u0], x.c[16 * TJ + u1]}, t[0] * g);
+            x.c[16 * TJ + u0] = cn[0]; x.c[16 * TJ + u1] = cn[1];
+            t[3] = tp_exp2_2(cn * (2.0f * kNegLog2e));
         } else if constexpr (S == 3) {     // o; 1 + e_c
-            t[8] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x.z[3][u0]));
-            t[9] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x.z[3][u1]));
-            t[6] = 1.0f + t[6]; t[7] = 1.0f + t[7];
+            t[4] = tp_rcp_2(tp_exp2_2((f32x2){x.z[3][u0], x.z[3][u1]}) + 1.0f);
+            t[3] = t[3] + 1.0f;
         } else {                           // h' = o tanh(c')
-            const float h0 = t[8] * HNS_FMA(2.0f, __builtin_amdgcn_rcpf(t[6]), -1.0f);
-            const float h1 = t[9] * HNS_FMA(2.0f, __builtin_amdgcn_rcpf(t[7]), -1.0f);
+            const f32x2 h = t[4] * tp_fma_2(tp_rcp_2(t[3]), (f32x2)2.0f, (f32x2)-1.0f);
             if constexpr (TJ == 0) {
-                x.h[u0] = h0; x.h[u1] = h1;
+                x.h[u0] = h[0]; x.h[u1] = h[1];
             } else {
                 _Float16 a0, b0, a1, b1;
-                tp_split(h0, a0, b0);
-                tp_split(h1, a1, b1);
+                tp_split(h[0], a0, b0);
+                tp_split(h[1], a1, b1);
                 x.hh[2 + (u0 >> 3)][u0 & 7] = a0; x.hl[2 + (u0 >> 3)][u0 & 7] = b0;
                 x.hh[2 + (u1 >> 3)][u1 & 7] = a1; x.hl[2 + (u1 >> 3)][u1 & 7] = b1;
             }
