@@ -15,6 +15,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built extension (the .so files are git-ignored): build once, here or on the GPU box
+    from hns_amd import abi
+    if not os.path.exists(abi.library_path()):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
