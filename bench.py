@@ -74,7 +74,13 @@ def main():
     device = torch.device("cuda", local_rank)
 
     import hns_amd  # noqa: F401
-    from hns_amd import config
+    from hns_amd import abi, config
+    if not os.path.exists(abi.library_path()):            # fresh checkout: the .so files are git-ignored
+        if rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        if world > 1:
+            dist.barrier()
     from hns_amd.env import HideAndSeek
 
     E, A, C, K = args.envs, args.agents, args.cylinders, 3
