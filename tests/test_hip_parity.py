@@ -306,3 +306,46 @@ def test_steps_captured_in_a_hip_graph_replay_identically():
     a, b = eager.export_state(), graphed.export_state()
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def test_stream_shards_reproduce_the_whole_batch():
+    """The batch as independent shards on separate HIP streams of one GPU (bench.py's `stream_shards` leg, the
+    multi-GPU sharding applied inside a GPU): every buffer equals the corresponding slice of the one-launch batch."""
+    from hns_amd.env import HideAndSeek
+    E, A, C, G = 640, 3, 8, 4
+    mk = lambda e, off: HideAndSeek(config.make_cfg({"num_agents": A, "cylinder": {"max_num": C, "min_num": 4},
+                                                     "env": {"num_envs": e, "max_episode_length": 12}}),
+                                    headless=True, env_index_offset=off, write_critic_state=True)
+    whole = mk(E, 0)
+    shards = [mk(E // G, g * (E // G)) for g in range(G)]
+    streams = [torch.cuda.Stream(whole.device) for _ in range(G)]
+    for env in [whole] + shards:
+        env.set_seed(77)
+        env.reset()
+    gen = torch.Generator().manual_seed(3)
+    for t in range(30):
+        act = (torch.randn(E, A, 4, generator=gen) * 0.8).to(whole.device)
+        td = whole.step(whole.rand_step_input(act))
+        torch.cuda.synchronize()
+        for g, (env, st) in enumerate(zip(shards, streams)):
+            with torch.cuda.stream(st):
+                env.step(env.rand_step_input(act[g * (E // G):(g + 1) * (E // G)].contiguous()))
+        torch.cuda.synchronize()                                # `act` is re-allocated next iteration
+        if (t + 1) % 12 == 0:                                   # lock-step episode end: masked reset everywhere
+            done = td[("next", "done")].squeeze(-1).clone()      # a view of the env's own buffer (reset clears it): clone, as consumers do
+            rtd = whole.rand_step_input()
+            rtd.set("_reset", done)
+            whole.reset(rtd)
+            torch.cuda.synchronize()
+            for g, (env, st) in enumerate(zip(shards, streams)):
+                with torch.cuda.stream(st):
+                    r = env.rand_step_input()
+                    r.set("_reset", done[g * (E // G):(g + 1) * (E // G)].contiguous())
+                    env.reset(r)
+    torch.cuda.synchronize()
+    ref = whole.export_state()
+    for g, env in enumerate(shards):
+        sl = slice(g * (E // G), (g + 1) * (E // G))
+        for k, v in env.export_state().items():
+            want = ref[k][:, sl] if k == "stats" else ref[k][sl]
+            np.testing.assert_array_equal(v, want, err_msg=f"shard {g}: buffer {k}")
