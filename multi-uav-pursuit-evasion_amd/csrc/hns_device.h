@@ -134,10 +134,15 @@ HNS_DEV Q4 d_euler_to_quat(float r, float p, float y) {
 // ---- A1 + A2: action -> CTBR -> body-rate PID -> motor commands ------------------------------
 // omni_drones/utils/torchrl/transforms.py:425-459,
 // omni_drones/controllers/lee_position_controller.py:476-550
-HNS_DEV void d_ctbr_pid(const hns_cfg &c, const float4 &action, const Q4 &q, const V3 &angvel,
-                        float4 &prev_action, float4 &integ4, float4 &last4, float cmd[4], float &action_error,
-                        float *ctbr_out = nullptr, float *target_out = nullptr) {
-    float a0 = d_tanhf(action.x), a1 = d_tanhf(action.y), a2 = d_tanhf(action.z), a3 = d_tanhf(action.w);
+// the squashing of the raw policy output (transforms.py:431) on its own: it needs nothing but the action, so the
+// step kernel evaluates it while the state is still on its way from HBM
+HNS_DEV float4 d_action_tanh(const float4 &action) {
+    return make_float4(d_tanhf(action.x), d_tanhf(action.y), d_tanhf(action.z), d_tanhf(action.w));
+}
+HNS_DEV void d_ctbr_pid_squashed(const hns_cfg &c, const float4 &ta, const Q4 &q, const V3 &angvel,
+                                 float4 &prev_action, float4 &integ4, float4 &last4, float cmd[4], float &action_error,
+                                 float *ctbr_out = nullptr, float *target_out = nullptr) {
+    float a0 = ta.x, a1 = ta.y, a2 = ta.z, a3 = ta.w;
     float ctbr[4] = {a0, a1, a2, d_clamp((a3 + 1.0f) / 2.0f, 0.0f, c.max_thrust_ratio)};
     if (c.fixed_yaw) ctbr[2] = 0.0f;
     float d0 = ctbr[0] - prev_action.x, d1 = ctbr[1] - prev_action.y, d2 = ctbr[2] - prev_action.z,
@@ -185,6 +190,12 @@ HNS_DEV void d_ctbr_pid(const hns_cfg &c, const float4 &action, const Q4 &q, con
         else if (v == -kInf) v = -3.4028234663852886e38f;
         cmd[i] = v;
     }
+}
+
+HNS_DEV void d_ctbr_pid(const hns_cfg &c, const float4 &action, const Q4 &q, const V3 &angvel,
+                        float4 &prev_action, float4 &integ4, float4 &last4, float cmd[4], float &action_error,
+                        float *ctbr_out = nullptr, float *target_out = nullptr) {
+    d_ctbr_pid_squashed(c, d_action_tanh(action), q, angvel, prev_action, integ4, last4, cmd, action_error, ctbr_out, target_out);
 }
 
 // ---- A3: rotor lag + thrust/moment   omni_drones/actuators/rotor_group.py:55-71 --------------

@@ -343,6 +343,9 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
     float st[HNS_NUM_STATS];
 #pragma unroll
     for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = 0.0f;
+    // tanh of the raw action needs only the first record loaded: evaluated here, under the load burst (VALU idle)
+    float4 ta = make_float4(0, 0, 0, 0);
+    if (!env_wave && valid) ta = d_action_tanh(act4);
     __syncthreads();
     prof_mark(p.prof, 1);
     // issued after the barrier: the statistics are first needed behind phase 1, so their 6 MB stay out of the
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         if (valid) {
             load_rigid(sDS + tid * 13, s);
             float cmd[4], thr_diff;
-            d_ctbr_pid(c, act4, s.q, s.ang, prev4, integ4, last4, cmd, aerr);    // A1 + A2
+            d_ctbr_pid_squashed(c, ta, s.q, s.ang, prev4, integ4, last4, cmd, aerr);    // A1 + A2
             prof_mark(p.prof, 10);
             d_rotor(c, cmd, thr4, thrust, moment, thr_diff);                      // A3
             prof_mark(p.prof, 11);
