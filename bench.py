@@ -52,7 +52,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=100)
     ap.add_argument("--time-every", type=int, default=32)
-    ap.add_argument("--stream-groups", type=int, default=2, help="secondary leg: shards of the env batch on separate HIP streams of one GPU (0/1 = skip)")
+    ap.add_argument("--stream-groups", type=int, default=0,
+                    help="optional extra leg (e.g. 2): the env batch as shards on separate HIP streams of one GPU, reported as "
+                         "`stream_shards`; off by default so that a profile of the default command holds whole-batch launches only")
     ap.add_argument("--group-steps", type=int, default=1000)
     ap.add_argument("--tp-steps", type=int, default=300,
                     help="extra untimed-in-`value` leg: steps with the trajectory predictor in the observation "
