@@ -311,8 +311,9 @@ uint32_t hns_get_reset_epoch(const hns_env *env);
 int hns_set_state(hns_env *env, const hns_buffers *host, void *stream);
 int hns_get_state(hns_env *env, const hns_buffers *host, void *stream);
 
-/* Kernel timing: hns_enable_timing(env, n) brackets every n-th hns_step launch with hipEvents on
- * the launch stream (n = 0 disables).  hns_step_kernel_ms returns the average device time (ms)
+/* Kernel timing: hns_enable_timing(env, n) times every n-th hns_step launch with a start / stop hipEvent pair bound
+ * to that dispatch (hipExtLaunchKernelGGL: the timestamps of the kernel itself, on the launch stream; n = 0
+ * disables; not for use inside a stream capture).  hns_step_kernel_ms returns the average device time (ms)
  * of the sampled launches since the last call (synchronises on the last sample); <0 if none. */
 int hns_enable_timing(hns_env *env, int every_n);
 float hns_step_kernel_ms(hns_env *env, int *num_launches);
