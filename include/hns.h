@@ -211,11 +211,13 @@ int hns_hover_reset(const hns_cfg *cfg, const hns_hover_cfg *hover, const hns_ho
 
 typedef struct hns_env hns_env;
 
-/* Validate cfg, select the kernel specialisation, allocate nothing on the device. */
+/* Validate cfg, select the kernel specialisation, allocate nothing on the device.  The env belongs to the HIP
+ * device that is current at this call: bind buffers of that device and launch with it current. */
 int hns_create(const hns_cfg *cfg, hns_env **out);
 void hns_destroy(hns_env *env);
 
-/* Attach caller-owned device buffers (may be called again to re-point). */
+/* Attach caller-owned device buffers (may be called again to re-point).  Host pointers and memory of another
+ * GPU are refused here (HNS_ERR_INVALID_ARG) rather than faulting in a kernel; alignment is checked too. */
 int hns_bind(hns_env *env, const hns_buffers *buffers);
 
 /* One environment step for all E envs.  `action` = raw policy output [E,A,4] (pre-tanh),

@@ -27,6 +27,7 @@ struct hns_env {
     hns_cfg cfg;
     hns_buffers buf;
     bool bound = false;
+    int device = 0;          // the HIP device that was current at hns_create; bound buffers must live there
     uint32_t epoch = 0;
     int grid = 0, threads = 0;
     size_t lds_step = 0, lds_reset = 0;
@@ -40,6 +41,13 @@ struct hns_env {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;     // free event pairs
     hns_tp_state tp;
 };
+
+// true iff `ptr` is device (or managed) memory of the GPU the env was created on
+inline bool hns_on_env_device(const hns_env *env, const void *ptr) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) && attr.device == env->device;
+}
 
 #define HNS_CHECK_HIP(expr)                                                        \
     do {                                                                           \

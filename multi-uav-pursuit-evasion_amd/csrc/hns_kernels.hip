@@ -1188,6 +1188,7 @@ int hns_create(const hns_cfg *cfg, hns_env **out) {
     hns_env *env = new (std::nothrow) hns_env();
     if (!env) { set_error("hns_create: out of host memory"); return HNS_ERR_INVALID_ARG; }
     env->cfg = *cfg;
+    if (hipGetDevice(&env->device) != hipSuccess) env->device = 0;
     std::memset(&env->buf, 0, sizeof(env->buf));
     switch (cfg->num_agents) {
         case 1: select_kernels<1>(env); break;
@@ -1245,6 +1246,12 @@ int hns_bind(hns_env *env, const hns_buffers *buffers) {
         set_error("hns_bind: obs_others must be 8-byte aligned");
         return HNS_ERR_INVALID_ARG;
     }
+    // a host pointer (or memory of another GPU) here would fault inside the kernel: check once, at bind time
+    for (const void *ptr : req)
+        if (!hns_on_env_device(env, ptr)) {
+            set_error("hns_bind: every buffer must be device memory of the GPU that was current at hns_create (no host pointers)");
+            return HNS_ERR_INVALID_ARG;
+        }
     env->buf = *buffers;
     env->bound = true;
     return HNS_OK;

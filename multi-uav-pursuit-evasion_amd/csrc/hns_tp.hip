@@ -39,6 +39,7 @@
 // the cell update of units 0..31 is issued between the MFMAs of units 32..63 (TpCell / TpGate SIDE).
 #include <hip/hip_runtime.h>
 
+#include <initializer_list>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -670,6 +671,13 @@ int hns_tp_bind(hns_env *env, const hns_tp_buffers *b, int32_t history_step, int
         hns_set_error("hns_tp_bind: null buffer (only state_drones may be null)");
         return HNS_ERR_INVALID_ARG;
     }
+    for (const void *ptr : {(const void *)b->w_ih, (const void *)b->w_hh, (const void *)b->b_ih, (const void *)b->b_hh, (const void *)b->w_fc,
+                            (const void *)b->b_fc, (const void *)b->packed, (const void *)b->history, (const void *)b->pred,
+                            (const void *)b->obs_self, (const void *)b->groundtruth, (const void *)b->tp_done})
+        if (!hns_on_env_device(env, ptr)) {
+            hns_set_error("hns_tp_bind: every buffer (parameters included) must be device memory of the env's GPU");
+            return HNS_ERR_INVALID_ARG;
+        }
     if ((reinterpret_cast<uintptr_t>(b->packed) & 15) != 0) { hns_set_error("hns_tp_bind: packed must be 16-byte aligned"); return HNS_ERR_INVALID_ARG; }
     if (env->cfg.num_targets == 2) { hns_set_error("hns_tp_bind: the predictor's frame holds one evader (num_targets = 2 is not supported)"); return HNS_ERR_CONFIG; }
     if (tp_nxc(tp_frame_dim(env->cfg)) > 2) {

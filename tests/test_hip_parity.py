@@ -183,6 +183,15 @@ def test_error_paths():
     with pytest.raises(HnsError):
         make_env(64, 3, 8, K=5)                                # obs_max_cylinder > 4 unsupported by the kernels
     assert HideAndSeek.REGISTRY["hideandseek"] is HideAndSeek
+    # the C ABI refuses host memory at bind time instead of faulting in the kernel
+    import ctypes as C
+    host = {k: np.zeros(s, dtype=d) for k, (s, d) in abi.buffer_shapes(64, 3, 5, 3).items()}
+    hb = abi.HnsBuffers()
+    for k in abi.BUFFER_FIELDS:
+        setattr(hb, k, host[k].ctypes.data_as(C.c_void_p).value)
+    assert env._lib.hns_bind(env._env, C.byref(hb)) == abi.HNS_ERR_INVALID_ARG
+    assert b"device memory" in env._lib.hns_last_error()
+    env.step(env.rand_step_input())                            # the previous binding is untouched
 
 
 def test_tp_net_observation_on_gpu(golden):
