@@ -1258,6 +1258,11 @@ int hns_bind(hns_env *env, const hns_buffers *buffers) {
 }
 
 static int launch(hns_env *env, bool is_step, const Params &p, hipStream_t stream) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != env->device) {
+        set_error("hns_step / hns_reset: the current HIP device is not the one this env was created on");
+        return HNS_ERR_DEVICE;
+    }
     std::pair<hipEvent_t, hipEvent_t> ev{};
     const bool time_it = is_step && env->timing > 0 && (env->step_count++ % (uint64_t)env->timing) == 0;
     auto fn = is_step ? env->step_fn : env->reset_fn;
