@@ -411,6 +411,16 @@ class HideAndSeek:
         return out
 
     # ---- checkpoint / resume of the env state (the reference checkpoints the policy only, train.py:288-292) ----
+    def load_policy_checkpoint(self, checkpoint):
+        """Take the trajectory predictor's parameters from a checkpoint of the reference's MAPPO policy
+        (`MAPPOPolicy.state_dict()`, learning/mappo.py:477-484: {"TP", "critic", "actor_params", "value_normalizer"};
+        written by scripts/train.py:292,318 with torch.save).  `checkpoint` is that dict or a path to it."""
+        if not self.use_TP_net:
+            raise HnsError("load_policy_checkpoint: algo.use_TP_net is off, there is no predictor to load")
+        if not isinstance(checkpoint, dict):
+            checkpoint = torch.load(checkpoint, map_location="cpu")
+        self.TP.load_state_dict(checkpoint["TP"])        # in-place copy: the version counters move, hns_tp_refresh follows
+
     def save_state(self, path):
         """Snapshot every bound buffer + the host-side counters to an .npz file."""
         import numpy as np

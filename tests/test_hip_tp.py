@@ -190,3 +190,23 @@ def test_tp_snapshot_resume(tmp_path):
     assert torch.equal(env2._bufs["obs_self"], want_obs)
     for k, v in want.items():
         assert torch.equal(env2._tp_bufs[k], v), k
+
+
+def test_load_policy_checkpoint(tmp_path):
+    """The "TP" entry of a reference MAPPO checkpoint (mappo.py:477-484) drives the predictor after loading."""
+    a, b = _env(64, 3), _env(64, 3)
+    with torch.no_grad():
+        for prm in a.TP.parameters():
+            prm.mul_(2.5)
+    ckpt = {"TP": {k: v.detach().cpu() for k, v in a.TP.state_dict().items()}, "critic": {}, "actor_params": None, "value_normalizer": {}}
+    path = tmp_path / "checkpoint_final.pt"
+    torch.save(ckpt, path)
+    for env in (a, b):
+        env.reset()
+    b.load_policy_checkpoint(str(path))
+    act = torch.randn(64, 3, 4, device=a.device)
+    for _ in range(3):
+        a.step(a.rand_step_input(act))
+        b.step(b.rand_step_input(act))
+    torch.testing.assert_close(a._tp_bufs["pred"], b._tp_bufs["pred"], rtol=0, atol=0)
+    assert float(a._tp_bufs["pred"].abs().max()) > 0
