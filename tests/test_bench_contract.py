@@ -1,0 +1,34 @@
+"""bench.py's output contract on the GPU box: ONE JSON line with the driver's keys, the roofline object of the
+dominant kernel and the cpu_baseline object (small sizes; the numbers themselves are not asserted)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "64", "--warmup", "8", "--envs", "4096",
+                          "--cpu-steps", "3", "--tp-steps", "8", "--stream-groups", "2", "--group-steps", "16"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 64 and d["warmup"] == 8 and d["higher_is_better"] is True
+    assert d["unit"] == "agent-steps/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 4096 * 3 * 64 / (d["ms_per_step"] * 1e-3 * 64)) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["kernel_us"] > 0 and r["samples"] >= 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "agent-steps/s" and "sample" in c
+    assert d["tp_mode"]["value"] > 0 and d["stream_shards"]["groups"] == 2
