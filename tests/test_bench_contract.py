@@ -32,3 +32,20 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "agent-steps/s" and "sample" in c
     assert d["tp_mode"]["value"] > 0 and d["stream_shards"]["groups"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """The N > 1 path end to end as the driver launches it (torch.distributed.run, one rank per 'GPU'): on a 1-GPU
+    box both ranks share cuda:0 and the collective runs over gloo (HNS_DIST_BACKEND) instead of RCCL."""
+    env = dict(os.environ, HNS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "192", "--warmup", "16", "--envs", "4096"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout            # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["sharding"].endswith("x2") and "all-gather" in d["config"]["collective"]
+    assert abs(d["value"] - 2 * 4096 * 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3      # whole-job aggregate
+    assert d["cpu_baseline"] is None              # rank 0 at N = 1 only
