@@ -167,7 +167,8 @@ LIB_NAME = "libhns.so"
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+    """In-tree libhns.so; HNS_LIBRARY names another build of the same ABI (measurement builds, tools/step_lab.py)."""
+    return os.environ.get("HNS_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 
 def load_library():

@@ -21,6 +21,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -61,7 +62,18 @@ struct Params {
     uint32_t cyl_magic;         // ceil(2^32 / (3*C)): index / (3*C) as a multiply-high
     const float *tasks;         // reset: optional [E, 3A+3+3C] task vectors (envgen), else null
     int32_t task_first;         // envs >= task_first take their placement from `tasks`
+    uint32_t lab_stagger;
+    uint32_t lab;               // ablation switches of the measurement build (-DHNS_LAB, tools/step_lab.py); unused otherwise
 };
+
+// Measurement build only: parts of the step kernel can be switched off at run time (HNS_LAB_FLAGS) to time what is left.
+#ifdef HNS_LAB
+#define LAB(bit) ((p.lab & (bit)) != 0u)
+#else
+#define LAB(bit) false
+#endif
+enum { LAB_NOSTORE = 1, LAB_NOP1 = 2, LAB_NOP2 = 4, LAB_NOP3A = 8, LAB_NOP3B = 16, LAB_NOLOAD = 32,
+       LAB_NOST_SELF = 64, LAB_NOST_OTH = 128, LAB_NOST_REC = 256, LAB_NOST_DS = 512, LAB_NOST_OCYL = 1024, LAB_NOST_STATS = 2048 };
 
 constexpr int kProfSlots = 16;
 // lane 0 of every wave stamps s_memtime at a phase boundary (only when a buffer is attached)
@@ -160,7 +172,7 @@ HNS_DEV void store_rigid(float *r, const Rigid &s) {
 template <int A, int NT>
 HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigid &s, const V3 &tp, const V3 &tpB, float progress,
                        const float *cyl, const float *sDS, float *gOth, float *sOCyl, float *gSelf, float *gState,
-                       bool &blocked, bool &det, bool &blockedB, bool &detB, int knn_idx[kMaxK], bool knn_masked[kMaxK]) {
+                       bool &blocked, bool &det, bool &blockedB, bool &detB, int knn_idx[kMaxK], bool knn_masked[kMaxK], bool st = true, bool st_oth = true) {
     float rtx = s.pos.x - tp.x, rty = s.pos.y - tp.y, rtz = s.pos.z - tp.z;
     float dist = d_norm3(rtx, rty, rtz);
     const float t = progress * c.inv_max_episode_length;              // :796 (CUDA scalar-division form)
@@ -172,8 +184,8 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
     float4 v3 = make_float4(heading.z, up.x, up.y, up.z);
     float4 v4 = make_float4(t, t, t, t);
     float4 *so = reinterpret_cast<float4 *>(gSelf);                   // :856-863
-    so[0] = v0; so[1] = v1; so[2] = v2; so[3] = v3; so[4] = v4;
-    if (gState) {                                                      // :871-886 (never masked)
+    if (st) { so[0] = v0; so[1] = v1; so[2] = v2; so[3] = v3; so[4] = v4; }
+    if (gState && st) {                                                      // :871-886 (never masked)
         float4 *ss = reinterpret_cast<float4 *>(gState);
         ss[0] = v0; ss[1] = v1; ss[2] = v2; ss[3] = v3; ss[4] = v4;
     }
@@ -182,8 +194,8 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
         const float r1x = s.pos.x - tpB.x, r1y = s.pos.y - tpB.y, r1z = s.pos.z - tpB.z;
         dist1 = d_norm3(r1x, r1y, r1z);
         const float4 v5 = make_float4(r1x, r1y, r1z, 0.0f);
-        so[5] = v5;
-        if (gState) reinterpret_cast<float4 *>(gState)[5] = v5;
+        if (st) so[5] = v5;
+        if (gState && st) reinterpret_cast<float4 *>(gState)[5] = v5;
     }
     // state_others: p_i - p_j, j != i ascending (:750-751, utils/torch.py:41-53); (A-1)*3 floats per
     // thread, thread-contiguous in global memory
@@ -195,7 +207,8 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
             const float *rj = sDS + (le * A + j) * 13;
             o[3 * w] = s.pos.x - rj[0]; o[3 * w + 1] = s.pos.y - rj[1]; o[3 * w + 2] = s.pos.z - rj[2];
         }
-        if ((((A - 1) * 3) & 1) == 0) {
+        if (!st_oth) {
+        } else if ((((A - 1) * 3) & 1) == 0) {
             float2 *g2 = reinterpret_cast<float2 *>(gOth);
 #pragma unroll
             for (int i = 0; i < (A - 1) * 3 / 2; ++i) g2[i] = make_float2(o[2 * i], o[2 * i + 1]);
@@ -317,10 +330,16 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
 
     prof_mark(p.prof, 0);
     prof_mark(p.prof, 14);
+#ifdef HNS_LAB
+    if (p.lab_stagger) {            // experiment: workgroups of later dispatch rounds start their loads later
+        const int slot = (blockIdx.x >> 8) & 3;
+        for (int i = 0; i < slot * (int)p.lab_stagger; ++i) __builtin_amdgcn_s_sleep(8);   // 8 x 64 cycles
+    }
+#endif
     // ---- load: per-agent float4 records straight to registers, the rest through LDS ------------
     float4 act4 = make_float4(0, 0, 0, 0), thr4 = act4, integ4 = act4, last4 = act4, prev4 = act4;
     float progress = 0.0f;
-    if (valid) {
+    if (valid && !LAB(LAB_NOLOAD)) {
         progress = b.progress[e];
         if (!env_wave) {
             act4 = reinterpret_cast<const float4 *>(p.action)[ia];
@@ -331,14 +350,15 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         }
     }
     const bool full = nenv == kEPB;
-    if (full) {
+    if (LAB(LAB_NOLOAD)) {
+    } else if (full) {
         coop_copy_full<T, kEPB * A * 13>(sDS, b.drone_state + (size_t)e0 * A * 13);
         coop_copy_full<T, kEPB * 3 * NT>(sTp, b.target_pos + (size_t)e0 * 3 * NT);
     } else {
         coop_g2s<T>(sDS, b.drone_state + (size_t)e0 * A * 13, nenv * A * 13);
         coop_g2s<T>(sTp, b.target_pos + (size_t)e0 * 3 * NT, nenv * 3 * NT);
     }
-    coop_cyl<T, true>(sCyl, b.cylinders + (size_t)e0 * C * 3, nenv, 3 * C, L.cyl_stride, p.cyl_magic, nullptr);
+    if (!LAB(LAB_NOLOAD)) coop_cyl<T, true>(sCyl, b.cylinders + (size_t)e0 * C * 3, nenv, 3 * C, L.cyl_stride, p.cyl_magic, nullptr);
     // the env wave keeps its env's statistics in registers: row-major [S][E] makes every row a
     // fully coalesced 256-byte wave access, no LDS staging needed
     float st[HNS_NUM_STATS];
@@ -351,7 +371,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
     prof_mark(p.prof, 1);
     // issued after the barrier: the statistics are first needed behind phase 1, so their 6 MB stay out of the
     // bandwidth-bound load burst at the head of the launch and stream in under the phase-1 arithmetic
-    if (env_wave && valid) {
+    if (env_wave && valid && !LAB(LAB_NOLOAD)) {
 #pragma unroll
         for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = b.stats[(size_t)i * E + e];
     }
@@ -370,7 +390,9 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
     V3 tp0 = {0.f, 0.f, 0.f};
     if (valid) tp0 = {sTp[le * 3 * NT], sTp[le * 3 * NT + 1], sTp[le * 3 * NT + 2]};
     if (NT == 2 && valid) tp1 = {sTp[le * 3 * NT + 3], sTp[le * 3 * NT + 4], sTp[le * 3 * NT + 5]};
-    if (!env_wave) {
+    if (LAB(LAB_NOP1)) {
+        if (!env_wave && valid) load_rigid(sDS + tid * 13, s);
+    } else if (!env_wave) {
         if (valid) {
             load_rigid(sDS + tid * 13, s);
             float cmd[4], thr_diff;
@@ -421,7 +443,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         }
     }
     __syncthreads();
-    if (env_wave && valid) {
+    if (env_wave && valid && !LAB(LAB_NOP1)) {
         // force = sum over pursuers (ascending) + arena + cylinders; per-axis velocity (:741)
         V3 F = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -474,7 +496,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
 
     // ================= phase 2: forces, torques, integration (agent waves) ===========================
     if (!env_wave) {
-        if (valid) {
+        if (valid && !LAB(LAB_NOP2)) {
             V3 fdw = {0.f, 0.f, 0.f};                                             // A4: downwash, partners ascending
 #pragma unroll
             for (int o = 0; o < A - 1; ++o) {
@@ -496,6 +518,8 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
             prof_mark(p.prof, 12);
             d_integrate(c, s, fw, tb);                                            // A5
             prof_mark(p.prof, 13);
+        }
+        if (valid && !LAB(LAB_NOSTORE | LAB_NOST_REC)) {
             reinterpret_cast<float4 *>(b.throttle)[ia] = thr4;
             reinterpret_cast<float4 *>(b.pid_integ)[ia] = integ4;
             reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
@@ -514,7 +538,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
     }
     __syncthreads();
     prof_mark(p.prof, 8);
-    if (env_wave) {
+    if (env_wave && !LAB(LAB_NOSTORE | LAB_NOST_DS)) {
         // the env wave is idle during phase 3a: it writes back S_{t+1} (drone_state slice, evader)
         const int lane = tid - NA;
         const float4 *s4 = reinterpret_cast<const float4 *>(sDS);
@@ -539,7 +563,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
     }
 
     // ================= phase 3a: observation + per-agent reward terms on S_{t+1} =====================
-    if (!env_wave && valid) {
+    if (!env_wave && valid && !LAB(LAB_NOP3A)) {
         V3 tp = {sTp[le * 3 * NT], sTp[le * 3 * NT + 1], sTp[le * 3 * NT + 2]};
         V3 tpB = tp;
         if constexpr (NT == 2) tpB = {sTp[le * 3 * NT + 3], sTp[le * 3 * NT + 4], sTp[le * 3 * NT + 5]};
@@ -547,7 +571,8 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         int knn_idx[kMaxK];
         bool knn_masked[kMaxK];
         agent_obs<A, NT>(c, C, K, le, a, s, tp, tpB, progress, cyl, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * SD,
-                         with_state ? b.state_drones + ia * SD : nullptr, blocked, det, blockedB, detB, knn_idx, knn_masked);
+                         with_state ? b.state_drones + ia * SD : nullptr, blocked, det, blockedB, detB, knn_idx, knn_masked, !LAB(LAB_NOSTORE | LAB_NOST_SELF),
+                         !LAB(LAB_NOSTORE | LAB_NOST_OTH));
         prof_mark(p.prof, 9);
         // hideandseek.py:919-995
         float d = d_norm3(tp.x - s.pos.x, tp.y - s.pos.y, tp.z - s.pos.z);
@@ -604,7 +629,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
     prof_mark(p.prof, 5);
 
     // ================= phase 3b: per-env reductions, reward, done, stats (env wave) ===================
-    if (env_wave && valid) {
+    if (env_wave && valid && !LAB(LAB_NOP3B)) {
         const float iA = c.inv_num_agents;             // mean over agents = sum * (1/A), as torch's CUDA mean
         bool any_cap = false, all_blocked = true, any_coll = false, det_any = false, det_any1 = false;
         float sum_dist = 0, sum_speed = 0, sum_cc = 0, sum_cd = 0, sum_cw = 0, sum_coll = 0, sum_smooth = 0;
@@ -634,10 +659,10 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         for (int j = 0; j < A; ++j) {
             const float *red = sRed + (le * A + j) * kRed;
             float r = ((((red[R_DIST] + detect_rew) + catch_rew) + red[R_COLL]) + red[R_SPEED]) + red[R_SMOOTH];
-            b.reward[(size_t)e * A + j] = r;
+            if (!LAB(LAB_NOSTORE)) b.reward[(size_t)e * A + j] = r;
             sum_rew = (j == 0) ? r : sum_rew + r;
         }
-        if (!det_any) {                                        // hideandseek.py:791-794: mask the evader's rpos
+        if (!det_any && !LAB(LAB_NOSTORE)) {                   // hideandseek.py:791-794: mask the evader's rpos
 #pragma unroll
             for (int j = 0; j < A; ++j) {
                 float *o = b.obs_self + ((size_t)e * A + j) * SD;
@@ -693,14 +718,16 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         if constexpr (NT == 2) { if (b.detect) b.detect[e] = (uint8_t)((det_any ? 1 : 0) | (det_any1 ? 2 : 0)); }   // bit k: evader k detected
         else { if (b.detect) b.detect[e] = (uint8_t)det_any; }
         b.progress[e] = progress;
+        if (!LAB(LAB_NOSTORE | LAB_NOST_STATS)) {
 #pragma unroll
-        for (int i = 0; i < HNS_NUM_STATS; ++i) b.stats[(size_t)i * E + e] = st[i];
+            for (int i = 0; i < HNS_NUM_STATS; ++i) b.stats[(size_t)i * E + e] = st[i];
+        }
     }
     prof_mark(p.prof, 6);
     __syncthreads();
 
     // ================= store: contiguous slices, 16 B per lane =========================================
-    coop_s2g<T>(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5);
+    if (!LAB(LAB_NOSTORE | LAB_NOST_OCYL)) coop_s2g<T>(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5);
     prof_mark(p.prof, 7);
     prof_mark(p.prof, 15);
 }
@@ -1299,6 +1326,13 @@ int hns_step(hns_env *env, const float *action, void *stream) {
     p.cyl_magic = env->cyl_magic;
     p.tasks = nullptr;
     p.task_first = 0;
+#ifdef HNS_LAB
+    { const char *f = getenv("HNS_LAB_FLAGS"); p.lab = f ? (uint32_t)atoi(f) : 0u; }
+    { const char *f = getenv("HNS_LAB_STAGGER"); p.lab_stagger = f ? (uint32_t)atoi(f) : 0u; }
+#else
+    p.lab = 0;
+    p.lab_stagger = 0;
+#endif
     return launch(env, true, p, static_cast<hipStream_t>(stream));
 }
 
@@ -1317,6 +1351,8 @@ int hns_reset(hns_env *env, const uint8_t *reset_mask, uint64_t seed, void *stre
     p.cyl_magic = env->cyl_magic;
     p.tasks = nullptr;
     p.task_first = 0;
+    p.lab = 0;
+    p.lab_stagger = 0;
     return launch(env, false, p, static_cast<hipStream_t>(stream));
 }
 
@@ -1336,6 +1372,8 @@ int hns_reset_tasks(hns_env *env, const uint8_t *reset_mask, const float *tasks,
     p.cyl_magic = env->cyl_magic;
     p.tasks = tasks;
     p.task_first = task_first;
+    p.lab = 0;
+    p.lab_stagger = 0;
     return launch(env, false, p, static_cast<hipStream_t>(stream));
 }
 
