@@ -34,14 +34,17 @@ namespace hns {
 
 constexpr int kEPB = 64;   // envs per workgroup = lanes of the env wave
 constexpr int kMaxK = 4;   // top-k insertion network width (obs_max_cylinder <= 4)
-constexpr int kRed = 11;   // per-agent scalars handed to the env wave (odd stride: conflict-free)
-enum { R_AERR = 0, R_TD, R_DIST, R_SPEED, R_CC, R_CD, R_CW, R_COLL, R_SMOOTH, R_FLAGS,
+// per-agent scalars handed to the env wave: 8 live values at any time (odd stride: conflict-free), 11 with a second evader
+__host__ __device__ constexpr int red_stride(int NT) { return NT == 2 ? 11 : 9; }
+enum { R_AERR = 0, R_TD, R_DIST, R_SPEED, R_CC, R_CD, R_CW, R_COLL,
+       // phase 3 reuses the two slots the env wave drained right behind the first barrier (action error, throttle difference)
+       R_SMOOTH = R_AERR, R_FLAGS = R_TD,
        // the pursuer's push on the evader is consumed before phase 3 writes the reward terms: same slots
        R_FX = R_DIST, R_FY = R_SPEED, R_FZ = R_CC,
        // so is the thrust vector handed to the downwash partners (3 consecutive slots)
        R_TWX = R_CD,
-       // two-evader extension: the push on the second evader (slots 8..10, free before phase 3)
-       R_F1X = R_SMOOTH };
+       // two-evader extension: the push on the second evader (slots 8..10)
+       R_F1X = 8 };
 enum { F_CAP = 1, F_BLOCKED = 2, F_DET = 4, F_DET1 = 8 };
 constexpr int kGridStride = 516;   // bytes of reset scratch per env: 2 x 256 + 4 (an odd dword stride: lanes = envs hit different LDS banks)
 constexpr int kMaxT = 2;   // evaders per env (1 = the reference; 2 = BASELINE config 5's extension)
@@ -89,7 +92,14 @@ HNS_DEV void prof_mark(unsigned long long *prof, int slot) {
 struct Lds {
     int ds, cyl, cyl_stride, tp, red, ocyl, total;
 };
+__host__ __device__ inline int slab_floats(int A, int K, int NT);
 __host__ __device__ inline int r4(int n) { return (n + 3) & ~3; }
+__host__ __device__ inline int slab_floats(int A, int K, int NT) {
+    int m = 64 * (NT == 2 ? 24 : HNS_SELF_DIM);
+    if (64 * K * 5 > m) m = 64 * K * 5;
+    if (64 * (A - 1) * 3 > m) m = 64 * (A - 1) * 3;
+    return r4(m);
+}
 __host__ __device__ inline Lds lds_layout(int A, int C, int K, int NT = 1) {
     Lds L;
     int o = 0;
@@ -97,8 +107,11 @@ __host__ __device__ inline Lds lds_layout(int A, int C, int K, int NT = 1) {
     L.cyl_stride = (3 * C) | 1;                 // odd per-env stride: env-wave reads are conflict-free
     L.cyl = o;   o += r4(kEPB * L.cyl_stride);
     L.tp = o;    o += r4(kEPB * 3 * NT);
-    L.red = o;   o += r4(kEPB * A * kRed);
-    L.ocyl = o;  o += r4(kEPB * A * K * 5);
+    L.red = o;   o += r4(kEPB * A * red_stride(NT));
+    // obs_cylinders staging [64*A][K*5] (reset kernel, ragged tiles) / one wave-private slab per agent wave (step kernel):
+    // the slab holds the widest of a wave's three output slices (64 rows of state_self / k-nearest rows / state_others)
+    const int rows = kEPB * A * K * 5, slabs = A * slab_floats(A, K, NT);
+    L.ocyl = o;  o += r4(rows > slabs ? rows : slabs);
     L.total = o;
     return L;
 }
@@ -162,6 +175,76 @@ HNS_DEV void store_rigid(float *r, const Rigid &s) {
     r[10] = s.ang.x; r[11] = s.ang.y; r[12] = s.ang.z;
 }
 
+// ---- stores with an explicit cache policy --------------------------------------------------------------------------
+// HNS_ST_POLICY: 0 = plain (write-back: the lines stay dirty in the XCD's L2 and are flushed at the end of the launch),
+// 1 = sc1 (write-through: the bytes leave the L2 while the launch still computes; MI355X_MICROARCH.md, stores of each flavour)
+#ifndef HNS_ST_POLICY
+#define HNS_ST_POLICY 1
+#endif
+HNS_DEV void st_f4(float4 *p, const float4 &v) {
+#if HNS_ST_POLICY == 1
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+#else
+    *p = v;
+#endif
+}
+HNS_DEV void st_f1(float *p, float v) {
+#if HNS_ST_POLICY == 1
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+
+// ---- output rows of one agent wave: registers -> wave-private LDS slab -> ONE contiguous slice of global memory -----
+// Every [E,A,...] output keeps the reference's layout, so the 64 rows a wave produces are one contiguous slice of
+// 64*NF floats.  A thread storing its own row issues 16- (or 8-/4-) byte pieces at a stride of NF floats: every lane of
+// the store instruction lands on a different cache line (measured: state_self 1.6 us, state_others 1.0 us of the
+// 28 us step).  Instead the wave parks its rows in its slab and stores the slice back linearly, 16 B per lane, whole
+// lines per instruction.  The slab is private to the wave: LDS operations of one wave execute in order, no barrier.
+template <int NF>
+HNS_DEV void wave_store_rows(float *__restrict__ slab, float *__restrict__ gslice, const float (&row)[NF], int lane) {
+    float *mine = slab + lane * NF;
+    if constexpr (NF % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < NF / 4; ++i) reinterpret_cast<float4 *>(mine)[i] = make_float4(row[4 * i], row[4 * i + 1], row[4 * i + 2], row[4 * i + 3]);
+    } else if constexpr (NF % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < NF / 2; ++i) reinterpret_cast<float2 *>(mine)[i] = make_float2(row[2 * i], row[2 * i + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) mine[i] = row[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int N4 = 64 * NF / 4;                      // float4 pieces in the slice (64*NF is a multiple of 4)
+    const float4 *s4 = reinterpret_cast<const float4 *>(slab) + lane;
+    float4 *g4 = reinterpret_cast<float4 *>(gslice) + lane;
+#ifndef HNS_OUT_AUX
+#define HNS_OUT_AUX 16
+#endif
+#if HNS_OUT_AUX != 0
+    // cache policy of the output stores (aux: 1 = sc0, 2 = nt, 16 = sc1 write-through; measured A/B: plain 28.3, nt 27.9, sc1 27.2 us)
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)gslice, 0, 64 * NF * 4, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < (N4 + 63) / 64; ++j)
+        if (j * 64 + lane < N4) {
+            const float4 v = s4[j * 64];
+            __builtin_amdgcn_raw_buffer_store_b128((u4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, rs,
+                                                   (j * 64 + lane) * 16, 0, HNS_OUT_AUX);
+        }
+#else
+#pragma unroll
+    for (int j = 0; j < (N4 + 63) / 64; ++j)
+        if (j * 64 + lane < N4) g4[j * 64] = s4[j * 64];
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                     // the next pass may overwrite the slab only behind these reads
+}
+
 // ---- A8 (agent thread): observation of one pursuer on the post-physics state -------------------
 // multirotor.py:599-633, hideandseek.py:746-917.  obs_self / state_drones are stored straight to
 // global memory (5 float4 per thread, thread-contiguous); the relative position of the evader is
@@ -169,10 +252,15 @@ HNS_DEV void store_rigid(float *r, const Rigid &s) {
 // evader (:791-794).  Returns the flags and the k-nearest selection the reward pass needs.
 // Two-evader extension (NT = 2, not in the reference): rows grow to 24 values = the reference's 20 +
 // the relative position of the second evader + one zero; line of sight / detection per evader.
-template <int A, int NT>
+// STAGED (step kernel, full tiles): every output slice goes through the wave's slab (wave_store_rows); `sOCyl` is then
+// the slab of this wave and gOth / gSelf / gState / gOCyl are still the THREAD's rows (the wave's slice starts `lane` rows earlier).
+template <int A, int NT, bool STAGED = false>
 HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigid &s, const V3 &tp, const V3 &tpB, float progress,
                        const float *cyl, const float *sDS, float *gOth, float *sOCyl, float *gSelf, float *gState,
-                       bool &blocked, bool &det, bool &blockedB, bool &detB, int knn_idx[kMaxK], bool knn_masked[kMaxK], bool st = true, bool st_oth = true) {
+                       bool &blocked, bool &det, bool &blockedB, bool &detB, int knn_idx[kMaxK], bool knn_masked[kMaxK], bool st = true, bool st_oth = true,
+                       float *gOCyl = nullptr) {
+    constexpr int SDW = NT == 2 ? 24 : HNS_SELF_DIM;
+    const int lane = threadIdx.x & 63;
     float rtx = s.pos.x - tp.x, rty = s.pos.y - tp.y, rtz = s.pos.z - tp.z;
     float dist = d_norm3(rtx, rty, rtz);
     const float t = progress * c.inv_max_episode_length;              // :796 (CUDA scalar-division form)
@@ -184,18 +272,29 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
     float4 v3 = make_float4(heading.z, up.x, up.y, up.z);
     float4 v4 = make_float4(t, t, t, t);
     float4 *so = reinterpret_cast<float4 *>(gSelf);                   // :856-863
-    if (st) { so[0] = v0; so[1] = v1; so[2] = v2; so[3] = v3; so[4] = v4; }
-    if (gState && st) {                                                      // :871-886 (never masked)
-        float4 *ss = reinterpret_cast<float4 *>(gState);
-        ss[0] = v0; ss[1] = v1; ss[2] = v2; ss[3] = v3; ss[4] = v4;
+    if constexpr (!STAGED) {
+        if (st) { so[0] = v0; so[1] = v1; so[2] = v2; so[3] = v3; so[4] = v4; }
+        if (gState && st) {                                                      // :871-886 (never masked)
+            float4 *ss = reinterpret_cast<float4 *>(gState);
+            ss[0] = v0; ss[1] = v1; ss[2] = v2; ss[3] = v3; ss[4] = v4;
+        }
     }
     float dist1 = 0.0f;
+    float4 v5 = make_float4(0, 0, 0, 0);
     if constexpr (NT == 2) {
         const float r1x = s.pos.x - tpB.x, r1y = s.pos.y - tpB.y, r1z = s.pos.z - tpB.z;
         dist1 = d_norm3(r1x, r1y, r1z);
-        const float4 v5 = make_float4(r1x, r1y, r1z, 0.0f);
-        if (st) so[5] = v5;
-        if (gState && st) reinterpret_cast<float4 *>(gState)[5] = v5;
+        v5 = make_float4(r1x, r1y, r1z, 0.0f);
+        if constexpr (!STAGED) {
+            if (st) so[5] = v5;
+            if (gState && st) reinterpret_cast<float4 *>(gState)[5] = v5;
+        }
+    }
+    if constexpr (STAGED) {
+        float row[SDW] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w, v4.x, v4.y, v4.z, v4.w};
+        if constexpr (NT == 2) { row[20] = v5.x; row[21] = v5.y; row[22] = v5.z; row[23] = v5.w; }
+        if (st) wave_store_rows<SDW>(sOCyl, gSelf - lane * SDW, row, lane);
+        if (gState && st) wave_store_rows<SDW>(sOCyl, gState - lane * SDW, row, lane);
     }
     // state_others: p_i - p_j, j != i ascending (:750-751, utils/torch.py:41-53); (A-1)*3 floats per
     // thread, thread-contiguous in global memory
@@ -207,7 +306,9 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
             const float *rj = sDS + (le * A + j) * 13;
             o[3 * w] = s.pos.x - rj[0]; o[3 * w + 1] = s.pos.y - rj[1]; o[3 * w + 2] = s.pos.z - rj[2];
         }
-        if (!st_oth) {
+        if constexpr (STAGED) {
+            if (st_oth) wave_store_rows<(A > 1 ? A - 1 : 1) * 3>(sOCyl, gOth - lane * (A - 1) * 3, o, lane);
+        } else if (!st_oth) {
         } else if ((((A - 1) * 3) & 1) == 0) {
             float2 *g2 = reinterpret_cast<float2 *>(gOth);
 #pragma unroll
@@ -283,6 +384,7 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
         detB = (dist1 < c.drone_detect_radius) && !any_block1;
     }
     float *oc = sOCyl + (le * A + a) * K * 5;
+    float krow[kMaxK * 5];
 #pragma unroll
     for (int sidx = 0; sidx < kMaxK; ++sidx) {
         if (sidx < K) {
@@ -290,12 +392,34 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
             bool masked = cc[2] < 0.0f;                                // :759,775-778
             knn_idx[sidx] = bi[sidx];
             knn_masked[sidx] = masked;
-            float *row = oc + sidx * 5;
+            float *row = STAGED ? krow + sidx * 5 : oc + sidx * 5;
             row[0] = masked ? c.mask_value : s.pos.x - cc[0];
             row[1] = masked ? c.mask_value : s.pos.y - cc[1];
             row[2] = masked ? c.mask_value : s.pos.z - cc[2];
             row[3] = masked ? c.mask_value : c.cylinder_height;
             row[4] = masked ? c.mask_value : c.cylinder_size;
+        }
+    }
+    if constexpr (STAGED) {
+        if (st) {
+            if (K == 3) {
+                float r[15];
+#pragma unroll
+                for (int i = 0; i < 15; ++i) r[i] = krow[i];
+                wave_store_rows<15>(sOCyl, gOCyl - lane * 15, r, lane);
+            } else if (K == 4) {
+                wave_store_rows<20>(sOCyl, gOCyl - lane * 20, krow, lane);
+            } else if (K == 2) {
+                float r[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) r[i] = krow[i];
+                wave_store_rows<10>(sOCyl, gOCyl - lane * 10, r, lane);
+            } else {
+                float r[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) r[i] = krow[i];
+                wave_store_rows<5>(sOCyl, gOCyl - lane * 5, r, lane);
+            }
         }
     }
 }
@@ -305,10 +429,13 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
 // =================================================================================================
 // (the second evader costs ~15 registers: without the cap of 128 the 7-wave workgroups of the 6-pursuer
 //  shape drop from two per CU to one)
-template <int A, int NT>
+// FULL: the batch is a whole number of 64-env tiles (E % 64 == 0) — no lane is ever idle, so every `valid` test and
+// every default value behind it is compiled out; the generic instantiation serves ragged batches.
+template <int A, int NT, bool FULL>
 __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(const Params p) {
     constexpr int T = Geo<A>::T, NA = Geo<A>::NA;
     constexpr int SD = NT == 2 ? 24 : HNS_SELF_DIM;      // floats per state_self / state_drones row
+    constexpr int kRedS = red_stride(NT);
     extern __shared__ __align__(16) float smem[];
     const hns_cfg &c = p.cfg;
     const hns_buffers &b = p.buf;
@@ -320,12 +447,12 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
 
     const int tid = threadIdx.x;
     const int e0 = blockIdx.x * kEPB;
-    const int nenv = min(kEPB, E - e0);
+    const int nenv = FULL ? kEPB : min(kEPB, E - e0);
     const bool env_wave = tid >= NA;
     const int le = env_wave ? tid - NA : tid / A;      // local env
     const int a = env_wave ? 0 : tid - le * A;         // agent index (agent threads)
     const int e = e0 + le;
-    const bool valid = le < nenv;
+    const bool valid = FULL ? true : le < nenv;
     const size_t ia = (size_t)e0 * A + (env_wave ? 0 : tid);
 
     prof_mark(p.prof, 0);
@@ -349,7 +476,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
             prev4 = reinterpret_cast<const float4 *>(b.prev_action)[ia];
         }
     }
-    const bool full = nenv == kEPB;
+    const bool full = FULL ? true : nenv == kEPB;
     if (LAB(LAB_NOLOAD)) {
     } else if (full) {
         coop_copy_full<T, kEPB * A * 13>(sDS, b.drone_state + (size_t)e0 * A * 13);
@@ -405,7 +532,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
             // this pursuer's push on the evader (hideandseek.py:1074-1088), summed by the env wave
             bool blocked_pre = d_blocked(c, C, s.pos, tp0, cyl);                  // :1080
             V3 fp = d_prey_pursuer_term(c, s.pos, tp0, blocked_pre);
-            float *red = sRed + tid * kRed;
+            float *red = sRed + tid * kRedS;
             red[R_AERR] = aerr; red[R_TD] = thr_diff;
             red[R_FX] = fp.x; red[R_FY] = fp.y; red[R_FZ] = fp.z;
             red[R_TWX] = tw.x; red[R_TWX + 1] = tw.y; red[R_TWX + 2] = tw.z;
@@ -448,7 +575,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         V3 F = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < A; ++j) {
-            const float *red = sRed + (le * A + j) * kRed;
+            const float *red = sRed + (le * A + j) * kRedS;
             F.x = (j == 0) ? red[R_FX] : F.x + red[R_FX];
             F.y = (j == 0) ? red[R_FY] : F.y + red[R_FY];
             F.z = (j == 0) ? red[R_FZ] : F.z + red[R_FZ];
@@ -462,7 +589,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
             V3 G = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < A; ++j) {
-                const float *red = sRed + (le * A + j) * kRed;
+                const float *red = sRed + (le * A + j) * kRedS;
                 G.x = (j == 0) ? red[R_F1X] : G.x + red[R_F1X];
                 G.y = (j == 0) ? red[R_F1X + 1] : G.y + red[R_F1X + 1];
                 G.z = (j == 0) ? red[R_F1X + 2] : G.z + red[R_F1X + 2];
@@ -478,7 +605,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         float sum_ae = 0.f, sum_td = 0.f, max_td = 0.f;
 #pragma unroll
         for (int j = 0; j < A; ++j) {
-            const float *red = sRed + (le * A + j) * kRed;
+            const float *red = sRed + (le * A + j) * kRedS;
             const float td = red[R_TD];
             sum_ae = (j == 0) ? red[R_AERR] : sum_ae + red[R_AERR];
             sum_td = (j == 0) ? td : sum_td + td;
@@ -502,7 +629,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
             for (int o = 0; o < A - 1; ++o) {
                 const int j = o + (o >= a ? 1 : 0);
                 const float *rj = sDS + (le * A + j) * 13;
-                const float *tj = sRed + (le * A + j) * kRed + R_TWX;
+                const float *tj = sRed + (le * A + j) * kRedS + R_TWX;
                 V3 pj = {rj[0], rj[1], rj[2]};
                 V3 twj = {tj[0], tj[1], tj[2]};
                 V3 fj = d_downwash_pair(s.pos, pj, twj);
@@ -520,11 +647,11 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
             prof_mark(p.prof, 13);
         }
         if (valid && !LAB(LAB_NOSTORE | LAB_NOST_REC)) {
-            reinterpret_cast<float4 *>(b.throttle)[ia] = thr4;
-            reinterpret_cast<float4 *>(b.pid_integ)[ia] = integ4;
-            reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
-            reinterpret_cast<float4 *>(b.prev_action)[ia] = prev4;
-            b.action_error[ia] = aerr;
+            st_f4(reinterpret_cast<float4 *>(b.throttle) + ia, thr4);
+            st_f4(reinterpret_cast<float4 *>(b.pid_integ) + ia, integ4);
+            st_f4(reinterpret_cast<float4 *>(b.pid_last_rate) + ia, last4);
+            st_f4(reinterpret_cast<float4 *>(b.prev_action) + ia, prev4);
+            st_f1(b.action_error + ia, aerr);
         }
     }
     progress += 1.0f;                                                             // isaac_env.py:236
@@ -546,15 +673,15 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         if (full) {
 #pragma unroll
             for (int k = 0; k < (kEPB * A * 13 / 4 + 63) / 64; ++k)
-                if (k * 64 + lane < kEPB * A * 13 / 4) g4[k * 64 + lane] = s4[k * 64 + lane];
+                if (k * 64 + lane < kEPB * A * 13 / 4) st_f4(g4 + k * 64 + lane, s4[k * 64 + lane]);
         } else {
             float *g = b.drone_state + (size_t)e0 * A * 13;
             for (int i = lane; i < nenv * A * 13; i += 64) g[i] = sDS[i];
         }
         if (valid) {
             float *gp = b.target_pos + (size_t)e * 3 * NT, *gv = b.target_vel + (size_t)e * 3 * NT;
-            gp[0] = tpn.x; gp[1] = tpn.y; gp[2] = tpn.z;
-            gv[0] = tvel.x; gv[1] = tvel.y; gv[2] = tvel.z;
+            st_f1(gp, tpn.x); st_f1(gp + 1, tpn.y); st_f1(gp + 2, tpn.z);
+            st_f1(gv, tvel.x); st_f1(gv + 1, tvel.y); st_f1(gv + 2, tvel.z);
             if constexpr (NT == 2) {
                 gp[3] = tpn1.x; gp[4] = tpn1.y; gp[5] = tpn1.z;
                 gv[3] = tvel1.x; gv[4] = tvel1.y; gv[5] = tvel1.z;
@@ -570,9 +697,14 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         bool blocked, det, blockedB = false, detB = false;
         int knn_idx[kMaxK];
         bool knn_masked[kMaxK];
-        agent_obs<A, NT>(c, C, K, le, a, s, tp, tpB, progress, cyl, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * SD,
-                         with_state ? b.state_drones + ia * SD : nullptr, blocked, det, blockedB, detB, knn_idx, knn_masked, !LAB(LAB_NOSTORE | LAB_NOST_SELF),
-                         !LAB(LAB_NOSTORE | LAB_NOST_OTH));
+        if (full)    // every output slice of the wave through its private slab: whole cache lines per store instruction
+            agent_obs<A, NT, true>(c, C, K, le, a, s, tp, tpB, progress, cyl, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl + (tid >> 6) * slab_floats(A, K, NT),
+                                   b.obs_self + ia * SD, with_state ? b.state_drones + ia * SD : nullptr, blocked, det, blockedB, detB, knn_idx, knn_masked,
+                                   !LAB(LAB_NOSTORE | LAB_NOST_SELF), !LAB(LAB_NOSTORE | LAB_NOST_OTH), b.obs_cylinders + ia * K * 5);
+        else
+            agent_obs<A, NT>(c, C, K, le, a, s, tp, tpB, progress, cyl, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * SD,
+                             with_state ? b.state_drones + ia * SD : nullptr, blocked, det, blockedB, detB, knn_idx, knn_masked, !LAB(LAB_NOSTORE | LAB_NOST_SELF),
+                             !LAB(LAB_NOSTORE | LAB_NOST_OTH));
         prof_mark(p.prof, 9);
         // hideandseek.py:919-995
         float d = d_norm3(tp.x - s.pos.x, tp.y - s.pos.y, tp.z - s.pos.z);
@@ -616,7 +748,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         cr = cr + -c.collision_coef * cw;
         float sm = c.smoothness_coef * d_expf(-aerr);
         if (!c.use_deployment) sm = 0.0f;
-        float *red = sRed + tid * kRed;
+        float *red = sRed + tid * kRedS;
         red[R_DIST] = dist_rew; red[R_SPEED] = speed_rew; red[R_CC] = cc; red[R_CD] = cd; red[R_CW] = cw;
         red[R_COLL] = cr; red[R_SMOOTH] = sm;
         if constexpr (NT == 2)
@@ -635,7 +767,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         float sum_dist = 0, sum_speed = 0, sum_cc = 0, sum_cd = 0, sum_cw = 0, sum_coll = 0, sum_smooth = 0;
 #pragma unroll
         for (int j = 0; j < A; ++j) {
-            const float *red = sRed + (le * A + j) * kRed;
+            const float *red = sRed + (le * A + j) * kRedS;
             int fl = __float_as_int(red[R_FLAGS]);
             any_cap |= (fl & F_CAP) != 0;
             all_blocked &= (fl & F_BLOCKED) != 0;
@@ -657,9 +789,9 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         float sum_rew = 0.f;
 #pragma unroll
         for (int j = 0; j < A; ++j) {
-            const float *red = sRed + (le * A + j) * kRed;
+            const float *red = sRed + (le * A + j) * kRedS;
             float r = ((((red[R_DIST] + detect_rew) + catch_rew) + red[R_COLL]) + red[R_SPEED]) + red[R_SMOOTH];
-            if (!LAB(LAB_NOSTORE)) b.reward[(size_t)e * A + j] = r;
+            if (!LAB(LAB_NOSTORE)) st_f1(b.reward + (size_t)e * A + j, r);
             sum_rew = (j == 0) ? r : sum_rew + r;
         }
         if (!det_any && !LAB(LAB_NOSTORE)) {                   // hideandseek.py:791-794: mask the evader's rpos
@@ -720,14 +852,20 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         b.progress[e] = progress;
         if (!LAB(LAB_NOSTORE | LAB_NOST_STATS)) {
 #pragma unroll
-            for (int i = 0; i < HNS_NUM_STATS; ++i) b.stats[(size_t)i * E + e] = st[i];
+            for (int i = 0; i < HNS_NUM_STATS; ++i) {
+#ifdef HNS_ST_STATS_PLAIN
+                b.stats[(size_t)i * E + e] = st[i];
+#else
+                st_f1(b.stats + (size_t)i * E + e, st[i]);
+#endif
+            }
         }
     }
     prof_mark(p.prof, 6);
-    __syncthreads();
-
-    // ================= store: contiguous slices, 16 B per lane =========================================
-    if (!LAB(LAB_NOSTORE | LAB_NOST_OCYL)) coop_s2g<T>(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5);
+    if (!full) {                // ragged last tile: the k-nearest rows were staged per workgroup, store the slice now
+        __syncthreads();
+        if (!LAB(LAB_NOSTORE | LAB_NOST_OCYL)) coop_s2g<T>(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5);
+    }
     prof_mark(p.prof, 7);
     prof_mark(p.prof, 15);
 }
@@ -1161,10 +1299,10 @@ template <int A>
 static void select_kernels(hns_env *env) {
     const hns_cfg &c = env->cfg;
     if (c.num_targets == 2) {
-        env->step_fn = hns::hns_step_kernel<A, 2>;
+        env->step_fn = (c.num_envs % hns::kEPB == 0) ? hns::hns_step_kernel<A, 2, true> : hns::hns_step_kernel<A, 2, false>;
         env->reset_fn = hns::hns_reset_kernel<A, 2>;
     } else {
-        env->step_fn = hns::hns_step_kernel<A, 1>;
+        env->step_fn = (c.num_envs % hns::kEPB == 0) ? hns::hns_step_kernel<A, 1, true> : hns::hns_step_kernel<A, 1, false>;
         env->reset_fn = hns::hns_reset_kernel<A, 1>;
     }
     env->threads = hns::Geo<A>::T;
