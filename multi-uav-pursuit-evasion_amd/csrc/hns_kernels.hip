@@ -254,7 +254,7 @@ HNS_DEV void wave_store_rows(float *__restrict__ slab, float *__restrict__ gslic
 // the relative position of the second evader + one zero; line of sight / detection per evader.
 // STAGED (step kernel, full tiles): every output slice goes through the wave's slab (wave_store_rows); `sOCyl` is then
 // the slab of this wave and gOth / gSelf / gState / gOCyl are still the THREAD's rows (the wave's slice starts `lane` rows earlier).
-template <int A, int NT, bool STAGED = false>
+template <int A, int NT, bool STAGED = false, int PS = 13>
 HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigid &s, const V3 &tp, const V3 &tpB, float progress,
                        const float *cyl, const float *sDS, float *gOth, float *sOCyl, float *gSelf, float *gState,
                        bool &blocked, bool &det, bool &blockedB, bool &detB, int knn_idx[kMaxK], bool knn_masked[kMaxK], bool st = true, bool st_oth = true,
@@ -303,7 +303,7 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
 #pragma unroll
         for (int w = 0; w < A - 1; ++w) {
             const int j = w + (w >= a ? 1 : 0);
-            const float *rj = sDS + (le * A + j) * 13;
+            const float *rj = sDS + (le * A + j) * PS;        // partner positions: rows of PS floats
             o[3 * w] = s.pos.x - rj[0]; o[3 * w + 1] = s.pos.y - rj[1]; o[3 * w + 2] = s.pos.z - rj[2];
         }
         if constexpr (STAGED) {
@@ -647,11 +647,25 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
             prof_mark(p.prof, 13);
         }
         if (valid && !LAB(LAB_NOSTORE | LAB_NOST_REC)) {
+#if defined(HNS_REC_PLAIN)
+            reinterpret_cast<float4 *>(b.throttle)[ia] = thr4;
+            reinterpret_cast<float4 *>(b.pid_integ)[ia] = integ4;
+            reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
+            reinterpret_cast<float4 *>(b.prev_action)[ia] = prev4;
+            b.action_error[ia] = aerr;
+#elif defined(HNS_REC_NT)
+            __builtin_nontemporal_store(thr4, reinterpret_cast<float4 *>(b.throttle) + ia);
+            __builtin_nontemporal_store(integ4, reinterpret_cast<float4 *>(b.pid_integ) + ia);
+            __builtin_nontemporal_store(last4, reinterpret_cast<float4 *>(b.pid_last_rate) + ia);
+            __builtin_nontemporal_store(prev4, reinterpret_cast<float4 *>(b.prev_action) + ia);
+            __builtin_nontemporal_store(aerr, b.action_error + ia);
+#else
             st_f4(reinterpret_cast<float4 *>(b.throttle) + ia, thr4);
             st_f4(reinterpret_cast<float4 *>(b.pid_integ) + ia, integ4);
             st_f4(reinterpret_cast<float4 *>(b.pid_last_rate) + ia, last4);
             st_f4(reinterpret_cast<float4 *>(b.prev_action) + ia, prev4);
             st_f1(b.action_error + ia, aerr);
+#endif
         }
     }
     progress += 1.0f;                                                             // isaac_env.py:236
@@ -865,6 +879,366 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
     if (!full) {                // ragged last tile: the k-nearest rows were staged per workgroup, store the slice now
         __syncthreads();
         if (!LAB(LAB_NOSTORE | LAB_NOST_OCYL)) coop_s2g<T>(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5);
+    }
+    prof_mark(p.prof, 7);
+    prof_mark(p.prof, 15);
+}
+
+// =================================================================================================
+// The fused step kernel, third design (one evader, whole 64-env tiles): no workgroup barrier in front of the
+// controller, loads issued in the order they are needed.
+// =================================================================================================
+// What the profiles of the first design showed: a launch is one residency round, so the load burst
+// (38 MB, 5.5-6 us at the ~7 TB/s this working set reaches), each wave's serial instruction stream (~10 us for the
+// oldest workgroup of a CU, +2 us for every younger one) and the store drain were paid one after the other.  Here
+//   * an agent wave needs nobody else's data for the controller: it loads ITS OWN 64 rigid-state rows (one contiguous
+//     3.3 KB slice) through its private LDS slab, so the controller starts as soon as the first-issued loads
+//     (action, previous action, rows, PID state) have landed, while throttle / cylinders / statistics still stream;
+//   * the env wave owns everything about the evader: it fetches its envs' cylinders and evader position itself, stages
+//     the cylinders for phase 3, runs the potential field INCLUDING the pursuers' line-of-sight tests (they are the
+//     evader's sensing, hideandseek.py:1074-1088) while the pursuer waves run controller and integration;
+//   * pursuer <-> pursuer and pursuer <-> evader exchange goes through small published records (position at t, thrust
+//     vector, position at t+1), three workgroup barriers in all (six before);
+//   * every store is a whole-line store from a wave-private slab.
+// Arithmetic, evaluation order and results are those of hns_step_kernel (bit-identical; tests/test_hip_parity.py).
+constexpr int kPub = 9;   // published per pursuer: position at t (3), thrust vector (3), position at t+1 (3); odd stride
+struct LdsV3 { int slab, slab_stride, pub, cyl, cyl_stride, tp, red, total; };
+__host__ __device__ inline LdsV3 lds_layout_v3(int A, int C, int K) {
+    LdsV3 L;
+    int o = 0;
+    L.slab_stride = slab_floats(A, K, 1);
+    if (L.slab_stride < 64 * 13 + 4) L.slab_stride = r4(64 * 13 + 4);
+    L.slab = o;  o += A * L.slab_stride;
+    L.pub = o;   o += r4(kEPB * A * kPub);
+    L.cyl_stride = (3 * C) | 1;
+    L.cyl = o;   o += r4(kEPB * L.cyl_stride);
+    L.tp = o;    o += r4(kEPB * 4);                      // evader at t+1 (3 per env) + the step counter (1 per env)
+    L.red = o;   o += r4(kEPB * A * red_stride(1));
+    L.total = o;
+    return L;
+}
+
+template <int A>
+__global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params p) {
+    constexpr int NA = Geo<A>::NA, SD = HNS_SELF_DIM, kRedS = red_stride(1);
+    extern __shared__ __align__(16) float smem[];
+    const hns_cfg &c = p.cfg;
+    const hns_buffers &b = p.buf;
+    const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.num_envs;
+    const bool with_state = c.write_critic_state && b.state_drones != nullptr;
+    const LdsV3 L = lds_layout_v3(A, C, K);
+    float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int e0 = blockIdx.x * kEPB;
+    prof_mark(p.prof, 0);
+    prof_mark(p.prof, 14);
+
+    if (tid < NA) {
+        // ================================= pursuer waves ==================================================
+        const int le = tid / A, a = tid - le * A;
+        const unsigned ia = (unsigned)e0 * A + tid;
+        float *slab = smem + L.slab + (tid >> 6) * L.slab_stride;
+        // loads, first needed first: action, previous action, the wave's 64 rigid-state rows, PID state, throttle
+        const float4 act4 = reinterpret_cast<const float4 *>(p.action)[ia];
+        float4 prev4 = reinterpret_cast<const float4 *>(b.prev_action)[ia];
+        constexpr int N4 = 64 * 13 / 4;                   // 208 float4 pieces per wave
+        const float4 *rows4 = reinterpret_cast<const float4 *>(b.drone_state + ((size_t)e0 * A + (tid & ~63)) * 13) + lane;
+        float4 rr[(N4 + 63) / 64];
+#pragma unroll
+        for (int j = 0; j < (N4 + 63) / 64; ++j)
+            if (j * 64 + lane < N4) rr[j] = rows4[j * 64];
+        float4 integ4 = reinterpret_cast<const float4 *>(b.pid_integ)[ia];
+        float4 last4 = reinterpret_cast<const float4 *>(b.pid_last_rate)[ia];
+        float4 thr4 = reinterpret_cast<const float4 *>(b.throttle)[ia];
+        const float4 ta = d_action_tanh(act4);           // needs the action only: evaluated while the rest is in flight
+        // own rows through the private slab
+        {
+            float4 *s4 = reinterpret_cast<float4 *>(slab) + lane;
+#pragma unroll
+            for (int j = 0; j < (N4 + 63) / 64; ++j)
+                if (j * 64 + lane < N4) s4[j * 64] = rr[j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        Rigid s;
+        load_rigid(slab + lane * 13, s);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        prof_mark(p.prof, 1);
+        // ---- phase 1: controller, rotors, thrust vector (A1-A3) ----
+        float cmd[4], thr_diff, aerr, thrust[4], moment[4];
+        d_ctbr_pid_squashed(c, ta, s.q, s.ang, prev4, integ4, last4, cmd, aerr);
+        d_rotor(c, cmd, thr4, thrust, moment, thr_diff);
+        const float ts = ((thrust[0] + thrust[1]) + thrust[2]) + thrust[3];
+        const V3 tw = d_quat_rot_z(s.q, ts);                                        // multirotor.py:491
+        {
+            float *pub = sPub + tid * kPub;
+            pub[0] = s.pos.x; pub[1] = s.pos.y; pub[2] = s.pos.z;
+            pub[3] = tw.x; pub[4] = tw.y; pub[5] = tw.z;
+            float *red = sRed + tid * kRedS;
+            red[R_AERR] = aerr; red[R_TD] = thr_diff;
+        }
+        prof_mark(p.prof, 2);
+        __syncthreads();                                                            // barrier 1
+        // ---- phase 2: downwash, torques, integration (A4, A5) ----
+        V3 fdw = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < A - 1; ++o) {
+            const int j = o + (o >= a ? 1 : 0);
+            const float *pj = sPub + (le * A + j) * kPub;
+            const V3 posj = {pj[0], pj[1], pj[2]}, twj = {pj[3], pj[4], pj[5]};
+            const V3 fj = d_downwash_pair(s.pos, posj, twj);
+            fdw.x = (o == 0) ? fj.x : fdw.x + fj.x;
+            fdw.y = (o == 0) ? fj.y : fdw.y + fj.y;
+            fdw.z = (o == 0) ? fj.z : fdw.z + fj.z;
+        }
+        const V3 fw = {tw.x + fdw.x, tw.y + fdw.y, tw.z + fdw.z};
+        V3 tb;
+        tb.x = ((c.rotor_py[0] * thrust[0] + c.rotor_py[1] * thrust[1]) + c.rotor_py[2] * thrust[2]) + c.rotor_py[3] * thrust[3];
+        tb.y = -(((c.rotor_px[0] * thrust[0] + c.rotor_px[1] * thrust[1]) + c.rotor_px[2] * thrust[2]) + c.rotor_px[3] * thrust[3]);
+        tb.z = ((moment[0] + moment[1]) + moment[2]) + moment[3];
+        d_integrate(c, s, fw, tb);
+        {
+            float *pub = sPub + tid * kPub;
+            pub[6] = s.pos.x; pub[7] = s.pos.y; pub[8] = s.pos.z;
+        }
+        // controller / rotor state: plain stores (they are early: write-through here stalls the wave, measured +0.45 us)
+#ifdef HNS_V3_REC_SC1
+        st_f4(reinterpret_cast<float4 *>(b.throttle) + ia, thr4);
+        st_f4(reinterpret_cast<float4 *>(b.pid_integ) + ia, integ4);
+        st_f4(reinterpret_cast<float4 *>(b.pid_last_rate) + ia, last4);
+        st_f4(reinterpret_cast<float4 *>(b.prev_action) + ia, prev4);
+        st_f1(b.action_error + ia, aerr);
+#else
+        reinterpret_cast<float4 *>(b.throttle)[ia] = thr4;
+        reinterpret_cast<float4 *>(b.pid_integ)[ia] = integ4;
+        reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
+        reinterpret_cast<float4 *>(b.prev_action)[ia] = prev4;
+        b.action_error[ia] = aerr;
+#endif
+        {   // S_{t+1}: the wave's 64 rows back through the slab, one contiguous slice
+            const float row[13] = {s.pos.x, s.pos.y, s.pos.z, s.q.w, s.q.x, s.q.y, s.q.z, s.lin.x, s.lin.y, s.lin.z, s.ang.x, s.ang.y, s.ang.z};
+            wave_store_rows<13>(slab, b.drone_state + ((size_t)e0 * A + (tid & ~63)) * 13, row, lane);
+        }
+        prof_mark(p.prof, 3);
+        __syncthreads();                                                            // barrier 2
+        prof_mark(p.prof, 8);
+        // ---- phase 3a: observation, per-pursuer reward terms on S_{t+1} ----
+        const float progress = sTp[kEPB * 3 + le];                                  // progress + 1, published by the env wave
+        const V3 tp = {sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]};
+        const float *cyl = sCyl + le * L.cyl_stride;
+        bool blocked, det, blockedB = false, detB = false;
+        int knn_idx[kMaxK];
+        bool knn_masked[kMaxK];
+        agent_obs<A, 1, true, kPub>(c, C, K, le, a, s, tp, tp, progress, cyl, sPub + 6, b.obs_others + (size_t)ia * (A - 1) * 3, slab,
+                                    b.obs_self + (size_t)ia * SD, with_state ? b.state_drones + (size_t)ia * SD : nullptr, blocked, det, blockedB, detB,
+                                    knn_idx, knn_masked, true, true, b.obs_cylinders + (size_t)ia * K * 5);
+        prof_mark(p.prof, 9);
+        const float d = d_norm3(tp.x - s.pos.x, tp.y - s.pos.y, tp.z - s.pos.z);   // hideandseek.py:919-995
+        const float act = (d > c.catch_radius) ? 1.0f : 0.0f;
+        const float dist_rew = (-c.dist_reward_coef * d) * act;
+        const bool cap_ok = (d < c.catch_radius) && !blocked;
+        const float sp = d_norm3(s.lin.x, s.lin.y, s.lin.z);
+        const float speed_rew = -c.speed_coef * ((sp > c.v_drone) ? 1.0f : 0.0f);
+        float cc = 0.f, cd = 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < kMaxK; ++sidx) {
+            if (sidx < K) {
+                const float *cy = cyl + 3 * knn_idx[sidx];
+                const float rx = s.pos.x - cy[0], ry = s.pos.y - cy[1];
+                const float dxy = d_norm2(rx, ry);
+                float hit = ((dxy - c.cylinder_size) < c.collision_radius) ? 1.0f : 0.0f;
+                if (knn_masked[sidx]) hit = 0.0f;
+                cc = (sidx == 0) ? hit : cc + hit;
+            }
+        }
+        float cr = -c.collision_coef * cc;
+#pragma unroll
+        for (int o = 0; o < A - 1; ++o) {
+            const int j = o + (o >= a ? 1 : 0);
+            const float *rj = sPub + (le * A + j) * kPub + 6;
+            const float dd = d_norm3(s.pos.x - rj[0], s.pos.y - rj[1], s.pos.z - rj[2]);
+            const float hit = (dd < c.coll_drone_dist) ? 1.0f : 0.0f;
+            cd = (o == 0) ? hit : cd + hit;
+        }
+        cr = cr + -c.collision_coef * cd;
+        const float cw = ((s.pos.z > c.max_height) ? 1.0f : 0.0f) + ((HNS_FMA(s.pos.y, s.pos.y, s.pos.x * s.pos.x) > c.arena_sq) ? 1.0f : 0.0f);
+        cr = cr + -c.collision_coef * cw;
+        float sm = c.smoothness_coef * d_expf(-aerr);
+        if (!c.use_deployment) sm = 0.0f;
+        {
+            float *red = sRed + tid * kRedS;
+            red[R_DIST] = dist_rew; red[R_SPEED] = speed_rew; red[R_CC] = cc; red[R_CD] = cd; red[R_CW] = cw;
+            red[R_COLL] = cr; red[R_SMOOTH] = sm;
+            red[R_FLAGS] = __int_as_float((cap_ok ? F_CAP : 0) | (blocked ? F_BLOCKED : 0) | (det ? F_DET : 0));
+        }
+        prof_mark(p.prof, 4);
+        __syncthreads();                                                            // barrier 3
+        prof_mark(p.prof, 5);
+        prof_mark(p.prof, 6);
+    } else {
+        // ================================= env wave: lane <-> env ========================================
+#ifndef HNS_ENV_PRIO
+#define HNS_ENV_PRIO 2
+#endif
+        if (HNS_ENV_PRIO) __builtin_amdgcn_s_setprio(HNS_ENV_PRIO);   // one wave in four, but every barrier of its workgroup waits for it
+        const int le = lane, e = e0 + le;
+        float *cylw = sCyl + le * L.cyl_stride;
+        // the evader and this env's cylinders, straight from global memory (this wave has nothing else to do yet)
+        const float *gt = b.target_pos + (size_t)e * 3;
+        const V3 tp0 = {gt[0], gt[1], gt[2]};
+        float progress = b.progress[e];
+        const float *gc = b.cylinders + (size_t)e * C * 3;
+#pragma unroll 12
+        for (int k = 0; k < 3 * C; ++k) cylw[k] = gc[k];
+        prof_mark(p.prof, 1);
+        // A6: arena + cylinder terms of the potential field (hideandseek.py:1090-1136)
+        bool out_of_arena = false;
+        const V3 Fenv = d_prey_arena_term(c, tp0, out_of_arena);
+        float fcx = 0.f, fcy = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < C; ++k) {
+            float tx, ty;
+            d_prey_cylinder_term(c, tp0, cylw[3 * k], cylw[3 * k + 1], cylw[3 * k + 2], tx, ty);
+            fcx += tx;
+            fcy += ty;
+        }
+        progress += 1.0f;                                                           // isaac_env.py:236
+        sTp[kEPB * 3 + le] = progress;
+        prof_mark(p.prof, 2);
+        __syncthreads();                                                            // barrier 1: positions at t, action errors
+        float st[HNS_NUM_STATS];
+#pragma unroll
+        for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = b.stats[(size_t)i * E + e];
+        // the pursuers' pushes (hideandseek.py:1074-1088), ascending; then arena, then cylinders
+        V3 F = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float *pj = sPub + (le * A + j) * kPub;
+            const V3 dp = {pj[0], pj[1], pj[2]};
+            const bool blocked_pre = d_blocked(c, C, dp, tp0, cylw);                // :1080
+            const V3 fp = d_prey_pursuer_term(c, dp, tp0, blocked_pre);
+            F.x = (j == 0) ? fp.x : F.x + fp.x;
+            F.y = (j == 0) ? fp.y : F.y + fp.y;
+            F.z = (j == 0) ? fp.z : F.z + fp.z;
+        }
+        F.x = F.x + Fenv.x; F.y = F.y + Fenv.y; F.z = F.z + Fenv.z;
+        F.x = F.x + fcx; F.y = F.y + fcy; F.z = F.z + 0.0f;
+        const V3 tvel = {(c.v_prey * F.x) / (__builtin_fabsf(F.x) + 1e-5f), (c.v_prey * F.y) / (__builtin_fabsf(F.y) + 1e-5f),
+                         (c.v_prey * F.z) / (__builtin_fabsf(F.z) + 1e-5f)};        // per-axis speed (:741)
+        const V3 tpn = {tp0.x + tvel.x * c.dt, tp0.y + tvel.y * c.dt, tp0.z + tvel.z * c.dt};
+        sTp[le * 3] = tpn.x; sTp[le * 3 + 1] = tpn.y; sTp[le * 3 + 2] = tpn.z;
+        {
+            float *gp = b.target_pos + (size_t)e * 3, *gv = b.target_vel + (size_t)e * 3;
+            st_f1(gp, tpn.x); st_f1(gp + 1, tpn.y); st_f1(gp + 2, tpn.z);
+            st_f1(gv, tvel.x); st_f1(gv + 1, tvel.y); st_f1(gv + 2, tvel.z);
+        }
+        {   // statistics that only need phase-1 data (A10 hideandseek.py:731-733, :1097-1098, :996-997)
+            float sum_ae = 0.f, sum_td = 0.f, max_td = 0.f;
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                const float *red = sRed + (le * A + j) * kRedS;
+                const float td = red[R_TD];
+                sum_ae = (j == 0) ? red[R_AERR] : sum_ae + red[R_AERR];
+                sum_td = (j == 0) ? td : sum_td + td;
+                max_td = (j == 0) ? td : (td > max_td ? td : max_td);
+            }
+            const float mae = sum_ae * c.inv_num_agents;
+            st[HNS_ST_ACTION_ERROR_ORDER1_MEAN] += mae;
+            if (mae > st[HNS_ST_ACTION_ERROR_ORDER1_MAX]) st[HNS_ST_ACTION_ERROR_ORDER1_MAX] = mae;
+            st[HNS_ST_OUT_OF_ARENA] = ((st[HNS_ST_OUT_OF_ARENA] != 0.0f) || out_of_arena) ? 1.0f : 0.0f;
+            st[HNS_ST_SMOOTHNESS_COEF] = c.smoothness_coef;
+            st[HNS_ST_SMOOTHNESS_MEAN] += sum_td * c.inv_num_agents;
+            if (max_td > st[HNS_ST_SMOOTHNESS_MAX]) st[HNS_ST_SMOOTHNESS_MAX] = max_td;
+        }
+        prof_mark(p.prof, 3);
+        __syncthreads();                                                            // barrier 2: evader at t+1 published
+        prof_mark(p.prof, 8);
+        prof_mark(p.prof, 4);
+        __syncthreads();                                                            // barrier 3: reward terms
+        prof_mark(p.prof, 5);
+        // ---- phase 3b: per-env reductions, reward, done, statistics (hideandseek.py:919-1065) ----
+        const float iA = c.inv_num_agents;
+        bool any_cap = false, all_blocked = true, any_coll = false, det_any = false;
+        float sum_dist = 0, sum_speed = 0, sum_cc = 0, sum_cd = 0, sum_cw = 0, sum_coll = 0, sum_smooth = 0;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float *red = sRed + (le * A + j) * kRedS;
+            const int fl = __float_as_int(red[R_FLAGS]);
+            any_cap |= (fl & F_CAP) != 0;
+            all_blocked &= (fl & F_BLOCKED) != 0;
+            det_any |= (fl & F_DET) != 0;
+            any_coll |= red[R_COLL] < 0.0f;
+            if (j == 0) {
+                sum_dist = red[R_DIST]; sum_speed = red[R_SPEED]; sum_cc = red[R_CC]; sum_cd = red[R_CD]; sum_cw = red[R_CW];
+                sum_coll = red[R_COLL]; sum_smooth = red[R_SMOOTH];
+            } else {
+                sum_dist += red[R_DIST]; sum_speed += red[R_SPEED]; sum_cc += red[R_CC]; sum_cd += red[R_CD]; sum_cw += red[R_CW];
+                sum_coll += red[R_COLL]; sum_smooth += red[R_SMOOTH];
+            }
+        }
+        const float detf = det_any ? 1.0f : 0.0f;
+        const float detect_rew = c.detect_reward_coef * detf;
+        const float catch_rew = c.catch_reward_coef * (any_cap ? 1.0f : 0.0f);
+        float sum_rew = 0.f;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float *red = sRed + (le * A + j) * kRedS;
+            const float r = ((((red[R_DIST] + detect_rew) + catch_rew) + red[R_COLL]) + red[R_SPEED]) + red[R_SMOOTH];
+            st_f1(b.reward + (size_t)e * A + j, r);
+            sum_rew = (j == 0) ? r : sum_rew + r;
+        }
+        if (!det_any) {                                        // hideandseek.py:791-794: mask the evader's relative position
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                float *o = b.obs_self + ((size_t)e * A + j) * SD;
+                o[0] = c.mask_value; o[1] = c.mask_value; o[2] = c.mask_value;
+            }
+        }
+#define ST(i) st[i]
+        ST(HNS_ST_DISTANCE_REWARD) += sum_dist * iA;
+        ST(HNS_ST_SUM_DETECT_STEP) += 1.0f * detf;
+        float sdet = detect_rew, scat = catch_rew;
+#pragma unroll
+        for (int j = 1; j < A; ++j) { sdet += detect_rew; scat += catch_rew; }
+        ST(HNS_ST_DETECT_REWARD) += sdet * iA;
+        const bool capture_flag = catch_rew != 0.0f;                              // :945
+        ST(HNS_ST_BLOCKED) += all_blocked ? 1.0f : 0.0f;
+        ST(HNS_ST_SUCCESS) = (capture_flag || ST(HNS_ST_SUCCESS) != 0.0f) ? 1.0f : 0.0f;
+        const float cur = (capture_flag ? 1.0f : 0.0f) * progress + (capture_flag ? 0.0f : 1.0f) * (float)c.max_episode_length;
+        if (cur < ST(HNS_ST_FIRST_CAPTURE_STEP)) ST(HNS_ST_FIRST_CAPTURE_STEP) = cur;
+        ST(HNS_ST_CATCH_REWARD) += scat * iA;
+        ST(HNS_ST_SPEED_REWARD) += sum_speed * iA;
+        ST(HNS_ST_COLLISION_CYLINDER) += sum_cc * iA;
+        ST(HNS_ST_COLLISION_DRONE) += sum_cd * iA;
+        ST(HNS_ST_COLLISION) += any_coll ? 1.0f : 0.0f;
+        ST(HNS_ST_COLLISION_WALL) += sum_cw * iA;
+        ST(HNS_ST_COLLISION_REWARD) += sum_coll * iA;
+        ST(HNS_ST_SMOOTHNESS_REWARD) += sum_smooth * iA;
+        const bool done = progress >= (float)c.max_episode_length;                // :1008-1010
+        if (done) {                                                               // :1017-1056
+            ST(HNS_ST_COLLISION) = ST(HNS_ST_COLLISION) / progress;
+            ST(HNS_ST_ACTION_ERROR_ORDER1_MEAN) = ST(HNS_ST_ACTION_ERROR_ORDER1_MEAN) / progress;
+            ST(HNS_ST_TARGET_PREDICTED_ERROR) = ST(HNS_ST_TARGET_PREDICTED_ERROR) / progress;
+            ST(HNS_ST_SMOOTHNESS_MEAN) = ST(HNS_ST_SMOOTHNESS_MEAN) / progress;
+            ST(HNS_ST_SMOOTHNESS_REWARD) = ST(HNS_ST_SMOOTHNESS_REWARD) / progress;
+            ST(HNS_ST_DISTANCE_REWARD) = ST(HNS_ST_DISTANCE_REWARD) / progress;
+            ST(HNS_ST_DETECT_REWARD) = ST(HNS_ST_DETECT_REWARD) / progress;
+            ST(HNS_ST_CATCH_REWARD) = ST(HNS_ST_CATCH_REWARD) / progress;
+            ST(HNS_ST_COLLISION_REWARD) = ST(HNS_ST_COLLISION_REWARD) / progress;
+            ST(HNS_ST_COLLISION_WALL) = ST(HNS_ST_COLLISION_WALL) / progress;
+            ST(HNS_ST_COLLISION_DRONE) = ST(HNS_ST_COLLISION_DRONE) / progress;
+            ST(HNS_ST_COLLISION_CYLINDER) = ST(HNS_ST_COLLISION_CYLINDER) / progress;
+            ST(HNS_ST_SPEED_REWARD) = ST(HNS_ST_SPEED_REWARD) / progress;
+        }
+        ST(HNS_ST_RETURN) += sum_rew * iA;
+#undef ST
+        b.done[e] = (uint8_t)done;
+        if (b.detect) b.detect[e] = (uint8_t)det_any;
+        b.progress[e] = progress;
+#pragma unroll
+        for (int i = 0; i < HNS_NUM_STATS; ++i) st_f1(b.stats + (size_t)i * E + e, st[i]);
+        prof_mark(p.prof, 6);
     }
     prof_mark(p.prof, 7);
     prof_mark(p.prof, 15);
@@ -1305,12 +1679,16 @@ static void select_kernels(hns_env *env) {
         env->step_fn = (c.num_envs % hns::kEPB == 0) ? hns::hns_step_kernel<A, 1, true> : hns::hns_step_kernel<A, 1, false>;
         env->reset_fn = hns::hns_reset_kernel<A, 1>;
     }
+    const char *force = getenv("HNS_STEP_DESIGN");        // "1" = the first design for every shape (A/B measurements)
+    const bool v3 = c.num_targets != 2 && c.num_envs % hns::kEPB == 0 && !(force && force[0] == '1');
+    if (v3) env->step_fn = hns::hns_step_v3_kernel<A>;
     env->threads = hns::Geo<A>::T;
     env->cyl_magic = (uint32_t)(0xFFFFFFFFull / (uint32_t)(3 * c.num_cylinders) + 1ull);
     env->grid = (c.num_envs + hns::kEPB - 1) / hns::kEPB;
     hns::Lds L = hns::lds_layout(A, c.num_cylinders, c.obs_max_cylinder, c.num_targets == 2 ? 2 : 1);
     env->lds_step = (size_t)L.total * sizeof(float);
     env->lds_reset = env->lds_step + (size_t)hns::kEPB * hns::kGridStride;   // + per-env occupancy grid / free-cell list
+    if (v3) env->lds_step = (size_t)hns::lds_layout_v3(A, c.num_cylinders, c.obs_max_cylinder).total * sizeof(float);
 }
 
 
