@@ -246,23 +246,27 @@ HNS_DEV V3 d_downwash_pair(const V3 &pi, const V3 &pj, const V3 &tj_w) {
 //   * RN(numt/d) <= 1  <=>  numt <= d   (a quotient in (1, 1+2^-23) needs numt = d*(1+2^-24) for a tie,
 //     which is not representable, so it rounds up; numt <= d gives a quotient <= 1)
 //   * RN(numt/d) >= 0  <=>  numt >= 0   (|numt| >= 1e-30 rules out underflow to -0; else exact path)
-//   * RN(num/d) <= s: with p = s*d, num < p*(1-2^-21) => true, num > p*(1+2^-21) => false
-//     (the margin is 8x the accumulated rounding of p and of the scaling), else exact path.
+//   * RN(num/d) <= s: with p = s*d, num < p*(1-2^-19) => true, num > p*(1+2^-19) => false
+//     (the margin is > 4x the accumulated error of p: 1 ulp of the approximate sqrt, the +1e-5, the product and the
+//     scaling), else exact path.
 // The fast tests are branch-free; a lane that meets an undecidable case redoes its whole loop in
 // the exact divide-and-compare form afterwards.  The result is bit-identical to that form
 // (tests/test_hip_parity.py).
 struct LosLine {          // per (drone, evader) constants of the line-of-sight test
-    float diffx, diffy, dx, dy, d1, dt1, plo, phi, dpx, dpy, tpx, tpy;
+    float diffx, diffy, dx, dy, dt1, plo, phi, dpx, dpy, tpx, tpy;
 };
+// The filter band is built on the hardware's approximate square root (v_sqrt_f32, 1 ulp): its value only positions a
+// band that is 4 x wider than its error, every decision inside the band is taken by the exact path (d_blocked_exact,
+// correctly rounded sqrt + divisions), so the results do not depend on the approximation.
 HNS_DEV LosLine d_los_setup(const hns_cfg &c, const V3 &dp, const V3 &tp) {
     LosLine l;
     l.diffx = dp.x - tp.x; l.diffy = dp.y - tp.y;
-    float den = d_norm2(l.diffx, l.diffy);
+    const float den = __builtin_amdgcn_sqrtf(HNS_FMA(l.diffy, l.diffy, l.diffx * l.diffx));
     l.dx = tp.x - dp.x; l.dy = tp.y - dp.y;
     float dent = HNS_FMA(l.dy, l.dy, l.dx * l.dx);
-    l.d1 = den + 1e-5f; l.dt1 = dent + 1e-5f;
-    float p = c.cylinder_size * l.d1;
-    l.plo = p * 0.99999952316284f; l.phi = p * 1.00000047683716f;   // 1 -+ 2^-21
+    l.dt1 = dent + 1e-5f;
+    float p = c.cylinder_size * (den + 1e-5f);
+    l.plo = p * 0.99999809265137f; l.phi = p * 1.00000190734863f;   // 1 -+ 2^-19
     l.dpx = dp.x; l.dpy = dp.y; l.tpx = tp.x; l.tpy = tp.y;
     return l;
 }
@@ -278,18 +282,19 @@ HNS_DEV bool d_los_cylinder_fast(const LosLine &l, float ccx, float ccy, float c
     return lo && tpos && (numt <= l.dt1) && (ccz > 0.0f);
 }
 // Exact form: divide and compare, as the reference does (hideandseek.py:47-103)
-HNS_DEV bool d_los_cylinder(const hns_cfg &c, const LosLine &l, float ccx, float ccy, float ccz) {
+HNS_DEV bool d_los_cylinder(const hns_cfg &c, const LosLine &l, float d1, float ccx, float ccy, float ccz) {
     float d2x = ccx - l.tpx, d2y = ccy - l.tpy;
     float num = __builtin_fabsf(HNS_FMA(l.diffx, d2y, -(l.diffy * d2x)));
     float numt = HNS_FMA(ccy - l.dpy, l.dy, (ccx - l.dpx) * l.dx);
-    bool blocked = (num / l.d1) <= c.cylinder_size;
+    bool blocked = (num / d1) <= c.cylinder_size;
     float t = numt / l.dt1;
     bool on = (t >= 0.0f) && (t <= 1.0f);
     return blocked && on && (ccz > 0.0f);
 }
 HNS_DEV bool d_blocked_exact(const hns_cfg &c, int C, const LosLine &l, const float *cyl) {
+    const float d1 = d_norm2(l.diffx, l.diffy) + 1e-5f;       // the correctly rounded denominator of :63
     bool any = false;
-    for (int k = 0; k < C; ++k) any = d_los_cylinder(c, l, cyl[3 * k], cyl[3 * k + 1], cyl[3 * k + 2]) || any;
+    for (int k = 0; k < C; ++k) any = d_los_cylinder(c, l, d1, cyl[3 * k], cyl[3 * k + 1], cyl[3 * k + 2]) || any;
     return any;
 }
 HNS_DEV bool d_blocked(const hns_cfg &c, int C, const V3 &dp, const V3 &tp, const float *cyl) {
@@ -368,10 +373,16 @@ HNS_DEV void d_integrate(const hns_cfg &c, Rigid &s, const V3 &force_w, const V3
     w2.x = HNS_FMA((torque_b.x - gx) * c.inv_inertia[0], dt, wb.x) * c.ang_damp_factor;
     w2.y = HNS_FMA((torque_b.y - gy) * c.inv_inertia[1], dt, wb.y) * c.ang_damp_factor;
     w2.z = HNS_FMA((torque_b.z - gz) * c.inv_inertia[2], dt, wb.z) * c.ang_damp_factor;
-    float wn = __builtin_sqrtf(HNS_FMA(w2.z, w2.z, HNS_FMA(w2.y, w2.y, w2.x * w2.x)));
-    if (wn > c.max_ang_vel) {
-        float sc = c.max_ang_vel / wn;
-        w2.x *= sc; w2.y *= sc; w2.z *= sc;
+    // |w| > max_ang_vel (1000 rad/s: practically never): decided on the squares unless within 2^-20 of the limit —
+    // RN(sqrt(x)) > m is then certain either way — the correctly rounded square root only on that path
+    const float wn2 = HNS_FMA(w2.z, w2.z, HNS_FMA(w2.y, w2.y, w2.x * w2.x));
+    const float m2 = c.max_ang_vel * c.max_ang_vel;
+    if (!(wn2 < m2 * 0.99999904632568f)) {
+        float wn = __builtin_sqrtf(wn2);
+        if (wn > c.max_ang_vel) {
+            float sc = c.max_ang_vel / wn;
+            w2.x *= sc; w2.y *= sc; w2.z *= sc;
+        }
     }
     V3 ww = d_quat_rot<false>(s.q, w2);
     float px = HNS_FMA(vx, dt, s.pos.x), py = HNS_FMA(vy, dt, s.pos.y), pz = HNS_FMA(vz, dt, s.pos.z);

@@ -55,6 +55,9 @@ struct Geo {
     static constexpr int T = kEPB * (A + 1);    // + the env wave
 };
 
+// Passed by value (~900 B of kernel arguments).  Measured alternatives (tools/microbench/launch_gap.hip, A/B in step_lab): arguments
+// of <= 64 B launch 0.5-0.6 us faster, but a configuration block in device memory read through the scalar cache costs
+// +1.8 us per step — every wave starts with two dependent cold scalar loads before it can issue its first global load.
 struct Params {
     hns_cfg cfg;
     hns_buffers buf;
@@ -258,11 +261,12 @@ template <int A, int NT, bool STAGED = false, int PS = 13>
 HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigid &s, const V3 &tp, const V3 &tpB, float progress,
                        const float *cyl, const float *sDS, float *gOth, float *sOCyl, float *gSelf, float *gState,
                        bool &blocked, bool &det, bool &blockedB, bool &detB, int knn_idx[kMaxK], bool knn_masked[kMaxK], bool st = true, bool st_oth = true,
-                       float *gOCyl = nullptr) {
+                       float *gOCyl = nullptr, float *dist_out = nullptr, bool st_ocyl = true) {
     constexpr int SDW = NT == 2 ? 24 : HNS_SELF_DIM;
     const int lane = threadIdx.x & 63;
     float rtx = s.pos.x - tp.x, rty = s.pos.y - tp.y, rtz = s.pos.z - tp.z;
     float dist = d_norm3(rtx, rty, rtz);
+    if (dist_out) *dist_out = dist;
     const float t = progress * c.inv_max_episode_length;              // :796 (CUDA scalar-division form)
     V3 heading = d_quat_rot_x(s.q);                                   // multirotor.py:613-614
     V3 up = d_quat_rot_z(s.q, 1.0f);
@@ -401,7 +405,7 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
         }
     }
     if constexpr (STAGED) {
-        if (st) {
+        if (st_ocyl) {
             if (K == 3) {
                 float r[15];
 #pragma unroll
@@ -1003,20 +1007,26 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
             pub[6] = s.pos.x; pub[7] = s.pos.y; pub[8] = s.pos.z;
         }
         // controller / rotor state: plain stores (they are early: write-through here stalls the wave, measured +0.45 us)
+        if (LAB(LAB_NOSTORE | LAB_NOST_REC)) {
+        } else
 #ifdef HNS_V3_REC_SC1
+        {
         st_f4(reinterpret_cast<float4 *>(b.throttle) + ia, thr4);
         st_f4(reinterpret_cast<float4 *>(b.pid_integ) + ia, integ4);
         st_f4(reinterpret_cast<float4 *>(b.pid_last_rate) + ia, last4);
         st_f4(reinterpret_cast<float4 *>(b.prev_action) + ia, prev4);
         st_f1(b.action_error + ia, aerr);
+        }
 #else
+        {
         reinterpret_cast<float4 *>(b.throttle)[ia] = thr4;
         reinterpret_cast<float4 *>(b.pid_integ)[ia] = integ4;
         reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
         reinterpret_cast<float4 *>(b.prev_action)[ia] = prev4;
         b.action_error[ia] = aerr;
+        }
 #endif
-        {   // S_{t+1}: the wave's 64 rows back through the slab, one contiguous slice
+        if (!LAB(LAB_NOSTORE | LAB_NOST_DS)) {   // S_{t+1}: the wave's 64 rows back through the slab, one contiguous slice
             const float row[13] = {s.pos.x, s.pos.y, s.pos.z, s.q.w, s.q.x, s.q.y, s.q.z, s.lin.x, s.lin.y, s.lin.z, s.ang.x, s.ang.y, s.ang.z};
             wave_store_rows<13>(slab, b.drone_state + ((size_t)e0 * A + (tid & ~63)) * 13, row, lane);
         }
@@ -1030,42 +1040,58 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
         bool blocked, det, blockedB = false, detB = false;
         int knn_idx[kMaxK];
         bool knn_masked[kMaxK];
+        float d;                       // |evader - pursuer| (hideandseek.py:921): the norm the observation pass just took, the squares are the same
         agent_obs<A, 1, true, kPub>(c, C, K, le, a, s, tp, tp, progress, cyl, sPub + 6, b.obs_others + (size_t)ia * (A - 1) * 3, slab,
                                     b.obs_self + (size_t)ia * SD, with_state ? b.state_drones + (size_t)ia * SD : nullptr, blocked, det, blockedB, detB,
-                                    knn_idx, knn_masked, true, true, b.obs_cylinders + (size_t)ia * K * 5);
+                                    knn_idx, knn_masked, !LAB(LAB_NOSTORE | LAB_NOST_SELF), !LAB(LAB_NOSTORE | LAB_NOST_OTH),
+                                    b.obs_cylinders + (size_t)ia * K * 5, &d, !LAB(LAB_NOSTORE | LAB_NOST_OCYL));
         prof_mark(p.prof, 9);
-        const float d = d_norm3(tp.x - s.pos.x, tp.y - s.pos.y, tp.z - s.pos.z);   // hideandseek.py:919-995
-        const float act = (d > c.catch_radius) ? 1.0f : 0.0f;
+        const float act = (d > c.catch_radius) ? 1.0f : 0.0f;                     // hideandseek.py:919-995
         const float dist_rew = (-c.dist_reward_coef * d) * act;
         const bool cap_ok = (d < c.catch_radius) && !blocked;
-        const float sp = d_norm3(s.lin.x, s.lin.y, s.lin.z);
-        const float speed_rew = -c.speed_coef * ((sp > c.v_drone) ? 1.0f : 0.0f);
+        // Threshold tests on norms: RN(sqrt(x)) compared with a limit is decided on x itself unless x lies within 2^-19 of
+        // the squared limit; only then the correctly rounded square root is taken (same booleans as the plain form).
+        bool fast = false;
+        {
+            const float sp2 = HNS_FMA(s.lin.z, s.lin.z, HNS_FMA(s.lin.y, s.lin.y, s.lin.x * s.lin.x));
+            const float v2 = c.v_drone * c.v_drone;
+            fast = sp2 > v2 * 1.00000190734863f;
+            if (!fast && !(sp2 < v2 * 0.99999809265137f)) fast = __builtin_sqrtf(sp2) > c.v_drone;
+        }
+        const float speed_rew = -c.speed_coef * (fast ? 1.0f : 0.0f);
         float cc = 0.f, cd = 0.f;
+        const float rc = c.cylinder_size + c.collision_radius, rc2 = rc * rc;
 #pragma unroll
         for (int sidx = 0; sidx < kMaxK; ++sidx) {
             if (sidx < K) {
                 const float *cy = cyl + 3 * knn_idx[sidx];
                 const float rx = s.pos.x - cy[0], ry = s.pos.y - cy[1];
-                const float dxy = d_norm2(rx, ry);
-                float hit = ((dxy - c.cylinder_size) < c.collision_radius) ? 1.0f : 0.0f;
+                const float s2 = HNS_FMA(ry, ry, rx * rx);
+                bool h = s2 < rc2 * 0.99999618530273f;                               // 1 - 2^-18: covers the roundings of rc, dxy - size
+                if (!h && !(s2 > rc2 * 1.00000381469727f)) h = (__builtin_sqrtf(s2) - c.cylinder_size) < c.collision_radius;
+                float hit = h ? 1.0f : 0.0f;
                 if (knn_masked[sidx]) hit = 0.0f;
                 cc = (sidx == 0) ? hit : cc + hit;
             }
         }
         float cr = -c.collision_coef * cc;
+        const float dd2 = c.coll_drone_dist * c.coll_drone_dist;
 #pragma unroll
         for (int o = 0; o < A - 1; ++o) {
             const int j = o + (o >= a ? 1 : 0);
             const float *rj = sPub + (le * A + j) * kPub + 6;
-            const float dd = d_norm3(s.pos.x - rj[0], s.pos.y - rj[1], s.pos.z - rj[2]);
-            const float hit = (dd < c.coll_drone_dist) ? 1.0f : 0.0f;
+            const float ex = s.pos.x - rj[0], ey = s.pos.y - rj[1], ez = s.pos.z - rj[2];
+            const float s3 = HNS_FMA(ez, ez, HNS_FMA(ey, ey, ex * ex));
+            bool h = s3 < dd2 * 0.99999809265137f;
+            if (!h && !(s3 > dd2 * 1.00000190734863f)) h = __builtin_sqrtf(s3) < c.coll_drone_dist;
+            const float hit = h ? 1.0f : 0.0f;
             cd = (o == 0) ? hit : cd + hit;
         }
         cr = cr + -c.collision_coef * cd;
         const float cw = ((s.pos.z > c.max_height) ? 1.0f : 0.0f) + ((HNS_FMA(s.pos.y, s.pos.y, s.pos.x * s.pos.x) > c.arena_sq) ? 1.0f : 0.0f);
         cr = cr + -c.collision_coef * cw;
-        float sm = c.smoothness_coef * d_expf(-aerr);
-        if (!c.use_deployment) sm = 0.0f;
+        float sm = 0.0f;
+        if (c.use_deployment) sm = c.smoothness_coef * d_expf(-aerr);
         {
             float *red = sRed + tid * kRedS;
             red[R_DIST] = dist_rew; red[R_SPEED] = speed_rew; red[R_CC] = cc; red[R_CD] = cd; red[R_CW] = cw;
@@ -1130,8 +1156,10 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
         sTp[le * 3] = tpn.x; sTp[le * 3 + 1] = tpn.y; sTp[le * 3 + 2] = tpn.z;
         {
             float *gp = b.target_pos + (size_t)e * 3, *gv = b.target_vel + (size_t)e * 3;
-            st_f1(gp, tpn.x); st_f1(gp + 1, tpn.y); st_f1(gp + 2, tpn.z);
-            st_f1(gv, tvel.x); st_f1(gv + 1, tvel.y); st_f1(gv + 2, tvel.z);
+            if (!LAB(LAB_NOSTORE)) {
+                st_f1(gp, tpn.x); st_f1(gp + 1, tpn.y); st_f1(gp + 2, tpn.z);
+                st_f1(gv, tvel.x); st_f1(gv + 1, tvel.y); st_f1(gv + 2, tvel.z);
+            }
         }
         {   // statistics that only need phase-1 data (A10 hideandseek.py:731-733, :1097-1098, :996-997)
             float sum_ae = 0.f, sum_td = 0.f, max_td = 0.f;
@@ -1185,10 +1213,10 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
         for (int j = 0; j < A; ++j) {
             const float *red = sRed + (le * A + j) * kRedS;
             const float r = ((((red[R_DIST] + detect_rew) + catch_rew) + red[R_COLL]) + red[R_SPEED]) + red[R_SMOOTH];
-            st_f1(b.reward + (size_t)e * A + j, r);
+            if (!LAB(LAB_NOSTORE)) st_f1(b.reward + (size_t)e * A + j, r);
             sum_rew = (j == 0) ? r : sum_rew + r;
         }
-        if (!det_any) {                                        // hideandseek.py:791-794: mask the evader's relative position
+        if (!det_any && !LAB(LAB_NOSTORE)) {                   // hideandseek.py:791-794: mask the evader's relative position
 #pragma unroll
             for (int j = 0; j < A; ++j) {
                 float *o = b.obs_self + ((size_t)e * A + j) * SD;
@@ -1236,8 +1264,10 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
         b.done[e] = (uint8_t)done;
         if (b.detect) b.detect[e] = (uint8_t)det_any;
         b.progress[e] = progress;
+        if (!LAB(LAB_NOSTORE | LAB_NOST_STATS)) {
 #pragma unroll
-        for (int i = 0; i < HNS_NUM_STATS; ++i) st_f1(b.stats + (size_t)i * E + e, st[i]);
+            for (int i = 0; i < HNS_NUM_STATS; ++i) st_f1(b.stats + (size_t)i * E + e, st[i]);
+        }
         prof_mark(p.prof, 6);
     }
     prof_mark(p.prof, 7);
