@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HNS_ABI_VERSION 1
+#define HNS_ABI_VERSION 2
 #define HNS_MAX_AGENTS 7    /* pursuers per env; lane group = next pow2 >= A+1 */
 #define HNS_MAX_CYLINDERS 16
 #define HNS_NUM_STATS 24    /* hideandseek.py:400-425 */
@@ -127,6 +127,8 @@ typedef struct hns_cfg {
     float inv_max_episode_length; /* 1.0f/max_len: CUDA `tensor / python_scalar` multiplies by the fp32 reciprocal */
     float max_lin_vel;         /* v_drone*(1-1e-6): PhysX max_linear_velocity (hideandseek.py:539), set a hair
                                   inside so the clamped speed never trips `speed > v_drone` (:952) by rounding */
+    float inv_dt;              /* fp32(1/fp32(dt)): `(rate - last) / self.dt` (lee_position_controller.py:509) on CUDA multiplies by the
+                                  fp32 reciprocal of the Python scalar (BinaryDivTrueKernel.cu) */
     /* reset distributions (hideandseek.py:283-313) */
     float drone_xy_lo[2], drone_xy_hi[2], target_xy_lo[2], target_xy_hi[2];
     float z_lo, z_hi;

@@ -6,7 +6,7 @@ been built (`python -c "import __graft_entry__ as g; g.build()"`).
 import ctypes as C
 import os
 
-HNS_ABI_VERSION = 1
+HNS_ABI_VERSION = 2
 HNS_MAX_AGENTS = 7
 HNS_MAX_CYLINDERS = 16
 HNS_NUM_STATS = 24
@@ -50,7 +50,7 @@ class HnsCfg(C.Structure):
         ("pid_kp", _f * 3), ("pid_ki", _f * 3), ("pid_kd", _f * 3), ("pid_ilimit", _f * 3),
         ("pid_outlimit", _f),
         ("lin_damp_factor", _f), ("ang_damp_factor", _f), ("max_ang_vel", _f), ("inv_mass", _f), ("inv_inertia", _f * 3), ("inv_num_agents", _f),
-        ("inv_max_episode_length", _f), ("max_lin_vel", _f),
+        ("inv_max_episode_length", _f), ("max_lin_vel", _f), ("inv_dt", _f),
         ("drone_xy_lo", _f * 2), ("drone_xy_hi", _f * 2), ("target_xy_lo", _f * 2),
         ("target_xy_hi", _f * 2), ("z_lo", _f), ("z_hi", _f), ("rpy_lo", _f * 3), ("rpy_hi", _f * 3),
         ("fixed_drone_pos", (_f * 3) * (HNS_MAX_AGENTS + 1)), ("fixed_target_pos", _f * 3),

@@ -321,6 +321,7 @@ def resolve_hns_cfg(cfg, num_envs=None, env_index_offset=0, drone_params=None, w
     c.inv_inertia[:] = [float(one / torch.tensor(x, dtype=torch.float32)) for x in c.inertia]
     c.inv_num_agents = float(one / torch.tensor(float(A), dtype=torch.float32))
     c.inv_max_episode_length = float(one / torch.tensor(float(c.max_episode_length), dtype=torch.float32))
+    c.inv_dt = float(one / torch.tensor(dt, dtype=torch.float32))
     # reset distributions, hideandseek.py:283-313
     r = float(t.arena_size) / math.sqrt(2.0)
     c.drone_xy_lo[:], c.drone_xy_hi[:] = [0.1, -r + 0.1], [r - 0.1, r - 0.1]

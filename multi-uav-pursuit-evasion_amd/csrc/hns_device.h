@@ -163,7 +163,7 @@ HNS_DEV void d_ctbr_pid_squashed(const hns_cfg &c, const float4 &ta, const Q4 &q
         br[i] = (br[i] * 180.0f) * kInvPi;       // `* 180.0 / torch.pi` (lee_position_controller.py:505), CUDA scalar-division form
         float err = target[i] - br[i];
         float P = err * c.pid_kp[i];
-        float deriv = -(br[i] - last[i]) / c.dt;
+        float deriv = -(br[i] - last[i]) * c.inv_dt;
         if (deriv != deriv) deriv = 0.0f;
         float D = deriv * c.pid_kd[i];
         float in = integ[i] + err * c.dt;
@@ -220,20 +220,24 @@ HNS_DEV void d_rotor(const hns_cfg &c, const float cmd[4], float4 &throttle4, fl
 }
 
 // ---- A4: downwash of drone j on drone i   omni_drones/robots/drone/multirotor.py:488-494,725-753
-HNS_DEV V3 d_downwash_pair(const V3 &pi, const V3 &pj, const V3 &tj_w) {
-    float n = d_norm3(tj_w.x, tj_w.y, tj_w.z);
-    float dx = tj_w.x / (n + 1e-6f), dy = tj_w.y / (n + 1e-6f), dz = tj_w.z / (n + 1e-6f);
+// 1 / (|thrust vector| + 1e-6): taken ONCE by the drone that owns the thrust vector and published beside it
+HNS_DEV float d_downwash_inv_norm(const V3 &t_w) { return 1.0f / (d_norm3(t_w.x, t_w.y, t_w.z) + 1e-6f); }
+// (kr r / z)^2 = 4 r^2 / z^2 from the squared radial distance: no square root; z = 0 gives +inf (r > 0) or NaN (r = 0)
+// exactly as kr r / z does
+HNS_DEV V3 d_downwash_pair(const V3 &pi, const V3 &pj, const V3 &tj_w, float inv_nj) {
+    float dx = tj_w.x * inv_nj, dy = tj_w.y * inv_nj, dz = tj_w.z * inv_nj;
     float rx = pj.x - pi.x, ry = pj.y - pi.y, rz = pj.z - pi.z;
     float zd = HNS_FMA(rz, dz, HNS_FMA(ry, dy, rx * dx));
     float ox = HNS_FMA(-zd, dx, rx), oy = HNS_FMA(-zd, dy, ry), oz = HNS_FMA(-zd, dz, rz);
-    float r = d_norm3(ox, oy, oz);
+    float r2 = HNS_FMA(oz, oz, HNS_FMA(oy, oy, ox * ox));
     float z = zd < 0.0f ? 0.0f : zd;
-    float u = (2.0f * r) / z;
+    float u2 = (4.0f * r2) / (z * z);
     float den = HNS_FMA(0.3f, z, 1.0f);
-    float v = d_expf(-0.5f * (u * u)) / (den * den);
+    float v = d_expf(-0.5f * u2) / (den * den);
     V3 f = {v * -tj_w.x, v * -tj_w.y, v * -tj_w.z};
     return f;
 }
+HNS_DEV V3 d_downwash_pair(const V3 &pi, const V3 &pj, const V3 &tj_w) { return d_downwash_pair(pi, pj, tj_w, d_downwash_inv_norm(tj_w)); }
 
 // ---- A7: line of sight drone->target blocked by any cylinder (xy plane) ---------------------
 // omni_drones/envs/hide_and_seek/hideandseek.py:47-103.  cyl: this env's [C,3] in LDS.
@@ -312,17 +316,18 @@ HNS_DEV V3 d_prey_pursuer_term(const hns_cfg &c, const V3 &dp, const V3 &tp, boo
     float rx = dp.x - tp.x, ry = dp.y - tp.y, rz = dp.z - tp.z;
     float dist = d_norm3(rx, ry, rz);
     float active = ((dist < c.target_detect_radius) && !blocked) ? 1.0f : 0.0f;
-    float rec = 1.0f / (dist + 1e-5f);
+    float rec = 1.0f / (dist + 1e-5f);           // one reciprocal: direction (:1084) and magnitude (:1085) both scale by it
     V3 f;
-    f.x = ((-rx / (dist + 1e-5f)) * rec) * active;
-    f.y = ((-ry / (dist + 1e-5f)) * rec) * active;
-    f.z = ((-rz / (dist + 1e-5f)) * rec) * active;
+    f.x = ((-rx * rec) * rec) * active;
+    f.y = ((-ry * rec) * rec) * active;
+    f.z = ((-rz * rec) * rec) * active;
     return f;
 }
 // arena walls/ceiling/floor (:1090-1112); also reports the out-of-arena flag (:1096-1098)
 HNS_DEV V3 d_prey_arena_term(const hns_cfg &c, const V3 &tp, bool &out_of_arena) {
     float od = d_norm2(tp.x, tp.y);
-    float dirx = -tp.x / (od + 1e-5f), diry = -tp.y / (od + 1e-5f);
+    float ro = 1.0f / (od + 1e-5f);
+    float dirx = -tp.x * ro, diry = -tp.y * ro;
     bool out = HNS_FMA(tp.y, tp.y, tp.x * tp.x) > c.arena_sq;
     out_of_arena = out;
     float outf = out ? 1.0f : 0.0f, nout = out ? 0.0f : 1.0f;
@@ -347,9 +352,9 @@ HNS_DEV void d_prey_cylinder_term(const hns_cfg &c, const V3 &tp, float ccx, flo
     float dc = d_norm2(rx, ry);
     float db = dc - c.cylinder_size;
     float act = (!(ccz < 0.0f) && (dc < c.target_detect_radius)) ? 1.0f : 0.0f;
-    float rec = 1.0f / (db + 1e-5f);
-    tx = (act * (rx / (dc + 1e-5f))) * rec;
-    ty = (act * (ry / (dc + 1e-5f))) * rec;
+    float w = 1.0f / ((dc + 1e-5f) * (db + 1e-5f));    // direction / (dc + eps) times magnitude 1 / (db + eps): one reciprocal
+    tx = (act * rx) * w;
+    ty = (act * ry) * w;
 }
 
 // ---- A5: rigid-body integration — the build's own spec -----------------------

@@ -231,7 +231,12 @@ HNS_DEV void wave_store_rows(float *__restrict__ slab, float *__restrict__ gslic
 #if HNS_OUT_AUX != 0
     // cache policy of the output stores (aux: 1 = sc0, 2 = nt, 16 = sc1 write-through; measured A/B: plain 28.3, nt 27.9, sc1 27.2 us)
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)gslice, 0, 64 * NF * 4, 0x00020000);
+    // the slice start is the same for all lanes, but derived from per-lane values: hand the compiler a provably uniform
+    // pointer, or it wraps every buffer store in a waterfall loop (4 readfirstlane + compare + exec mask, ~10 instructions each)
+    const uintptr_t gaddr = reinterpret_cast<uintptr_t>(gslice);
+    const uintptr_t guni = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gaddr >> 32)) << 32) |
+                           (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gaddr);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(guni), 0, 64 * NF * 4, 0x00020000);
 #pragma unroll
     for (int j = 0; j < (N4 + 63) / 64; ++j)
         if (j * 64 + lane < N4) {
@@ -905,7 +910,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
 //     vector, position at t+1), three workgroup barriers in all (six before);
 //   * every store is a whole-line store from a wave-private slab.
 // Arithmetic, evaluation order and results are those of hns_step_kernel (bit-identical; tests/test_hip_parity.py).
-constexpr int kPub = 9;   // published per pursuer: position at t (3), thrust vector (3), position at t+1 (3); odd stride
+constexpr int kPub = 11;  // published per pursuer: position at t (3), thrust vector (3), position at t+1 (3), 1 / (|thrust| + 1e-6); odd stride
 struct LdsV3 { int slab, slab_stride, pub, cyl, cyl_stride, tp, red, total; };
 __host__ __device__ inline LdsV3 lds_layout_v3(int A, int C, int K) {
     LdsV3 L;
@@ -979,6 +984,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
             float *pub = sPub + tid * kPub;
             pub[0] = s.pos.x; pub[1] = s.pos.y; pub[2] = s.pos.z;
             pub[3] = tw.x; pub[4] = tw.y; pub[5] = tw.z;
+            pub[9] = d_downwash_inv_norm(tw);
             float *red = sRed + tid * kRedS;
             red[R_AERR] = aerr; red[R_TD] = thr_diff;
         }
@@ -991,7 +997,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
             const int j = o + (o >= a ? 1 : 0);
             const float *pj = sPub + (le * A + j) * kPub;
             const V3 posj = {pj[0], pj[1], pj[2]}, twj = {pj[3], pj[4], pj[5]};
-            const V3 fj = d_downwash_pair(s.pos, posj, twj);
+            const V3 fj = d_downwash_pair(s.pos, posj, twj, pj[9]);
             fdw.x = (o == 0) ? fj.x : fdw.x + fj.x;
             fdw.y = (o == 0) ? fj.y : fdw.y + fj.y;
             fdw.z = (o == 0) ? fj.z : fdw.z + fj.z;

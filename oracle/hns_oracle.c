@@ -168,7 +168,7 @@ static void o_ctbr_pid(const hns_cfg *c, const float action[4], const float q[4]
         br[i] = (br[i] * 180.0f) * O_INV_PI;   /* CUDA `tensor / python_scalar` = multiply by the fp32 reciprocal */
         float err = target[i] - br[i];
         float P = err * c->pid_kp[i];
-        float deriv = -(br[i] - last[i]) / c->dt;
+        float deriv = -(br[i] - last[i]) * c->inv_dt;   /* `/ self.dt` (:509): CUDA multiplies by the fp32 reciprocal of the scalar */
         if (deriv != deriv) deriv = 0.0f;
         float D = deriv * c->pid_kd[i];
         float in = integ[i] + err * c->dt;
@@ -218,17 +218,21 @@ static void o_rotor(const hns_cfg *c, const float cmd[4], float throttle[4], flo
  * A4: downwash of drone j on drone i   multirotor.py:488-494, 725-753
  * tj_w = quat_rotate(q_j, [0,0,sum thrust_j])
  * ---------------------------------------------------------------------------------------- */
+/* Evaluation form (same quantities as :725-753, fewer roundings): the unit thrust direction is tj_w times ONE reciprocal
+ * of (|tj_w| + 1e-6); (kr r / z)^2 is formed from the squared radial distance, 4 r^2 / z^2, without taking r itself
+ * (z = 0: +inf for r > 0, NaN for r = 0, as kr r / z gives). */
 static void o_downwash_pair(const float pi[3], const float pj[3], const float tj_w[3], float f[3]) {
     float n = o_norm3(tj_w[0], tj_w[1], tj_w[2]);
-    float d[3] = {tj_w[0] / (n + 1e-6f), tj_w[1] / (n + 1e-6f), tj_w[2] / (n + 1e-6f)};
+    float inv = 1.0f / (n + 1e-6f);
+    float d[3] = {tj_w[0] * inv, tj_w[1] * inv, tj_w[2] * inv};
     float rel[3] = {pj[0] - pi[0], pj[1] - pi[1], pj[2] - pi[2]};
     float zd = O_FMA(rel[2], d[2], O_FMA(rel[1], d[1], rel[0] * d[0]));
     float rx = O_FMA(-zd, d[0], rel[0]), ry = O_FMA(-zd, d[1], rel[1]), rz = O_FMA(-zd, d[2], rel[2]);
-    float r = o_norm3(rx, ry, rz);
+    float r2 = O_FMA(rz, rz, O_FMA(ry, ry, rx * rx));
     float z = zd < 0.0f ? 0.0f : zd;
-    float u = (2.0f * r) / z;
+    float u2 = (4.0f * r2) / (z * z);
     float den = O_FMA(0.3f, z, 1.0f);
-    float v = o_expf(-0.5f * (u * u)) / (den * den);
+    float v = o_expf(-0.5f * u2) / (den * den);
     f[0] = v * -tj_w[0]; f[1] = v * -tj_w[1]; f[2] = v * -tj_w[2];
 }
 
@@ -269,16 +273,17 @@ static void o_prey(const hns_cfg *c, int A, int C, const float *drone_pos, const
         float dist = o_norm3(rp[0], rp[1], rp[2]);
         int blocked = o_blocked(c, C, dp, tp, cyl);
         float active = ((dist < c->target_detect_radius) && !blocked) ? 1.0f : 0.0f;
-        float rec = 1.0f / (dist + 1e-5f);
+        float rec = 1.0f / (dist + 1e-5f);           /* one reciprocal: direction (:1084) and magnitude (:1085) both scale by it */
         for (int i = 0; i < 3; ++i) {
-            float dir = -rp[i] / (dist + 1e-5f);
+            float dir = -rp[i] * rec;
             float fp = (dir * rec) * active;
             F[i] = (a == 0) ? fp : F[i] + fp;
         }
     }
     /* arena  :1094-1112 */
     float od = o_norm2(tp[0], tp[1]);
-    float dirx = -tp[0] / (od + 1e-5f), diry = -tp[1] / (od + 1e-5f);
+    float ro = 1.0f / (od + 1e-5f);
+    float dirx = -tp[0] * ro, diry = -tp[1] * ro;
     int out = O_FMA(tp[1], tp[1], tp[0] * tp[0]) > c->arena_sq;
     if (out_of_arena_stat) *out_of_arena_stat = ((*out_of_arena_stat != 0.0f) || out) ? 1.0f : 0.0f;
     float outf = out ? 1.0f : 0.0f, nout = out ? 0.0f : 1.0f;
@@ -303,9 +308,9 @@ static void o_prey(const hns_cfg *c, int A, int C, const float *drone_pos, const
         float dc = o_norm2(rx, ry);
         float db = dc - c->cylinder_size;
         float act = (!(cc[2] < 0.0f) && (dc < c->target_detect_radius)) ? 1.0f : 0.0f;
-        float rec = 1.0f / (db + 1e-5f);
-        float tx = (act * (rx / (dc + 1e-5f))) * rec;
-        float ty = (act * (ry / (dc + 1e-5f))) * rec;
+        float w = 1.0f / ((dc + 1e-5f) * (db + 1e-5f));    /* direction / (dc + eps) times magnitude 1 / (db + eps): one reciprocal */
+        float tx = (act * rx) * w;
+        float ty = (act * ry) * w;
         fcx += tx;
         fcy += ty;
     }

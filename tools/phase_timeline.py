@@ -13,7 +13,7 @@ import hns_amd
 from hns_amd import config
 from hns_amd.env import HideAndSeek
 
-E, A, Cn = 65536, 3, 8
+E, A, Cn = int(os.environ.get("HNS_TL_ENVS", "65536")), 3, 8
 cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": Cn, "min_num": Cn}, "env": {"num_envs": E}})
 env = HideAndSeek(cfg)
 env.reset()
@@ -34,6 +34,7 @@ f = np.median(dur_c / np.maximum(rt1 - rt0, 1.0))          # shader cycles per n
 print("shader clock ~ %.2f GHz; kernel span %.0f ns" % (f, rt1.max() - z))
 marks = [("start", 0), ("loaded(b0)", 1), ("p1 done", 2), ("p2 done", 3), ("published", 8), ("obs done", 9), ("3a done", 4), ("b4 passed", 5), ("3b done", 6), ("end", 7)]
 rounds = (np.arange(E // 64) >> 8) & 3
+print("envs", E)
 for role, sl in (("agent waves", slice(0, A)), ("env wave", slice(A, A + 1))):
     print(role + " — median absolute time (ns) of each mark by dispatch round")
     print("%-12s" % "mark" + "".join("%10s" % ("round %d" % r) for r in range(4)))
