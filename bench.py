@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """bench.py — env agent-steps/s of the fused HideAndSeek step on MI355X.
 
-Workload = BASELINE.json configs[2]: HideAndSeek 3 pursuers / 1 evader, 8 cylinders
-(k-nearest + line-of-sight sensing), 65 536 envs per GPU, synthetic N(0,1) policy outputs
-resident in HBM.  A "step" is one `hns_step` over the whole env batch (+ the `hns_reset` launch
-at the natural 1/800 episode boundary).  Multi-GPU: one process per GPU (torchrun), contiguous
-env-index shards, weak scaling; the only collective is one RCCL all-gather of 5 fp64 values per
-64-step rollout (the advantage-normalisation moments named by north_star).
+Workload = BASELINE.json configs[2]: HideAndSeek 3 pursuers / 1 evader, 8 cylinders (k-nearest + line-of-sight
+sensing), 65 536 envs per GPU, synthetic N(0,1) policy outputs resident in HBM.  A "step" is one `env.step(td)` of the
+Python class ("time env.step") = one `hns_step` launch over the whole env batch, plus the `reset` at the
+natural 1/800 episode boundary.  Multi-GPU: one process per GPU, contiguous env-index shards, weak scaling; the only
+collective is one RCCL all-gather of 5 fp64 values per 64-step rollout (the advantage-normalisation moments named by
+north_star).  `python bench.py --gpus N` launches its own N ranks when it was not started by torchrun.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live: every 32nd step launch inside the
-timed region is bracketed by hipEvents on the launch stream (hns_enable_timing).
-`cpu_baseline` (N=1 only) times the CPU oracle — test infrastructure, never the product — on a
-bounded sample of the same workload.
+Prints ONE JSON line (rank 0):
+  * `value` / `ms_per_step`: the timed `env.step` loop; `abi_rate`: the same steps through the bare C ABI;
+  * `roofline`: the step kernel, measured live — every 32nd launch of the timed region carries dispatch-bound hipEvents
+    (hns_enable_timing), per-rank min/max in `kernel_us_by_rank`; `traffic` is a LOOK-UP of the committed PMC profile;
+  * `configs`: the other BASELINE configurations (cfg2 4 096 envs / no cylinders, cfg4 envgen with the generator's cost
+    per episode, cfg5_shard 6v2 / 16 cylinders — one GPU's shard), each with its own ms_per_step and roofline fraction;
+  * `tp_mode`: step + trajectory predictor (the reference's default `use_TP_net: 1`);
+  * `cpu_baseline` (N = 1 only): the CPU oracle — test infrastructure, never the product — on a bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,9 +30,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F16_PEAK_TFLOPS = 2500.0
 NUM_STATS = 24
 
 
@@ -38,7 +43,7 @@ def algorithmic_bytes_per_env(A, C, k, S=NUM_STATS, NT=1):
     return base + (NT - 1) * (12 + 24 + 16 * A)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -52,18 +57,48 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=100)
     ap.add_argument("--time-every", type=int, default=32)
+    ap.add_argument("--abi-steps", type=int, default=500, help="secondary leg: the same steps through the bare C ABI (0 = skip)")
+    ap.add_argument("--config-steps", type=int, default=400, help="steps of each extra BASELINE configuration leg (0 = skip the legs)")
+    ap.add_argument("--envgen-episodes", type=int, default=7, help="cfg4 leg: episodes (of --envgen-episode-length steps) incl. the generator")
+    ap.add_argument("--envgen-episode-length", type=int, default=200)
     ap.add_argument("--stream-groups", type=int, default=0,
                     help="optional extra leg (e.g. 2): the env batch as shards on separate HIP streams of one GPU, reported as "
                          "`stream_shards`; off by default so that a profile of the default command holds whole-batch launches only")
     ap.add_argument("--group-steps", type=int, default=1000)
     ap.add_argument("--tp-steps", type=int, default=300,
-                    help="extra untimed-in-`value` leg: steps with the trajectory predictor in the observation "
-                         "(algo.use_TP_net: 1, the reference's default config), reported as `tp_mode`; 0 = skip")
-    args = ap.parse_args()
+                    help="extra leg: steps with the trajectory predictor in the observation (algo.use_TP_net: 1, the reference's "
+                         "default config), reported as `tp_mode`; 0 = skip")
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU, RCCL) and relay rank 0's line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(out.stdout[-2000:] + "\n" + out.stderr[-4000:] + "\n")
+        raise SystemExit(out.returncode or 1)
+    sys.stderr.write(out.stderr[-2000:])
+    print(lines[0])
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -74,9 +109,10 @@ def main():
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_dev = device if (dist is not None and dist.get_backend() == "nccl") else "cpu"
 
     import hns_amd  # noqa: F401
-    from hns_amd import abi, config
+    from hns_amd import abi, config, sharding
     if not os.path.exists(abi.library_path()):            # fresh checkout: the .so files are git-ignored
         if rank == 0:
             import __graft_entry__
@@ -84,45 +120,8 @@ def main():
         if world > 1:
             dist.barrier()
     from hns_amd.env import HideAndSeek
-
-    E, A, C, K = args.envs, args.agents, args.cylinders, 3
-    cfg = config.make_cfg({"num_agents": A, "num_targets": args.targets, "cylinder": {"max_num": C, "min_num": C, "obs_max_cylinder": K},
-                           "env": {"num_envs": E, "max_episode_length": args.episode},
-                           "sim": {"device": f"cuda:{local_rank}"}})
-    env = HideAndSeek(cfg, headless=True, env_index_offset=rank * E, write_critic_state=args.critic_state)
-    env.set_seed(0)
-    env.reset()
-    lib, henv = env._lib, env._env
+    from hns_amd.tensordict_shim import TensorDict
     import ctypes as Cx
-    stream = torch.cuda.current_stream(device)
-    sptr = Cx.c_void_p(stream.cuda_stream)
-
-    # synthetic policy outputs: a ring of pre-generated N(0,1) action batches resident in HBM
-    R = 8
-    gen = torch.Generator(device=device).manual_seed(1000 + rank)
-    actions = [torch.randn(E, A, 4, generator=gen, device=device) for _ in range(R)]
-    aptr = [Cx.c_void_p(a.data_ptr()) for a in actions]
-    done_ptr = Cx.c_void_p(env._bufs["done"].data_ptr())
-    reward = env._bufs["reward"]
-    success = env.stats["success"]
-    from hns_amd import sharding
-    rollout = int(cfg.algo.get("train_every", 64))
-    progress = {"t": 0}
-
-    def run(n):
-        for _ in range(n):
-            i = progress["t"]
-            rc = lib.hns_step(henv, aptr[i % R], sptr)
-            assert rc == 0, lib.hns_last_error()
-            progress["t"] = i + 1
-            if (i + 1) % args.episode == 0:          # lock-step episodes: every env is done now
-                rc = lib.hns_reset(henv, done_ptr, Cx.c_uint64(env.seed), sptr)
-                assert rc == 0, lib.hns_last_error()
-            if world > 1 and (i + 1) % rollout == 0:
-                # per-rollout moments for advantage normalisation (learning/mappo.py:391-396 made
-                # data-parallel) + the success rate of the curriculum (hideandseek.py:1012-1015):
-                # ONE all-gather of 5 fp64 values per rank over RCCL/xGMI
-                sharding.allgather_moments(sharding.local_moments(reward, success))
 
     def sync():
         torch.cuda.synchronize(device)
@@ -130,122 +129,256 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    def make_env(E, A, C, NT=1, K=3, task=None, algo=None, cls=HideAndSeek, offset=0, episode=None):
+        t = {"num_agents": A, "num_targets": NT, "cylinder": {"max_num": C, "min_num": C, "obs_max_cylinder": K},
+             "env": {"num_envs": E, "max_episode_length": episode or args.episode}, "sim": {"device": f"cuda:{local_rank}"}}
+        if task:
+            cyl = dict(t["cylinder"], **task.pop("cylinder", {}))
+            t.update(task)
+            t["cylinder"] = cyl
+        env = cls(config.make_cfg(t, algo=algo or {}), headless=True, env_index_offset=offset, write_critic_state=args.critic_state)
+        env.set_seed(0)
+        env.reset()
+        return env
+
+    def action_ring(E, A, seed, R=8):
+        gen = torch.Generator(device=device).manual_seed(seed)
+        acts = [torch.randn(E, A, 4, generator=gen, device=device) for _ in range(R)]
+        return acts, [TensorDict({"agents": {"action": a}}, [E]) for a in acts]
+
+    def kernel_roofline(env, E, A, C, NT=1, K=3):
+        """Roofline object of the step kernel from the launches timed since hns_enable_timing."""
+        kernel_ms, n = env.kernel_ms()
+        if kernel_ms <= 0:
+            return None, kernel_ms
+        b_env = algorithmic_bytes_per_env(A, C, K, NT=NT)
+        achieved = b_env * E / (kernel_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "kernel_us": round(kernel_ms * 1e3, 2), "samples": n, "bytes_per_launch": b_env * E, "bytes_per_env": b_env}, kernel_ms
+
+    def timed_steps(env, tds, n, warm, reset_every=None, timing=0):
+        """n `env.step` calls (with the episode-boundary reset when given); returns wall seconds."""
+        done_td = TensorDict({}, [env.num_envs])
+        for i in range(warm):
+            env.step(tds[i % len(tds)])
+        torch.cuda.synchronize(device)
+        if timing:
+            env.enable_kernel_timing(timing)
+        t0 = time.perf_counter()
+        for i in range(n):
+            env.step(tds[i % len(tds)])
+            if reset_every and (i + 1) % reset_every == 0:
+                done_td.set("_reset", env._bufs["done"])
+                env.reset(done_td)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        if timing:
+            env.enable_kernel_timing(0)
+        return dt
+
+    # ======================= headline: cfg3 through env.step =====================================================
+    E, A, C, K = args.envs, args.agents, args.cylinders, 3
+    env = make_env(E, A, C, NT=args.targets, offset=rank * E)
+    lib, henv = env._lib, env._env
+    stream = torch.cuda.current_stream(device)
+    sptr = Cx.c_void_p(stream.cuda_stream)
+    actions, tds = action_ring(E, A, 1000 + rank)
+    aptr = [Cx.c_void_p(a.data_ptr()) for a in actions]
+    R = len(actions)
+    reward, success = env._bufs["reward"], env.stats["success"]
+    rollout = int(env.cfg.algo.get("train_every", 64))
+    reset_td = TensorDict({}, [E])
+    progress = {"t": 0}
+    rate_hook = sharding.GlobalSuccessRate()
+    env.success_rate_fn = rate_hook
+
+    def run(n):
+        for _ in range(n):
+            i = progress["t"]
+            env.step(tds[i % R])
+            progress["t"] = i + 1
+            if (i + 1) % args.episode == 0:          # lock-step episodes: every env is done now
+                reset_td.set("_reset", env._bufs["done"])
+                env.reset(reset_td)
+            if world > 1 and (i + 1) % rollout == 0:
+                # per-rollout moments for advantage normalisation (learning/mappo.py:391-396 made data-parallel) + the success
+                # rate of the curriculum (hideandseek.py:1012-1015): ONE all-gather of 5 fp64 values per rank over RCCL/xGMI
+                rate_hook.update(sharding.allgather_moments(sharding.local_moments(reward, success)))
+
     run(args.warmup)
     sync()
-    lib.hns_enable_timing(henv, args.time_every)
+    env.enable_kernel_timing(args.time_every)
     t0 = time.perf_counter()
     run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
-    lib.hns_enable_timing(henv, 0)
-    kernel_ms, n_samples = env.kernel_ms()
+    env.enable_kernel_timing(0)
+    roofline, kernel_ms = kernel_roofline(env, E, A, C, NT=args.targets)
+
+    # ranks that actually took part (an all-reduce of ones), slowest rank's wall time, per-rank kernel time
+    n_ranks, kernel_by_rank = 1, None
     if world > 1:
-        tt = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        ones = torch.ones(1, device=coll_dev, dtype=torch.float64)
+        dist.all_reduce(ones)
+        n_ranks = int(round(float(ones.item())))
+        tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
+        kk = [torch.zeros(1, device=coll_dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(kk, torch.tensor([kernel_ms * 1e3], device=coll_dev, dtype=torch.float64))
+        kernel_by_rank = [round(float(x.item()), 2) for x in kk]
     assert torch.isfinite(env._bufs["reward"]).all(), "non-finite reward"
-    total_agent_steps = world * E * A * args.steps
-    value = total_agent_steps / elapsed
-    b_env = algorithmic_bytes_per_env(A, C, K, NT=args.targets)
-    roofline = None
-    traffic = None
-    try:   # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), see profiles/
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        key = f"hns_step_kernel<{A}>|E{E}|C{C}|k{K}|critic_state_{'on' if args.critic_state else 'off'}"
-        traffic = tj.get(key, {}).get("traffic_bytes_per_launch")
-    except Exception:  # noqa: BLE001
-        pass
-    # achievable HBM bandwidth on this box ("measure achievable with a device copy kernel and report both")
-    copy_gbs = None
-    try:
-        src = torch.empty(256 * 1024 * 1024 // 4, dtype=torch.float32, device=device).normal_()
-        dst = torch.empty_like(src)
-        for _ in range(3):
-            dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            dst.copy_(src)
-        e1.record()
+    assert env.check_finite(), "non-finite state"
+    value = n_ranks * E * A * args.steps / elapsed
+
+    if roofline is not None:
+        traffic = None
+        try:   # HBM bytes per launch measured in the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            key = f"hns_step_kernel<{A}>|E{E}|C{C}|k{K}|critic_state_{'on' if args.critic_state else 'off'}"
+            traffic = tj.get(key, {}).get("traffic_bytes_per_launch")
+            roofline["traffic_source"] = tj.get(key, {}).get("source", "profiles/traffic.json") + " (static look-up of the committed rocprofv3 PMC passes, not measured in this run)"
+        except Exception:  # noqa: BLE001
+            pass
+        roofline["traffic"] = traffic
+        roofline["kernel"] = "hns_step_v3_kernel<%d>" % A if (args.targets == 1 and E % 64 == 0) else "hns_step_kernel<%d,%d>" % (A, args.targets)
+        if kernel_by_rank:
+            roofline["kernel_us_by_rank"] = {"min": min(kernel_by_rank), "max": max(kernel_by_rank), "all": kernel_by_rank}
+        # achievable HBM bandwidth on this box (SURVEY §8d: "measure achievable with a device copy kernel and report both")
+        try:
+            src = torch.empty(256 * 1024 * 1024 // 4, dtype=torch.float32, device=device).normal_()
+            dst = torch.empty_like(src)
+            for _ in range(3):
+                dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize(device)
+            copy_gbs = round(20 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del src, dst
+            roofline["device_copy_GBs"] = copy_gbs
+            roofline["frac_of_device_copy"] = round(roofline["achieved"] / copy_gbs, 4)
+        except Exception:  # noqa: BLE001
+            pass
+
+    single = world == 1
+    # secondary: the same steps through the bare C ABI (what the Python class adds is the difference)
+    abi_rate = None
+    if args.abi_steps > 0 and single:
+        for i in range(50):
+            lib.hns_step(henv, aptr[i % R], sptr)
         torch.cuda.synchronize(device)
-        copy_gbs = round(20 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-        del src, dst
-    except Exception:  # noqa: BLE001
-        pass
-    if kernel_ms > 0:
-        achieved = b_env * E / (kernel_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": f"hns_step_kernel<{A}>", "kernel_us": round(kernel_ms * 1e3, 2), "samples": n_samples,
-                    "bytes_per_launch": b_env * E, "device_copy_GBs": copy_gbs,
-                    "frac_of_device_copy": round(achieved / copy_gbs, 4) if copy_gbs else None}
+        t1 = time.perf_counter()
+        for i in range(args.abi_steps):
+            assert lib.hns_step(henv, aptr[i % R], sptr) == 0, lib.hns_last_error()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t1
+        abi_rate = {"value": round(E * A * args.abi_steps / dt, 1), "unit": "agent-steps/s", "steps": args.abi_steps,
+                    "ms_per_step": round(dt / args.abi_steps * 1e3, 5), "what": "hns_step through ctypes, no Python class, no resets"}
+
+    # ======================= the other BASELINE configurations ================================================
+    configs = {}
+    if args.config_steps > 0 and single and args.targets == 1:
+        n = args.config_steps
+        # cfg2: 4 096 envs, the default 5 cylinder slots all inactive (BASELINE configs[1]; bytes per env 1 497)
+        e2 = make_env(4096, 3, 5, task={"cylinder": {"fixed_num": 0, "min_num": 0}})
+        _, td2 = action_ring(4096, 3, 7)
+        dt = timed_steps(e2, td2, n, 50, timing=8)
+        r2, _ = kernel_roofline(e2, 4096, 3, 5)
+        configs["cfg2"] = {"workload": "HideAndSeek 3v1, 5 cylinder slots all inactive, 4 096 envs", "value": round(4096 * 3 * n / dt, 1), "unit": "agent-steps/s",
+                           "ms_per_step": round(dt / n * 1e3, 5), "steps": n, "roofline": r2,
+                           "note": "64 workgroups on 256 CUs: one launch is a single workgroup's latency, not a bandwidth figure"}
+        del e2
+        # cfg5's per-GPU shard: 6 pursuers / 2 evaders / 16 cylinders / 65 536 envs (the two-evader extension)
+        e5 = make_env(E, 6, 16, NT=2)
+        _, td5 = action_ring(E, 6, 9)
+        dt = timed_steps(e5, td5, n, 30, timing=8)
+        r5, _ = kernel_roofline(e5, E, 6, 16, NT=2)
+        assert e5.check_finite()
+        configs["cfg5_shard"] = {"workload": f"HideAndSeek 6v2 (extension), 16 cylinders, {E} envs = one GPU's shard of the 8 x 65 536 job",
+                                 "value": round(E * 6 * n / dt, 1), "unit": "agent-steps/s", "ms_per_step": round(dt / n * 1e3, 5), "steps": n, "roofline": r5}
+        del e5
+        # cfg4: HideAndSeek_envgen — steps + the Adaptive Environment Generator at every episode boundary
+        from hns_amd.envgen import HideAndSeek_envgen
+        L, EP = args.envgen_episode_length, args.envgen_episodes
+        t0c = time.perf_counter()
+        e4 = make_env(E, 3, 8, cls=HideAndSeek_envgen, episode=L,
+                      task={"name": "HideAndSeek_envgen", "use_particle_generator": 1, "ratio_unif": 0.3, "eval_iter": 3, "R_min": 0.0, "R_max": 1.0})
+        torch.cuda.synchronize(device)
+        first_reset_ms = (time.perf_counter() - t0c) * 1e3
+        _, td4 = action_ring(E, 3, 11)
+        gen_ms, step_s = [], 0.0
+        rtd = TensorDict({}, [E])
+        e4.enable_kernel_timing(8)
+        t_all = time.perf_counter()
+        for ep in range(EP):
+            g0 = e4.generator_seconds
+            ts = time.perf_counter()
+            for t in range(L):
+                e4.step(td4[t % len(td4)])
+            torch.cuda.synchronize(device)
+            step_s += time.perf_counter() - ts - (e4.generator_seconds - g0)
+            rtd.set("_reset", e4._bufs["done"])
+            e4.reset(rtd)
+            torch.cuda.synchronize(device)
+            gen_ms.append((e4.generator_seconds - g0) * 1e3)
+        total = time.perf_counter() - t_all
+        e4.enable_kernel_timing(0)
+        r4, _ = kernel_roofline(e4, E, 3, 8)
+        steady = sorted(gen_ms[1:])
+        configs["cfg4"] = {"workload": f"HideAndSeek_envgen, 3v1, 8 cylinders, {E} envs, episodes of {L} steps (the reference: 800), new task batch every 3 episodes",
+                           "value": round(E * 3 * L * EP / step_s, 1), "unit": "agent-steps/s (stepping only)", "ms_per_step": round(step_s / (L * EP) * 1e3, 5),
+                           "roofline": r4, "episodes": EP, "generator_ms_per_episode": [round(x, 2) for x in gen_ms],
+                           "generator_ms_per_episode_steady_median": round(steady[len(steady) // 2], 2) if steady else None,
+                           "generator_ms_task_batch_max": round(max(gen_ms), 2), "construction_and_first_reset_ms": round(first_reset_ms, 1),
+                           "value_incl_generator": round(E * 3 * L * EP / total, 1),
+                           "value_incl_generator_at_800_step_episodes": round(E * 3 * 800 / (800 * step_s / (L * EP) + sum(gen_ms[1:]) / max(EP - 1, 1) * 1e-3), 1),
+                           "history_size": len(e4.gen_buffer)}
+        del e4
 
     # secondary leg (SURVEY §8d: "use_TP_net=1 reported separately"): step + hns_tp_observe
     tp_mode = None
-    if args.tp_steps > 0 and world == 1 and args.targets == 1:
-        cfg_tp = config.make_cfg({"num_agents": A, "cylinder": {"max_num": C, "min_num": C, "obs_max_cylinder": K},
-                                  "env": {"num_envs": E, "max_episode_length": args.episode},
-                                  "sim": {"device": f"cuda:{local_rank}"}}, algo={"use_TP_net": 1})
-        env_tp = HideAndSeek(cfg_tp, headless=True, write_critic_state=args.critic_state)
-        env_tp.set_seed(0)
-        env_tp.reset()                              # binds + packs the predictor's parameters
-        h2 = env_tp._env
-
-        def run_tp(n):
-            for i in range(n):
-                assert lib.hns_step(h2, aptr[i % R], sptr) == 0, lib.hns_last_error()
-                assert lib.hns_tp_observe(h2, 0, sptr) == 0, lib.hns_last_error()
-        run_tp(20)
-        torch.cuda.synchronize(device)
-        t1 = time.perf_counter()
-        run_tp(args.tp_steps)
-        torch.cuda.synchronize(device)
-        dt_tp = time.perf_counter() - t1
-        tp_mode = {"value": round(E * A * args.tp_steps / dt_tp, 1), "unit": "agent-steps/s", "steps": args.tp_steps,
-                   "ms_per_step": round(dt_tp / args.tp_steps * 1e3, 5),
-                   "what": "hns_step + hns_tp_observe (window shift, LSTM(16->64)x10 + FC on the matrix cores, 35-value rows)"}
+    if args.tp_steps > 0 and single and args.targets == 1:
+        env_tp = make_env(E, A, C, algo={"use_TP_net": 1})
+        n = args.tp_steps
+        dt_tp = timed_steps(env_tp, tds, n, 20)
+        T, F, I = env_tp.tp_history_step, env_tp.tp_future_step, env_tp.tp_frame_dim
+        flop_env = 2.0 * (T * 4 * 64 * (I + 64) + 64 * 3 * F)          # useful FLOP of LSTM(I->64) x T + Linear(64->3F), per env and step
+        tp_mode = {"value": round(E * A * n / dt_tp, 1), "unit": "agent-steps/s", "steps": n, "ms_per_step": round(dt_tp / n * 1e3, 5),
+                   "useful_mflop_per_env": round(flop_env / 1e6, 4),
+                   "what": "env.step with algo.use_TP_net=1: hns_step + hns_tp_observe (window shift, LSTM(16->64)x10 + FC on the matrix cores, 35-value rows)"}
         del env_tp
 
-    # secondary leg: the same 65 536 envs as G shards on G HIP streams of this GPU (the multi-GPU sharding applied
-    # inside one GPU).  Shards are independent, so the tail of one shard's launch — workgroups draining their stores —
-    # overlaps the load burst and the arithmetic of the others; an asynchronous (double-buffered) collector gets this
-    # rate.  Not the headline: the per-launch roofline above needs serial launches to mean anything.
+    # secondary leg: the same envs as G shards on G HIP streams of this GPU (the multi-GPU sharding applied inside one GPU)
     streams_mode = None
-    if args.stream_groups > 1 and world == 1 and args.targets == 1 and E % args.stream_groups == 0:
+    if args.stream_groups > 1 and single and args.targets == 1 and E % args.stream_groups == 0:
         G, Eg = args.stream_groups, E // args.stream_groups
-        cfg_g = config.make_cfg({"num_agents": A, "cylinder": {"max_num": C, "min_num": C, "obs_max_cylinder": K},
-                                 "env": {"num_envs": Eg, "max_episode_length": args.episode},
-                                 "sim": {"device": f"cuda:{local_rank}"}})
-        shards = []
-        for gidx in range(G):
-            sh = HideAndSeek(cfg_g, headless=True, env_index_offset=gidx * Eg, write_critic_state=args.critic_state)
-            sh.set_seed(0)
-            sh.reset()
-            shards.append(sh)
+        shards = [make_env(Eg, A, C, offset=g * Eg) for g in range(G)]
         gstreams = [torch.cuda.Stream(device) for _ in range(G)]
         gptr = [Cx.c_void_p(st.cuda_stream) for st in gstreams]
-        gact = [[Cx.c_void_p(a[gidx * Eg:(gidx + 1) * Eg].data_ptr()) for a in actions] for gidx in range(G)]
+        gact = [[Cx.c_void_p(a[g * Eg:(g + 1) * Eg].data_ptr()) for a in actions] for g in range(G)]
         torch.cuda.synchronize(device)
 
         def run_groups(n):
             for i in range(n):
-                for gidx in range(G):
-                    assert lib.hns_step(shards[gidx]._env, gact[gidx][i % R], gptr[gidx]) == 0, lib.hns_last_error()
+                for g in range(G):
+                    assert lib.hns_step(shards[g]._env, gact[g][i % R], gptr[g]) == 0, lib.hns_last_error()
         run_groups(100)
         torch.cuda.synchronize(device)
         t2 = time.perf_counter()
         run_groups(args.group_steps)
         torch.cuda.synchronize(device)
-        dt_g = time.perf_counter() - t2
-        ms_g = dt_g / args.group_steps * 1e3
-        streams_mode = {"groups": G, "value": round(E * A * args.group_steps / dt_g, 1), "unit": "agent-steps/s", "steps": args.group_steps,
+        ms_g = (time.perf_counter() - t2) / args.group_steps * 1e3
+        b_env = algorithmic_bytes_per_env(A, C, K)
+        streams_mode = {"groups": G, "value": round(E * A / (ms_g * 1e-3), 1), "unit": "agent-steps/s", "steps": args.group_steps,
                         "ms_per_step": round(ms_g, 5), "hbm_frac": round(b_env * E / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "what": f"the same {E} envs as {G} shards of {Eg} on {G} HIP streams (no join between steps)"}
         del shards
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and single and not args.no_cpu_baseline:
         import numpy as np
         import hns_oracle as O
         host = O.alloc_buffers(env.hcfg)
@@ -275,32 +408,32 @@ def main():
             rate = E * A * 6 / (time.perf_counter() - p0)
             if rate > best_rate:
                 best_n, best_rate = n, rate
-        ncores = best_n
-        O.set_threads(ncores)
+        O.set_threads(best_n)
         m0 = time.perf_counter()
         for _ in range(args.cpu_steps):
             O.step(env.hcfg, host, act)
         mdt = time.perf_counter() - m0
         O.set_threads(1)
-        cpu_baseline = {"value": round(E * A * args.cpu_steps / mdt, 1), "unit": "agent-steps/s", "cores": ncores,
+        cpu_baseline = {"value": round(E * A * args.cpu_steps / mdt, 1), "unit": "agent-steps/s", "cores": best_n,
                         "kind": "port", "one_core_value": round(one_core, 1),
                         "sample": f"{args.cpu_steps} steps of the same {E}-env workload with the C oracle "
-                                  f"(oracle/hns_oracle.c): {ncores} threads (best of a probe up to {avail}) {mdt:.1f} s, 1 thread {cdt:.1f} s"}
+                                  f"(oracle/hns_oracle.c): {best_n} threads (best of a probe up to {avail}) {mdt:.1f} s, 1 thread {cdt:.1f} s"}
 
     if rank == 0:
         out = {
             "metric": "env agent-steps/sec at 65536 envs, HideAndSeek 3v1; 1/2/4/8 GPU",
-            "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": n_ranks, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"HideAndSeek {A}v{args.targets}, {C} random cylinders + LOS/k-nearest sensing, "
-                                   f"{E} envs per GPU (BASELINE configs[2])",
+                                   f"{E} envs per GPU (BASELINE configs[2]), timed through env.step(td)",
                        "num_envs_per_gpu": E, "num_agents": A, "num_targets": args.targets, "num_cylinders": C, "obs_max_cylinder": K,
                        "episode_length": args.episode, "critic_state_output": args.critic_state,
-                       "sharding": f"contiguous env slices x{world}",
+                       "sharding": f"contiguous env slices x{n_ranks}", "world_size_launched": world,
                        "collective": "1 all-gather of 5 fp64 per 64-step rollout" if world > 1 else "none"},
             "env_frames_per_s": round(value / A, 1),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "tp_mode": tp_mode, "stream_shards": streams_mode,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "abi_rate": abi_rate, "configs": configs or None,
+            "tp_mode": tp_mode, "stream_shards": streams_mode,
         }
         print(json.dumps(out))
     if world > 1:

@@ -68,8 +68,9 @@ _fp = C.c_void_p  # device (or, for the oracle, host) pointers travel as integer
 BUFFER_FIELDS = [
     "drone_state", "throttle", "pid_integ", "pid_last_rate", "prev_action", "target_pos",
     "target_vel", "cylinders", "progress", "stats", "obs_self", "obs_others", "obs_cylinders",
-    "state_drones", "reward", "action_error", "done", "detect",
+    "state_drones", "reward", "action_error", "done", "detect", "ctbr", "target_rate",
 ]
+OPTIONAL_BUFFER_FIELDS = ("ctbr", "target_rate")     # bound only with task.publish_ctbr (transforms.py:456-457); NULL otherwise
 
 
 class HnsBuffers(C.Structure):
@@ -81,10 +82,15 @@ def self_dim(num_targets=1):
     return 24 if num_targets == 2 else HNS_SELF_DIM
 
 
-def buffer_shapes(E, A, Cn, K, num_targets=1):
-    """Shape (and dtype name) of every hns_buffers field."""
+def buffer_shapes(E, A, Cn, K, num_targets=1, publish_ctbr=False):
+    """Shape (and dtype name) of every hns_buffers field (the optional ones only when asked for)."""
     tgt = (E, 2, 3) if num_targets == 2 else (E, 3)
     D = self_dim(num_targets)
+    extra = {"ctbr": ((E, A, 4), "float32"), "target_rate": ((E, A, 4), "float32")} if publish_ctbr else {}
+    return {**_required_buffer_shapes(E, A, Cn, K, tgt, D), **extra}
+
+
+def _required_buffer_shapes(E, A, Cn, K, tgt, D):
     return {
         "drone_state": ((E, A, 13), "float32"), "throttle": ((E, A, 4), "float32"),
         "pid_integ": ((E, A, 4), "float32"), "pid_last_rate": ((E, A, 4), "float32"),

@@ -346,11 +346,11 @@ def resolve_hns_cfg(cfg, num_envs=None, env_index_offset=0, drone_params=None, w
         for a in range(min(A, len(eval_xy))):
             c.fixed_drone_pos[a][0], c.fixed_drone_pos[a][1] = eval_xy[a]
         c.fixed_target_pos[0], c.fixed_target_pos[1] = -0.8, 0.0
-        # free cells inside the disc minus (A + 1) occupied must cover the cylinder slots (:112-113)
+        # free cells inside the disc minus the cells of the pursuers and the evader(s) must cover the cylinder slots (:112-113)
         half = c.grid_num // 2
         free = sum(1 for i in range(c.grid_num) for j in range(c.grid_num)
                    if math.sqrt((i - half) ** 2 + (j - half) ** 2) < half)
-        if free - (A + 1) < Cn:
+        if free - (A + (2 if int(t.get("num_targets", 1)) == 2 else 1)) < Cn:
             raise ValueError("Not enough available grid cells for cylinder.max_num")
     else:
         c.init_mode = abi.HNS_INIT_SCENARIO

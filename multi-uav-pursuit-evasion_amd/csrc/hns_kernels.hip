@@ -97,10 +97,14 @@ struct Lds {
 };
 __host__ __device__ inline int slab_floats(int A, int K, int NT);
 __host__ __device__ inline int r4(int n) { return (n + 3) & ~3; }
+// rows per staging pass: the whole wave (64) or, for wide workgroups whose slabs would otherwise push the workgroup past half
+// of the CU's LDS, half a wave at a time (two passes per output, half the slab)
+__host__ __device__ constexpr int slab_rows(int A) { return A > 4 ? 32 : 64; }
 __host__ __device__ inline int slab_floats(int A, int K, int NT) {
-    int m = 64 * (NT == 2 ? 24 : HNS_SELF_DIM);
-    if (64 * K * 5 > m) m = 64 * K * 5;
-    if (64 * (A - 1) * 3 > m) m = 64 * (A - 1) * 3;
+    const int rows = slab_rows(A);
+    int m = rows * (NT == 2 ? 24 : HNS_SELF_DIM);
+    if (rows * K * 5 > m) m = rows * K * 5;
+    if (rows * (A - 1) * 3 > m) m = rows * (A - 1) * 3;
     return r4(m);
 }
 __host__ __device__ inline Lds lds_layout(int A, int C, int K, int NT = 1) {
@@ -207,50 +211,56 @@ HNS_DEV void st_f1(float *p, float v) {
 // the store instruction lands on a different cache line (measured: state_self 1.6 us, state_others 1.0 us of the
 // 28 us step).  Instead the wave parks its rows in its slab and stores the slice back linearly, 16 B per lane, whole
 // lines per instruction.  The slab is private to the wave: LDS operations of one wave execute in order, no barrier.
-template <int NF>
+template <int NF, int ROWS = 64>
 HNS_DEV void wave_store_rows(float *__restrict__ slab, float *__restrict__ gslice, const float (&row)[NF], int lane) {
-    float *mine = slab + lane * NF;
-    if constexpr (NF % 4 == 0) {
-#pragma unroll
-        for (int i = 0; i < NF / 4; ++i) reinterpret_cast<float4 *>(mine)[i] = make_float4(row[4 * i], row[4 * i + 1], row[4 * i + 2], row[4 * i + 3]);
-    } else if constexpr (NF % 2 == 0) {
-#pragma unroll
-        for (int i = 0; i < NF / 2; ++i) reinterpret_cast<float2 *>(mine)[i] = make_float2(row[2 * i], row[2 * i + 1]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < NF; ++i) mine[i] = row[i];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    constexpr int N4 = 64 * NF / 4;                      // float4 pieces in the slice (64*NF is a multiple of 4)
-    const float4 *s4 = reinterpret_cast<const float4 *>(slab) + lane;
-    float4 *g4 = reinterpret_cast<float4 *>(gslice) + lane;
-#ifndef HNS_OUT_AUX
-#define HNS_OUT_AUX 16
-#endif
-#if HNS_OUT_AUX != 0
-    // cache policy of the output stores (aux: 1 = sc0, 2 = nt, 16 = sc1 write-through; measured A/B: plain 28.3, nt 27.9, sc1 27.2 us)
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    static_assert(ROWS == 64 || ROWS == 32, "whole wave or half a wave per pass");
     // the slice start is the same for all lanes, but derived from per-lane values: hand the compiler a provably uniform
     // pointer, or it wraps every buffer store in a waterfall loop (4 readfirstlane + compare + exec mask, ~10 instructions each)
     const uintptr_t gaddr = reinterpret_cast<uintptr_t>(gslice);
     const uintptr_t guni = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gaddr >> 32)) << 32) |
                            (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gaddr);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(guni), 0, 64 * NF * 4, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < (N4 + 63) / 64; ++j)
-        if (j * 64 + lane < N4) {
-            const float4 v = s4[j * 64];
-            __builtin_amdgcn_raw_buffer_store_b128((u4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, rs,
-                                                   (j * 64 + lane) * 16, 0, HNS_OUT_AUX);
+    for (int half = 0; half < 64 / ROWS; ++half) {
+        if (ROWS == 64 || (lane >> 5) == half) {
+            float *mine = slab + (lane & (ROWS - 1)) * NF;
+            if constexpr (NF % 4 == 0) {
+#pragma unroll
+                for (int i = 0; i < NF / 4; ++i) reinterpret_cast<float4 *>(mine)[i] = make_float4(row[4 * i], row[4 * i + 1], row[4 * i + 2], row[4 * i + 3]);
+            } else if constexpr (NF % 2 == 0) {
+#pragma unroll
+                for (int i = 0; i < NF / 2; ++i) reinterpret_cast<float2 *>(mine)[i] = make_float2(row[2 * i], row[2 * i + 1]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NF; ++i) mine[i] = row[i];
+            }
         }
-#else
-#pragma unroll
-    for (int j = 0; j < (N4 + 63) / 64; ++j)
-        if (j * 64 + lane < N4) g4[j * 64] = s4[j * 64];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        constexpr int N4 = ROWS * NF / 4;                    // float4 pieces in this pass's slice (ROWS*NF is a multiple of 4)
+        const float4 *s4 = reinterpret_cast<const float4 *>(slab) + lane;
+#ifndef HNS_OUT_AUX
+#define HNS_OUT_AUX 16
 #endif
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                     // the next pass may overwrite the slab only behind these reads
+#if HNS_OUT_AUX != 0
+        // cache policy of the output stores (aux: 1 = sc0, 2 = nt, 16 = sc1 write-through; measured A/B: plain 28.3, nt 27.9, sc1 27.2 us)
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(guni + (uintptr_t)half * ROWS * NF * 4), 0, ROWS * NF * 4, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < (N4 + 63) / 64; ++j)
+            if (j * 64 + lane < N4) {
+                const float4 v = s4[j * 64];
+                __builtin_amdgcn_raw_buffer_store_b128((u4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, rs,
+                                                       (j * 64 + lane) * 16, 0, HNS_OUT_AUX);
+            }
+#else
+        float4 *g4 = reinterpret_cast<float4 *>(guni + (uintptr_t)half * ROWS * NF * 4) + lane;
+#pragma unroll
+        for (int j = 0; j < (N4 + 63) / 64; ++j)
+            if (j * 64 + lane < N4) g4[j * 64] = s4[j * 64];
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                     // the next pass may overwrite the slab only behind these reads
+    }
 }
 
 // ---- A8 (agent thread): observation of one pursuer on the post-physics state -------------------
@@ -302,8 +312,8 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
     if constexpr (STAGED) {
         float row[SDW] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w, v4.x, v4.y, v4.z, v4.w};
         if constexpr (NT == 2) { row[20] = v5.x; row[21] = v5.y; row[22] = v5.z; row[23] = v5.w; }
-        if (st) wave_store_rows<SDW>(sOCyl, gSelf - lane * SDW, row, lane);
-        if (gState && st) wave_store_rows<SDW>(sOCyl, gState - lane * SDW, row, lane);
+        if (st) wave_store_rows<SDW, slab_rows(A)>(sOCyl, gSelf - lane * SDW, row, lane);
+        if (gState && st) wave_store_rows<SDW, slab_rows(A)>(sOCyl, gState - lane * SDW, row, lane);
     }
     // state_others: p_i - p_j, j != i ascending (:750-751, utils/torch.py:41-53); (A-1)*3 floats per
     // thread, thread-contiguous in global memory
@@ -316,7 +326,7 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
             o[3 * w] = s.pos.x - rj[0]; o[3 * w + 1] = s.pos.y - rj[1]; o[3 * w + 2] = s.pos.z - rj[2];
         }
         if constexpr (STAGED) {
-            if (st_oth) wave_store_rows<(A > 1 ? A - 1 : 1) * 3>(sOCyl, gOth - lane * (A - 1) * 3, o, lane);
+            if (st_oth) wave_store_rows<(A > 1 ? A - 1 : 1) * 3, slab_rows(A)>(sOCyl, gOth - lane * (A - 1) * 3, o, lane);
         } else if (!st_oth) {
         } else if ((((A - 1) * 3) & 1) == 0) {
             float2 *g2 = reinterpret_cast<float2 *>(gOth);
@@ -415,19 +425,19 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
                 float r[15];
 #pragma unroll
                 for (int i = 0; i < 15; ++i) r[i] = krow[i];
-                wave_store_rows<15>(sOCyl, gOCyl - lane * 15, r, lane);
+                wave_store_rows<15, slab_rows(A)>(sOCyl, gOCyl - lane * 15, r, lane);
             } else if (K == 4) {
-                wave_store_rows<20>(sOCyl, gOCyl - lane * 20, krow, lane);
+                wave_store_rows<20, slab_rows(A)>(sOCyl, gOCyl - lane * 20, krow, lane);
             } else if (K == 2) {
                 float r[10];
 #pragma unroll
                 for (int i = 0; i < 10; ++i) r[i] = krow[i];
-                wave_store_rows<10>(sOCyl, gOCyl - lane * 10, r, lane);
+                wave_store_rows<10, slab_rows(A)>(sOCyl, gOCyl - lane * 10, r, lane);
             } else {
                 float r[5];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) r[i] = krow[i];
-                wave_store_rows<5>(sOCyl, gOCyl - lane * 5, r, lane);
+                wave_store_rows<5, slab_rows(A)>(sOCyl, gOCyl - lane * 5, r, lane);
             }
         }
     }
@@ -532,7 +542,10 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         if (valid) {
             load_rigid(sDS + tid * 13, s);
             float cmd[4], thr_diff;
-            d_ctbr_pid_squashed(c, ta, s.q, s.ang, prev4, integ4, last4, cmd, aerr);    // A1 + A2
+            float ctbr4[4], trate[3];
+            d_ctbr_pid_squashed(c, ta, s.q, s.ang, prev4, integ4, last4, cmd, aerr, ctbr4, trate);    // A1 + A2
+            if (b.ctbr) reinterpret_cast<float4 *>(b.ctbr)[ia] = make_float4(ctbr4[0], ctbr4[1], ctbr4[2], ctbr4[3]);           // transforms.py:456
+            if (b.target_rate) reinterpret_cast<float4 *>(b.target_rate)[ia] = make_float4(trate[0], trate[1], trate[2], 0.0f);  // :457
             prof_mark(p.prof, 10);
             d_rotor(c, cmd, thr4, thrust, moment, thr_diff);                      // A3
             prof_mark(p.prof, 11);
@@ -976,7 +989,10 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
         prof_mark(p.prof, 1);
         // ---- phase 1: controller, rotors, thrust vector (A1-A3) ----
         float cmd[4], thr_diff, aerr, thrust[4], moment[4];
-        d_ctbr_pid_squashed(c, ta, s.q, s.ang, prev4, integ4, last4, cmd, aerr);
+        float ctbr4[4], trate[3];
+        d_ctbr_pid_squashed(c, ta, s.q, s.ang, prev4, integ4, last4, cmd, aerr, ctbr4, trate);
+        if (b.ctbr) reinterpret_cast<float4 *>(b.ctbr)[ia] = make_float4(ctbr4[0], ctbr4[1], ctbr4[2], ctbr4[3]);           // transforms.py:456
+        if (b.target_rate) reinterpret_cast<float4 *>(b.target_rate)[ia] = make_float4(trate[0], trate[1], trate[2], 0.0f);  // :457
         d_rotor(c, cmd, thr4, thrust, moment, thr_diff);
         const float ts = ((thrust[0] + thrust[1]) + thrust[2]) + thrust[3];
         const V3 tw = d_quat_rot_z(s.q, ts);                                        // multirotor.py:491
@@ -1754,7 +1770,7 @@ int hns_create(const hns_cfg *cfg, hns_env **out) {
         for (int i = 0; i < cfg->grid_num; ++i)
             for (int j = 0; j < cfg->grid_num; ++j)
                 if (sqrtf((float)((i - half) * (i - half) + (j - half) * (j - half))) < (float)half) ++free_cells;
-        if (free_cells - (cfg->num_agents + 1) < cfg->num_cylinders) {
+        if (free_cells - (cfg->num_agents + (cfg->num_targets == 2 ? 2 : 1)) < cfg->num_cylinders) {   // pursuers and evader(s) occupy cells first
             set_error("hns_create: not enough free grid cells for the cylinders (hideandseek.py:112-113)");
             return HNS_ERR_CONFIG;
         }
@@ -1818,7 +1834,7 @@ int hns_bind(hns_env *env, const hns_buffers *buffers) {
     }
     const void *al16[] = {buffers->throttle, buffers->pid_integ, buffers->pid_last_rate, buffers->prev_action,
                           buffers->drone_state, buffers->target_pos, buffers->target_vel, buffers->obs_self,
-                          buffers->state_drones, buffers->obs_cylinders};
+                          buffers->state_drones, buffers->obs_cylinders, buffers->ctbr, buffers->target_rate};
     for (const void *ptr : al16)
         if (reinterpret_cast<uintptr_t>(ptr) & 15) { set_error("hns_bind: buffers must be 16-byte aligned"); return HNS_ERR_INVALID_ARG; }
     if (env->cfg.num_agents > 1 && (reinterpret_cast<uintptr_t>(buffers->obs_others) & 7)) {
@@ -2029,7 +2045,7 @@ static int copy_state(hns_env *env, const hns_buffers *host, void *stream, bool 
         {host->progress, d.progress, E * 4}, {host->stats, d.stats, (size_t)HNS_NUM_STATS * E * 4}, {host->obs_self, d.obs_self, E * A * SD * 4},
         {host->obs_others, d.obs_others, E * A * (A - 1) * 12}, {host->obs_cylinders, d.obs_cylinders, E * A * K * 20},
         {host->state_drones, d.state_drones, E * A * SD * 4}, {host->reward, d.reward, E * A * 4}, {host->action_error, d.action_error, E * A * 4},
-        {host->done, d.done, E}, {host->detect, d.detect, E}};
+        {host->done, d.done, E}, {host->detect, d.detect, E}, {host->ctbr, d.ctbr, E * A * 16}, {host->target_rate, d.target_rate, E * A * 16}};
     for (const Field &x : f) {
         if (!x.host || !x.dev || x.bytes == 0) continue;
         if (to_device) HNS_CHECK_HIP(hipMemcpyAsync(x.dev, x.host, x.bytes, hipMemcpyHostToDevice, (hipStream_t)stream));

@@ -721,10 +721,12 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
     const int nxc = tp_nxc(p.I);
     void (*fn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_kernel<1> : hns::hns_tp_lstm_kernel<2>;
     const size_t lds = (size_t)hns::tp_image(nxc).bytes + (size_t)hns::kTpWaves * 8 * nxc * 64 * sizeof(float);   // image + parked new frame
-    static thread_local const void *attr_set[2] = {nullptr, nullptr};
-    if (attr_set[nxc - 1] != (const void *)fn) {
+    // the attribute is per device: remembered per (frame width, device), so envs on two GPUs driven from one thread both get it
+    static thread_local unsigned long long attr_devs[2] = {0ull, 0ull};
+    const unsigned long long dev_bit = 1ull << (env->device & 63);
+    if (!(attr_devs[nxc - 1] & dev_bit)) {
         HNS_CHECK_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[nxc - 1] = (const void *)fn;
+        attr_devs[nxc - 1] |= dev_bit;
     }
     hipStream_t s = (hipStream_t)stream;
     const int grid = (p.E + hns::kTpEnvs - 1) / hns::kTpEnvs;

@@ -23,7 +23,8 @@ import torch
 
 from . import abi
 from .config import CRAZYFLIE, resolve_hns_cfg
-from .tensordict_shim import USING_REAL_TENSORDICT, CompositeSpec, TensorDict, TensorSpec
+from .tensordict_shim import (USING_REAL_TENSORDICT, USING_REAL_TORCHRL, TensorDict, TorchrlEnvBase, bool_spec, bounded_spec,
+                              composite_spec, unbounded_spec)
 
 
 @dataclass
@@ -60,33 +61,95 @@ class HnsError(RuntimeError):
 
 class _LazyState(TensorDict):
     """`agents.state` whose `state_drones` entry is assembled in torch only if somebody reads it
-    (the kernel skips that output unless `algo.critic_input: state`)."""
+    (the kernel skips that output unless `algo.critic_input: state`).  The entry is ONE persistent
+    `[E,A,D]` buffer, refilled in place the first time it is read after each `step()` / `reset()` —
+    the same aliasing contract as every other leaf (a view of a buffer the next step overwrites)."""
 
     def __init__(self, env, source, batch_size):
         super().__init__(source, batch_size)
         object.__setattr__(self, "_hns_env", env)
+        object.__setattr__(self, "_filled_at", -1)
+
+    def _refresh(self):
+        env = self._hns_env
+        if self._filled_at != env._state_version:
+            buf = env._lazy_state_drones()
+            if not dict.__contains__(self, "state_drones"):
+                dict.__setitem__(self, "state_drones", buf)
+            object.__setattr__(self, "_filled_at", env._state_version)
 
     def __getitem__(self, key):
-        if key == "state_drones" and not dict.__contains__(self, key):
-            dict.__setitem__(self, key, self._hns_env._lazy_state_drones())
+        if key == "state_drones":
+            self._refresh()
         return super().__getitem__(key)
 
     def keys(self, *a, **k):
-        self["state_drones"]
+        self._refresh()
         return super().keys(*a, **k)
 
+    def items(self):
+        self._refresh()
+        return super().items()
 
-class HideAndSeek:
+    def values(self):
+        self._refresh()
+        return super().values()
+
+    def _map(self, fn, batch_size=None):
+        self._refresh()
+        return super()._map(fn, batch_size)
+
+
+class _PlainEnvBase:
+    """What `torchrl.envs.EnvBase` gives the caller (`reset` / `step` / `set_seed` around `_reset` / `_step` /
+    `_set_seed`, isaac_env.py:47-57) for installations without torchrl — this build image has none."""
+
+    def __init__(self, device, batch_size, run_type_checks=False):
+        self.device = torch.device(device)
+        self.batch_size = torch.Size(batch_size)
+        self.training = True
+
+    def set_seed(self, seed=-1):
+        self._set_seed(seed)
+        return seed
+
+    def reset(self, tensordict=None, **kwargs):
+        td = self._reset(tensordict, **kwargs)
+        if "done" not in td.keys():
+            td.set("done", torch.zeros(self.batch_size[0], 1, dtype=torch.bool, device=self.device))
+        return td
+
+    def step(self, tensordict):
+        out = self._step(tensordict)
+        tensordict.set("next", out["next"])
+        return tensordict
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+
+# With torchrl importable the class IS a torchrl `EnvBase` subclass, constructed the way `IsaacEnv` constructs itself
+# (isaac_env.py:54-57: device, batch_size = [num_envs], run_type_checks = False), so `TransformedEnv(base_env, ...)`,
+# the `SyncDataCollector` and MAPPO (scripts/train.py:165-205) take it as they take the reference's env.
+_EnvBase = TorchrlEnvBase if USING_REAL_TORCHRL else _PlainEnvBase
+
+
+class HideAndSeek(_EnvBase):
     REGISTRY = {}
 
     def __init__(self, cfg, headless=True, env_index_offset=0, write_critic_state=None):
-        self.cfg = cfg
-        self.headless = headless
-        self.device = torch.device(cfg.sim.get("device", "cuda:0"))
-        if self.device.type != "cuda":
+        device = torch.device(cfg.sim.get("device", "cuda:0"))
+        if device.type != "cuda":
             raise HnsError("HideAndSeek runs on an AMD GPU only (cfg.sim.device must be a cuda/hip device)")
         if not torch.cuda.is_available():
             raise HnsError("no GPU visible: the HIP step has no CPU fallback")
+        super().__init__(device=device, batch_size=[int(cfg.env.num_envs)], run_type_checks=False)
+        self.cfg = cfg
+        self.headless = headless
         self._lib = abi.load_library()
         if write_critic_state is None:
             # the centralised-critic state [E,A,20] is extra HBM traffic that only `critic_input: state`
@@ -98,7 +161,6 @@ class HideAndSeek:
         self.num_envs = int(cfg.env.num_envs)
         self.max_episode_length = int(cfg.env.max_episode_length)
         self.dt = float(cfg.sim.dt)
-        self.batch_size = torch.Size([self.num_envs])
         self.hcfg = resolve_hns_cfg(cfg, env_index_offset=env_index_offset, write_critic_state=write_critic_state)
         self.num_agents = self.hcfg.num_agents
         self.num_cylinders = self.hcfg.num_cylinders
@@ -106,22 +168,23 @@ class HideAndSeek:
         self.v_prey = float(self.hcfg.v_prey)
         self.update_epoch = 0
         self.seed = 0
-        self.training = True
         self._render = not headless
+        # transforms.py:456-457: `ctbr` and `target_rate` on the input tensordict — extra outputs, written only when asked for
+        self.publish_ctbr = bool(int(cfg.task.get("publish_ctbr", 0)))
         E, A, Cn, K = self.num_envs, self.num_agents, self.num_cylinders, self.obs_max_cylinder
 
         torch.cuda.set_device(self.device)
         self._bufs = {}
         self.num_targets = 2 if int(self.hcfg.num_targets) == 2 else 1
-        for name, (shape, dt) in abi.buffer_shapes(E, A, Cn, K, self.num_targets).items():
+        for name, (shape, dt) in abi.buffer_shapes(E, A, Cn, K, self.num_targets, publish_ctbr=self.publish_ctbr).items():
             n = 1
             for s in shape:
                 n *= s
             self._bufs[name] = torch.zeros(max(n, 1), dtype=getattr(torch, dt), device=self.device)[:n].view(shape)
         self._hbuf = abi.HnsBuffers()
         for name in abi.BUFFER_FIELDS:
-            t = self._bufs[name]
-            setattr(self._hbuf, name, t.data_ptr() if t.numel() else None)
+            t = self._bufs.get(name)
+            setattr(self._hbuf, name, t.data_ptr() if (t is not None and t.numel()) else None)
         if not write_critic_state:
             self._hbuf.state_drones = None
         self._env = C.c_void_p()
@@ -132,7 +195,6 @@ class HideAndSeek:
         self.progress_buf = b["progress"]
         self._tensordict = TensorDict({"progress": self.progress_buf}, self.batch_size)
         self.stats = TensorDict({k: b["stats"][i].unsqueeze(-1) for i, k in enumerate(abi.STAT_NAMES)}, self.batch_size)
-        self.stats.set("action_error_order1", b["action_error"])          # transforms.py:441
         self.info = TensorDict({"drone_state": b["drone_state"], "prev_action": b["prev_action"]}, self.batch_size)
         self.drone = SimpleNamespace(n=A, params=CRAZYFLIE, throttle=b["throttle"], name="crazyflie",
                                      MASS_0=torch.tensor([CRAZYFLIE["mass"]]), num_rotors=4)
@@ -157,9 +219,12 @@ class HideAndSeek:
             self._tp_weight_versions = None
             self._tp_filled = False
         self._set_specs()
+        self.success_rate_fn = None      # optional callable(env) -> success rate over the WHOLE (sharded) batch
         self._since_full_reset = 0
         self._needs_reset = True
         self._next_cache = None
+        self._state_version = 0          # bumped by every step()/reset(): lazily assembled entries refill once per version
+        self._state_buf = None
         self._action_shape = torch.Size([self.num_envs, self.num_agents, 4])
 
     # ---- registry (isaac_env.py:154-161) ----------------------------------------------------------
@@ -172,34 +237,33 @@ class HideAndSeek:
         if rc != 0:
             raise HnsError(f"{what} failed ({rc}): {self._lib.hns_last_error().decode()}")
 
-    # ---- specs (hideandseek.py:327-433, use_TP_net=0 branch) ------------------------------------------
+    # ---- specs (hideandseek.py:327-433) ----------------------------------------------------------------------------
     def _set_specs(self):
         A, K, E, dev = self.num_agents, self.obs_max_cylinder, self.num_envs, self.device
-        D = abi.self_dim(self.num_targets) + (3 * self.tp_future_step if self.use_TP_net else 0)      # 20 or 35 (24: two evaders)
-        obs = {"state_self": TensorSpec((1, D)), "cylinders": TensorSpec((K, 5))}
+        t = self.cfg.task
+        F = int(t.get("future_predcition_step", 5))
+        D = abi.self_dim(self.num_targets) + (3 * F if self.use_TP_net else 0)      # 20 or 35 (24: two evaders)
+        obs = {"state_self": unbounded_spec((E, A, 1, D), dev), "cylinders": unbounded_spec((E, A, K, 5), dev)}
         if A > 1:
-            obs["state_others"] = TensorSpec((A - 1, 3))
-        observation_spec = CompositeSpec(obs)
-        state_spec = CompositeSpec({"state_drones": TensorSpec((A, D)), "cylinders": TensorSpec((K, 5))})
-        stats_spec = CompositeSpec({k: TensorSpec((1,)) for k in abi.STAT_NAMES})
-        info_spec = CompositeSpec({"drone_state": TensorSpec((A, 13)), "prev_action": TensorSpec((A, 4), low=-1.0, high=1.0)})
-        agents = {"observation": observation_spec.expand(A), "state": state_spec}
-        if self.use_TP_net:                                              # hideandseek.py:368-374
-            agents["TP"] = CompositeSpec({"TP_input": TensorSpec((self.tp_history_step, self.tp_frame_dim)),
-                                          "TP_groundtruth": TensorSpec((1, 3)), "TP_done": TensorSpec((1, 3))})
-        self.observation_spec = CompositeSpec({
-            "agents": CompositeSpec(agents), "stats": stats_spec, "info": info_spec}).expand(E).to(dev)
-        self.action_spec = CompositeSpec({"agents": CompositeSpec({"action": TensorSpec((A, 4), low=-1.0, high=1.0)})}).expand(E).to(dev)
-        self.reward_spec = CompositeSpec({"agents": CompositeSpec({"reward": TensorSpec((A, 1))})}).expand(E).to(dev)
-        self.done_spec = TensorSpec((E, 1), dtype=torch.bool, device=dev)
-        self.input_spec = CompositeSpec({"_action_spec": self.action_spec})
+            obs["state_others"] = unbounded_spec((E, A, A - 1, 3), dev)
+        # (`state.cylinders` is declared (k, 5) although the tensor the reference returns is [E, A, k, 5], :887)
+        state = {"state_drones": unbounded_spec((E, A, D), dev), "cylinders": unbounded_spec((E, K, 5), dev)}
+        # the TP entry is part of the spec whether or not the predictor is used (:358-374)
+        frame = abi.tp_frame_dim(A, self.num_cylinders, int(t.get("use_obstacles", 0)))
+        tp = {"TP_input": unbounded_spec((E, int(t.get("history_step", 10)), frame), dev),
+              "TP_groundtruth": unbounded_spec((E, 1, 3), dev), "TP_done": unbounded_spec((E, 1, 3), dev)}
+        self.observation_spec = composite_spec({
+            "agents": {"observation": obs, "state": state, "TP": tp},
+            "stats": {k: unbounded_spec((E, 1), dev) for k in abi.STAT_NAMES},
+            "info": {"drone_state": unbounded_spec((E, A, 13), dev), "prev_action": bounded_spec(-1.0, 1.0, (E, A, 4), dev)}})
+        self.action_spec = composite_spec({"agents": {"action": bounded_spec(-1.0, 1.0, (E, A, 4), dev)}})
+        self.reward_spec = composite_spec({"agents": {"reward": unbounded_spec((E, A, 1), dev)}})
+        if not USING_REAL_TORCHRL:                                # torchrl derives these two itself
+            self.done_spec = bool_spec((E, 1), dev)
+            self.input_spec = composite_spec({"_action_spec": self.action_spec})
         self.agent_spec = {"drone": AgentSpec("drone", A, _env=self)}
 
-    # ---- EnvBase-like public surface -----------------------------------------------------------------
-    def set_seed(self, seed=-1):
-        self._set_seed(seed)
-        return seed
-
+    # ---- besides reset / step / set_seed / train / eval, which the base class provides --------------------------------
     def _set_seed(self, seed=-1):
         """isaac_env.py:256-259: seeds torch; here it also keys the reset Philox stream."""
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -209,13 +273,6 @@ class HideAndSeek:
     @property
     def reset_epoch(self):
         return int(self._lib.hns_get_reset_epoch(self._env))
-
-    def train(self, mode=True):
-        self.training = mode
-        return self
-
-    def eval(self):
-        return self.train(False)
 
     def enable_render(self, enable=True):
         self._render = bool(enable)
@@ -243,19 +300,6 @@ class HideAndSeek:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def reset(self, tensordict=None, **kwargs):
-        td = self._reset(tensordict, **kwargs)
-        if "done" not in td.keys():
-            td.set("done", torch.zeros(self.num_envs, 1, dtype=torch.bool, device=self.device))
-        return td
-
-    def step(self, tensordict):
-        if self._needs_reset:
-            raise HnsError("step() called before reset()")
-        out = self._step(tensordict)
-        tensordict.set("next", out["next"])
-        return tensordict
-
     # ---- isaac_env.py:210-225 -----------------------------------------------------------------------------
     def _reset(self, tensordict=None, **kwargs):
         mask_t = None
@@ -265,8 +309,8 @@ class HideAndSeek:
         ptr = C.c_void_p(mask_t.data_ptr()) if mask_t is not None else None
         self._check(self._lib.hns_reset(self._env, ptr, C.c_uint64(self.seed), self._stream()), "hns_reset")
         self._reset_mask_keepalive = mask_t
-        if mask_t is None:
-            self._since_full_reset = 0
+        self._state_version += 1
+        self._note_reset(mask_t)
         self._needs_reset = False
         if self.use_TP_net:
             self._tp_observe()
@@ -275,8 +319,19 @@ class HideAndSeek:
         td.set("truncated", (self.progress_buf > self.max_episode_length).unsqueeze(1))
         return td
 
+    def _note_reset(self, mask_t):
+        """Host mirror of "steps since the oldest running episode began": no env can be `done` before it reaches
+        max_episode_length, so the per-step host checks (curriculum, generator) stay off until then.  A masked reset
+        costs ONE read-back of max(progress) per reset call (once per episode), never one per step."""
+        if mask_t is None:
+            self._since_full_reset = 0
+        else:
+            self._since_full_reset = int(self.progress_buf.max().item())
+
     # ---- transforms.py:425-459 + isaac_env.py:231-240 ------------------------------------------------
     def _step(self, tensordict):
+        if self._needs_reset:
+            raise HnsError("step() called before reset()")
         action = tensordict[("agents", "action")]
         if action.dtype != torch.float32 or not action.is_contiguous():
             action = action.float().contiguous()
@@ -287,12 +342,23 @@ class HideAndSeek:
             self._check(rc, "hns_step")
         self._action_keepalive = action
         self._since_full_reset += 1
+        self._state_version += 1
+        # what PIDRateController._inv_call leaves on the caller's tensordict (transforms.py:438-457); hideandseek.py:726-731 reads
+        # the first two back — here they are views of the buffers the kernel just updated
+        tensordict.set(("stats", "action_error_order1"), self._bufs["action_error"])
+        tensordict.set(("info", "prev_action"), self._bufs["prev_action"])
+        if self.publish_ctbr:
+            tensordict.set("ctbr", self._bufs["ctbr"])
+            tensordict.set("target_rate", self._bufs["target_rate"][..., :3])
         b = self._bufs
         # hideandseek.py:1012-1015 — evader-speed curriculum; v_prey starts at its 1.3 cap with the
         # reference's defaults, in which case no host sync is ever needed
         if self.v_prey < 1.3 - 1e-6 and self._since_full_reset >= self.max_episode_length:
             done = b["done"].bool()
-            if bool(done.any()) and float(self.stats["success"].mean()) >= 0.98:
+            # the reference averages over ALL envs (:1012-1015); a shard of a data-parallel run plugs the global rate in
+            # through `success_rate_fn` (sharding.GlobalSuccessRate), otherwise the local batch is the whole batch
+            rate = self.success_rate_fn(self) if self.success_rate_fn is not None else float(self.stats["success"].mean())
+            if bool(done.any()) and rate >= 0.98:
                 self.v_prey = min(1.3, self.v_prey + 0.05)
                 self._check(self._lib.hns_set_v_prey(self._env, C.c_float(self.v_prey)), "hns_set_v_prey")
         if self.use_TP_net:
@@ -335,11 +401,13 @@ class HideAndSeek:
         """hideandseek.py:871-886: state_self with the UNMASKED relative position of the evader."""
         b = self._bufs
         rest = self._tp_bufs["obs_self"] if self.use_TP_net else b["obs_self"]       # :873-880 / :881-886
+        if self._state_buf is None:
+            self._state_buf = torch.empty_like(rest)
         if self.num_targets == 2:                                                    # extension: both relative positions unmasked
             rpos = b["drone_state"][..., None, 0:3] - b["target_pos"].unsqueeze(1)   # [E,A,2,3]
-            return torch.cat([rpos[:, :, 0], rest[..., 3:20], rpos[:, :, 1], rest[..., 23:]], dim=-1)
+            return torch.cat([rpos[:, :, 0], rest[..., 3:20], rpos[:, :, 1], rest[..., 23:]], dim=-1, out=self._state_buf)
         rpos = b["drone_state"][..., 0:3] - b["target_pos"].unsqueeze(1)
-        return torch.cat([rpos, rest[..., 3:]], dim=-1)
+        return torch.cat([rpos, rest[..., 3:]], dim=-1, out=self._state_buf)
 
     def _tp_observe(self):
         """The TP branch of `_compute_state_and_obs` (hideandseek.py:805-854) on the device: frame
@@ -369,6 +437,12 @@ class HideAndSeek:
         if rc != 0:
             self._check(rc, "hns_tp_observe")
         self._tp_filled = True                      # the window is never reset per env (hideandseek.py:825-830)
+
+    def refresh_tp_weights(self):
+        """Re-pack the predictor's parameters now.  `_tp_observe` notices optimiser steps and `load_state_dict` through
+        the tensors' version counters; writes through `.data` do not move them — call this after such an update."""
+        if self.use_TP_net and self._tp_weight_ptrs is not None:
+            self._check(self._lib.hns_tp_refresh(self._env, self._stream()), "hns_tp_refresh")
 
     # ---- schedule hooks -------------------------------------------------------------------------------------------
     def set_update_epoch(self, epoch):
@@ -401,6 +475,7 @@ class HideAndSeek:
         for k, v in arrays.items():
             self._bufs[k].copy_(torch.as_tensor(v).to(self.device).view(self._bufs[k].shape))
         self._needs_reset = False
+        self._state_version += 1
 
     def raycast(self, num_rays=16, max_range=2.0, out=None):
         """Extension (not in the reference): planar ray-fan ranges [E,A,num_rays] on the current state."""
@@ -453,3 +528,4 @@ class HideAndSeek:
 
 HideAndSeek.REGISTRY["HideAndSeek"] = HideAndSeek
 HideAndSeek.REGISTRY["hideandseek"] = HideAndSeek
+HideAndSeek.REGISTRY["HideAndSeek_hip"] = HideAndSeek        # cfg/task/HideAndSeek_hip.yaml (action_transform: none)

@@ -307,6 +307,25 @@ class HideAndSeek_envgen(HideAndSeek):
         for k, v in self._extra.items():
             self.stats.set(k, v)
         self.generator_seconds = 0.0
+        self._prewarm()
+
+    def _prewarm(self):
+        """Run the two generator kernels once on a toy problem: the first launch of a kernel pays its code-object load
+        (the first task batch used to cost ~240 ms, later ones 26 ms); construction is the place for that."""
+        g = self.gen_buffer
+        toy = torch.rand(96, g.task_dim, device=self.device).contiguous()
+        idx = torch.zeros(32, dtype=torch.int32, device=self.device)
+        self._check(self._lib.hns_fps(toy.data_ptr(), 96, g.task_dim, 32, 0, idx.data_ptr(), g._fps_scratch.data_ptr(), self._stream()), "hns_fps")
+        out = torch.zeros(8, g.task_dim, device=self.device)
+        self._check(self._lib.hns_perturb_tasks(self._env, toy.data_ptr(), 96, out.data_ptr(), 8, 0, C.c_float(0.1), C.c_uint64(1), self._stream()),
+                    "hns_perturb_tasks")
+        torch.cat([toy, toy]).index_select(0, idx.long()).min(0)          # the torch ops of the trim (allocator, kernels)
+        # and one trim at the size of a real update (history + every env's task), so the allocator holds those blocks
+        keep = g._history
+        g._history = torch.rand(g.buffer_length, g.task_dim, device=self.device)
+        g.insert_history(torch.rand(self.num_envs, g.task_dim, device=self.device))
+        g._history = keep
+        torch.cuda.synchronize(self.device)
 
     @property
     def all_tasks(self):
@@ -344,8 +363,8 @@ class HideAndSeek_envgen(HideAndSeek):
         self.active_cylinders = (self._bufs["cylinders"][..., 2] > 0.0).float().sum(-1, keepdim=True)   # :902
         self.generator_seconds += time.perf_counter() - t0
         self._keep_mask = mask_t
-        if mask_t is None:
-            self._since_full_reset = 0
+        self._state_version += 1
+        self._note_reset(mask_t)
         self._needs_reset = False
         if self.use_TP_net:
             self._tp_observe()

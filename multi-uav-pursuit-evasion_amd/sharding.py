@@ -65,3 +65,21 @@ def normalise_advantages(adv, success=None, eps=1e-7):
         tot = table.sum(0)
         rate = float(tot[3] / tot[4])
     return (adv - mean.to(adv.dtype)) / std.clamp(min=eps).to(adv.dtype), rate
+
+
+class GlobalSuccessRate:
+    """`env.success_rate_fn` for a shard of a data-parallel run: the success rate over the WHOLE batch, as the reference's
+    `stats["success"].mean()` sees it (hideandseek.py:1012-1015), so that every shard raises the evader's speed at the
+    same step.  The rate is the one gathered with the last rollout's moments (`update(table)`), i.e. one rollout old —
+    episodes are 800 steps, rollouts 64; until the first rollout it falls back to the local shard."""
+
+    def __init__(self):
+        self.rate = None
+
+    def update(self, table):
+        tot = table.sum(0)
+        if float(tot[4]) > 0:
+            self.rate = float(tot[3] / tot[4])
+
+    def __call__(self, env):
+        return self.rate if self.rate is not None else float(env.stats["success"].mean())

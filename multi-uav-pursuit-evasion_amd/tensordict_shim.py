@@ -201,3 +201,51 @@ class CompositeSpec(dict):
 
     def rand(self):
         return _ShimTensorDict({k: v.rand() for k, v in self.items()}, self.shape)
+
+
+# ---- one construction surface for both worlds ---------------------------------------------------------------------
+# With torchrl importable the env is a real `torchrl.envs.EnvBase` and its specs are real torchrl specs (the caller —
+# scripts/train.py:165-205, utils/torchrl/collector.py, learning/mappo.py — type-checks against them); without it the
+# records above stand in.  The reference pins torchrl 0.1.1 (README.md:59): spec class names of that release first.
+try:  # pragma: no cover - not installed in the build image
+    from torchrl.envs import EnvBase as TorchrlEnvBase  # type: ignore
+    import torchrl.data as _trd  # type: ignore
+    _RealComposite = getattr(_trd, "CompositeSpec", None) or getattr(_trd, "Composite")
+    _RealUnbounded = getattr(_trd, "UnboundedContinuousTensorSpec", None) or getattr(_trd, "Unbounded")
+    _RealBounded = getattr(_trd, "BoundedTensorSpec", None) or getattr(_trd, "Bounded")
+    _RealDiscrete = getattr(_trd, "DiscreteTensorSpec", None) or getattr(_trd, "Categorical")
+    USING_REAL_TORCHRL = _RealTensorDict is not None
+except Exception:  # noqa: BLE001
+    TorchrlEnvBase = None
+    USING_REAL_TORCHRL = False
+
+
+def unbounded_spec(shape, device=None, dtype=torch.float32):
+    if USING_REAL_TORCHRL:
+        return _RealUnbounded(shape, device=device, dtype=dtype)
+    return TensorSpec(shape, dtype=dtype, device=device)
+
+
+def bounded_spec(low, high, shape, device=None):
+    if USING_REAL_TORCHRL:
+        return _RealBounded(low, high, shape, device=device)
+    return TensorSpec(shape, device=device, low=low, high=high)
+
+
+def bool_spec(shape, device=None):
+    if USING_REAL_TORCHRL:
+        return _RealDiscrete(2, shape, dtype=torch.bool, device=device)
+    return TensorSpec(shape, dtype=torch.bool, device=device)
+
+
+def composite_spec(d):
+    if USING_REAL_TORCHRL:
+        return _RealComposite({k: (composite_spec(v) if isinstance(v, dict) and not isinstance(v, _RealComposite) else v) for k, v in d.items()})
+    return CompositeSpec(d)
+
+
+def spec_tree(spec):
+    """{key: {...} | [shape, dtype]} of a (real or stand-in) spec tree — what the manifest test compares."""
+    if hasattr(spec, "items") and not hasattr(spec, "dtype"):
+        return {k: spec_tree(v) for k, v in spec.items()}
+    return [list(spec.shape), str(spec.dtype).replace("torch.", "")]

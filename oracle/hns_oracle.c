@@ -613,9 +613,14 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
         float sum_ae = 0.0f;
         for (int a = 0; a < A; ++a) {
             size_t ia = (size_t)e * A + a;
-            float cmd[4];
+            float cmd[4], ctbr[4], trate[3];
             o_ctbr_pid(c, action + ia * 4, ds + 13 * a + 3, ds + 13 * a + 10, b->prev_action + ia * 4,
-                       b->pid_integ + ia * 4, b->pid_last_rate + ia * 4, cmd, b->action_error + ia, NULL, NULL);
+                       b->pid_integ + ia * 4, b->pid_last_rate + ia * 4, cmd, b->action_error + ia, ctbr, trate);
+            if (b->ctbr) for (int i = 0; i < 4; ++i) b->ctbr[ia * 4 + i] = ctbr[i];                 /* transforms.py:456 */
+            if (b->target_rate) {                                                                     /* transforms.py:457 */
+                for (int i = 0; i < 3; ++i) b->target_rate[ia * 4 + i] = trate[i];
+                b->target_rate[ia * 4 + 3] = 0.0f;
+            }
             sum_ae = (a == 0) ? b->action_error[ia] : sum_ae + b->action_error[ia];
             o_rotor(c, cmd, b->throttle + ia * 4, thrust[a], moment[a], &thr_diff[a]);
             float ts = ((thrust[a][0] + thrust[a][1]) + thrust[a][2]) + thrust[a][3];

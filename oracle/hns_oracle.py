@@ -52,7 +52,10 @@ def alloc_buffers(cfg):
 def as_struct(arrs):
     b = abi.HnsBuffers()
     for k in abi.BUFFER_FIELDS:
-        a = arrs[k]
+        a = arrs.get(k)
+        if a is None:
+            assert k in abi.OPTIONAL_BUFFER_FIELDS, k
+            continue
         assert a.flags["C_CONTIGUOUS"]
         setattr(b, k, a.ctypes.data)
     return b

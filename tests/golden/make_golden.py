@@ -138,8 +138,14 @@ class TensorDict(dict):
 
     def update(self, other):
         for k, v in other.items():
-            self[k] = v
+            if isinstance(v, dict) and isinstance(dict.get(self, k), TensorDict):
+                dict.__getitem__(self, k).update(v)          # nested merge, as tensordict does
+            else:
+                self[k] = TensorDict(v, self.batch_size) if isinstance(v, dict) and not isinstance(v, TensorDict) else v
         return self
+
+    def clone(self):
+        return TensorDict({k: v.clone() for k, v in self.items()}, self.batch_size)
 
 
 class View:
@@ -1020,3 +1026,125 @@ def gen_envgen_sanity():
 
 if __name__ == "__main__":
     gen_envgen_sanity()
+
+
+# ---- key / shape / dtype manifest of the env boundary ------------------------------------------
+# The reference's own `_set_specs` (hideandseek.py:327-433) is executed against recording spec shims, and the
+# reference's own `IsaacEnv._reset` / `_step` (isaac_env.py:210-240) around its `_compute_state_and_obs` /
+# `_compute_reward_and_done` against the tensor shims above: what comes out is the key tree a caller of
+# `env.reset()` / `env.step()` sees, with shapes and dtypes, for use_TP_net 0 and 1.  Only names/shapes/dtypes are stored.
+class _Spec:
+    def __init__(self, shape, dtype="float32", kind="unbounded", low=None, high=None):
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        self.shape, self.dtype, self.kind, self.low, self.high = torch.Size(shape), dtype, kind, low, high
+
+    def expand(self, *sizes):
+        sizes = sizes[0] if len(sizes) == 1 and isinstance(sizes[0], (tuple, list, torch.Size)) else sizes
+        return _Spec((*sizes, *self.shape), self.dtype, self.kind, self.low, self.high)
+
+    def to(self, device):
+        return self
+
+    def zero(self):
+        return torch.zeros(self.shape)
+
+    @classmethod
+    def __torch_function__(cls, func, types_, args=(), kwargs=None):
+        if func is torch.stack:                      # torch.stack([spec] * n, dim=0)  (hideandseek.py:382,428)
+            specs = args[0]
+            return _Spec((len(specs), *specs[0].shape), specs[0].dtype, specs[0].kind, specs[0].low, specs[0].high)
+        return NotImplemented
+
+
+class _Composite(dict):
+    def __init__(self, d=None, shape=()):
+        super().__init__()
+        self.shape = torch.Size(shape)
+        for k, v in (d or {}).items():
+            self[k] = v
+
+    def expand(self, *sizes):
+        sizes = sizes[0] if len(sizes) == 1 and isinstance(sizes[0], (tuple, list, torch.Size)) else sizes
+        return _Composite({k: v.expand(*sizes) for k, v in self.items()}, (*sizes, *self.shape))
+
+    def to(self, device):
+        return self
+
+    def zero(self):
+        return TensorDict({k: v.zero() for k, v in self.items()}, list(self.shape))
+
+
+def _spec_tree(spec):
+    if isinstance(spec, _Composite):
+        return {k: _spec_tree(v) for k, v in spec.items()}
+    out = {"shape": list(spec.shape), "dtype": spec.dtype, "kind": spec.kind}
+    if spec.low is not None:
+        out["low"], out["high"] = spec.low, spec.high
+    return out
+
+
+def _td_tree(td):
+    out = {}
+    for k, v in td.items():
+        if isinstance(v, dict):
+            out[k] = _td_tree(v)
+        else:
+            out[k] = {"shape": list(v.shape), "dtype": str(v.dtype).replace("torch.", "")}
+    return out
+
+
+def gen_manifest(E=6, A=3, C=5):
+    import collections
+    import json
+    ns = {"torch": torch, "CompositeSpec": _Composite,
+          "UnboundedContinuousTensorSpec": lambda shape, device=None: _Spec(shape),
+          "AgentSpec": lambda name, n, **keys: {"name": name, "n": n, **{k: list(v) for k, v in keys.items()}}}
+    set_specs = exec_functions(extract_source("omni_drones/envs/hide_and_seek/hideandseek.py", ["_set_specs"], "HideAndSeek"), ns)["_set_specs"]
+    base = exec_functions(extract_source("omni_drones/envs/isaac_env.py", ["_reset", "_step"], "IsaacEnv"),
+                          {"torch": torch, "TensorDict": TensorDict, "TensorDictBase": TensorDict, "Optional": None})
+    manifest = {"meta": {"num_envs": E, "num_agents": A, "num_cylinders": C, "obs_max_cylinder": 3, "history_step": 10, "future_predcition_step": 5,
+                         "source": "hideandseek.py:327-433 (_set_specs), isaac_env.py:210-240 (_reset/_step), :746-917, :919-1065 executed on shims"}}
+    for tp in (0, 1):
+        env = ShimEnv(E, A, C, {"drone_detect_radius": 0.9}, max_len=20)
+        env.use_TP_net = tp
+        # what _set_specs reads (hideandseek.py:327-335; drone specs: multirotor.py state 23 values, action 4 values in [-1, 1])
+        env.drone.state_spec = _Spec(23)
+        env.drone.action_spec = _Spec(4, kind="bounded", low=-1.0, high=1.0)
+        env.drone.n = A
+        t = env.cfg.task
+        t.time_encoding, t.future_predcition_step, t.history_step, t.window_step, t.use_obstacles = True, 5, 10, 1, 0
+        t.cylinder = types.SimpleNamespace(obs_max_cylinder=3)
+        env.agent_spec = {}
+        set_specs(env)
+        specs = {"observation_spec": _spec_tree(env.observation_spec), "action_spec": _spec_tree(env.action_spec),
+                 "reward_spec": _spec_tree(env.reward_spec), "agent_spec": env.agent_spec["drone"]}
+        # runtime trees: the reference's own _reset/_step wrappers around its obs / reward passes
+        env2 = ShimEnv(E, A, C, {"drone_detect_radius": 0.9}, max_len=20)
+        env2.use_TP_net = tp
+        env2.future_predcition_step, env2.history_step, env2.window_step = 5, 10, 1
+        if tp:
+            torch.manual_seed(1)
+            env2.TP = _tp_class()(input_dim=1 + 3 + 3 + 3 * A, output_dim=15, future_predcition_step=5, window_step=1)
+            env2.history_data = collections.deque(maxlen=10)
+        g = torch.Generator().manual_seed(5)
+        s = rand_scene(g, E, A, C)
+        env2.cylinders.pos = s["cyl"]
+        env2.drone.set_state(s["pos"], s["rot"], s["vel"])
+        env2.target.pos = s["tpos"]
+        env2.target.vel = torch.zeros(E, 1, 6)
+        env2._reset_idx = lambda env_ids: None
+        env2.sim = types.SimpleNamespace(_physics_sim_view=types.SimpleNamespace(flush=lambda: None), step=lambda render=False: None)
+        env2._post_sim_step = lambda td: None
+        env2._pre_sim_step = lambda td: None
+        env2.action_error_order1 = torch.zeros(E, A)       # what _pre_sim_step leaves behind (:731)
+        with torch.no_grad():
+            reset_td = base["_reset"](env2, None)
+            step_td = base["_step"](env2, TensorDict({}, [E]))
+        manifest[f"use_TP_net={tp}"] = {"specs": specs, "reset": _td_tree(reset_td), "step": _td_tree(step_td)}
+    with open(os.path.join(OUT, "g_manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("wrote g_manifest.json")
+
+
+if __name__ == "__main__":
+    gen_manifest()

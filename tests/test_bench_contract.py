@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "64", "--warmup", "8", "--envs", "4096",
-                          "--cpu-steps", "3", "--tp-steps", "8", "--stream-groups", "2", "--group-steps", "16"],
+                          "--cpu-steps", "3", "--tp-steps", "8", "--stream-groups", "2", "--group-steps", "16", "--abi-steps", "16",
+                          "--config-steps", "16", "--envgen-episodes", "4", "--envgen-episode-length", "8"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
@@ -32,6 +33,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "agent-steps/s" and "sample" in c
     assert d["tp_mode"]["value"] > 0 and d["stream_shards"]["groups"] == 2
+    assert "env.step" in d["config"]["workload"] and d["abi_rate"]["value"] > 0        # headline through the Python class, bare ABI beside it
+    assert "look-up" in r["traffic_source"] or r["traffic"] is None                       # PMC traffic is a static look-up, labelled so
+    cf = d["configs"]                                                                      # every other BASELINE configuration
+    assert set(cf) == {"cfg2", "cfg4", "cfg5_shard"}
+    assert cf["cfg2"]["roofline"]["bytes_per_env"] == 1497 and cf["cfg5_shard"]["roofline"]["frac"] > 0
+    assert len(cf["cfg4"]["generator_ms_per_episode"]) == 4 and cf["cfg4"]["value_incl_generator"] > 0
 
 
 @pytest.mark.gpu
@@ -49,3 +56,21 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["config"]["sharding"].endswith("x2") and "all-gather" in d["config"]["collective"]
     assert abs(d["value"] - 2 * 4096 * 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3      # whole-job aggregate
     assert d["cpu_baseline"] is None              # rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself and reports the rank count it
+    OBSERVED (an all-reduce of ones), with the per-rank kernel times (gloo on a 1-GPU box)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HNS_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "128", "--warmup", "8", "--envs", "4096"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size_launched"] == 2
+    k = d["roofline"]["kernel_us_by_rank"]
+    assert len(k["all"]) == 2 and 0 < k["min"] <= k["max"]
+    assert abs(d["value"] - 2 * 4096 * 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3

@@ -187,7 +187,7 @@ def test_error_paths():
     import ctypes as C
     host = {k: np.zeros(s, dtype=d) for k, (s, d) in abi.buffer_shapes(64, 3, 5, 3).items()}
     hb = abi.HnsBuffers()
-    for k in abi.BUFFER_FIELDS:
+    for k in host:
         setattr(hb, k, host[k].ctypes.data_as(C.c_void_p).value)
     assert env._lib.hns_bind(env._env, C.byref(hb)) == abi.HNS_ERR_INVALID_ARG
     assert b"device memory" in env._lib.hns_last_error()
@@ -358,3 +358,26 @@ def test_stream_shards_reproduce_the_whole_batch():
         for k, v in env.export_state().items():
             want = ref[k][:, sl] if k == "stats" else ref[k][sl]
             np.testing.assert_array_equal(v, want, err_msg=f"shard {g}: buffer {k}")
+
+
+def test_lazy_critic_state_is_refreshed_every_step():
+    """`agents.state.state_drones` is assembled on access when the kernel does not write it (critic_input: obs, the
+    reference's default): it must follow the state step after step (it once froze at its first-read values)."""
+    from hns_amd.env import HideAndSeek
+    cfg = config.make_cfg({"num_agents": 3, "cylinder": {"max_num": 5, "min_num": 4}, "env": {"num_envs": 128, "max_episode_length": 50}})
+    env = HideAndSeek(cfg, headless=True)                    # critic_input: obs -> lazy state
+    assert not env.write_critic_state
+    env.set_seed(3)
+    td = env.reset()
+    g = torch.Generator().manual_seed(11)
+    first = None
+    for t in range(4):
+        td = env.step(env.rand_step_input(torch.randn(128, 3, 4, generator=g).to(env.device)))
+        sd = td["next"]["agents"]["state"]["state_drones"]
+        want = env.info["drone_state"][..., 0:3] - env._bufs["target_pos"].unsqueeze(1)
+        assert torch.equal(sd[..., 0:3], want), f"state_drones stale at step {t}"
+        assert torch.equal(sd[..., 3:], env._bufs["obs_self"][..., 3:])
+        if first is None:
+            first = sd.clone()
+    assert not torch.equal(first, sd)                        # the drones moved
+    assert "state_drones" in td["next"]["agents"]["state"].keys()
