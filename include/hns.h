@@ -174,6 +174,10 @@ typedef struct hns_buffers {
     float *action_error;   /* [E,A]          stats.action_error_order1 (transforms.py:441) */
     uint8_t *done;         /* [E]            bool */
     uint8_t *detect;       /* [E]            bool, nullable: broadcast_detect (hideandseek.py:791), used by the TP_net input */
+    /* failure detection (nullable): one sticky word, OR-ed by hns_step on the device, never cleared by the library.
+     * bit 0: some pursuer's new rigid state is not finite; bit 1: some evader's new position; bit 2: some reward.
+     * "Not finite" is decided on the left-to-right fp32 sum s of the values concerned: (s - s) != 0. */
+    uint32_t *nonfinite;   /* [1] */
     /* optional outputs (nullable): the two extra keys PIDRateController._inv_call leaves on the tensordict (transforms.py:456-457) */
     float *ctbr;           /* [E,A,4]        controller output (roll, pitch, yaw command, thrust), lee_position_controller.py:548 */
     float *target_rate;    /* [E,A,4]        target body rate in deg/s (x, y, z, 0), transforms.py:447 */

@@ -68,7 +68,7 @@ _fp = C.c_void_p  # device (or, for the oracle, host) pointers travel as integer
 BUFFER_FIELDS = [
     "drone_state", "throttle", "pid_integ", "pid_last_rate", "prev_action", "target_pos",
     "target_vel", "cylinders", "progress", "stats", "obs_self", "obs_others", "obs_cylinders",
-    "state_drones", "reward", "action_error", "done", "detect", "ctbr", "target_rate",
+    "state_drones", "reward", "action_error", "done", "detect", "nonfinite", "ctbr", "target_rate",
 ]
 OPTIONAL_BUFFER_FIELDS = ("ctbr", "target_rate")     # bound only with task.publish_ctbr (transforms.py:456-457); NULL otherwise
 
@@ -100,7 +100,7 @@ def _required_buffer_shapes(E, A, Cn, K, tgt, D):
         "obs_self": ((E, A, D), "float32"), "obs_others": ((E, A, max(A - 1, 0), 3), "float32"),
         "obs_cylinders": ((E, A, K, 5), "float32"), "state_drones": ((E, A, D), "float32"),
         "reward": ((E, A), "float32"), "action_error": ((E, A), "float32"), "done": ((E,), "uint8"),
-        "detect": ((E,), "uint8"),
+        "detect": ((E,), "uint8"), "nonfinite": ((1,), "int32"),
     }
 
 

@@ -270,6 +270,10 @@ int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start,
 int hns_perturb_tasks(hns_env *env, const float *history, int32_t n_hist, float *tasks_out, int32_t n_tasks, int32_t expand_cylinders,
                       float expand_step, uint64_t seed, void *stream) {
     if (!env || !history || !tasks_out || n_hist < 1 || n_tasks < 0) { hns_set_error("hns_perturb_tasks: bad argument"); return HNS_ERR_INVALID_ARG; }
+    if (env->cfg.num_targets == 2) {
+        hns_set_error("hns_perturb_tasks: the task generator is built for one evader (num_targets = 2, the two-evader extension, runs without it)");
+        return HNS_ERR_CONFIG;
+    }
     if (n_tasks == 0) return HNS_OK;
     hns::PerturbParams p;
     p.cfg = env->cfg;

@@ -169,6 +169,16 @@ HNS_DEV void coop_cyl(float *__restrict__ lds, float *__restrict__ g, int nenv, 
         else if (smask[le]) g[i] = lds[le * stride + j];
     }
 }
+// failure detection (include/hns.h: hns_buffers.nonfinite): left-to-right sum of the 13 state values; (s - s) != 0 <=> not finite
+HNS_DEV bool rigid_not_finite(const Rigid &s) {
+    float a = s.pos.x;
+    a = a + s.pos.y; a = a + s.pos.z; a = a + s.q.w; a = a + s.q.x; a = a + s.q.y; a = a + s.q.z;
+    a = a + s.lin.x; a = a + s.lin.y; a = a + s.lin.z; a = a + s.ang.x; a = a + s.ang.y; a = a + s.ang.z;
+    return (a - a) != 0.0f;
+}
+HNS_DEV void flag_nonfinite(uint32_t *word, bool bad, uint32_t bit) {
+    if (word && bad) atomicOr(word, bit);          // rare: no traffic when everything is finite
+}
 HNS_DEV void load_rigid(const float *r, Rigid &s) {
     s.pos = {r[0], r[1], r[2]};
     s.q = {r[3], r[4], r[5], r[6]};
@@ -607,6 +617,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         tvel = {(c.v_prey * F.x) / (__builtin_fabsf(F.x) + 1e-5f), (c.v_prey * F.y) / (__builtin_fabsf(F.y) + 1e-5f),
                 (c.v_prey * F.z) / (__builtin_fabsf(F.z) + 1e-5f)};
         tpn = {tp0.x + tvel.x * c.dt, tp0.y + tvel.y * c.dt, tp0.z + tvel.z * c.dt};   // evader: p += v dt
+        { const float sf = (tpn.x + tpn.y) + tpn.z; flag_nonfinite(b.nonfinite, (sf - sf) != 0.0f, 2u); }
         if constexpr (NT == 2) {
             V3 G = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -621,6 +632,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
             tvel1 = {(c.v_prey * G.x) / (__builtin_fabsf(G.x) + 1e-5f), (c.v_prey * G.y) / (__builtin_fabsf(G.y) + 1e-5f),
                      (c.v_prey * G.z) / (__builtin_fabsf(G.z) + 1e-5f)};
             tpn1 = {tp1.x + tvel1.x * c.dt, tp1.y + tvel1.y * c.dt, tp1.z + tvel1.z * c.dt};
+            { const float sf = (tpn1.x + tpn1.y) + tpn1.z; flag_nonfinite(b.nonfinite, (sf - sf) != 0.0f, 2u); }
         }
         // statistics that only need phase-1 data are folded in now, while the agent waves integrate
         // (A10 hideandseek.py:731-733, :1097-1098, :996-997)
@@ -666,6 +678,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
             tb.z = ((moment[0] + moment[1]) + moment[2]) + moment[3];
             prof_mark(p.prof, 12);
             d_integrate(c, s, fw, tb);                                            // A5
+            flag_nonfinite(b.nonfinite, rigid_not_finite(s), 1u);
             prof_mark(p.prof, 13);
         }
         if (valid && !LAB(LAB_NOSTORE | LAB_NOST_REC)) {
@@ -830,6 +843,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
             if (!LAB(LAB_NOSTORE)) st_f1(b.reward + (size_t)e * A + j, r);
             sum_rew = (j == 0) ? r : sum_rew + r;
         }
+        flag_nonfinite(b.nonfinite, (sum_rew - sum_rew) != 0.0f, 4u);
         if (!det_any && !LAB(LAB_NOSTORE)) {                   // hideandseek.py:791-794: mask the evader's rpos
 #pragma unroll
             for (int j = 0; j < A; ++j) {
@@ -1024,6 +1038,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
         tb.y = -(((c.rotor_px[0] * thrust[0] + c.rotor_px[1] * thrust[1]) + c.rotor_px[2] * thrust[2]) + c.rotor_px[3] * thrust[3]);
         tb.z = ((moment[0] + moment[1]) + moment[2]) + moment[3];
         d_integrate(c, s, fw, tb);
+        flag_nonfinite(b.nonfinite, rigid_not_finite(s), 1u);
         {
             float *pub = sPub + tid * kPub;
             pub[6] = s.pos.x; pub[7] = s.pos.y; pub[8] = s.pos.z;
@@ -1176,6 +1191,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
                          (c.v_prey * F.z) / (__builtin_fabsf(F.z) + 1e-5f)};        // per-axis speed (:741)
         const V3 tpn = {tp0.x + tvel.x * c.dt, tp0.y + tvel.y * c.dt, tp0.z + tvel.z * c.dt};
         sTp[le * 3] = tpn.x; sTp[le * 3 + 1] = tpn.y; sTp[le * 3 + 2] = tpn.z;
+        { const float sf = (tpn.x + tpn.y) + tpn.z; flag_nonfinite(b.nonfinite, (sf - sf) != 0.0f, 2u); }
         {
             float *gp = b.target_pos + (size_t)e * 3, *gv = b.target_vel + (size_t)e * 3;
             if (!LAB(LAB_NOSTORE)) {
@@ -1238,6 +1254,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
             if (!LAB(LAB_NOSTORE)) st_f1(b.reward + (size_t)e * A + j, r);
             sum_rew = (j == 0) ? r : sum_rew + r;
         }
+        flag_nonfinite(b.nonfinite, (sum_rew - sum_rew) != 0.0f, 4u);
         if (!det_any && !LAB(LAB_NOSTORE)) {                   // hideandseek.py:791-794: mask the evader's relative position
 #pragma unroll
             for (int j = 0; j < A; ++j) {
@@ -1928,6 +1945,10 @@ int hns_reset_tasks(hns_env *env, const uint8_t *reset_mask, const float *tasks,
     if (!env || !tasks) { set_error("hns_reset_tasks: null argument"); return HNS_ERR_INVALID_ARG; }
     if (!env->bound) { set_error("hns_reset_tasks: buffers not bound"); return HNS_ERR_NOT_BOUND; }
     if (task_first < 0 || task_first > env->cfg.num_envs) { set_error("hns_reset_tasks: task_first out of range"); return HNS_ERR_INVALID_ARG; }
+    if (env->cfg.num_targets == 2) {
+        set_error("hns_reset_tasks: task vectors hold one evader (num_targets = 2, the two-evader extension, resets with hns_reset only)");
+        return HNS_ERR_CONFIG;
+    }
     Params p;
     p.cfg = env->cfg;
     p.buf = env->buf;
@@ -2045,7 +2066,7 @@ static int copy_state(hns_env *env, const hns_buffers *host, void *stream, bool 
         {host->progress, d.progress, E * 4}, {host->stats, d.stats, (size_t)HNS_NUM_STATS * E * 4}, {host->obs_self, d.obs_self, E * A * SD * 4},
         {host->obs_others, d.obs_others, E * A * (A - 1) * 12}, {host->obs_cylinders, d.obs_cylinders, E * A * K * 20},
         {host->state_drones, d.state_drones, E * A * SD * 4}, {host->reward, d.reward, E * A * 4}, {host->action_error, d.action_error, E * A * 4},
-        {host->done, d.done, E}, {host->detect, d.detect, E}, {host->ctbr, d.ctbr, E * A * 16}, {host->target_rate, d.target_rate, E * A * 16}};
+        {host->done, d.done, E}, {host->detect, d.detect, E}, {host->nonfinite, d.nonfinite, 4}, {host->ctbr, d.ctbr, E * A * 16}, {host->target_rate, d.target_rate, E * A * 16}};
     for (const Field &x : f) {
         if (!x.host || !x.dev || x.bytes == 0) continue;
         if (to_device) HNS_CHECK_HIP(hipMemcpyAsync(x.dev, x.host, x.bytes, hipMemcpyHostToDevice, (hipStream_t)stream));

@@ -521,9 +521,21 @@ class HideAndSeek(_EnvBase):
             self._tp_bufs["history"].copy_(torch.from_numpy(z["_tp_history"]))
             self._tp_filled = bool(int(z["_tp_filled"]))
 
-    def check_finite(self):
-        """Failure detection: True iff every state/output buffer is finite (one device reduction per buffer)."""
-        return all(bool(torch.isfinite(v).all()) for k, v in self._bufs.items() if v.dtype.is_floating_point)
+    def check_finite(self, clear=False, deep=False):
+        """Failure detection: True iff no step since the word was last cleared produced a non-finite pursuer state, evader
+        position or reward.  The step kernel ORs one sticky device word (hns_buffers.nonfinite); this reads that word —
+        one 4-byte read-back, no reduction over the buffers.  `deep=True` also reduces every float buffer (diagnostics)."""
+        word = int(self._bufs["nonfinite"].item())
+        if clear:
+            self._bufs["nonfinite"].zero_()
+        ok = word == 0
+        if deep:
+            ok = ok and all(bool(torch.isfinite(v).all()) for k, v in self._bufs.items() if v.dtype.is_floating_point)
+        return ok
+
+    def nonfinite_bits(self):
+        """The raw word: bit 0 pursuer state, bit 1 evader position, bit 2 reward."""
+        return int(self._bufs["nonfinite"].item())
 
 
 HideAndSeek.REGISTRY["HideAndSeek"] = HideAndSeek

@@ -656,6 +656,12 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
             tb[a][2] = ((moment[a][0] + moment[a][1]) + moment[a][2]) + moment[a][3];
         }
         for (int a = 0; a < A; ++a) o_integrate(c, ds + 13 * a, fw[a], tb[a]);
+        uint32_t bad = 0;                                   /* failure-detection word (include/hns.h: hns_buffers.nonfinite) */
+        for (int a = 0; a < A; ++a) {
+            float s = ds[13 * a];
+            for (int i = 1; i < 13; ++i) s = s + ds[13 * a + i];
+            if ((s - s) != 0.0f) bad |= 1u;
+        }
         for (int i = 0; i < 3; ++i) {
             b->target_vel[(size_t)e * 3 * NT + i] = tvel[i];
             tp[i] = tp[i] + tvel[i] * c->dt;
@@ -672,6 +678,20 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
         o_reward(c, A, C, K, ds, tp, cyl, b->progress[e], &side, b->action_error + (size_t)e * A, thr_diff,
                  stats, (size_t)E, b->reward + (size_t)e * A, b->done + e);
         if (b->detect) b->detect[e] = (uint8_t)(side.bdetect | (side.bdetect1 << 1));
+        for (int k = 0; k < NT; ++k) {
+            float s = (tp[3 * k] + tp[3 * k + 1]) + tp[3 * k + 2];
+            if ((s - s) != 0.0f) bad |= 2u;
+        }
+        {
+            const float *r = b->reward + (size_t)e * A;
+            float s = r[0];
+            for (int a = 1; a < A; ++a) s = s + r[a];
+            if ((s - s) != 0.0f) bad |= 4u;
+        }
+        if (bad && b->nonfinite) {
+#pragma omp atomic
+            *b->nonfinite |= bad;
+        }
     }
     return HNS_OK;
 }

@@ -245,7 +245,7 @@ def test_snapshot_resume_is_bit_exact(tmp_path):
     st = a.export_state()
     st["drone_state"][0, 0, 0] = np.nan
     a.import_state(st)
-    assert not a.check_finite()
+    assert not a.check_finite(deep=True)            # injected, not stepped: only the buffer scan sees it
 
 
 def test_set_state_get_state_round_trip():
@@ -356,10 +356,11 @@ def test_stream_shards_reproduce_the_whole_batch():
     for g, env in enumerate(shards):
         sl = slice(g * (E // G), (g + 1) * (E // G))
         for k, v in env.export_state().items():
-            want = ref[k][:, sl] if k == "stats" else ref[k][sl]
+            want = ref[k] if k == "nonfinite" else ref[k][:, sl] if k == "stats" else ref[k][sl]     # the health word is per env object
             np.testing.assert_array_equal(v, want, err_msg=f"shard {g}: buffer {k}")
 
 
+@pytest.mark.gpu
 def test_lazy_critic_state_is_refreshed_every_step():
     """`agents.state.state_drones` is assembled on access when the kernel does not write it (critic_input: obs, the
     reference's default): it must follow the state step after step (it once froze at its first-read values)."""
@@ -381,3 +382,31 @@ def test_lazy_critic_state_is_refreshed_every_step():
             first = sd.clone()
     assert not torch.equal(first, sd)                        # the drones moved
     assert "state_drones" in td["next"]["agents"]["state"].keys()
+
+
+@pytest.mark.gpu
+def test_nonfinite_word_is_set_by_the_step_kernel():
+    """SURVEY §5 failure detection: the step kernel itself reports non-finite results in ONE sticky device word
+    (bit 0 pursuer state, bit 1 evader position, bit 2 reward); `check_finite()` reads 4 bytes, no buffer reductions."""
+    env = make_env(256, 3, 5, max_len=50)
+    env.set_seed(5)
+    env.reset()
+    g = torch.Generator().manual_seed(1)
+    for _ in range(5):
+        env.step(env.rand_step_input(torch.randn(256, 3, 4, generator=g).to(env.device)))
+    assert env.nonfinite_bits() == 0 and env.check_finite() and env.check_finite(deep=True)
+    host = env.export_state()
+    host["drone_state"][17, 1, 0] = np.nan                     # one pursuer's position
+    env.import_state(host)
+    act = torch.randn(256, 3, 4, generator=g)
+    env.step(env.rand_step_input(act.to(env.device)))
+    O.step(env.hcfg, host, act.numpy())
+    assert env.nonfinite_bits() & 1 and not env.check_finite()
+    assert env.nonfinite_bits() == int(host["nonfinite"][0])   # same word as the oracle
+    assert not env.check_finite(clear=True) and env.nonfinite_bits() == 0
+    host = env.export_state()
+    host["target_pos"][200] = np.inf                           # an evader at infinity: its position and the distance rewards
+    host["drone_state"][17] = host["drone_state"][16]
+    env.import_state(host)
+    env.step(env.rand_step_input(act.to(env.device)))
+    assert env.nonfinite_bits() & 2 and env.nonfinite_bits() & 4

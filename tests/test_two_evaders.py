@@ -101,10 +101,11 @@ def test_capture_of_either_evader_counts():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("E,A,Cn", [(100, 3, 8), (64, 6, 16), (257, 1, 3), (130, 2, 5), (16384, 6, 16)])
+@pytest.mark.parametrize("E,A,Cn", [(100, 3, 8), (64, 6, 16), (257, 1, 3), (130, 2, 5), (16384, 6, 16), (65536, 6, 16)])
 def test_hip_two_evaders_matches_oracle(E, A, Cn):
+    """(65 536, 6, 16) is BASELINE config 5's per-GPU shard at its stated size: every buffer bit for bit."""
     from hns_amd.env import HideAndSeek
-    O.set_threads(8 if E > 4096 else 1)
+    O.set_threads(32 if E > 30000 else 8 if E > 4096 else 1)
     cfg = config.make_cfg({"num_agents": A, "num_targets": 2, "cylinder": {"max_num": Cn, "min_num": min(3, Cn)},
                            "env": {"num_envs": E, "max_episode_length": 12}}, algo={"critic_input": "state"})
     env = HideAndSeek(cfg)
@@ -117,7 +118,7 @@ def test_hip_two_evaders_matches_oracle(E, A, Cn):
     for k in host:
         assert np.array_equal(host[k], dev[k], equal_nan=True), f"reset: {k}"
     g = torch.Generator(device="cpu").manual_seed(E)
-    for t in range(30):
+    for t in range(14 if E > 30000 else 30):
         act = torch.randn(E, A, 4, generator=g)
         td = env.step(env.rand_step_input(act.to(env.device)))
         O.step(env.hcfg, host, act.numpy())
@@ -147,3 +148,40 @@ def test_hip_two_evaders_lazy_state_and_bench_shape():
     assert torch.equal(sd[..., 0:3], b["drone_state"][..., 0:3] - b["target_pos"][:, None, 0])
     assert torch.equal(sd[..., 20:23], b["drone_state"][..., 0:3] - b["target_pos"][:, None, 1])
     assert torch.equal(sd[..., 3:20], b["obs_self"][..., 3:20])
+
+
+@pytest.mark.gpu
+def test_two_evaders_full_shard_properties_and_rejections():
+    """Config 5's shard (6v2, 16 cylinders, 65 536 envs): size-independent properties over 40 steps, determinism, and the
+    combinations the extension does not support fail loudly instead of silently (predictor, task generator)."""
+    import ctypes as C
+    from hns_amd.env import HideAndSeek, HnsError
+    E, A, Cn = 65536, 6, 16
+    def mk():
+        cfg = config.make_cfg({"num_agents": A, "num_targets": 2, "cylinder": {"max_num": Cn, "min_num": Cn}, "env": {"num_envs": E, "max_episode_length": 800}})
+        e = HideAndSeek(cfg)
+        e.set_seed(11)
+        e.reset()
+        return e
+    e1, e2 = mk(), mk()
+    g = torch.Generator(device=e1.device).manual_seed(5)
+    for t in range(40):
+        act = torch.randn(E, A, 4, generator=g, device=e1.device)
+        e1.step(e1.rand_step_input(act)); e2.step(e2.rand_step_input(act))
+    a, b = e1.export_state(), e2.export_state()
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), f"not deterministic: {k}"
+    assert e1.check_finite()
+    q = a["drone_state"][..., 3:7]
+    assert np.abs(np.linalg.norm(q, axis=-1) - 1.0).max() < 1e-5                   # unit quaternions
+    assert np.linalg.norm(a["drone_state"][..., 7:10], axis=-1).max() <= 1.0 + 1e-6   # |v| <= v_drone
+    assert (a["progress"] == 40).all() and not a["done"].any()
+    assert np.array_equal(a["obs_self"][..., 3:7], q) and (a["obs_self"][..., 23] == 0).all()
+    tp = a["target_pos"]
+    assert tp.shape == (E, 2, 3) and np.isfinite(tp).all()
+    # rejections
+    assert e1._lib.hns_reset_tasks(e1._env, None, C.c_void_p(e1._bufs["target_pos"].data_ptr()), 0, C.c_uint64(0), None) == abi.HNS_ERR_CONFIG
+    assert b"one evader" in e1._lib.hns_last_error()
+    with pytest.raises(NotImplementedError):
+        config.make_cfg({"num_agents": A, "num_targets": 2, "cylinder": {"max_num": Cn, "min_num": Cn}, "env": {"num_envs": 64}}, algo={"use_TP_net": 1}) and \
+            HideAndSeek(config.make_cfg({"num_agents": A, "num_targets": 2, "cylinder": {"max_num": Cn, "min_num": Cn}, "env": {"num_envs": 64}}, algo={"use_TP_net": 1}))
