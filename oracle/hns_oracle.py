@@ -18,11 +18,13 @@ _LIB = None
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "libhns_oracle.so")
+    # HNS_ORACLE_SANITIZE=1: the AddressSanitizer + UBSan build (the process must run with libasan preloaded)
+    name = "libhns_oracle_asan.so" if os.environ.get("HNS_ORACLE_SANITIZE") == "1" else "libhns_oracle.so"
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "hns_oracle.c")
     hdr = os.path.join(_HERE, "..", "include", "hns.h")
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libhns_oracle.so"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", name])
     return so
 
 
