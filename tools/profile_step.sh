@@ -6,7 +6,7 @@ TAG=${1:-run}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-B="python bench.py --no-cpu-baseline --tp-steps 0 --stream-groups 0 $*"
+B="python bench.py --no-cpu-baseline --tp-steps 0 --stream-groups 0 --config-steps 0 --abi-steps 0 $*"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -- $B --steps 400 --warmup 50 > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc1 -- $B --steps 60 --warmup 10 > $OUT/pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc2 -- $B --steps 60 --warmup 10 > $OUT/pmc2.log 2>&1
