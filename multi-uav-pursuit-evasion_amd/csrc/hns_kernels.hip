@@ -938,7 +938,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
 //   * every store is a whole-line store from a wave-private slab.
 // Arithmetic, evaluation order and results are those of hns_step_kernel (bit-identical; tests/test_hip_parity.py).
 constexpr int kPub = 11;  // published per pursuer: position at t (3), thrust vector (3), position at t+1 (3), 1 / (|thrust| + 1e-6); odd stride
-struct LdsV3 { int slab, slab_stride, pub, cyl, cyl_stride, tp, red, total; };
+struct LdsV3 { int slab, slab_stride, pub, cyl, cyl_stride, tp, red, envout, total; };
 __host__ __device__ inline LdsV3 lds_layout_v3(int A, int C, int K) {
     LdsV3 L;
     int o = 0;
@@ -950,8 +950,19 @@ __host__ __device__ inline LdsV3 lds_layout_v3(int A, int C, int K) {
     L.cyl = o;   o += r4(kEPB * L.cyl_stride);
     L.tp = o;    o += r4(kEPB * 4);                      // evader at t+1 (3 per env) + the step counter (1 per env)
     L.red = o;   o += r4(kEPB * A * red_stride(1));
+    L.envout = o; o += r4(kEPB * (A > 3 ? A : 3));           // the env wave's own staging: evader velocity [64,3], rewards [64,A]
     L.total = o;
     return L;
+}
+
+// env wave: `n` floats that sit contiguously in LDS -> one contiguous, 16-byte aligned slice of global memory, 16 B per lane
+// (n % 4 == 0), write-through.  Per-lane 4-byte stores at a 12-byte stride would each be a partial-line write.
+HNS_DEV void env_store_slice(const float *lds, float *g, int n, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < n / 4; i += 64) st_f4(reinterpret_cast<float4 *>(g) + i, reinterpret_cast<const float4 *>(lds)[i]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 template <int A>
@@ -963,7 +974,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
     const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.num_envs;
     const bool with_state = c.write_critic_state && b.state_drones != nullptr;
     const LdsV3 L = lds_layout_v3(A, C, K);
-    float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red;
+    float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red, *sEnvOut = smem + L.envout;
     const int tid = threadIdx.x, lane = tid & 63;
     const int e0 = blockIdx.x * kEPB;
     prof_mark(p.prof, 0);
@@ -1151,9 +1162,18 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
         const float *gt = b.target_pos + (size_t)e * 3;
         const V3 tp0 = {gt[0], gt[1], gt[2]};
         float progress = b.progress[e];
-        const float *gc = b.cylinders + (size_t)e * C * 3;
-#pragma unroll 12
-        for (int k = 0; k < 3 * C; ++k) cylw[k] = gc[k];
+        {   // this workgroup's cylinders are one contiguous slice [64][3C]: coalesced 4-byte loads (lane <-> consecutive floats), scattered
+            // into rows of odd stride (lane = env reads its row conflict-free); index / 3C by multiply-high
+            const float *gc = b.cylinders + (size_t)e0 * C * 3;
+            const int c3 = 3 * C, n = kEPB * c3;
+#pragma unroll 8
+            for (int i = lane; i < n; i += 64) {
+                const int row = (int)__umulhi((unsigned)i, p.cyl_magic), col = i - row * c3;
+                sCyl[row * L.cyl_stride + col] = gc[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         prof_mark(p.prof, 1);
         // A6: arena + cylinder terms of the potential field (hideandseek.py:1090-1136)
         bool out_of_arena = false;
@@ -1192,12 +1212,10 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
         const V3 tpn = {tp0.x + tvel.x * c.dt, tp0.y + tvel.y * c.dt, tp0.z + tvel.z * c.dt};
         sTp[le * 3] = tpn.x; sTp[le * 3 + 1] = tpn.y; sTp[le * 3 + 2] = tpn.z;
         { const float sf = (tpn.x + tpn.y) + tpn.z; flag_nonfinite(b.nonfinite, (sf - sf) != 0.0f, 2u); }
-        {
-            float *gp = b.target_pos + (size_t)e * 3, *gv = b.target_vel + (size_t)e * 3;
-            if (!LAB(LAB_NOSTORE)) {
-                st_f1(gp, tpn.x); st_f1(gp + 1, tpn.y); st_f1(gp + 2, tpn.z);
-                st_f1(gv, tvel.x); st_f1(gv + 1, tvel.y); st_f1(gv + 2, tvel.z);
-            }
+        if (!LAB(LAB_NOSTORE)) {            // [64,3] slices, whole lines: the new position is already laid out in sTp
+            sEnvOut[le * 3] = tvel.x; sEnvOut[le * 3 + 1] = tvel.y; sEnvOut[le * 3 + 2] = tvel.z;
+            env_store_slice(sTp, b.target_pos + (size_t)e0 * 3, kEPB * 3, lane);
+            env_store_slice(sEnvOut, b.target_vel + (size_t)e0 * 3, kEPB * 3, lane);
         }
         {   // statistics that only need phase-1 data (A10 hideandseek.py:731-733, :1097-1098, :996-997)
             float sum_ae = 0.f, sum_td = 0.f, max_td = 0.f;
@@ -1251,9 +1269,10 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
         for (int j = 0; j < A; ++j) {
             const float *red = sRed + (le * A + j) * kRedS;
             const float r = ((((red[R_DIST] + detect_rew) + catch_rew) + red[R_COLL]) + red[R_SPEED]) + red[R_SMOOTH];
-            if (!LAB(LAB_NOSTORE)) st_f1(b.reward + (size_t)e * A + j, r);
+            sEnvOut[le * A + j] = r;
             sum_rew = (j == 0) ? r : sum_rew + r;
         }
+        if (!LAB(LAB_NOSTORE)) env_store_slice(sEnvOut, b.reward + (size_t)e0 * A, kEPB * A, lane);
         flag_nonfinite(b.nonfinite, (sum_rew - sum_rew) != 0.0f, 4u);
         if (!det_any && !LAB(LAB_NOSTORE)) {                   // hideandseek.py:791-794: mask the evader's relative position
 #pragma unroll
