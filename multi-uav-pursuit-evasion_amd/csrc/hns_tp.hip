@@ -55,9 +55,10 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kTpH = HNS_TP_HIDDEN;
-constexpr int kTpWaves = 8;
-constexpr int kTpThreads = kTpWaves * 64;
-constexpr int kTpEnvs = kTpWaves * 32;      // envs per workgroup
+// waves per workgroup: 8 (2 per SIMD, 256 envs) while the operand image + the parked frames fit the CU's 160 KB of LDS with them;
+// three frame chunks (33..48 values) need 123 KB of image, so that shape runs 6 waves (192 envs) per workgroup
+__host__ __device__ constexpr int tp_waves(int nxc) { return nxc <= 2 ? 8 : 6; }
+constexpr int kTpWaves = 8;                 // the widest workgroup (host-side sizing of the diagnostics buffer)
 constexpr int kTpMaxRows = 32;              // 3F <= 32: one M tile for the output layer
 constexpr float kTpLoScale = 2048.0f;       // 2^11: the low split term, kept in fp16's normal range
 constexpr float kTpLoInv = 1.0f / 2048.0f;
@@ -346,9 +347,11 @@ HNS_DEV void tp_gate_tiles(f32x16 (&acc)[4], const uint4 *aw, int tj, int hb, co
     G::run_steps(c, std::make_integer_sequence<int, G::N>{});
 }
 
-// NXC = 16-wide k-chunks of the frame (1: I <= 16, i.e. up to 3 pursuers; 2: I <= 32)
+// NXC = 16-wide k-chunks of the frame (1: I <= 16, i.e. up to 3 pursuers; 2: I <= 32; 3: I <= 48, e.g. 3 pursuers + 8 cylinders
+// with task.use_obstacles, hideandseek.py:808-816)
 template <int NXC>
-__global__ __launch_bounds__(kTpThreads) void hns_tp_lstm_kernel(const TpParams p) {
+__global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const TpParams p) {
+    constexpr int kTpWaves = tp_waves(NXC), kTpThreads = kTpWaves * 64, kTpEnvs = kTpWaves * 32;
     extern __shared__ __align__(16) uint4 simg[];
     const TpImage L = tp_image(NXC);
     const int tid = threadIdx.x, I = p.I, T = p.T, R = 3 * p.F;
@@ -654,7 +657,7 @@ static void tp_fill_params(const hns_env *env, TpParams &p) {
 
 extern "C" {
 
-size_t hns_tp_packed_bytes(void) { return (size_t)hns::tp_image(2).bytes; }
+size_t hns_tp_packed_bytes(void) { return (size_t)hns::tp_image(3).bytes; }       // the widest frame (three 16-value chunks)
 
 int hns_tp_bind(hns_env *env, const hns_tp_buffers *b, int32_t history_step, int32_t future_step) {
     if (!env || !b) { hns_set_error("hns_tp_bind: null argument"); return HNS_ERR_INVALID_ARG; }
@@ -680,8 +683,8 @@ int hns_tp_bind(hns_env *env, const hns_tp_buffers *b, int32_t history_step, int
         }
     if ((reinterpret_cast<uintptr_t>(b->packed) & 15) != 0) { hns_set_error("hns_tp_bind: packed must be 16-byte aligned"); return HNS_ERR_INVALID_ARG; }
     if (env->cfg.num_targets == 2) { hns_set_error("hns_tp_bind: the predictor's frame holds one evader (num_targets = 2 is not supported)"); return HNS_ERR_CONFIG; }
-    if (tp_nxc(tp_frame_dim(env->cfg)) > 2) {
-        hns_set_error("hns_tp_bind: frame wider than 32 values (7 + 3 num_agents + 3 num_cylinders with tp_use_obstacles)");
+    if (tp_nxc(tp_frame_dim(env->cfg)) > 3) {
+        hns_set_error("hns_tp_bind: frame wider than 48 values (7 + 3 num_agents + 3 num_cylinders with tp_use_obstacles)");
         return HNS_ERR_CONFIG;
     }
     if (env->cfg.max_episode_length > 60000) {
@@ -719,18 +722,19 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
     tp_fill_params(env, p);
     p.fill = fill_history ? 1 : 0;
     const int nxc = tp_nxc(p.I);
-    void (*fn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_kernel<1> : hns::hns_tp_lstm_kernel<2>;
-    const size_t lds = (size_t)hns::tp_image(nxc).bytes + (size_t)hns::kTpWaves * 8 * nxc * 64 * sizeof(float);   // image + parked new frame
+    void (*fn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_kernel<1> : nxc == 2 ? hns::hns_tp_lstm_kernel<2> : hns::hns_tp_lstm_kernel<3>;
+    const int waves = hns::tp_waves(nxc);
+    const size_t lds = (size_t)hns::tp_image(nxc).bytes + (size_t)waves * 8 * nxc * 64 * sizeof(float);   // image + parked new frame
     // the attribute is per device: remembered per (frame width, device), so envs on two GPUs driven from one thread both get it
-    static thread_local unsigned long long attr_devs[2] = {0ull, 0ull};
+    static thread_local unsigned long long attr_devs[3] = {0ull, 0ull, 0ull};
     const unsigned long long dev_bit = 1ull << (env->device & 63);
     if (!(attr_devs[nxc - 1] & dev_bit)) {
         HNS_CHECK_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_devs[nxc - 1] |= dev_bit;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int grid = (p.E + hns::kTpEnvs - 1) / hns::kTpEnvs;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(hns::kTpThreads), lds, s, p);
+    const int grid = (p.E + waves * 32 - 1) / (waves * 32);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), lds, s, p);
     HNS_CHECK_HIP(hipGetLastError());
     const int D = HNS_SELF_DIM + 3 * p.F;
     const int rgrid = (p.E * p.A + hns::kRowThreads - 1) / hns::kRowThreads;

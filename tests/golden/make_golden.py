@@ -992,6 +992,7 @@ if __name__ == "__main__":
     gen_tp_obs()
     gen_tp_obs("g_tp_obs_a6", E=10, A=6, C=8, seed=20241021)      # 25-value frames: the two-chunk path of the HIP kernel
     gen_tp_obs("g_tp_obs_obst", E=12, A=3, C=5, seed=20241023, use_obstacles=1)   # task.use_obstacles: 31-value frames
+    gen_tp_obs("g_tp_obs_obst_c8", E=12, A=3, C=8, seed=20241027, use_obstacles=1)   # 40-value frames: the three-chunk path
 
 
 # ---- envgen grid sanity check (hideandseek_envgen.py:145-207), module-level functions executed as they are ----

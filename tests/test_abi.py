@@ -73,8 +73,9 @@ def test_config_schema_and_validation(tmp_path):
     config.resolve_hns_cfg(config.make_cfg(algo={"use_TP_net": 1}))          # TP_net runs above the kernel (tp_net.py)
     assert config.resolve_hns_cfg(config.make_cfg({"use_obstacles": 1}, algo={"use_TP_net": 1})).tp_use_obstacles == 1   # 7+9+15 = 31 values
     assert config.resolve_hns_cfg(config.make_cfg({"use_obstacles": 1})).tp_use_obstacles == 0                           # only read with TP_net
-    with pytest.raises(NotImplementedError):                                 # 7 + 9 + 24 = 40 > 32 values per frame
-        config.resolve_hns_cfg(config.make_cfg({"use_obstacles": 1, "cylinder": {"max_num": 8}}, algo={"use_TP_net": 1}))
+    assert config.resolve_hns_cfg(config.make_cfg({"use_obstacles": 1, "cylinder": {"max_num": 8}}, algo={"use_TP_net": 1})).tp_use_obstacles == 1   # 40 values: three chunks
+    with pytest.raises(NotImplementedError):                                 # 7 + 9 + 48 = 64 > 48 values per frame
+        config.resolve_hns_cfg(config.make_cfg({"use_obstacles": 1, "cylinder": {"max_num": 16}}, algo={"use_TP_net": 1}))
     with pytest.raises(ValueError):
         config.resolve_hns_cfg(config.make_cfg({"cylinder": {"max_num": 40}}))
     sc = config.resolve_hns_cfg(config.make_cfg({"use_random_cylinder": 0, "scenario_flag": "wall"}))

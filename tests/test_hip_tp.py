@@ -104,7 +104,7 @@ def test_tp_env_matches_torch_lstm():
         env.step(env.rand_step_input(torch.randn(E, A, 4, device=env.device)))
 
 
-@pytest.mark.parametrize("name", ["g_tp_obs", "g_tp_obs_a6", "g_tp_obs_obst"])
+@pytest.mark.parametrize("name", ["g_tp_obs", "g_tp_obs_a6", "g_tp_obs_obst", "g_tp_obs_obst_c8"])
 def test_tp_matches_reference_golden(golden, name):
     """hns_tp_observe fed with the golden's states (obs rows from the oracle's observation pass) against
     the reference's own `_compute_state_and_obs` + TP_net outputs."""

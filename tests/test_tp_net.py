@@ -17,7 +17,7 @@ def _load_weights(tp, g):
 
 import pytest
 
-GOLDENS = ["g_tp_obs", "g_tp_obs_a6", "g_tp_obs_obst"]     # 3 pursuers, 6 pursuers, 3 pursuers + task.use_obstacles
+GOLDENS = ["g_tp_obs", "g_tp_obs_a6", "g_tp_obs_obst", "g_tp_obs_obst_c8"]     # 3 pursuers, 6 pursuers, 3 pursuers + task.use_obstacles (5 / 8 cylinders: 31 / 40 values)
 
 
 def _golden_cfg(g):
