@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define HNS_ABI_VERSION 2
-#define HNS_MAX_AGENTS 7    /* pursuers per env; lane group = next pow2 >= A+1 */
+#define HNS_MAX_AGENTS 7    /* pursuers per env: a workgroup is 64 envs = A pursuer waves + one env wave (<= 512 threads) */
 #define HNS_MAX_CYLINDERS 16
 #define HNS_NUM_STATS 24    /* hideandseek.py:400-425 */
 #define HNS_SELF_DIM 20     /* state_self without TP prediction, hideandseek.py:856-863 */

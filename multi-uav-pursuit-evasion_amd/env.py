@@ -345,11 +345,18 @@ class HideAndSeek(_EnvBase):
         self._state_version += 1
         # what PIDRateController._inv_call leaves on the caller's tensordict (transforms.py:438-457); hideandseek.py:726-731 reads
         # the first two back — here they are views of the buffers the kernel just updated
-        tensordict.set(("stats", "action_error_order1"), self._bufs["action_error"])
-        tensordict.set(("info", "prev_action"), self._bufs["prev_action"])
-        if self.publish_ctbr:
-            tensordict.set("ctbr", self._bufs["ctbr"])
-            tensordict.set("target_rate", self._bufs["target_rate"][..., :3])
+        # (the entries are the same persistent tensors every step: a tensordict that already carries them — a collector steps
+        #  the same one again and again, return_same_td — is not touched again)
+        if getattr(tensordict, "_hns_transform_keys", None) is not self:
+            tensordict.set(("stats", "action_error_order1"), self._bufs["action_error"])
+            tensordict.set(("info", "prev_action"), self._bufs["prev_action"])
+            if self.publish_ctbr:
+                tensordict.set("ctbr", self._bufs["ctbr"])
+                tensordict.set("target_rate", self._bufs["target_rate"][..., :3])
+            try:
+                object.__setattr__(tensordict, "_hns_transform_keys", self)
+            except Exception:  # noqa: BLE001  (a tensordict class without instance attributes: set the keys every step)
+                pass
         b = self._bufs
         # hideandseek.py:1012-1015 — evader-speed curriculum; v_prey starts at its 1.3 cap with the
         # reference's defaults, in which case no host sync is ever needed
