@@ -11,6 +11,8 @@
 #include "../../include/hns.h"
 
 #define HNS_DEV static __device__ __forceinline__
+// (the functions that read the configuration take it as `const Cfg &`: hns_cfg in generic memory, or the same struct behind a
+//  constant-address-space reference — the step kernel reads its device-resident copy through the scalar cache that way)
 
 namespace hns {
 
@@ -139,7 +141,8 @@ HNS_DEV Q4 d_euler_to_quat(float r, float p, float y) {
 HNS_DEV float4 d_action_tanh(const float4 &action) {
     return make_float4(d_tanhf(action.x), d_tanhf(action.y), d_tanhf(action.z), d_tanhf(action.w));
 }
-HNS_DEV void d_ctbr_pid_squashed(const hns_cfg &c, const float4 &ta, const Q4 &q, const V3 &angvel,
+template <class Cfg>
+HNS_DEV void d_ctbr_pid_squashed(const Cfg &c, const float4 &ta, const Q4 &q, const V3 &angvel,
                                  float4 &prev_action, float4 &integ4, float4 &last4, float cmd[4], float &action_error,
                                  float *ctbr_out = nullptr, float *target_out = nullptr) {
     float a0 = ta.x, a1 = ta.y, a2 = ta.z, a3 = ta.w;
@@ -192,14 +195,16 @@ HNS_DEV void d_ctbr_pid_squashed(const hns_cfg &c, const float4 &ta, const Q4 &q
     }
 }
 
-HNS_DEV void d_ctbr_pid(const hns_cfg &c, const float4 &action, const Q4 &q, const V3 &angvel,
+template <class Cfg>
+HNS_DEV void d_ctbr_pid(const Cfg &c, const float4 &action, const Q4 &q, const V3 &angvel,
                         float4 &prev_action, float4 &integ4, float4 &last4, float cmd[4], float &action_error,
                         float *ctbr_out = nullptr, float *target_out = nullptr) {
     d_ctbr_pid_squashed(c, d_action_tanh(action), q, angvel, prev_action, integ4, last4, cmd, action_error, ctbr_out, target_out);
 }
 
 // ---- A3: rotor lag + thrust/moment   omni_drones/actuators/rotor_group.py:55-71 --------------
-HNS_DEV void d_rotor(const hns_cfg &c, const float cmd[4], float4 &throttle4, float thrust[4], float moment[4],
+template <class Cfg>
+HNS_DEV void d_rotor(const Cfg &c, const float cmd[4], float4 &throttle4, float thrust[4], float moment[4],
                      float &throttle_difference) {
     float thr_in[4] = {throttle4.x, throttle4.y, throttle4.z, throttle4.w};
     float thr_out[4];
@@ -262,7 +267,8 @@ struct LosLine {          // per (drone, evader) constants of the line-of-sight 
 // The filter band is built on the hardware's approximate square root (v_sqrt_f32, 1 ulp): its value only positions a
 // band that is 4 x wider than its error, every decision inside the band is taken by the exact path (d_blocked_exact,
 // correctly rounded sqrt + divisions), so the results do not depend on the approximation.
-HNS_DEV LosLine d_los_setup(const hns_cfg &c, const V3 &dp, const V3 &tp) {
+template <class Cfg>
+HNS_DEV LosLine d_los_setup(const Cfg &c, const V3 &dp, const V3 &tp) {
     LosLine l;
     l.diffx = dp.x - tp.x; l.diffy = dp.y - tp.y;
     const float den = __builtin_amdgcn_sqrtf(HNS_FMA(l.diffy, l.diffy, l.diffx * l.diffx));
@@ -286,7 +292,8 @@ HNS_DEV bool d_los_cylinder_fast(const LosLine &l, float ccx, float ccy, float c
     return lo && tpos && (numt <= l.dt1) && (ccz > 0.0f);
 }
 // Exact form: divide and compare, as the reference does (hideandseek.py:47-103)
-HNS_DEV bool d_los_cylinder(const hns_cfg &c, const LosLine &l, float d1, float ccx, float ccy, float ccz) {
+template <class Cfg>
+HNS_DEV bool d_los_cylinder(const Cfg &c, const LosLine &l, float d1, float ccx, float ccy, float ccz) {
     float d2x = ccx - l.tpx, d2y = ccy - l.tpy;
     float num = __builtin_fabsf(HNS_FMA(l.diffx, d2y, -(l.diffy * d2x)));
     float numt = HNS_FMA(ccy - l.dpy, l.dy, (ccx - l.dpx) * l.dx);
@@ -295,13 +302,15 @@ HNS_DEV bool d_los_cylinder(const hns_cfg &c, const LosLine &l, float d1, float 
     bool on = (t >= 0.0f) && (t <= 1.0f);
     return blocked && on && (ccz > 0.0f);
 }
-HNS_DEV bool d_blocked_exact(const hns_cfg &c, int C, const LosLine &l, const float *cyl) {
+template <class Cfg>
+HNS_DEV bool d_blocked_exact(const Cfg &c, int C, const LosLine &l, const float *cyl) {
     const float d1 = d_norm2(l.diffx, l.diffy) + 1e-5f;       // the correctly rounded denominator of :63
     bool any = false;
     for (int k = 0; k < C; ++k) any = d_los_cylinder(c, l, d1, cyl[3 * k], cyl[3 * k + 1], cyl[3 * k + 2]) || any;
     return any;
 }
-HNS_DEV bool d_blocked(const hns_cfg &c, int C, const V3 &dp, const V3 &tp, const float *cyl) {
+template <class Cfg>
+HNS_DEV bool d_blocked(const Cfg &c, int C, const V3 &dp, const V3 &tp, const float *cyl) {
     const LosLine l = d_los_setup(c, dp, tp);
     bool any = false, uncertain = false;
 #pragma unroll 4
@@ -312,7 +321,8 @@ HNS_DEV bool d_blocked(const hns_cfg &c, int C, const V3 &dp, const V3 &tp, cons
 
 // ---- A6 pieces: evader potential field   hideandseek.py:1067-1141 -----------------------------
 // pursuer term of one drone (:1074-1088)
-HNS_DEV V3 d_prey_pursuer_term(const hns_cfg &c, const V3 &dp, const V3 &tp, bool blocked) {
+template <class Cfg>
+HNS_DEV V3 d_prey_pursuer_term(const Cfg &c, const V3 &dp, const V3 &tp, bool blocked) {
     float rx = dp.x - tp.x, ry = dp.y - tp.y, rz = dp.z - tp.z;
     float dist = d_norm3(rx, ry, rz);
     float active = ((dist < c.target_detect_radius) && !blocked) ? 1.0f : 0.0f;
@@ -324,7 +334,8 @@ HNS_DEV V3 d_prey_pursuer_term(const hns_cfg &c, const V3 &dp, const V3 &tp, boo
     return f;
 }
 // arena walls/ceiling/floor (:1090-1112); also reports the out-of-arena flag (:1096-1098)
-HNS_DEV V3 d_prey_arena_term(const hns_cfg &c, const V3 &tp, bool &out_of_arena) {
+template <class Cfg>
+HNS_DEV V3 d_prey_arena_term(const Cfg &c, const V3 &tp, bool &out_of_arena) {
     float od = d_norm2(tp.x, tp.y);
     float ro = 1.0f / (od + 1e-5f);
     float dirx = -tp.x * ro, diry = -tp.y * ro;
@@ -347,7 +358,8 @@ HNS_DEV V3 d_prey_arena_term(const hns_cfg &c, const V3 &tp, bool &out_of_arena)
     return f;
 }
 // repulsion of one cylinder (:1129-1136)
-HNS_DEV void d_prey_cylinder_term(const hns_cfg &c, const V3 &tp, float ccx, float ccy, float ccz, float &tx, float &ty) {
+template <class Cfg>
+HNS_DEV void d_prey_cylinder_term(const Cfg &c, const V3 &tp, float ccx, float ccy, float ccz, float &tx, float &ty) {
     float rx = tp.x - ccx, ry = tp.y - ccy;
     float dc = d_norm2(rx, ry);
     float db = dc - c.cylinder_size;
@@ -360,7 +372,8 @@ HNS_DEV void d_prey_cylinder_term(const hns_cfg &c, const V3 &tp, float ccx, flo
 // ---- A5: rigid-body integration — the build's own spec -----------------------
 struct Rigid { V3 pos; Q4 q; V3 lin; V3 ang; };
 
-HNS_DEV void d_integrate(const hns_cfg &c, Rigid &s, const V3 &force_w, const V3 &torque_b) {
+template <class Cfg>
+HNS_DEV void d_integrate(const Cfg &c, Rigid &s, const V3 &force_w, const V3 &torque_b) {
     const float dt = c.dt;
     float ax = force_w.x * c.inv_mass, ay = force_w.y * c.inv_mass, az = HNS_FMA(force_w.z, c.inv_mass, -c.gravity);
     float vx = HNS_FMA(ax, dt, s.lin.x) * c.lin_damp_factor;

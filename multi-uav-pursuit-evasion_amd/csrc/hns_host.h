@@ -11,6 +11,7 @@
 
 namespace hns {
 struct Params;
+struct StepArgs;
 }
 
 void hns_set_error(const std::string &m);
@@ -33,6 +34,9 @@ struct hns_env {
     size_t lds_step = 0, lds_reset = 0;
     void (*step_fn)(const hns::Params) = nullptr;
     void (*reset_fn)(const hns::Params) = nullptr;
+    void (*step_args_fn)(const hns::StepArgs) = nullptr;   // step kernel taking the split argument block (else step_fn)
+    hns::Params *params_dev = nullptr, *params_host = nullptr;   // device copy of the step launch's Params + its pinned host image
+    bool params_valid = false;
     unsigned long long *prof = nullptr;
     uint32_t cyl_magic = 0;
     int timing = 0;          // 0 = off, n = bracket every n-th step launch with hipEvents

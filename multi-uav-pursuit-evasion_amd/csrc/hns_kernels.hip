@@ -55,9 +55,10 @@ struct Geo {
     static constexpr int T = kEPB * (A + 1);    // + the env wave
 };
 
-// Passed by value (~900 B of kernel arguments).  Measured alternatives (tools/microbench/launch_gap.hip, A/B in step_lab): arguments
-// of <= 64 B launch 0.5-0.6 us faster, but a configuration block in device memory read through the scalar cache costs
-// +1.8 us per step — every wave starts with two dependent cold scalar loads before it can issue its first global load.
+// Reset / first-design step: passed by value (~900 B of kernel arguments).  A launch with <= 64 B of arguments is 0.5-0.6 us
+// faster (tools/microbench/launch_gap.hip), but a block in device memory read through the scalar cache in front of a wave's
+// first global load costs more than that (+1.8 us measured) — so the step kernel of the fourth design takes StepArgs: the
+// pointers behind its first loads by value, everything else through `rest`, whose scalar loads travel beside those loads.
 struct Params {
     hns_cfg cfg;
     hns_buffers buf;
@@ -72,6 +73,14 @@ struct Params {
     uint32_t lab;               // ablation switches of the measurement build (-DHNS_LAB, tools/step_lab.py); unused otherwise
 };
 
+struct StepArgs {               // 64 B
+    const float *action;
+    float *prev_action, *drone_state, *pid_integ, *pid_last_rate, *throttle;
+    const float *cylinders;
+    const Params *rest;         // device copy of the launch's Params (action = null), kept by the env handle
+};
+static_assert(sizeof(StepArgs) == 64, "the argument block of the step kernel is sized for the fast launch path");
+
 // Measurement build only: parts of the step kernel can be switched off at run time (HNS_LAB_FLAGS) to time what is left.
 #ifdef HNS_LAB
 #define LAB(bit) ((p.lab & (bit)) != 0u)
@@ -79,7 +88,7 @@ struct Params {
 #define LAB(bit) false
 #endif
 enum { LAB_NOSTORE = 1, LAB_NOP1 = 2, LAB_NOP2 = 4, LAB_NOP3A = 8, LAB_NOP3B = 16, LAB_NOLOAD = 32,
-       LAB_NOST_SELF = 64, LAB_NOST_OTH = 128, LAB_NOST_REC = 256, LAB_NOST_DS = 512, LAB_NOST_OCYL = 1024, LAB_NOST_STATS = 2048 };
+       LAB_NOST_SELF = 64, LAB_NOST_OTH = 128, LAB_NOST_REC = 256, LAB_NOST_DS = 512, LAB_NOST_OCYL = 1024, LAB_NOST_STATS = 2048, LAB_HWID = 4096, LAB_NOLOS1 = 8192, LAB_NOLOS2 = 16384 };
 
 constexpr int kProfSlots = 16;
 // lane 0 of every wave stamps s_memtime at a phase boundary (only when a buffer is attached)
@@ -273,6 +282,71 @@ HNS_DEV void wave_store_rows(float *__restrict__ slab, float *__restrict__ gslic
     }
 }
 
+// ONE pass over the env's cylinders: line of sight to the evader (:786, LOS) and the k nearest by
+// (3-D distance - size), ties -> lower index (:767-778).  The ordering is decided on SQUARED
+// distances (no sqrt): md = RN(RN(sqrt(d2)) - size) is monotone in d2, so both orders agree
+// whenever consecutive candidates differ by more than 2^-16 relative (then their md differ by
+// >= 4 ulp and cannot tie); otherwise the exact md insertion below decides.
+// Fast path: 32-bit keys = squared-distance bits with the cylinder index in the 4 low mantissa
+// bits (non-negative floats order like unsigned ints), kept sorted by a branch-free min/max
+// insertion network.  The 2^-19 truncation is covered by the 2^-16 gap test below.
+template <int NT, bool LOS, class Cfg>
+HNS_DEV void cylinder_pass(const Cfg &c, int C, int K, const V3 &pos, const V3 &tp, const V3 &tpB, const float *cyl,
+                           int bi[kMaxK + 1], bool &any_block, bool &any_block1) {
+    constexpr int kTrack = kMaxK + 1;           // one more than k: guards the k-th/(k+1)-th boundary
+    uint32_t key[kTrack];
+#pragma unroll
+    for (int i = 0; i < kTrack; ++i) key[i] = 0x7F80000Fu;             // +inf | 15
+    LosLine los = {}, los1 = {};
+    if constexpr (LOS) los = d_los_setup(c, pos, tp);
+    bool los_uncertain = false, los_uncertain1 = false;
+    any_block = false; any_block1 = false;
+    if constexpr (LOS && NT == 2) los1 = d_los_setup(c, pos, tpB);
+#pragma unroll 4
+    for (int k = 0; k < C; ++k) {
+        const float ccx = cyl[3 * k], ccy = cyl[3 * k + 1], ccz = cyl[3 * k + 2];
+        if constexpr (LOS) any_block = d_los_cylinder_fast(los, ccx, ccy, ccz, los_uncertain) || any_block;
+        if constexpr (LOS && NT == 2) any_block1 = d_los_cylinder_fast(los1, ccx, ccy, ccz, los_uncertain1) || any_block1;
+        const float ex = pos.x - ccx, ey = pos.y - ccy, ez = pos.z - ccz;
+        const float d2 = HNS_FMA(ez, ez, HNS_FMA(ey, ey, ex * ex));          // the radicand of d_norm3
+        uint32_t nk = (__float_as_uint(d2) & 0xFFFFFFF0u) | (uint32_t)k;
+#pragma unroll
+        for (int i = 0; i < kTrack; ++i) {
+            uint32_t lo = min(key[i], nk);
+            nk = max(key[i], nk);
+            key[i] = lo;
+        }
+    }
+    if constexpr (LOS) {
+        if (los_uncertain) any_block = d_blocked_exact(c, C, los, cyl);
+        if (NT == 2 && los_uncertain1) any_block1 = d_blocked_exact(c, C, los1, cyl);
+    }
+    float bd[kTrack];
+#pragma unroll
+    for (int i = 0; i < kTrack; ++i) { bd[i] = __uint_as_float(key[i] & 0xFFFFFFF0u); bi[i] = (int)(key[i] & 15u); }
+    bool order_safe = bd[0] > 1e-5f;
+#pragma unroll
+    for (int i = 0; i < kMaxK; ++i)
+        if (i < K) order_safe = order_safe && (bd[i + 1] > bd[i] * 1.0000152587890625f);   // 1 + 2^-16
+    if (!order_safe) {                          // rare: exact (distance - size) keys, as the reference sorts
+#pragma unroll
+        for (int i = 0; i < kTrack; ++i) { bd[i] = kInf; bi[i] = 0; }
+        for (int k = 0; k < C; ++k) {
+            float md = d_norm3(pos.x - cyl[3 * k], pos.y - cyl[3 * k + 1], pos.z - cyl[3 * k + 2]) - c.cylinder_size;
+            if (md < bd[kMaxK - 1]) {
+                bd[kMaxK - 1] = md; bi[kMaxK - 1] = k;
+#pragma unroll
+                for (int i = kMaxK - 1; i > 0; --i) {
+                    if (bd[i] < bd[i - 1]) {
+                        float td = bd[i]; bd[i] = bd[i - 1]; bd[i - 1] = td;
+                        int ti = bi[i]; bi[i] = bi[i - 1]; bi[i - 1] = ti;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- A8 (agent thread): observation of one pursuer on the post-physics state -------------------
 // multirotor.py:599-633, hideandseek.py:746-917.  obs_self / state_drones are stored straight to
 // global memory (5 float4 per thread, thread-contiguous); the relative position of the evader is
@@ -282,8 +356,8 @@ HNS_DEV void wave_store_rows(float *__restrict__ slab, float *__restrict__ gslic
 // the relative position of the second evader + one zero; line of sight / detection per evader.
 // STAGED (step kernel, full tiles): every output slice goes through the wave's slab (wave_store_rows); `sOCyl` is then
 // the slab of this wave and gOth / gSelf / gState / gOCyl are still the THREAD's rows (the wave's slice starts `lane` rows earlier).
-template <int A, int NT, bool STAGED = false, int PS = 13>
-HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigid &s, const V3 &tp, const V3 &tpB, float progress,
+template <int A, int NT, bool STAGED = false, int PS = 13, class Cfg = hns_cfg>
+HNS_DEV void agent_obs(const Cfg &c, int C, int K, int le, int a, const Rigid &s, const V3 &tp, const V3 &tpB, float progress,
                        const float *cyl, const float *sDS, float *gOth, float *sOCyl, float *gSelf, float *gState,
                        bool &blocked, bool &det, bool &blockedB, bool &detB, int knn_idx[kMaxK], bool knn_masked[kMaxK], bool st = true, bool st_oth = true,
                        float *gOCyl = nullptr, float *dist_out = nullptr, bool st_ocyl = true) {
@@ -347,65 +421,9 @@ HNS_DEV void agent_obs(const hns_cfg &c, int C, int K, int le, int a, const Rigi
             for (int i = 0; i < (A - 1) * 3; ++i) gOth[i] = o[i];
         }
     }
-    // ONE pass over the env's cylinders: line of sight to the evader (:786) and the k nearest by
-    // (3-D distance - size), ties -> lower index (:767-778).  The ordering is decided on SQUARED
-    // distances (no sqrt): md = RN(RN(sqrt(d2)) - size) is monotone in d2, so both orders agree
-    // whenever consecutive candidates differ by more than 2^-16 relative (then their md differ by
-    // >= 4 ulp and cannot tie); otherwise the exact md insertion below decides.
-    // Fast path: 32-bit keys = squared-distance bits with the cylinder index in the 4 low mantissa
-    // bits (non-negative floats order like unsigned ints), kept sorted by a branch-free min/max
-    // insertion network.  The 2^-19 truncation is covered by the 2^-16 gap test below.
-    constexpr int kTrack = kMaxK + 1;           // one more than k: guards the k-th/(k+1)-th boundary
-    uint32_t key[kTrack];
-#pragma unroll
-    for (int i = 0; i < kTrack; ++i) key[i] = 0x7F80000Fu;             // +inf | 15
-    const LosLine los = d_los_setup(c, s.pos, tp);
-    bool any_block = false, los_uncertain = false;
-    LosLine los1 = los;
-    bool any_block1 = false, los_uncertain1 = false;
-    if constexpr (NT == 2) los1 = d_los_setup(c, s.pos, tpB);
-#pragma unroll 4
-    for (int k = 0; k < C; ++k) {
-        const float ccx = cyl[3 * k], ccy = cyl[3 * k + 1], ccz = cyl[3 * k + 2];
-        any_block = d_los_cylinder_fast(los, ccx, ccy, ccz, los_uncertain) || any_block;
-        if constexpr (NT == 2) any_block1 = d_los_cylinder_fast(los1, ccx, ccy, ccz, los_uncertain1) || any_block1;
-        const float ex = s.pos.x - ccx, ey = s.pos.y - ccy, ez = s.pos.z - ccz;
-        const float d2 = HNS_FMA(ez, ez, HNS_FMA(ey, ey, ex * ex));          // the radicand of d_norm3
-        uint32_t nk = (__float_as_uint(d2) & 0xFFFFFFF0u) | (uint32_t)k;
-#pragma unroll
-        for (int i = 0; i < kTrack; ++i) {
-            uint32_t lo = min(key[i], nk);
-            nk = max(key[i], nk);
-            key[i] = lo;
-        }
-    }
-    if (los_uncertain) any_block = d_blocked_exact(c, C, los, cyl);
-    if (NT == 2 && los_uncertain1) any_block1 = d_blocked_exact(c, C, los1, cyl);
-    float bd[kTrack];
-    int bi[kTrack];
-#pragma unroll
-    for (int i = 0; i < kTrack; ++i) { bd[i] = __uint_as_float(key[i] & 0xFFFFFFF0u); bi[i] = (int)(key[i] & 15u); }
-    bool order_safe = bd[0] > 1e-5f;
-#pragma unroll
-    for (int i = 0; i < kMaxK; ++i)
-        if (i < K) order_safe = order_safe && (bd[i + 1] > bd[i] * 1.0000152587890625f);   // 1 + 2^-16
-    if (!order_safe) {                          // rare: exact (distance - size) keys, as the reference sorts
-#pragma unroll
-        for (int i = 0; i < kTrack; ++i) { bd[i] = kInf; bi[i] = 0; }
-        for (int k = 0; k < C; ++k) {
-            float md = d_norm3(s.pos.x - cyl[3 * k], s.pos.y - cyl[3 * k + 1], s.pos.z - cyl[3 * k + 2]) - c.cylinder_size;
-            if (md < bd[kMaxK - 1]) {
-                bd[kMaxK - 1] = md; bi[kMaxK - 1] = k;
-#pragma unroll
-                for (int i = kMaxK - 1; i > 0; --i) {
-                    if (bd[i] < bd[i - 1]) {
-                        float td = bd[i]; bd[i] = bd[i - 1]; bd[i - 1] = td;
-                        int ti = bi[i]; bi[i] = bi[i - 1]; bi[i - 1] = ti;
-                    }
-                }
-            }
-        }
-    }
+    int bi[kMaxK + 1];
+    bool any_block, any_block1;
+    cylinder_pass<NT, true>(c, C, K, s.pos, tp, tpB, cyl, bi, any_block, any_block1);
     blocked = any_block;
     det = (dist < c.drone_detect_radius) && !blocked;                 // :787-789
     if constexpr (NT == 2) {
@@ -937,6 +955,9 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
 //     vector, position at t+1), three workgroup barriers in all (six before);
 //   * every store is a whole-line store from a wave-private slab.
 // Arithmetic, evaluation order and results are those of hns_step_kernel (bit-identical; tests/test_hip_parity.py).
+#ifndef HNS_ENV_PRIO
+#define HNS_ENV_PRIO 2
+#endif
 constexpr int kPub = 11;  // published per pursuer: position at t (3), thrust vector (3), position at t+1 (3), 1 / (|thrust| + 1e-6); odd stride
 struct LdsV3 { int slab, slab_stride, pub, cyl, cyl_stride, tp, red, envout, total; };
 __host__ __device__ inline LdsV3 lds_layout_v3(int A, int C, int K) {
@@ -990,10 +1011,10 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
         float4 prev4 = reinterpret_cast<const float4 *>(b.prev_action)[ia];
         constexpr int N4 = 64 * 13 / 4;                   // 208 float4 pieces per wave
         const float4 *rows4 = reinterpret_cast<const float4 *>(b.drone_state + ((size_t)e0 * A + (tid & ~63)) * 13) + lane;
-        float4 rr[(N4 + 63) / 64];
-#pragma unroll
-        for (int j = 0; j < (N4 + 63) / 64; ++j)
-            if (j * 64 + lane < N4) rr[j] = rows4[j * 64];
+        static_assert(N4 > 192 && N4 <= 256, "three full passes and a partial one");
+        const float4 rr0 = rows4[0], rr1 = rows4[64], rr2 = rows4[128];      // (named values: an array with a predicated element went to scratch)
+        float4 rr3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < N4 - 192) rr3 = rows4[192];
         float4 integ4 = reinterpret_cast<const float4 *>(b.pid_integ)[ia];
         float4 last4 = reinterpret_cast<const float4 *>(b.pid_last_rate)[ia];
         float4 thr4 = reinterpret_cast<const float4 *>(b.throttle)[ia];
@@ -1001,9 +1022,8 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
         // own rows through the private slab
         {
             float4 *s4 = reinterpret_cast<float4 *>(slab) + lane;
-#pragma unroll
-            for (int j = 0; j < (N4 + 63) / 64; ++j)
-                if (j * 64 + lane < N4) s4[j * 64] = rr[j];
+            s4[0] = rr0; s4[64] = rr1; s4[128] = rr2;
+            if (lane < N4 - 192) s4[192] = rr3;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1152,9 +1172,6 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
         prof_mark(p.prof, 6);
     } else {
         // ================================= env wave: lane <-> env ========================================
-#ifndef HNS_ENV_PRIO
-#define HNS_ENV_PRIO 2
-#endif
         if (HNS_ENV_PRIO) __builtin_amdgcn_s_setprio(HNS_ENV_PRIO);   // one wave in four, but every barrier of its workgroup waits for it
         const int le = lane, e = e0 + le;
         float *cylw = sCyl + le * L.cyl_stride;
@@ -1330,6 +1347,499 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
     }
     prof_mark(p.prof, 7);
     prof_mark(p.prof, 15);
+#ifdef HNS_LAB
+    if (p.prof && lane == 0 && LAB(LAB_HWID)) {                   // where the hardware put this wave (tools/wave_placement.py)
+        unsigned long long *pr = p.prof + (size_t)(blockIdx.x * (A + 1) + (tid >> 6)) * kProfSlots;
+        pr[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+        pr[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+        pr[12] = (unsigned long long)(tid >= NA);
+    }
+#endif
+}
+
+// Fourth design = the third with the phases re-cut so that the env wave — ONE wave, issuing one instruction every 5-7 cycles —
+// carries as little serial work as possible (tools/phase_timeline.py; in the third design 5.8 us of the 14.5 us of a workgroup's life
+// were env-wave work that the pursuer waves waited for):
+//   * line of sight evader -> pursuer at t (:1080) runs on the pursuers' lanes (A x fewer tests per lane, three waves instead of
+//     one) behind an extra barrier that sits after the controller, where the env wave's LDS image has long been written;
+//   * the pursuers publish their reward terms BEFORE they build and store their observation rows, so the env wave's reductions, reward,
+//     statistics and done run beside those stores instead of behind them; the detection mask of the evader's relative position
+//     (:791-794) is applied by the pursuers themselves (was: the env wave patched the stored rows);
+//   * the cylinders are brought into LDS by the pursuer waves with their own rows (one wave needed 5.5 us for the 24 passes).
+// Four workgroup barriers.
+template <int A>
+__global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArgs ka) {
+    // the block behind `rest` is never written while the kernel runs: read it as constant memory (scalar loads, placed like kernel-argument loads)
+    typedef const Params __attribute__((address_space(4))) ParamsC;
+    ParamsC &p = *(ParamsC *)ka.rest;
+    constexpr int NA = Geo<A>::NA, SD = HNS_SELF_DIM, kRedS = red_stride(1);
+    extern __shared__ __align__(16) float smem[];
+    const auto &c = p.cfg;
+    const auto &b = p.buf;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int e0 = blockIdx.x * kEPB;
+    // NOTHING that reads the block (`p`, `c`, `b`) may precede a wave's first global loads: those scalar loads are cold, and a wait for
+    // them in front of the vector loads is what a device-resident configuration used to cost (+1.8 us).
+    if (tid < NA) {
+        // ================================= pursuer waves ==================================================
+        const int le = tid / A, a = tid - le * A;
+        const unsigned ia = (unsigned)e0 * A + tid;
+        // loads, first needed first: action, previous action, the wave's 64 rigid-state rows, PID state, throttle
+        const float4 act4 = reinterpret_cast<const float4 *>(ka.action)[ia];
+        float4 prev4 = reinterpret_cast<const float4 *>(ka.prev_action)[ia];
+        constexpr int N4 = 64 * 13 / 4;                   // 208 float4 pieces per wave
+        const float4 *rows4 = reinterpret_cast<const float4 *>(ka.drone_state + ((size_t)e0 * A + (tid & ~63)) * 13) + lane;
+        static_assert(N4 > 192 && N4 <= 256, "three full passes and a partial one");
+        const float4 rr0 = rows4[0], rr1 = rows4[64], rr2 = rows4[128];      // (named values: an array with a predicated element went to scratch)
+        float4 rr3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < N4 - 192) rr3 = rows4[192];
+        float4 integ4 = reinterpret_cast<const float4 *>(ka.pid_integ)[ia];
+        float4 last4 = reinterpret_cast<const float4 *>(ka.pid_last_rate)[ia];
+        float4 thr4 = reinterpret_cast<const float4 *>(ka.throttle)[ia];
+        __builtin_amdgcn_sched_barrier(0);
+        prof_mark(p.prof, 0);
+        prof_mark(p.prof, 14);
+        const int C = c.num_cylinders, K = c.obs_max_cylinder;
+        const bool with_state = c.write_critic_state && b.state_drones != nullptr;
+        const LdsV3 L = lds_layout_v3(A, C, K);
+        float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red;
+        float *slab = smem + L.slab + (tid >> 6) * L.slab_stride;
+        // this workgroup's cylinders are one contiguous slice [64][3C] = 3C passes of 64 consecutive floats, dealt round-robin to the A pursuer
+        // waves: coalesced 4-byte loads issued with the wave's own rows (the env wave alone needed 5.5 us to bring them in)
+        constexpr int kCylGroups = (3 * HNS_MAX_CYLINDERS + 8 * A - 1) / (8 * A);
+        const int c3 = 3 * C, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        float cv[kCylGroups][8];
+        {
+            const float *gc = ka.cylinders + (size_t)e0 * c3 + lane;
+#pragma unroll
+            for (int g = 0; g < kCylGroups; ++g)
+                if (g * 8 * A < c3) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = min(wv + (g * 8 + j) * A, c3 - 1);         // past the end: the last pass again (same value, same place)
+                        cv[g][j] = gc[i * 64];
+                    }
+                }
+        }
+        const float4 ta = d_action_tanh(act4);           // needs the action only: evaluated while the rest is in flight
+        // own rows through the private slab
+        {
+            float4 *s4 = reinterpret_cast<float4 *>(slab) + lane;
+            s4[0] = rr0; s4[64] = rr1; s4[128] = rr2;
+            if (lane < N4 - 192) s4[192] = rr3;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        Rigid s;
+        load_rigid(slab + lane * 13, s);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        prof_mark(p.prof, 1);
+        // ---- phase 1: controller, rotors, thrust vector (A1-A3) ----
+        float cmd[4], thr_diff, aerr, thrust[4], moment[4];
+        float ctbr4[4], trate[3];
+        d_ctbr_pid_squashed(c, ta, s.q, s.ang, prev4, integ4, last4, cmd, aerr, ctbr4, trate);
+        if (b.ctbr) reinterpret_cast<float4 *>(b.ctbr)[ia] = make_float4(ctbr4[0], ctbr4[1], ctbr4[2], ctbr4[3]);           // transforms.py:456
+        if (b.target_rate) reinterpret_cast<float4 *>(b.target_rate)[ia] = make_float4(trate[0], trate[1], trate[2], 0.0f);  // :457
+        d_rotor(c, cmd, thr4, thrust, moment, thr_diff);
+        const float ts = ((thrust[0] + thrust[1]) + thrust[2]) + thrust[3];
+        const V3 tw = d_quat_rot_z(s.q, ts);                                        // multirotor.py:491
+        const float inv_ntw = d_downwash_inv_norm(tw);
+        // (the cylinder loads were the wave's last: they came in under the controller)
+#pragma unroll
+        for (int g = 0; g < kCylGroups; ++g)                // cylinders into rows of odd stride (lane = env reads its row conflict-free);
+            if (g * 8 * A < c3) {                           // index / 3C by multiply-high
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int idx = min(wv + (g * 8 + j) * A, c3 - 1) * 64 + lane;
+                    const int row = (int)__umulhi((unsigned)idx, p.cyl_magic), col = idx - row * c3;
+                    sCyl[row * L.cyl_stride + col] = cv[g][j];
+                }
+            }
+        prof_mark(p.prof, 10);
+        if (!LAB(LAB_NOLOS1))
+        __syncthreads();                                                            // barrier 0: cylinders and evader at t are in LDS
+        prof_mark(p.prof, 11);
+        // line of sight evader -> this pursuer at t (:1080): on the pursuers' lanes, A x fewer tests per lane than on the env wave
+        const bool blocked_pre = LAB(LAB_NOLOS1) ? false : d_blocked(c, C, s.pos, V3{sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]}, sCyl + le * L.cyl_stride);
+        {
+            float *pub = sPub + tid * kPub;
+            pub[0] = s.pos.x; pub[1] = s.pos.y; pub[2] = s.pos.z;
+            pub[3] = tw.x; pub[4] = tw.y; pub[5] = tw.z;
+            pub[9] = inv_ntw;
+            pub[10] = blocked_pre ? 1.0f : 0.0f;
+            float *red = sRed + tid * kRedS;
+            red[R_AERR] = aerr; red[R_TD] = thr_diff;
+        }
+        prof_mark(p.prof, 2);
+        __syncthreads();                                                            // barrier 1
+        prof_mark(p.prof, 12);
+        // ---- phase 2: downwash, torques, integration (A4, A5) ----
+        V3 fdw = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < A - 1; ++o) {
+            const int j = o + (o >= a ? 1 : 0);
+            const float *pj = sPub + (le * A + j) * kPub;
+            const V3 posj = {pj[0], pj[1], pj[2]}, twj = {pj[3], pj[4], pj[5]};
+            const V3 fj = d_downwash_pair(s.pos, posj, twj, pj[9]);
+            fdw.x = (o == 0) ? fj.x : fdw.x + fj.x;
+            fdw.y = (o == 0) ? fj.y : fdw.y + fj.y;
+            fdw.z = (o == 0) ? fj.z : fdw.z + fj.z;
+        }
+        const V3 fw = {tw.x + fdw.x, tw.y + fdw.y, tw.z + fdw.z};
+        V3 tb;
+        tb.x = ((c.rotor_py[0] * thrust[0] + c.rotor_py[1] * thrust[1]) + c.rotor_py[2] * thrust[2]) + c.rotor_py[3] * thrust[3];
+        tb.y = -(((c.rotor_px[0] * thrust[0] + c.rotor_px[1] * thrust[1]) + c.rotor_px[2] * thrust[2]) + c.rotor_px[3] * thrust[3]);
+        tb.z = ((moment[0] + moment[1]) + moment[2]) + moment[3];
+        d_integrate(c, s, fw, tb);
+        flag_nonfinite(b.nonfinite, rigid_not_finite(s), 1u);
+        {
+            float *pub = sPub + tid * kPub;
+            pub[6] = s.pos.x; pub[7] = s.pos.y; pub[8] = s.pos.z;
+        }
+        // controller / rotor state: plain stores (they are early: write-through here stalls the wave, measured +0.45 us)
+        if (LAB(LAB_NOSTORE | LAB_NOST_REC)) {
+        } else
+#ifdef HNS_V3_REC_SC1
+        {
+        st_f4(reinterpret_cast<float4 *>(b.throttle) + ia, thr4);
+        st_f4(reinterpret_cast<float4 *>(b.pid_integ) + ia, integ4);
+        st_f4(reinterpret_cast<float4 *>(b.pid_last_rate) + ia, last4);
+        st_f4(reinterpret_cast<float4 *>(b.prev_action) + ia, prev4);
+        st_f1(b.action_error + ia, aerr);
+        }
+#else
+        {
+        reinterpret_cast<float4 *>(b.throttle)[ia] = thr4;
+        reinterpret_cast<float4 *>(b.pid_integ)[ia] = integ4;
+        reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
+        reinterpret_cast<float4 *>(b.prev_action)[ia] = prev4;
+        b.action_error[ia] = aerr;
+        }
+#endif
+        if (!LAB(LAB_NOSTORE | LAB_NOST_DS)) {   // S_{t+1}: the wave's 64 rows back through the slab, one contiguous slice
+            const float row[13] = {s.pos.x, s.pos.y, s.pos.z, s.q.w, s.q.x, s.q.y, s.q.z, s.lin.x, s.lin.y, s.lin.z, s.ang.x, s.ang.y, s.ang.z};
+            wave_store_rows<13>(slab, b.drone_state + ((size_t)e0 * A + (tid & ~63)) * 13, row, lane);
+        }
+        prof_mark(p.prof, 3);
+        __syncthreads();                                                            // barrier 2
+        prof_mark(p.prof, 8);
+        // ---- phase 3a: distance and line of sight to the evader, the k nearest cylinders, per-pursuer reward terms on S_{t+1} ----
+        const float progress = sTp[kEPB * 3 + le];                                  // progress + 1, published by the env wave
+        const V3 tp = {sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]};
+        const float *cyl = sCyl + le * L.cyl_stride;
+        const float rtx = s.pos.x - tp.x, rty = s.pos.y - tp.y, rtz = s.pos.z - tp.z;
+        const float d = d_norm3(rtx, rty, rtz);                                     // |evader - pursuer| (hideandseek.py:921, :780)
+        int knn_idx[kMaxK + 1];
+        bool knn_masked[kMaxK];
+        bool blocked, unused;
+#ifdef HNS_LAB
+        if (LAB(LAB_NOLOS2)) { cylinder_pass<1, false>(c, C, K, s.pos, tp, tp, cyl, knn_idx, blocked, unused); } else
+#endif
+        cylinder_pass<1, true>(c, C, K, s.pos, tp, tp, cyl, knn_idx, blocked, unused);
+        const bool det = (d < c.drone_detect_radius) && !blocked;                   // :787-789
+#pragma unroll
+        for (int sidx = 0; sidx < kMaxK; ++sidx) knn_masked[sidx] = (sidx < K) ? cyl[3 * knn_idx[sidx] + 2] < 0.0f : false;   // :759,775-778
+        prof_mark(p.prof, 9);
+        const float act = (d > c.catch_radius) ? 1.0f : 0.0f;                     // hideandseek.py:919-995
+        const float dist_rew = (-c.dist_reward_coef * d) * act;
+        const bool cap_ok = (d < c.catch_radius) && !blocked;
+        // Threshold tests on norms: RN(sqrt(x)) compared with a limit is decided on x itself unless x lies within 2^-19 of
+        // the squared limit; only then the correctly rounded square root is taken (same booleans as the plain form).
+        bool fast = false;
+        {
+            const float sp2 = HNS_FMA(s.lin.z, s.lin.z, HNS_FMA(s.lin.y, s.lin.y, s.lin.x * s.lin.x));
+            const float v2 = c.v_drone * c.v_drone;
+            fast = sp2 > v2 * 1.00000190734863f;
+            if (!fast && !(sp2 < v2 * 0.99999809265137f)) fast = __builtin_sqrtf(sp2) > c.v_drone;
+        }
+        const float speed_rew = -c.speed_coef * (fast ? 1.0f : 0.0f);
+        float cc = 0.f, cd = 0.f;
+        const float rc = c.cylinder_size + c.collision_radius, rc2 = rc * rc;
+#pragma unroll
+        for (int sidx = 0; sidx < kMaxK; ++sidx) {
+            if (sidx < K) {
+                const float *cy = cyl + 3 * knn_idx[sidx];
+                const float rx = s.pos.x - cy[0], ry = s.pos.y - cy[1];
+                const float s2 = HNS_FMA(ry, ry, rx * rx);
+                bool h = s2 < rc2 * 0.99999618530273f;                               // 1 - 2^-18: covers the roundings of rc, dxy - size
+                if (!h && !(s2 > rc2 * 1.00000381469727f)) h = (__builtin_sqrtf(s2) - c.cylinder_size) < c.collision_radius;
+                float hit = h ? 1.0f : 0.0f;
+                if (knn_masked[sidx]) hit = 0.0f;
+                cc = (sidx == 0) ? hit : cc + hit;
+            }
+        }
+        float cr = -c.collision_coef * cc;
+        const float dd2 = c.coll_drone_dist * c.coll_drone_dist;
+#pragma unroll
+        for (int o = 0; o < A - 1; ++o) {
+            const int j = o + (o >= a ? 1 : 0);
+            const float *rj = sPub + (le * A + j) * kPub + 6;
+            const float ex = s.pos.x - rj[0], ey = s.pos.y - rj[1], ez = s.pos.z - rj[2];
+            const float s3 = HNS_FMA(ez, ez, HNS_FMA(ey, ey, ex * ex));
+            bool h = s3 < dd2 * 0.99999809265137f;
+            if (!h && !(s3 > dd2 * 1.00000190734863f)) h = __builtin_sqrtf(s3) < c.coll_drone_dist;
+            const float hit = h ? 1.0f : 0.0f;
+            cd = (o == 0) ? hit : cd + hit;
+        }
+        cr = cr + -c.collision_coef * cd;
+        const float cw = ((s.pos.z > c.max_height) ? 1.0f : 0.0f) + ((HNS_FMA(s.pos.y, s.pos.y, s.pos.x * s.pos.x) > c.arena_sq) ? 1.0f : 0.0f);
+        cr = cr + -c.collision_coef * cw;
+        float sm = 0.0f;
+        if (c.use_deployment) sm = c.smoothness_coef * d_expf(-aerr);
+        {
+            float *red = sRed + tid * kRedS;
+            red[R_DIST] = dist_rew; red[R_SPEED] = speed_rew; red[R_CC] = cc; red[R_CD] = cd; red[R_CW] = cw;
+            red[R_COLL] = cr; red[R_SMOOTH] = sm;
+            red[R_FLAGS] = __int_as_float((cap_ok ? F_CAP : 0) | (blocked ? F_BLOCKED : 0) | (det ? F_DET : 0));
+        }
+        prof_mark(p.prof, 4);
+        __syncthreads();                                                            // barrier 3
+        prof_mark(p.prof, 5);
+        // ---- phase 3c: the observation rows, beside the env wave's reductions (A8 hideandseek.py:741-886) ----
+        bool det_any = false;                                                       // :787-794: any pursuer sees the evader
+#pragma unroll
+        for (int j = 0; j < A; ++j)
+            det_any = det_any || (__float_as_int(sRed[(le * A + j) * kRedS + R_FLAGS]) & F_DET) != 0;
+        {
+            const float t = progress * c.inv_max_episode_length;                  // :796
+            const V3 heading = d_quat_rot_x(s.q), up = d_quat_rot_z(s.q, 1.0f);   // multirotor.py:613-614
+            const float m = c.mask_value;
+            const float row[SD] = {det_any ? rtx : m, det_any ? rty : m, det_any ? rtz : m, s.q.w, s.q.x, s.q.y, s.q.z, s.lin.x, s.lin.y, s.lin.z,
+                                   heading.x, heading.y, heading.z, up.x, up.y, up.z, t, t, t, t};            // :856-863
+            if (!LAB(LAB_NOSTORE | LAB_NOST_SELF)) wave_store_rows<SD, slab_rows(A)>(slab, b.obs_self + ((size_t)e0 * A + (tid & ~63)) * SD, row, lane);
+            if (with_state && !LAB(LAB_NOSTORE | LAB_NOST_SELF)) {                  // :871-886 (never masked)
+                float rs[SD];
+#pragma unroll
+                for (int i = 0; i < SD; ++i) rs[i] = row[i];
+                rs[0] = rtx; rs[1] = rty; rs[2] = rtz;
+                wave_store_rows<SD, slab_rows(A)>(slab, b.state_drones + ((size_t)e0 * A + (tid & ~63)) * SD, rs, lane);
+            }
+        }
+        if constexpr (A > 1) {                                                      // p_i - p_j, j != i ascending (:750-751)
+            float o[(A > 1 ? A - 1 : 1) * 3];
+#pragma unroll
+            for (int w = 0; w < A - 1; ++w) {
+                const int j = w + (w >= a ? 1 : 0);
+                const float *rj = sPub + (le * A + j) * kPub + 6;
+                o[3 * w] = s.pos.x - rj[0]; o[3 * w + 1] = s.pos.y - rj[1]; o[3 * w + 2] = s.pos.z - rj[2];
+            }
+            if (!LAB(LAB_NOSTORE | LAB_NOST_OTH))
+                wave_store_rows<(A > 1 ? A - 1 : 1) * 3, slab_rows(A)>(slab, b.obs_others + ((size_t)e0 * A + (tid & ~63)) * (A - 1) * 3, o, lane);
+        }
+        if (!LAB(LAB_NOSTORE | LAB_NOST_OCYL)) {                                     // the k nearest cylinders (:767-778)
+            float krow[kMaxK * 5];
+#pragma unroll
+            for (int sidx = 0; sidx < kMaxK; ++sidx) {
+                const float *cc = cyl + 3 * ((sidx < K) ? knn_idx[sidx] : 0);
+                const bool masked = knn_masked[sidx];
+                krow[sidx * 5] = masked ? c.mask_value : s.pos.x - cc[0];
+                krow[sidx * 5 + 1] = masked ? c.mask_value : s.pos.y - cc[1];
+                krow[sidx * 5 + 2] = masked ? c.mask_value : s.pos.z - cc[2];
+                krow[sidx * 5 + 3] = masked ? c.mask_value : c.cylinder_height;
+                krow[sidx * 5 + 4] = masked ? c.mask_value : c.cylinder_size;
+            }
+            float *g = b.obs_cylinders + ((size_t)e0 * A + (tid & ~63)) * K * 5;
+            if (K == 3) {
+                float r[15];
+#pragma unroll
+                for (int i = 0; i < 15; ++i) r[i] = krow[i];
+                wave_store_rows<15, slab_rows(A)>(slab, g, r, lane);
+            } else if (K == 4) {
+                wave_store_rows<20, slab_rows(A)>(slab, g, krow, lane);
+            } else if (K == 2) {
+                float r[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) r[i] = krow[i];
+                wave_store_rows<10, slab_rows(A)>(slab, g, r, lane);
+            } else {
+                float r[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) r[i] = krow[i];
+                wave_store_rows<5, slab_rows(A)>(slab, g, r, lane);
+            }
+        }
+        prof_mark(p.prof, 6);
+    } else {
+        // ================================= env wave: lane <-> env ========================================
+#ifdef HNS_LAB
+        if (p.lab_stagger == 3) __builtin_amdgcn_s_setprio(3); else if (p.lab_stagger == 0)
+#endif
+        if (HNS_ENV_PRIO) __builtin_amdgcn_s_setprio(HNS_ENV_PRIO);   // one wave in four, but every barrier of its workgroup waits for it
+        const int le = lane, e = e0 + le;
+        prof_mark(p.prof, 0);
+        prof_mark(p.prof, 14);
+        const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.num_envs;
+        const LdsV3 L = lds_layout_v3(A, C, K);
+        float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red, *sEnvOut = smem + L.envout;
+        float *cylw = sCyl + le * L.cyl_stride;
+        // the evader at t
+        const float *gt = b.target_pos + (size_t)e * 3;
+        const V3 tp0 = {gt[0], gt[1], gt[2]};
+        float progress = b.progress[e];
+        sTp[le * 3] = tp0.x; sTp[le * 3 + 1] = tp0.y; sTp[le * 3 + 2] = tp0.z;
+        progress += 1.0f;                                                           // isaac_env.py:236
+        sTp[kEPB * 3 + le] = progress;
+        prof_mark(p.prof, 1);
+        prof_mark(p.prof, 10);
+        if (!LAB(LAB_NOLOS1))
+        __syncthreads();                                                            // barrier 0: the cylinders (pursuer waves) and the evader at t are in LDS
+        prof_mark(p.prof, 11);
+        float st[HNS_NUM_STATS];                  // the statistics rows of these envs: needed behind barrier 1 (not earlier: the first microseconds
+#pragma unroll                                  // of the launch are HBM-bound and these 6 MB are not on the critical path)
+        for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = b.stats[(size_t)i * E + e];
+        // A6: arena + cylinder terms of the potential field (hideandseek.py:1090-1136), beside the pursuers' line-of-sight tests
+        bool out_of_arena = false;
+        const V3 Fenv = d_prey_arena_term(c, tp0, out_of_arena);
+        float fcx = 0.f, fcy = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < C; ++k) {
+            float tx, ty;
+            d_prey_cylinder_term(c, tp0, cylw[3 * k], cylw[3 * k + 1], cylw[3 * k + 2], tx, ty);
+            fcx += tx;
+            fcy += ty;
+        }
+        prof_mark(p.prof, 2);
+        __syncthreads();                                                            // barrier 1: positions at t, line-of-sight flags, action errors
+        prof_mark(p.prof, 12);
+        // the pursuers' pushes (hideandseek.py:1074-1088), ascending; then arena, then cylinders
+        V3 F = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float *pj = sPub + (le * A + j) * kPub;
+            const V3 dp = {pj[0], pj[1], pj[2]};
+            const bool blocked_pre = pj[10] != 0.0f;                                // :1080, taken on the pursuer's lane
+            const V3 fp = d_prey_pursuer_term(c, dp, tp0, blocked_pre);
+            F.x = (j == 0) ? fp.x : F.x + fp.x;
+            F.y = (j == 0) ? fp.y : F.y + fp.y;
+            F.z = (j == 0) ? fp.z : F.z + fp.z;
+        }
+        F.x = F.x + Fenv.x; F.y = F.y + Fenv.y; F.z = F.z + Fenv.z;
+        F.x = F.x + fcx; F.y = F.y + fcy; F.z = F.z + 0.0f;
+        const V3 tvel = {(c.v_prey * F.x) / (__builtin_fabsf(F.x) + 1e-5f), (c.v_prey * F.y) / (__builtin_fabsf(F.y) + 1e-5f),
+                         (c.v_prey * F.z) / (__builtin_fabsf(F.z) + 1e-5f)};        // per-axis speed (:741)
+        const V3 tpn = {tp0.x + tvel.x * c.dt, tp0.y + tvel.y * c.dt, tp0.z + tvel.z * c.dt};
+        sTp[le * 3] = tpn.x; sTp[le * 3 + 1] = tpn.y; sTp[le * 3 + 2] = tpn.z;
+        { const float sf = (tpn.x + tpn.y) + tpn.z; flag_nonfinite(b.nonfinite, (sf - sf) != 0.0f, 2u); }
+        if (!LAB(LAB_NOSTORE)) {            // [64,3] slices, whole lines: the new position is already laid out in sTp
+            sEnvOut[le * 3] = tvel.x; sEnvOut[le * 3 + 1] = tvel.y; sEnvOut[le * 3 + 2] = tvel.z;
+            env_store_slice(sTp, b.target_pos + (size_t)e0 * 3, kEPB * 3, lane);
+            env_store_slice(sEnvOut, b.target_vel + (size_t)e0 * 3, kEPB * 3, lane);
+        }
+        {   // statistics that only need phase-1 data (A10 hideandseek.py:731-733, :1097-1098, :996-997)
+            float sum_ae = 0.f, sum_td = 0.f, max_td = 0.f;
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                const float *red = sRed + (le * A + j) * kRedS;
+                const float td = red[R_TD];
+                sum_ae = (j == 0) ? red[R_AERR] : sum_ae + red[R_AERR];
+                sum_td = (j == 0) ? td : sum_td + td;
+                max_td = (j == 0) ? td : (td > max_td ? td : max_td);
+            }
+            const float mae = sum_ae * c.inv_num_agents;
+            st[HNS_ST_ACTION_ERROR_ORDER1_MEAN] += mae;
+            if (mae > st[HNS_ST_ACTION_ERROR_ORDER1_MAX]) st[HNS_ST_ACTION_ERROR_ORDER1_MAX] = mae;
+            st[HNS_ST_OUT_OF_ARENA] = ((st[HNS_ST_OUT_OF_ARENA] != 0.0f) || out_of_arena) ? 1.0f : 0.0f;
+            st[HNS_ST_SMOOTHNESS_COEF] = c.smoothness_coef;
+            st[HNS_ST_SMOOTHNESS_MEAN] += sum_td * c.inv_num_agents;
+            if (max_td > st[HNS_ST_SMOOTHNESS_MAX]) st[HNS_ST_SMOOTHNESS_MAX] = max_td;
+        }
+        prof_mark(p.prof, 3);
+        __syncthreads();                                                            // barrier 2
+        prof_mark(p.prof, 8);
+        prof_mark(p.prof, 4);
+        __syncthreads();                                                            // barrier 3: reward terms
+        prof_mark(p.prof, 5);
+        // ---- phase 3b: per-env reductions, reward, done, statistics (hideandseek.py:919-1065) ----
+        const float iA = c.inv_num_agents;
+        bool any_cap = false, all_blocked = true, any_coll = false, det_any = false;
+        float sum_dist = 0, sum_speed = 0, sum_cc = 0, sum_cd = 0, sum_cw = 0, sum_coll = 0, sum_smooth = 0;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float *red = sRed + (le * A + j) * kRedS;
+            const int fl = __float_as_int(red[R_FLAGS]);
+            any_cap |= (fl & F_CAP) != 0;
+            all_blocked &= (fl & F_BLOCKED) != 0;
+            det_any |= (fl & F_DET) != 0;
+            any_coll |= red[R_COLL] < 0.0f;
+            if (j == 0) {
+                sum_dist = red[R_DIST]; sum_speed = red[R_SPEED]; sum_cc = red[R_CC]; sum_cd = red[R_CD]; sum_cw = red[R_CW];
+                sum_coll = red[R_COLL]; sum_smooth = red[R_SMOOTH];
+            } else {
+                sum_dist += red[R_DIST]; sum_speed += red[R_SPEED]; sum_cc += red[R_CC]; sum_cd += red[R_CD]; sum_cw += red[R_CW];
+                sum_coll += red[R_COLL]; sum_smooth += red[R_SMOOTH];
+            }
+        }
+        const float detf = det_any ? 1.0f : 0.0f;
+        const float detect_rew = c.detect_reward_coef * detf;
+        const float catch_rew = c.catch_reward_coef * (any_cap ? 1.0f : 0.0f);
+        float sum_rew = 0.f;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float *red = sRed + (le * A + j) * kRedS;
+            const float r = ((((red[R_DIST] + detect_rew) + catch_rew) + red[R_COLL]) + red[R_SPEED]) + red[R_SMOOTH];
+            sEnvOut[le * A + j] = r;
+            sum_rew = (j == 0) ? r : sum_rew + r;
+        }
+        if (!LAB(LAB_NOSTORE)) env_store_slice(sEnvOut, b.reward + (size_t)e0 * A, kEPB * A, lane);
+        flag_nonfinite(b.nonfinite, (sum_rew - sum_rew) != 0.0f, 4u);
+#define ST(i) st[i]
+        ST(HNS_ST_DISTANCE_REWARD) += sum_dist * iA;
+        ST(HNS_ST_SUM_DETECT_STEP) += 1.0f * detf;
+        float sdet = detect_rew, scat = catch_rew;
+#pragma unroll
+        for (int j = 1; j < A; ++j) { sdet += detect_rew; scat += catch_rew; }
+        ST(HNS_ST_DETECT_REWARD) += sdet * iA;
+        const bool capture_flag = catch_rew != 0.0f;                              // :945
+        ST(HNS_ST_BLOCKED) += all_blocked ? 1.0f : 0.0f;
+        ST(HNS_ST_SUCCESS) = (capture_flag || ST(HNS_ST_SUCCESS) != 0.0f) ? 1.0f : 0.0f;
+        const float cur = (capture_flag ? 1.0f : 0.0f) * progress + (capture_flag ? 0.0f : 1.0f) * (float)c.max_episode_length;
+        if (cur < ST(HNS_ST_FIRST_CAPTURE_STEP)) ST(HNS_ST_FIRST_CAPTURE_STEP) = cur;
+        ST(HNS_ST_CATCH_REWARD) += scat * iA;
+        ST(HNS_ST_SPEED_REWARD) += sum_speed * iA;
+        ST(HNS_ST_COLLISION_CYLINDER) += sum_cc * iA;
+        ST(HNS_ST_COLLISION_DRONE) += sum_cd * iA;
+        ST(HNS_ST_COLLISION) += any_coll ? 1.0f : 0.0f;
+        ST(HNS_ST_COLLISION_WALL) += sum_cw * iA;
+        ST(HNS_ST_COLLISION_REWARD) += sum_coll * iA;
+        ST(HNS_ST_SMOOTHNESS_REWARD) += sum_smooth * iA;
+        const bool done = progress >= (float)c.max_episode_length;                // :1008-1010
+        if (done) {                                                               // :1017-1056
+            ST(HNS_ST_COLLISION) = ST(HNS_ST_COLLISION) / progress;
+            ST(HNS_ST_ACTION_ERROR_ORDER1_MEAN) = ST(HNS_ST_ACTION_ERROR_ORDER1_MEAN) / progress;
+            ST(HNS_ST_TARGET_PREDICTED_ERROR) = ST(HNS_ST_TARGET_PREDICTED_ERROR) / progress;
+            ST(HNS_ST_SMOOTHNESS_MEAN) = ST(HNS_ST_SMOOTHNESS_MEAN) / progress;
+            ST(HNS_ST_SMOOTHNESS_REWARD) = ST(HNS_ST_SMOOTHNESS_REWARD) / progress;
+            ST(HNS_ST_DISTANCE_REWARD) = ST(HNS_ST_DISTANCE_REWARD) / progress;
+            ST(HNS_ST_DETECT_REWARD) = ST(HNS_ST_DETECT_REWARD) / progress;
+            ST(HNS_ST_CATCH_REWARD) = ST(HNS_ST_CATCH_REWARD) / progress;
+            ST(HNS_ST_COLLISION_REWARD) = ST(HNS_ST_COLLISION_REWARD) / progress;
+            ST(HNS_ST_COLLISION_WALL) = ST(HNS_ST_COLLISION_WALL) / progress;
+            ST(HNS_ST_COLLISION_DRONE) = ST(HNS_ST_COLLISION_DRONE) / progress;
+            ST(HNS_ST_COLLISION_CYLINDER) = ST(HNS_ST_COLLISION_CYLINDER) / progress;
+            ST(HNS_ST_SPEED_REWARD) = ST(HNS_ST_SPEED_REWARD) / progress;
+        }
+        ST(HNS_ST_RETURN) += sum_rew * iA;
+#undef ST
+        b.done[e] = (uint8_t)done;
+        if (b.detect) b.detect[e] = (uint8_t)det_any;
+        b.progress[e] = progress;
+        if (!LAB(LAB_NOSTORE | LAB_NOST_STATS)) {
+#pragma unroll
+            for (int i = 0; i < HNS_NUM_STATS; ++i) st_f1(b.stats + (size_t)i * E + e, st[i]);
+        }
+        prof_mark(p.prof, 6);
+    }
+    prof_mark(p.prof, 7);
+    prof_mark(p.prof, 15);
+#ifdef HNS_LAB
+    if (p.prof && lane == 0 && LAB(LAB_HWID)) {                   // where the hardware put this wave (tools/wave_placement.py)
+        unsigned long long *pr = p.prof + (size_t)(blockIdx.x * (A + 1) + (tid >> 6)) * kProfSlots;
+        pr[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+        pr[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+        pr[12] = (unsigned long long)(tid >= NA);
+    }
+#endif
 }
 
 // =================================================================================================
@@ -1769,7 +2279,8 @@ static void select_kernels(hns_env *env) {
     }
     const char *force = getenv("HNS_STEP_DESIGN");        // "1" = the first design for every shape (A/B measurements)
     const bool v3 = c.num_targets != 2 && c.num_envs % hns::kEPB == 0 && !(force && force[0] == '1');
-    if (v3) env->step_fn = hns::hns_step_v3_kernel<A>;
+    if (v3 && force && force[0] == '3') env->step_fn = hns::hns_step_v3_kernel<A>;                          // "3" = the third design (A/B)
+    else if (v3) env->step_args_fn = hns::hns_step_v4_kernel<A>;
     env->threads = hns::Geo<A>::T;
     env->cyl_magic = (uint32_t)(0xFFFFFFFFull / (uint32_t)(3 * c.num_cylinders) + 1ull);
     env->grid = (c.num_envs + hns::kEPB - 1) / hns::kEPB;
@@ -1779,6 +2290,8 @@ static void select_kernels(hns_env *env) {
     if (v3) env->lds_step = (size_t)hns::lds_layout_v3(A, c.num_cylinders, c.obs_max_cylinder).total * sizeof(float);
 }
 
+
+static int upload_step_params(hns_env *env);
 
 extern "C" {
 
@@ -1852,6 +2365,8 @@ void hns_destroy(hns_env *env) {
     if (!env) return;
     for (auto &p : env->events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &p : env->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    if (env->params_dev) (void)hipFree(env->params_dev);
+    delete env->params_host;
     delete env;
 }
 
@@ -1885,6 +2400,38 @@ int hns_bind(hns_env *env, const hns_buffers *buffers) {
         }
     env->buf = *buffers;
     env->bound = true;
+    return upload_step_params(env);
+}
+
+// the step launch's parameter block (everything but the action)
+static void fill_step_params(const hns_env *env, Params &p) {
+    memset(&p, 0, sizeof(p));          // compared bytewise with the device copy: no stack garbage in the padding
+    p.cfg = env->cfg;
+    p.buf = env->buf;
+    p.prof = env->prof;
+    p.cyl_magic = env->cyl_magic;
+#ifdef HNS_LAB
+    { const char *f = getenv("HNS_LAB_FLAGS"); p.lab = f ? (uint32_t)atoi(f) : 0u; }
+    { const char *f = getenv("HNS_LAB_STAGGER"); p.lab_stagger = f ? (uint32_t)atoi(f) : 0u; }
+#endif
+}
+
+// Device copy of that block for the step kernel that reads it through `StepArgs::rest`.  Called where the block changes (bind, the
+// configuration setters, the profiling buffer), never from a steady-state step: it synchronises the device — launches in
+// flight still read the old block — and must not run inside a stream capture.
+static int upload_step_params(hns_env *env) {
+    if (!env->step_args_fn || !env->bound) return HNS_OK;
+    if (!env->params_dev) {
+        HNS_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&env->params_dev), sizeof(Params)));
+        env->params_host = new Params;
+    }
+    Params q;
+    fill_step_params(env, q);
+    if (env->params_valid && memcmp(&q, env->params_host, sizeof(Params)) == 0) return HNS_OK;
+    HNS_CHECK_HIP(hipDeviceSynchronize());
+    memcpy(env->params_host, &q, sizeof(Params));
+    HNS_CHECK_HIP(hipMemcpy(env->params_dev, env->params_host, sizeof(Params), hipMemcpyHostToDevice));
+    env->params_valid = true;
     return HNS_OK;
 }
 
@@ -1898,6 +2445,16 @@ static int launch(hns_env *env, bool is_step, const Params &p, hipStream_t strea
     const bool time_it = is_step && env->timing > 0 && (env->step_count++ % (uint64_t)env->timing) == 0;
     auto fn = is_step ? env->step_fn : env->reset_fn;
     size_t lds = is_step ? env->lds_step : env->lds_reset;
+    const bool split = is_step && env->step_args_fn != nullptr;
+    hns::StepArgs ka{};
+    if (split) {
+#ifdef HNS_LAB
+        { const int rc = upload_step_params(env); if (rc != HNS_OK) return rc; }     // the ablation switches come from the environment, per launch
+#endif
+        if (!env->params_valid) { set_error("hns_step: the device copy of the launch parameters is missing (bind first)"); return HNS_ERR_NOT_BOUND; }
+        ka = hns::StepArgs{p.action, p.buf.prev_action, p.buf.drone_state, p.buf.pid_integ, p.buf.pid_last_rate, p.buf.throttle,
+                           p.buf.cylinders, env->params_dev};
+    }
     if (time_it) {
         if (!env->pool.empty()) { ev = env->pool.back(); env->pool.pop_back(); }
         else {
@@ -1906,12 +2463,14 @@ static int launch(hns_env *env, bool is_step, const Params &p, hipStream_t strea
         }
         // the events ride on the dispatch itself (start / stop of THIS kernel, the timestamps a profiler reads),
         // not on separate marker packets before and after it
-        hipExtLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads), (uint32_t)lds, stream, ev.first, ev.second, 0, p);
+        if (split) hipExtLaunchKernelGGL(env->step_args_fn, dim3(env->grid), dim3(env->threads), (uint32_t)lds, stream, ev.first, ev.second, 0, ka);
+        else hipExtLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads), (uint32_t)lds, stream, ev.first, ev.second, 0, p);
         HNS_CHECK_HIP(hipGetLastError());
         env->events.push_back(ev);
         return HNS_OK;
     }
-    hipLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads), lds, stream, p);
+    if (split) hipLaunchKernelGGL(env->step_args_fn, dim3(env->grid), dim3(env->threads), lds, stream, ka);
+    else hipLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads), lds, stream, p);
     HNS_CHECK_HIP(hipGetLastError());
     return HNS_OK;
 }
@@ -1921,22 +2480,8 @@ int hns_step(hns_env *env, const float *action, void *stream) {
     if (!env->bound) { set_error("hns_step: buffers not bound"); return HNS_ERR_NOT_BOUND; }
     if (reinterpret_cast<uintptr_t>(action) & 15) { set_error("hns_step: action must be 16-byte aligned"); return HNS_ERR_INVALID_ARG; }
     Params p;
-    p.cfg = env->cfg;
-    p.buf = env->buf;
+    fill_step_params(env, p);
     p.action = action;
-    p.reset_mask = nullptr;
-    p.seed_lo = p.seed_hi = p.epoch = 0;
-    p.prof = env->prof;
-    p.cyl_magic = env->cyl_magic;
-    p.tasks = nullptr;
-    p.task_first = 0;
-#ifdef HNS_LAB
-    { const char *f = getenv("HNS_LAB_FLAGS"); p.lab = f ? (uint32_t)atoi(f) : 0u; }
-    { const char *f = getenv("HNS_LAB_STAGGER"); p.lab_stagger = f ? (uint32_t)atoi(f) : 0u; }
-#else
-    p.lab = 0;
-    p.lab_stagger = 0;
-#endif
     return launch(env, true, p, static_cast<hipStream_t>(stream));
 }
 
@@ -2054,12 +2599,12 @@ int hns_raycast(hns_env *env, int num_rays, float max_range, float *out, void *s
 int hns_set_v_prey(hns_env *env, float v_prey) {
     if (!env) return HNS_ERR_INVALID_ARG;
     env->cfg.v_prey = v_prey;
-    return HNS_OK;
+    return upload_step_params(env);
 }
 int hns_set_smoothness_coef(hns_env *env, float coef) {
     if (!env) return HNS_ERR_INVALID_ARG;
     env->cfg.smoothness_coef = coef;
-    return HNS_OK;
+    return upload_step_params(env);
 }
 int hns_set_reset_epoch(hns_env *env, uint32_t epoch) {
     if (!env) return HNS_ERR_INVALID_ARG;
@@ -2099,7 +2644,7 @@ int hns_get_state(hns_env *env, const hns_buffers *host, void *stream) { return 
 int hns_set_phase_profile(hns_env *env, unsigned long long *device_buf) {
     if (!env) return HNS_ERR_INVALID_ARG;
     env->prof = device_buf;
-    return HNS_OK;
+    return upload_step_params(env);
 }
 
 int hns_enable_timing(hns_env *env, int on) {
