@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HNS_ABI_VERSION 2
+#define HNS_ABI_VERSION 3
 #define HNS_MAX_AGENTS 7    /* pursuers per env: a workgroup is 64 envs = A pursuer waves + one env wave (<= 512 threads) */
 #define HNS_MAX_CYLINDERS 16
 #define HNS_NUM_STATS 24    /* hideandseek.py:400-425 */
@@ -158,7 +158,10 @@ typedef struct hns_buffers {
     float *drone_state;    /* [E,A,13] pos3 quat4 linvel3 angvel3, world frame == info.drone_state */
     float *throttle;       /* [E,A,4]  rotor throttle, multirotor.py:216 */
     float *pid_integ;      /* [E,A,4]  xyz + pad, lee_position_controller.py:497-502 */
-    float *pid_last_rate;  /* [E,A,4]  xyz + pad */
+    float *pid_last_rate;  /* [E,A,4]  xyz + the pursuer's line-of-sight flag(s) in the state the buffers hold: 1 = the line to the evader
+                            *          is blocked by a cylinder (+2 = to the second evader).  Derived state: written by step and reset
+                            *          from the observation pass (hideandseek.py:786), read by the next step as the evader policy's
+                            *          test (:1080) — same positions, same result; hns_set_state recomputes it from what it uploads. */
     float *prev_action;    /* [E,A,4]  == info.prev_action (ctbr of the last step) */
     float *target_pos;     /* [E,3]    evader position ([E,2,3] with num_targets = 2) */
     float *target_vel;     /* [E,3]    evader linear velocity set this step (hideandseek.py:741) */
@@ -321,6 +324,10 @@ uint32_t hns_get_reset_epoch(const hns_env *env);
  * reading what hns_get_state wrote).  Equivalent to the caller copying into / out of its own bound buffers. */
 int hns_set_state(hns_env *env, const hns_buffers *host, void *stream);
 int hns_get_state(hns_env *env, const hns_buffers *host, void *stream);
+/* Recomputes the derived part of the state (the line-of-sight column of pid_last_rate, see hns_buffers) from drone_state, target_pos and
+ * cylinders as the bound buffers hold them.  For callers that write positions into those buffers themselves instead of going through
+ * hns_reset / hns_set_state (a checkpoint restored with tensor copies); hns_set_state runs it on what it uploads. */
+int hns_refresh_derived_state(hns_env *env, void *stream);
 
 /* Kernel timing: hns_enable_timing(env, n) times every n-th hns_step launch with a start / stop hipEvent pair bound
  * to that dispatch (hipExtLaunchKernelGGL: the timestamps of the kernel itself, on the launch stream; n = 0

@@ -6,7 +6,7 @@ been built (`python -c "import __graft_entry__ as g; g.build()"`).
 import ctypes as C
 import os
 
-HNS_ABI_VERSION = 2
+HNS_ABI_VERSION = 3
 HNS_MAX_AGENTS = 7
 HNS_MAX_CYLINDERS = 16
 HNS_NUM_STATS = 24
@@ -234,6 +234,8 @@ def load_library():
     lib.hns_set_state.restype = C.c_int
     lib.hns_get_state.argtypes = [C.c_void_p, C.POINTER(HnsBuffers), C.c_void_p]
     lib.hns_get_state.restype = C.c_int
+    lib.hns_refresh_derived_state.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hns_refresh_derived_state.restype = C.c_int
     lib.hns_fps_scratch_bytes.argtypes = []
     lib.hns_fps_scratch_bytes.restype = C.c_size_t
     lib.hns_fps.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -259,5 +261,5 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "hns_create", "hns_destroy", "hns_bind", "hns_step", "hns_reset", "hns_reset_tasks", "hns_raycast", "hns_set_v_prey",
     "hns_set_smoothness_coef", "hns_set_reset_epoch", "hns_get_reset_epoch", "hns_enable_timing",
-    "hns_step_kernel_ms", "hns_set_phase_profile", "hns_set_state", "hns_get_state", "hns_fps", "hns_fps_scratch_bytes", "hns_perturb_tasks", "hns_tp_bind", "hns_tp_refresh", "hns_tp_packed_bytes", "hns_tp_observe", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
+    "hns_step_kernel_ms", "hns_set_phase_profile", "hns_set_state", "hns_get_state", "hns_refresh_derived_state", "hns_fps", "hns_fps_scratch_bytes", "hns_perturb_tasks", "hns_tp_bind", "hns_tp_refresh", "hns_tp_packed_bytes", "hns_tp_observe", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
 ]

@@ -773,6 +773,8 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
                              with_state ? b.state_drones + ia * SD : nullptr, blocked, det, blockedB, detB, knn_idx, knn_masked, !LAB(LAB_NOSTORE | LAB_NOST_SELF),
                              !LAB(LAB_NOSTORE | LAB_NOST_OTH));
         prof_mark(p.prof, 9);
+        // the line of sight just taken is the next step's test at ITS t: carried in the fourth column of the controller record (hns.h)
+        if (!LAB(LAB_NOSTORE | LAB_NOST_REC)) b.pid_last_rate[ia * 4 + 3] = (float)((blocked ? 1 : 0) + (blockedB ? 2 : 0));
         // hideandseek.py:919-995
         float d = d_norm3(tp.x - s.pos.x, tp.y - s.pos.y, tp.z - s.pos.z);
         float act = (d > c.catch_radius) ? 1.0f : 0.0f;
@@ -1357,16 +1359,16 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
 #endif
 }
 
-// Fourth design = the third with the phases re-cut so that the env wave — ONE wave, issuing one instruction every 5-7 cycles —
-// carries as little serial work as possible (tools/phase_timeline.py; in the third design 5.8 us of the 14.5 us of a workgroup's life
-// were env-wave work that the pursuer waves waited for):
-//   * line of sight evader -> pursuer at t (:1080) runs on the pursuers' lanes (A x fewer tests per lane, three waves instead of
-//     one) behind an extra barrier that sits after the controller, where the env wave's LDS image has long been written;
+// Fourth design = the third with the env wave — ONE wave, issuing one instruction every 5-7 cycles — relieved of most of its serial
+// work (tools/phase_timeline.py: in the third design 5.8 us of the 14.5 us of a workgroup's life were env-wave work that the pursuer
+// waves waited for):
+//   * the line of sight evader -> pursuer at t (:1080) is not evaluated at all: it is the test the previous step (or the reset) ran on
+//     the same positions for the observation (:786), carried in the fourth column of pid_last_rate (hns.h);
 //   * the pursuers publish their reward terms BEFORE they build and store their observation rows, so the env wave's reductions, reward,
 //     statistics and done run beside those stores instead of behind them; the detection mask of the evader's relative position
 //     (:791-794) is applied by the pursuers themselves (was: the env wave patched the stored rows);
-//   * the cylinders are brought into LDS by the pursuer waves with their own rows (one wave needed 5.5 us for the 24 passes).
-// Four workgroup barriers.
+//   * everything but the pointers behind the first loads comes from a device-resident block through the scalar cache (StepArgs).
+// Three workgroup barriers.
 template <int A>
 __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArgs ka) {
     // the block behind `rest` is never written while the kernel runs: read it as constant memory (scalar loads, placed like kernel-argument loads)
@@ -1404,23 +1406,6 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         const LdsV3 L = lds_layout_v3(A, C, K);
         float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red;
         float *slab = smem + L.slab + (tid >> 6) * L.slab_stride;
-        // this workgroup's cylinders are one contiguous slice [64][3C] = 3C passes of 64 consecutive floats, dealt round-robin to the A pursuer
-        // waves: coalesced 4-byte loads issued with the wave's own rows (the env wave alone needed 5.5 us to bring them in)
-        constexpr int kCylGroups = (3 * HNS_MAX_CYLINDERS + 8 * A - 1) / (8 * A);
-        const int c3 = 3 * C, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        float cv[kCylGroups][8];
-        {
-            const float *gc = ka.cylinders + (size_t)e0 * c3 + lane;
-#pragma unroll
-            for (int g = 0; g < kCylGroups; ++g)
-                if (g * 8 * A < c3) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int i = min(wv + (g * 8 + j) * A, c3 - 1);         // past the end: the last pass again (same value, same place)
-                        cv[g][j] = gc[i * 64];
-                    }
-                }
-        }
         const float4 ta = d_action_tanh(act4);           // needs the action only: evaluated while the rest is in flight
         // own rows through the private slab
         {
@@ -1436,6 +1421,9 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         __builtin_amdgcn_wave_barrier();
         prof_mark(p.prof, 1);
         // ---- phase 1: controller, rotors, thrust vector (A1-A3) ----
+        // line of sight evader -> this pursuer at t (:1080): positions, evader and cylinders are those the previous step (or the reset)
+        // evaluated it on for the observation, so that result is carried in the spare fourth column of the controller record
+        const float los_t = last4.w;
         float cmd[4], thr_diff, aerr, thrust[4], moment[4];
         float ctbr4[4], trate[3];
         d_ctbr_pid_squashed(c, ta, s.q, s.ang, prev4, integ4, last4, cmd, aerr, ctbr4, trate);
@@ -1445,29 +1433,12 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         const float ts = ((thrust[0] + thrust[1]) + thrust[2]) + thrust[3];
         const V3 tw = d_quat_rot_z(s.q, ts);                                        // multirotor.py:491
         const float inv_ntw = d_downwash_inv_norm(tw);
-        // (the cylinder loads were the wave's last: they came in under the controller)
-#pragma unroll
-        for (int g = 0; g < kCylGroups; ++g)                // cylinders into rows of odd stride (lane = env reads its row conflict-free);
-            if (g * 8 * A < c3) {                           // index / 3C by multiply-high
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int idx = min(wv + (g * 8 + j) * A, c3 - 1) * 64 + lane;
-                    const int row = (int)__umulhi((unsigned)idx, p.cyl_magic), col = idx - row * c3;
-                    sCyl[row * L.cyl_stride + col] = cv[g][j];
-                }
-            }
-        prof_mark(p.prof, 10);
-        if (!LAB(LAB_NOLOS1))
-        __syncthreads();                                                            // barrier 0: cylinders and evader at t are in LDS
-        prof_mark(p.prof, 11);
-        // line of sight evader -> this pursuer at t (:1080): on the pursuers' lanes, A x fewer tests per lane than on the env wave
-        const bool blocked_pre = LAB(LAB_NOLOS1) ? false : d_blocked(c, C, s.pos, V3{sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]}, sCyl + le * L.cyl_stride);
         {
             float *pub = sPub + tid * kPub;
             pub[0] = s.pos.x; pub[1] = s.pos.y; pub[2] = s.pos.z;
             pub[3] = tw.x; pub[4] = tw.y; pub[5] = tw.z;
             pub[9] = inv_ntw;
-            pub[10] = blocked_pre ? 1.0f : 0.0f;
+            pub[10] = los_t;
             float *red = sRed + tid * kRedS;
             red[R_AERR] = aerr; red[R_TD] = thr_diff;
         }
@@ -1504,7 +1475,6 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         {
         st_f4(reinterpret_cast<float4 *>(b.throttle) + ia, thr4);
         st_f4(reinterpret_cast<float4 *>(b.pid_integ) + ia, integ4);
-        st_f4(reinterpret_cast<float4 *>(b.pid_last_rate) + ia, last4);
         st_f4(reinterpret_cast<float4 *>(b.prev_action) + ia, prev4);
         st_f1(b.action_error + ia, aerr);
         }
@@ -1512,7 +1482,6 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         {
         reinterpret_cast<float4 *>(b.throttle)[ia] = thr4;
         reinterpret_cast<float4 *>(b.pid_integ)[ia] = integ4;
-        reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
         reinterpret_cast<float4 *>(b.prev_action)[ia] = prev4;
         b.action_error[ia] = aerr;
         }
@@ -1538,6 +1507,8 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
 #endif
         cylinder_pass<1, true>(c, C, K, s.pos, tp, tp, cyl, knn_idx, blocked, unused);
         const bool det = (d < c.drone_detect_radius) && !blocked;                   // :787-789
+        last4.w = blocked ? 1.0f : 0.0f;                                            // = the next step's line of sight at ITS t
+        if (!LAB(LAB_NOSTORE | LAB_NOST_REC)) reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
 #pragma unroll
         for (int sidx = 0; sidx < kMaxK; ++sidx) knn_masked[sidx] = (sidx < K) ? cyl[3 * knn_idx[sidx] + 2] < 0.0f : false;   // :759,775-778
         prof_mark(p.prof, 9);
@@ -1677,18 +1648,44 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         const float *gt = b.target_pos + (size_t)e * 3;
         const V3 tp0 = {gt[0], gt[1], gt[2]};
         float progress = b.progress[e];
-        sTp[le * 3] = tp0.x; sTp[le * 3 + 1] = tp0.y; sTp[le * 3 + 2] = tp0.z;
+        {   // this workgroup's cylinders are one contiguous slice [64][3C]: coalesced 4-byte loads (lane <-> consecutive floats), scattered
+            // into rows of odd stride (lane = env reads its row conflict-free); index / 3C by multiply-high.  Eight cylinders (24 passes)
+            // at a time with every load issued before the first LDS write: one memory round trip per chunk.
+            const float *gc = b.cylinders + (size_t)e0 * C * 3 + lane;
+            const int c3 = 3 * C;                                   // = the number of 64-float passes
+            int i0 = 0;
+            for (; i0 + 24 <= c3; i0 += 24) {
+                float cv[24];
+#pragma unroll
+                for (int i = 0; i < 24; ++i) cv[i] = gc[(i0 + i) * 64];
+#pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    const int idx = (i0 + i) * 64 + lane;
+                    const int row = (int)__umulhi((unsigned)idx, p.cyl_magic), col = idx - row * c3;
+                    sCyl[row * L.cyl_stride + col] = cv[i];
+                }
+            }
+            for (; i0 < c3; i0 += 3) {                              // the cylinders beyond a multiple of eight
+                float cv[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) cv[i] = gc[(i0 + i) * 64];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int idx = (i0 + i) * 64 + lane;
+                    const int row = (int)__umulhi((unsigned)idx, p.cyl_magic), col = idx - row * c3;
+                    sCyl[row * L.cyl_stride + col] = cv[i];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         progress += 1.0f;                                                           // isaac_env.py:236
         sTp[kEPB * 3 + le] = progress;
         prof_mark(p.prof, 1);
-        prof_mark(p.prof, 10);
-        if (!LAB(LAB_NOLOS1))
-        __syncthreads();                                                            // barrier 0: the cylinders (pursuer waves) and the evader at t are in LDS
-        prof_mark(p.prof, 11);
         float st[HNS_NUM_STATS];                  // the statistics rows of these envs: needed behind barrier 1 (not earlier: the first microseconds
 #pragma unroll                                  // of the launch are HBM-bound and these 6 MB are not on the critical path)
         for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = b.stats[(size_t)i * E + e];
-        // A6: arena + cylinder terms of the potential field (hideandseek.py:1090-1136), beside the pursuers' line-of-sight tests
+        // A6: arena + cylinder terms of the potential field (hideandseek.py:1090-1136)
         bool out_of_arena = false;
         const V3 Fenv = d_prey_arena_term(c, tp0, out_of_arena);
         float fcx = 0.f, fcy = 0.f;
@@ -1708,7 +1705,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         for (int j = 0; j < A; ++j) {
             const float *pj = sPub + (le * A + j) * kPub;
             const V3 dp = {pj[0], pj[1], pj[2]};
-            const bool blocked_pre = pj[10] != 0.0f;                                // :1080, taken on the pursuer's lane
+            const bool blocked_pre = pj[10] != 0.0f;                                // :1080, carried over from the previous step's observation
             const V3 fp = d_prey_pursuer_term(c, dp, tp0, blocked_pre);
             F.x = (j == 0) ? fp.x : F.x + fp.x;
             F.y = (j == 0) ? fp.y : F.y + fp.y;
@@ -1840,6 +1837,20 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         pr[12] = (unsigned long long)(tid >= NA);
     }
 #endif
+}
+
+// Line-of-sight column of pid_last_rate from the state the buffers hold (hns_set_state: the uploaded record may come from anywhere).
+// One thread per pursuer, cylinders straight from global memory; not on any hot path.
+__global__ __launch_bounds__(256) void hns_refresh_los_kernel(const hns_cfg c, const hns_buffers b) {
+    const int A = c.num_agents, C = c.num_cylinders, NT = c.num_targets == 2 ? 2 : 1;
+    const int ia = blockIdx.x * 256 + threadIdx.x;
+    if (ia >= c.num_envs * A) return;
+    const int e = ia / A;
+    const float *ds = b.drone_state + (size_t)ia * 13, *cyl = b.cylinders + (size_t)e * C * 3, *tp = b.target_pos + (size_t)e * 3 * NT;
+    const V3 pos = {ds[0], ds[1], ds[2]};
+    int flag = d_blocked(c, C, pos, V3{tp[0], tp[1], tp[2]}, cyl) ? 1 : 0;
+    if (NT == 2) flag |= d_blocked(c, C, pos, V3{tp[3], tp[4], tp[5]}, cyl) ? 2 : 0;
+    b.pid_last_rate[(size_t)ia * 4 + 3] = (float)flag;
 }
 
 // =================================================================================================
@@ -2005,6 +2016,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
         bool knn_masked[kMaxK];
         agent_obs<A, NT>(c, C, K, le, a, s, tp, tpB, 0.0f, sCyl + le * L.cyl_stride, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * SD,
                          with_state ? b.state_drones + ia * SD : nullptr, blocked, det, blockedB, detB, knn_idx, knn_masked);
+        b.pid_last_rate[ia * 4 + 3] = (float)((blocked ? 1 : 0) + (blockedB ? 2 : 0));   // line of sight of the new state (the env wave zeroed the record above)
         if (det) sDet[le] = 1;
         if (NT == 2 && detB) sDet1[le] = 1;
     }
@@ -2615,6 +2627,15 @@ uint32_t hns_get_reset_epoch(const hns_env *env) { return env ? env->epoch : 0u;
 
 // Fixture injection / read-back: copies between HOST arrays and the bound device buffers, field
 // by field (null host fields are skipped), asynchronously on `stream`.
+int hns_refresh_derived_state(hns_env *env, void *stream) {
+    if (!env) { set_error("hns_refresh_derived_state: null argument"); return HNS_ERR_INVALID_ARG; }
+    if (!env->bound) { set_error("hns_refresh_derived_state: hns_bind first"); return HNS_ERR_NOT_BOUND; }
+    const int n = env->cfg.num_envs * env->cfg.num_agents;
+    hipLaunchKernelGGL(hns::hns_refresh_los_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env->cfg, env->buf);
+    HNS_CHECK_HIP(hipGetLastError());
+    return HNS_OK;
+}
+
 static int copy_state(hns_env *env, const hns_buffers *host, void *stream, bool to_device) {
     if (!env || !host) { set_error("hns_set_state/hns_get_state: null argument"); return HNS_ERR_INVALID_ARG; }
     if (!env->bound) { set_error("hns_set_state/hns_get_state: hns_bind first"); return HNS_ERR_NOT_BOUND; }
@@ -2636,6 +2657,7 @@ static int copy_state(hns_env *env, const hns_buffers *host, void *stream, bool 
         if (to_device) HNS_CHECK_HIP(hipMemcpyAsync(x.dev, x.host, x.bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
         else HNS_CHECK_HIP(hipMemcpyAsync(const_cast<void *>(x.host), x.dev, x.bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     }
+    if (to_device) return hns_refresh_derived_state(env, stream);   // the line-of-sight column belongs to the positions just uploaded
     return HNS_OK;
 }
 int hns_set_state(hns_env *env, const hns_buffers *host, void *stream) { return copy_state(env, host, stream, true); }

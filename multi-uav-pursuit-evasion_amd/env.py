@@ -481,6 +481,8 @@ class HideAndSeek(_EnvBase):
     def import_state(self, arrays):
         for k, v in arrays.items():
             self._bufs[k].copy_(torch.as_tensor(v).to(self.device).view(self._bufs[k].shape))
+        # the line-of-sight column of pid_last_rate is derived from the positions just written (include/hns.h)
+        self._check(self._lib.hns_refresh_derived_state(self._env, self._stream()), "hns_refresh_derived_state")
         self._needs_reset = False
         self._state_version += 1
 

@@ -675,6 +675,10 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
         o_obs(c, A, C, K, ds, tp, cyl, b->progress[e], b->obs_self + (size_t)e * A * SD,
               b->obs_others + (size_t)e * A * (A - 1) * 3, b->obs_cylinders + (size_t)e * A * K * 5,
               (c->write_critic_state && b->state_drones) ? b->state_drones + (size_t)e * A * SD : NULL, &side);
+        /* include/hns.h: the line-of-sight flags of S_{t+1} ride in the spare column of the controller record.  The oracle only WRITES
+         * them — its evader policy above tests the line of sight afresh every step, as the reference does (hideandseek.py:1080) — so the
+         * parity tests check the kernel's carried-over flag against an independent evaluation. */
+        for (int a = 0; a < A; ++a) b->pid_last_rate[((size_t)e * A + a) * 4 + 3] = (float)(side.blocked[a] + 2 * side.blocked1[a]);
         o_reward(c, A, C, K, ds, tp, cyl, b->progress[e], &side, b->action_error + (size_t)e * A, thr_diff,
                  stats, (size_t)E, b->reward + (size_t)e * A, b->done + e);
         if (b->detect) b->detect[e] = (uint8_t)(side.bdetect | (side.bdetect1 << 1));
@@ -858,6 +862,7 @@ static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *m
         o_obs(c, A, C, K, ds, tp, cyl, 0.0f, b->obs_self + (size_t)e * A * SD,
               b->obs_others + (size_t)e * A * (A - 1) * 3, b->obs_cylinders + (size_t)e * A * K * 5,
               (c->write_critic_state && b->state_drones) ? b->state_drones + (size_t)e * A * SD : NULL, &side);
+        for (int a = 0; a < A; ++a) b->pid_last_rate[((size_t)e * A + a) * 4 + 3] = (float)(side.blocked[a] + 2 * side.blocked1[a]);
         if (b->detect) b->detect[e] = (uint8_t)(side.bdetect | (side.bdetect1 << 1));
     }
     return HNS_OK;

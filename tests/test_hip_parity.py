@@ -317,6 +317,41 @@ def test_steps_captured_in_a_hip_graph_replay_identically():
         assert np.array_equal(a[k], b[k], equal_nan=True), k
 
 
+def test_line_of_sight_flag_is_derived_state():
+    """The step kernel does not re-evaluate the evader policy's line of sight (hideandseek.py:1080): it reads the flag the previous
+    step / the reset stored in pid_last_rate[..., 3] for the same positions (include/hns.h).  (i) after resets and steps the stored
+    flag equals an independent evaluation of the exported state by the oracle; (ii) a state imported with a wrong flag column steps
+    exactly like the original, because import recomputes it (hns_refresh_derived_state)."""
+    import hns_oracle as orc
+    E, A, C = 192, 3, 8
+    env = make_env(E, A, C, max_len=9, cylinder={"min_num": 3})
+    env.set_seed(11)
+    env.reset()
+    gen = torch.Generator(device=env.device).manual_seed(3)
+    for t in range(14):                                   # crosses an episode end: masked resets in between
+        if t:
+            td = env.step(env.rand_step_input(torch.randn(E, A, 4, generator=gen, device=env.device)))
+            done = td[("next", "done")].reshape(E)
+            if bool(done.any()):
+                rtd = env.rand_step_input()
+                rtd.set("_reset", done)
+                env.reset(rtd)
+        st = env.export_state()
+        want = orc.blocked(env.hcfg, st["drone_state"][..., :3], st["target_pos"], st["cylinders"])
+        assert np.array_equal(st["pid_last_rate"][..., 3], want.astype(np.float32)), t
+    twin = make_env(E, A, C, max_len=9, cylinder={"min_num": 3})
+    twin.reset()
+    bad = {k: v.copy() for k, v in st.items()}
+    bad["pid_last_rate"][..., 3] = 1.0 - bad["pid_last_rate"][..., 3]
+    twin.import_state(bad)
+    act = torch.randn(E, A, 4, generator=gen, device=env.device)
+    env.step(env.rand_step_input(act))
+    twin.step(twin.rand_step_input(act))
+    a, b = env.export_state(), twin.export_state()
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
 def test_stream_shards_reproduce_the_whole_batch():
     """The batch as independent shards on separate HIP streams of one GPU (bench.py's `stream_shards` leg, the
     multi-GPU sharding applied inside a GPU): every buffer equals the corresponding slice of the one-launch batch."""
