@@ -26,7 +26,9 @@ constexpr float kInvPi = 0.31830987334251404f;   // RN(1/fp32(pi)): CUDA `tensor
 HNS_DEV float d_expf(float x) {
     // branch-free: evaluate on a clamped argument, pick the special cases at the end (same values
     // as the guarded form in the oracle: 0 for x <= -87 and -inf, +inf above 88, NaN for NaN)
-    float xc = x < -87.5f ? -87.5f : (x > 88.5f ? 88.5f : x);
+    // (min / max, not compare-and-select: the compiler threads a jump around the polynomial on a compare against a constant,
+    //  and a branch costs a wave more than the polynomial; NaN comes out as a clamp value here and is restored by the last select)
+    float xc = __builtin_fmaxf(__builtin_fminf(x, 88.5f), -87.5f);
     float k = __builtin_rintf(xc * 1.44269504088896341f);
     float r = HNS_FMA(k, -0.693359375f, xc);
     r = HNS_FMA(k, 2.12194440e-4f, r);
@@ -39,8 +41,11 @@ HNS_DEV float d_expf(float x) {
     float y = HNS_FMA(p, r * r, r) + 1.0f;
     int ki = (int)k;
     float v = y * __uint_as_float((uint32_t)(ki + 127) << 23);
+    // special cases without control flow: v is finite here (|xc| <= 88.5), so v * 0 = +0 is the underflow result, exactly; a select
+    // with v on one side only would let the compiler sink the whole polynomial into a branch
+    v = v * ((x > -87.0f) ? 1.0f : 0.0f);
     v = (x > 88.0f) ? kInf : v;
-    v = (x > -87.0f) ? v : ((x != x) ? x : 0.0f);
+    v = (x != x) ? x : v;
     return v;
 }
 
@@ -188,10 +193,8 @@ HNS_DEV void d_ctbr_pid_squashed(const Cfg &c, const float4 &ta, const Q4 &q, co
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float v = (m[i] / 65536.0f) * 2.0f - c.max_thrust_ratio;
-        if (v != v) v = 0.0f;                                  // torch.nan_to_num_(cmds, 0.)
-        else if (v == kInf) v = 3.4028234663852886e38f;
-        else if (v == -kInf) v = -3.4028234663852886e38f;
-        cmd[i] = v;
+        v = (v != v) ? 0.0f : v;                               // torch.nan_to_num_(cmds, 0.): NaN -> 0, +-inf -> +-FLT_MAX (no control flow)
+        cmd[i] = __builtin_fminf(__builtin_fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);
     }
 }
 
@@ -209,10 +212,13 @@ HNS_DEV void d_rotor(const Cfg &c, const float cmd[4], float4 &throttle4, float 
     float thr_in[4] = {throttle4.x, throttle4.y, throttle4.z, throttle4.w};
     float thr_out[4];
     float dd[4];
+    // into values first: `cond ? c.a : c.b` on two fields is an lvalue and compiles to ONE load from a per-lane selected address —
+    // a vector memory load of a configuration constant
+    const float tau_up = c.tau_up, tau_down = c.tau_down;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float tgt = __builtin_sqrtf(d_clamp((cmd[i] + 1.0f) / 2.0f, 0.0f, 1.0f));
-        float tau = (tgt > thr_in[i]) ? c.tau_up : c.tau_down;
+        float tau = (tgt > thr_in[i]) ? tau_up : tau_down;
         float thr = thr_in[i] + tau * (tgt - thr_in[i]);
         thr_out[i] = thr;
         float t = d_clamp(thr * thr + 0.0f, 0.0f, 1.0f);

@@ -35,6 +35,7 @@ struct hns_env {
     void (*step_fn)(const hns::Params) = nullptr;
     void (*reset_fn)(const hns::Params) = nullptr;
     void (*step_args_fn)(const hns::StepArgs) = nullptr;   // step kernel taking the split argument block (else step_fn)
+    void (*step_args_prof_fn)(const hns::StepArgs) = nullptr;   // ... compiled with the per-wave phase stamps (hns_set_phase_profile)
     hns::Params *params_dev = nullptr, *params_host = nullptr;   // device copy of the step launch's Params + its pinned host image
     bool params_valid = false;
     unsigned long long *prof = nullptr;

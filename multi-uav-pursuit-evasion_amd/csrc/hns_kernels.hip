@@ -440,11 +440,12 @@ HNS_DEV void agent_obs(const Cfg &c, int C, int K, int le, int a, const Rigid &s
             knn_idx[sidx] = bi[sidx];
             knn_masked[sidx] = masked;
             float *row = STAGED ? krow + sidx * 5 : oc + sidx * 5;
-            row[0] = masked ? c.mask_value : s.pos.x - cc[0];
-            row[1] = masked ? c.mask_value : s.pos.y - cc[1];
-            row[2] = masked ? c.mask_value : s.pos.z - cc[2];
-            row[3] = masked ? c.mask_value : c.cylinder_height;
-            row[4] = masked ? c.mask_value : c.cylinder_size;
+            const float mv = c.mask_value, ch = c.cylinder_height, cs = c.cylinder_size;   // values, not lvalues (see d_rotor)
+            row[0] = masked ? mv : s.pos.x - cc[0];
+            row[1] = masked ? mv : s.pos.y - cc[1];
+            row[2] = masked ? mv : s.pos.z - cc[2];
+            row[3] = masked ? mv : ch;
+            row[4] = masked ? mv : cs;
         }
     }
     if constexpr (STAGED) {
@@ -944,17 +945,14 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
 // The fused step kernel, third design (one evader, whole 64-env tiles): no workgroup barrier in front of the
 // controller, loads issued in the order they are needed.
 // =================================================================================================
-// What the profiles of the first design showed: a launch is one residency round, so the load burst
-// (38 MB, 5.5-6 us at the ~7 TB/s this working set reaches), each wave's serial instruction stream (~10 us for the
-// oldest workgroup of a CU, +2 us for every younger one) and the store drain were paid one after the other.  Here
-//   * an agent wave needs nobody else's data for the controller: it loads ITS OWN 64 rigid-state rows (one contiguous
-//     3.3 KB slice) through its private LDS slab, so the controller starts as soon as the first-issued loads
-//     (action, previous action, rows, PID state) have landed, while throttle / cylinders / statistics still stream;
+// Wave-specialised step kernel (full tiles, one evader).  What the profiles of the first design showed: a launch is one
+// residency round, so the load burst, each wave's serial instruction stream and the store drain were paid one after the other.  Here
+//   * a pursuer wave needs nobody else's data for the controller: it loads ITS OWN 64 rigid-state rows (one contiguous
+//     3.3 KB slice) through its private LDS slab, so the controller starts as soon as the first-issued loads have landed;
 //   * the env wave owns everything about the evader: it fetches its envs' cylinders and evader position itself, stages
-//     the cylinders for phase 3, runs the potential field INCLUDING the pursuers' line-of-sight tests (they are the
-//     evader's sensing, hideandseek.py:1074-1088) while the pursuer waves run controller and integration;
+//     the cylinders for phase 3 and runs the potential field while the pursuer waves run controller and integration;
 //   * pursuer <-> pursuer and pursuer <-> evader exchange goes through small published records (position at t, thrust
-//     vector, position at t+1), three workgroup barriers in all (six before);
+//     vector, position at t+1, line-of-sight flag), three workgroup barriers in all (six before);
 //   * every store is a whole-line store from a wave-private slab.
 // Arithmetic, evaluation order and results are those of hns_step_kernel (bit-identical; tests/test_hip_parity.py).
 #ifndef HNS_ENV_PRIO
@@ -988,378 +986,7 @@ HNS_DEV void env_store_slice(const float *lds, float *g, int n, int lane) {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int A>
-__global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params p) {
-    constexpr int NA = Geo<A>::NA, SD = HNS_SELF_DIM, kRedS = red_stride(1);
-    extern __shared__ __align__(16) float smem[];
-    const hns_cfg &c = p.cfg;
-    const hns_buffers &b = p.buf;
-    const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.num_envs;
-    const bool with_state = c.write_critic_state && b.state_drones != nullptr;
-    const LdsV3 L = lds_layout_v3(A, C, K);
-    float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red, *sEnvOut = smem + L.envout;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int e0 = blockIdx.x * kEPB;
-    prof_mark(p.prof, 0);
-    prof_mark(p.prof, 14);
-
-    if (tid < NA) {
-        // ================================= pursuer waves ==================================================
-        const int le = tid / A, a = tid - le * A;
-        const unsigned ia = (unsigned)e0 * A + tid;
-        float *slab = smem + L.slab + (tid >> 6) * L.slab_stride;
-        // loads, first needed first: action, previous action, the wave's 64 rigid-state rows, PID state, throttle
-        const float4 act4 = reinterpret_cast<const float4 *>(p.action)[ia];
-        float4 prev4 = reinterpret_cast<const float4 *>(b.prev_action)[ia];
-        constexpr int N4 = 64 * 13 / 4;                   // 208 float4 pieces per wave
-        const float4 *rows4 = reinterpret_cast<const float4 *>(b.drone_state + ((size_t)e0 * A + (tid & ~63)) * 13) + lane;
-        static_assert(N4 > 192 && N4 <= 256, "three full passes and a partial one");
-        const float4 rr0 = rows4[0], rr1 = rows4[64], rr2 = rows4[128];      // (named values: an array with a predicated element went to scratch)
-        float4 rr3 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < N4 - 192) rr3 = rows4[192];
-        float4 integ4 = reinterpret_cast<const float4 *>(b.pid_integ)[ia];
-        float4 last4 = reinterpret_cast<const float4 *>(b.pid_last_rate)[ia];
-        float4 thr4 = reinterpret_cast<const float4 *>(b.throttle)[ia];
-        const float4 ta = d_action_tanh(act4);           // needs the action only: evaluated while the rest is in flight
-        // own rows through the private slab
-        {
-            float4 *s4 = reinterpret_cast<float4 *>(slab) + lane;
-            s4[0] = rr0; s4[64] = rr1; s4[128] = rr2;
-            if (lane < N4 - 192) s4[192] = rr3;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        Rigid s;
-        load_rigid(slab + lane * 13, s);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        prof_mark(p.prof, 1);
-        // ---- phase 1: controller, rotors, thrust vector (A1-A3) ----
-        float cmd[4], thr_diff, aerr, thrust[4], moment[4];
-        float ctbr4[4], trate[3];
-        d_ctbr_pid_squashed(c, ta, s.q, s.ang, prev4, integ4, last4, cmd, aerr, ctbr4, trate);
-        if (b.ctbr) reinterpret_cast<float4 *>(b.ctbr)[ia] = make_float4(ctbr4[0], ctbr4[1], ctbr4[2], ctbr4[3]);           // transforms.py:456
-        if (b.target_rate) reinterpret_cast<float4 *>(b.target_rate)[ia] = make_float4(trate[0], trate[1], trate[2], 0.0f);  // :457
-        d_rotor(c, cmd, thr4, thrust, moment, thr_diff);
-        const float ts = ((thrust[0] + thrust[1]) + thrust[2]) + thrust[3];
-        const V3 tw = d_quat_rot_z(s.q, ts);                                        // multirotor.py:491
-        {
-            float *pub = sPub + tid * kPub;
-            pub[0] = s.pos.x; pub[1] = s.pos.y; pub[2] = s.pos.z;
-            pub[3] = tw.x; pub[4] = tw.y; pub[5] = tw.z;
-            pub[9] = d_downwash_inv_norm(tw);
-            float *red = sRed + tid * kRedS;
-            red[R_AERR] = aerr; red[R_TD] = thr_diff;
-        }
-        prof_mark(p.prof, 2);
-        __syncthreads();                                                            // barrier 1
-        // ---- phase 2: downwash, torques, integration (A4, A5) ----
-        V3 fdw = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int o = 0; o < A - 1; ++o) {
-            const int j = o + (o >= a ? 1 : 0);
-            const float *pj = sPub + (le * A + j) * kPub;
-            const V3 posj = {pj[0], pj[1], pj[2]}, twj = {pj[3], pj[4], pj[5]};
-            const V3 fj = d_downwash_pair(s.pos, posj, twj, pj[9]);
-            fdw.x = (o == 0) ? fj.x : fdw.x + fj.x;
-            fdw.y = (o == 0) ? fj.y : fdw.y + fj.y;
-            fdw.z = (o == 0) ? fj.z : fdw.z + fj.z;
-        }
-        const V3 fw = {tw.x + fdw.x, tw.y + fdw.y, tw.z + fdw.z};
-        V3 tb;
-        tb.x = ((c.rotor_py[0] * thrust[0] + c.rotor_py[1] * thrust[1]) + c.rotor_py[2] * thrust[2]) + c.rotor_py[3] * thrust[3];
-        tb.y = -(((c.rotor_px[0] * thrust[0] + c.rotor_px[1] * thrust[1]) + c.rotor_px[2] * thrust[2]) + c.rotor_px[3] * thrust[3]);
-        tb.z = ((moment[0] + moment[1]) + moment[2]) + moment[3];
-        d_integrate(c, s, fw, tb);
-        flag_nonfinite(b.nonfinite, rigid_not_finite(s), 1u);
-        {
-            float *pub = sPub + tid * kPub;
-            pub[6] = s.pos.x; pub[7] = s.pos.y; pub[8] = s.pos.z;
-        }
-        // controller / rotor state: plain stores (they are early: write-through here stalls the wave, measured +0.45 us)
-        if (LAB(LAB_NOSTORE | LAB_NOST_REC)) {
-        } else
-#ifdef HNS_V3_REC_SC1
-        {
-        st_f4(reinterpret_cast<float4 *>(b.throttle) + ia, thr4);
-        st_f4(reinterpret_cast<float4 *>(b.pid_integ) + ia, integ4);
-        st_f4(reinterpret_cast<float4 *>(b.pid_last_rate) + ia, last4);
-        st_f4(reinterpret_cast<float4 *>(b.prev_action) + ia, prev4);
-        st_f1(b.action_error + ia, aerr);
-        }
-#else
-        {
-        reinterpret_cast<float4 *>(b.throttle)[ia] = thr4;
-        reinterpret_cast<float4 *>(b.pid_integ)[ia] = integ4;
-        reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
-        reinterpret_cast<float4 *>(b.prev_action)[ia] = prev4;
-        b.action_error[ia] = aerr;
-        }
-#endif
-        if (!LAB(LAB_NOSTORE | LAB_NOST_DS)) {   // S_{t+1}: the wave's 64 rows back through the slab, one contiguous slice
-            const float row[13] = {s.pos.x, s.pos.y, s.pos.z, s.q.w, s.q.x, s.q.y, s.q.z, s.lin.x, s.lin.y, s.lin.z, s.ang.x, s.ang.y, s.ang.z};
-            wave_store_rows<13>(slab, b.drone_state + ((size_t)e0 * A + (tid & ~63)) * 13, row, lane);
-        }
-        prof_mark(p.prof, 3);
-        __syncthreads();                                                            // barrier 2
-        prof_mark(p.prof, 8);
-        // ---- phase 3a: observation, per-pursuer reward terms on S_{t+1} ----
-        const float progress = sTp[kEPB * 3 + le];                                  // progress + 1, published by the env wave
-        const V3 tp = {sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]};
-        const float *cyl = sCyl + le * L.cyl_stride;
-        bool blocked, det, blockedB = false, detB = false;
-        int knn_idx[kMaxK];
-        bool knn_masked[kMaxK];
-        float d;                       // |evader - pursuer| (hideandseek.py:921): the norm the observation pass just took, the squares are the same
-        agent_obs<A, 1, true, kPub>(c, C, K, le, a, s, tp, tp, progress, cyl, sPub + 6, b.obs_others + (size_t)ia * (A - 1) * 3, slab,
-                                    b.obs_self + (size_t)ia * SD, with_state ? b.state_drones + (size_t)ia * SD : nullptr, blocked, det, blockedB, detB,
-                                    knn_idx, knn_masked, !LAB(LAB_NOSTORE | LAB_NOST_SELF), !LAB(LAB_NOSTORE | LAB_NOST_OTH),
-                                    b.obs_cylinders + (size_t)ia * K * 5, &d, !LAB(LAB_NOSTORE | LAB_NOST_OCYL));
-        prof_mark(p.prof, 9);
-        const float act = (d > c.catch_radius) ? 1.0f : 0.0f;                     // hideandseek.py:919-995
-        const float dist_rew = (-c.dist_reward_coef * d) * act;
-        const bool cap_ok = (d < c.catch_radius) && !blocked;
-        // Threshold tests on norms: RN(sqrt(x)) compared with a limit is decided on x itself unless x lies within 2^-19 of
-        // the squared limit; only then the correctly rounded square root is taken (same booleans as the plain form).
-        bool fast = false;
-        {
-            const float sp2 = HNS_FMA(s.lin.z, s.lin.z, HNS_FMA(s.lin.y, s.lin.y, s.lin.x * s.lin.x));
-            const float v2 = c.v_drone * c.v_drone;
-            fast = sp2 > v2 * 1.00000190734863f;
-            if (!fast && !(sp2 < v2 * 0.99999809265137f)) fast = __builtin_sqrtf(sp2) > c.v_drone;
-        }
-        const float speed_rew = -c.speed_coef * (fast ? 1.0f : 0.0f);
-        float cc = 0.f, cd = 0.f;
-        const float rc = c.cylinder_size + c.collision_radius, rc2 = rc * rc;
-#pragma unroll
-        for (int sidx = 0; sidx < kMaxK; ++sidx) {
-            if (sidx < K) {
-                const float *cy = cyl + 3 * knn_idx[sidx];
-                const float rx = s.pos.x - cy[0], ry = s.pos.y - cy[1];
-                const float s2 = HNS_FMA(ry, ry, rx * rx);
-                bool h = s2 < rc2 * 0.99999618530273f;                               // 1 - 2^-18: covers the roundings of rc, dxy - size
-                if (!h && !(s2 > rc2 * 1.00000381469727f)) h = (__builtin_sqrtf(s2) - c.cylinder_size) < c.collision_radius;
-                float hit = h ? 1.0f : 0.0f;
-                if (knn_masked[sidx]) hit = 0.0f;
-                cc = (sidx == 0) ? hit : cc + hit;
-            }
-        }
-        float cr = -c.collision_coef * cc;
-        const float dd2 = c.coll_drone_dist * c.coll_drone_dist;
-#pragma unroll
-        for (int o = 0; o < A - 1; ++o) {
-            const int j = o + (o >= a ? 1 : 0);
-            const float *rj = sPub + (le * A + j) * kPub + 6;
-            const float ex = s.pos.x - rj[0], ey = s.pos.y - rj[1], ez = s.pos.z - rj[2];
-            const float s3 = HNS_FMA(ez, ez, HNS_FMA(ey, ey, ex * ex));
-            bool h = s3 < dd2 * 0.99999809265137f;
-            if (!h && !(s3 > dd2 * 1.00000190734863f)) h = __builtin_sqrtf(s3) < c.coll_drone_dist;
-            const float hit = h ? 1.0f : 0.0f;
-            cd = (o == 0) ? hit : cd + hit;
-        }
-        cr = cr + -c.collision_coef * cd;
-        const float cw = ((s.pos.z > c.max_height) ? 1.0f : 0.0f) + ((HNS_FMA(s.pos.y, s.pos.y, s.pos.x * s.pos.x) > c.arena_sq) ? 1.0f : 0.0f);
-        cr = cr + -c.collision_coef * cw;
-        float sm = 0.0f;
-        if (c.use_deployment) sm = c.smoothness_coef * d_expf(-aerr);
-        {
-            float *red = sRed + tid * kRedS;
-            red[R_DIST] = dist_rew; red[R_SPEED] = speed_rew; red[R_CC] = cc; red[R_CD] = cd; red[R_CW] = cw;
-            red[R_COLL] = cr; red[R_SMOOTH] = sm;
-            red[R_FLAGS] = __int_as_float((cap_ok ? F_CAP : 0) | (blocked ? F_BLOCKED : 0) | (det ? F_DET : 0));
-        }
-        prof_mark(p.prof, 4);
-        __syncthreads();                                                            // barrier 3
-        prof_mark(p.prof, 5);
-        prof_mark(p.prof, 6);
-    } else {
-        // ================================= env wave: lane <-> env ========================================
-        if (HNS_ENV_PRIO) __builtin_amdgcn_s_setprio(HNS_ENV_PRIO);   // one wave in four, but every barrier of its workgroup waits for it
-        const int le = lane, e = e0 + le;
-        float *cylw = sCyl + le * L.cyl_stride;
-        // the evader and this env's cylinders, straight from global memory (this wave has nothing else to do yet)
-        const float *gt = b.target_pos + (size_t)e * 3;
-        const V3 tp0 = {gt[0], gt[1], gt[2]};
-        float progress = b.progress[e];
-        {   // this workgroup's cylinders are one contiguous slice [64][3C]: coalesced 4-byte loads (lane <-> consecutive floats), scattered
-            // into rows of odd stride (lane = env reads its row conflict-free); index / 3C by multiply-high
-            const float *gc = b.cylinders + (size_t)e0 * C * 3;
-            const int c3 = 3 * C, n = kEPB * c3;
-#pragma unroll 8
-            for (int i = lane; i < n; i += 64) {
-                const int row = (int)__umulhi((unsigned)i, p.cyl_magic), col = i - row * c3;
-                sCyl[row * L.cyl_stride + col] = gc[i];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        prof_mark(p.prof, 1);
-        // A6: arena + cylinder terms of the potential field (hideandseek.py:1090-1136)
-        bool out_of_arena = false;
-        const V3 Fenv = d_prey_arena_term(c, tp0, out_of_arena);
-        float fcx = 0.f, fcy = 0.f;
-#pragma unroll 4
-        for (int k = 0; k < C; ++k) {
-            float tx, ty;
-            d_prey_cylinder_term(c, tp0, cylw[3 * k], cylw[3 * k + 1], cylw[3 * k + 2], tx, ty);
-            fcx += tx;
-            fcy += ty;
-        }
-        progress += 1.0f;                                                           // isaac_env.py:236
-        sTp[kEPB * 3 + le] = progress;
-        prof_mark(p.prof, 2);
-        __syncthreads();                                                            // barrier 1: positions at t, action errors
-        float st[HNS_NUM_STATS];
-#pragma unroll
-        for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = b.stats[(size_t)i * E + e];
-        // the pursuers' pushes (hideandseek.py:1074-1088), ascending; then arena, then cylinders
-        V3 F = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-            const float *pj = sPub + (le * A + j) * kPub;
-            const V3 dp = {pj[0], pj[1], pj[2]};
-            const bool blocked_pre = d_blocked(c, C, dp, tp0, cylw);                // :1080
-            const V3 fp = d_prey_pursuer_term(c, dp, tp0, blocked_pre);
-            F.x = (j == 0) ? fp.x : F.x + fp.x;
-            F.y = (j == 0) ? fp.y : F.y + fp.y;
-            F.z = (j == 0) ? fp.z : F.z + fp.z;
-        }
-        F.x = F.x + Fenv.x; F.y = F.y + Fenv.y; F.z = F.z + Fenv.z;
-        F.x = F.x + fcx; F.y = F.y + fcy; F.z = F.z + 0.0f;
-        const V3 tvel = {(c.v_prey * F.x) / (__builtin_fabsf(F.x) + 1e-5f), (c.v_prey * F.y) / (__builtin_fabsf(F.y) + 1e-5f),
-                         (c.v_prey * F.z) / (__builtin_fabsf(F.z) + 1e-5f)};        // per-axis speed (:741)
-        const V3 tpn = {tp0.x + tvel.x * c.dt, tp0.y + tvel.y * c.dt, tp0.z + tvel.z * c.dt};
-        sTp[le * 3] = tpn.x; sTp[le * 3 + 1] = tpn.y; sTp[le * 3 + 2] = tpn.z;
-        { const float sf = (tpn.x + tpn.y) + tpn.z; flag_nonfinite(b.nonfinite, (sf - sf) != 0.0f, 2u); }
-        if (!LAB(LAB_NOSTORE)) {            // [64,3] slices, whole lines: the new position is already laid out in sTp
-            sEnvOut[le * 3] = tvel.x; sEnvOut[le * 3 + 1] = tvel.y; sEnvOut[le * 3 + 2] = tvel.z;
-            env_store_slice(sTp, b.target_pos + (size_t)e0 * 3, kEPB * 3, lane);
-            env_store_slice(sEnvOut, b.target_vel + (size_t)e0 * 3, kEPB * 3, lane);
-        }
-        {   // statistics that only need phase-1 data (A10 hideandseek.py:731-733, :1097-1098, :996-997)
-            float sum_ae = 0.f, sum_td = 0.f, max_td = 0.f;
-#pragma unroll
-            for (int j = 0; j < A; ++j) {
-                const float *red = sRed + (le * A + j) * kRedS;
-                const float td = red[R_TD];
-                sum_ae = (j == 0) ? red[R_AERR] : sum_ae + red[R_AERR];
-                sum_td = (j == 0) ? td : sum_td + td;
-                max_td = (j == 0) ? td : (td > max_td ? td : max_td);
-            }
-            const float mae = sum_ae * c.inv_num_agents;
-            st[HNS_ST_ACTION_ERROR_ORDER1_MEAN] += mae;
-            if (mae > st[HNS_ST_ACTION_ERROR_ORDER1_MAX]) st[HNS_ST_ACTION_ERROR_ORDER1_MAX] = mae;
-            st[HNS_ST_OUT_OF_ARENA] = ((st[HNS_ST_OUT_OF_ARENA] != 0.0f) || out_of_arena) ? 1.0f : 0.0f;
-            st[HNS_ST_SMOOTHNESS_COEF] = c.smoothness_coef;
-            st[HNS_ST_SMOOTHNESS_MEAN] += sum_td * c.inv_num_agents;
-            if (max_td > st[HNS_ST_SMOOTHNESS_MAX]) st[HNS_ST_SMOOTHNESS_MAX] = max_td;
-        }
-        prof_mark(p.prof, 3);
-        __syncthreads();                                                            // barrier 2: evader at t+1 published
-        prof_mark(p.prof, 8);
-        prof_mark(p.prof, 4);
-        __syncthreads();                                                            // barrier 3: reward terms
-        prof_mark(p.prof, 5);
-        // ---- phase 3b: per-env reductions, reward, done, statistics (hideandseek.py:919-1065) ----
-        const float iA = c.inv_num_agents;
-        bool any_cap = false, all_blocked = true, any_coll = false, det_any = false;
-        float sum_dist = 0, sum_speed = 0, sum_cc = 0, sum_cd = 0, sum_cw = 0, sum_coll = 0, sum_smooth = 0;
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-            const float *red = sRed + (le * A + j) * kRedS;
-            const int fl = __float_as_int(red[R_FLAGS]);
-            any_cap |= (fl & F_CAP) != 0;
-            all_blocked &= (fl & F_BLOCKED) != 0;
-            det_any |= (fl & F_DET) != 0;
-            any_coll |= red[R_COLL] < 0.0f;
-            if (j == 0) {
-                sum_dist = red[R_DIST]; sum_speed = red[R_SPEED]; sum_cc = red[R_CC]; sum_cd = red[R_CD]; sum_cw = red[R_CW];
-                sum_coll = red[R_COLL]; sum_smooth = red[R_SMOOTH];
-            } else {
-                sum_dist += red[R_DIST]; sum_speed += red[R_SPEED]; sum_cc += red[R_CC]; sum_cd += red[R_CD]; sum_cw += red[R_CW];
-                sum_coll += red[R_COLL]; sum_smooth += red[R_SMOOTH];
-            }
-        }
-        const float detf = det_any ? 1.0f : 0.0f;
-        const float detect_rew = c.detect_reward_coef * detf;
-        const float catch_rew = c.catch_reward_coef * (any_cap ? 1.0f : 0.0f);
-        float sum_rew = 0.f;
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-            const float *red = sRed + (le * A + j) * kRedS;
-            const float r = ((((red[R_DIST] + detect_rew) + catch_rew) + red[R_COLL]) + red[R_SPEED]) + red[R_SMOOTH];
-            sEnvOut[le * A + j] = r;
-            sum_rew = (j == 0) ? r : sum_rew + r;
-        }
-        if (!LAB(LAB_NOSTORE)) env_store_slice(sEnvOut, b.reward + (size_t)e0 * A, kEPB * A, lane);
-        flag_nonfinite(b.nonfinite, (sum_rew - sum_rew) != 0.0f, 4u);
-        if (!det_any && !LAB(LAB_NOSTORE)) {                   // hideandseek.py:791-794: mask the evader's relative position
-#pragma unroll
-            for (int j = 0; j < A; ++j) {
-                float *o = b.obs_self + ((size_t)e * A + j) * SD;
-                o[0] = c.mask_value; o[1] = c.mask_value; o[2] = c.mask_value;
-            }
-        }
-#define ST(i) st[i]
-        ST(HNS_ST_DISTANCE_REWARD) += sum_dist * iA;
-        ST(HNS_ST_SUM_DETECT_STEP) += 1.0f * detf;
-        float sdet = detect_rew, scat = catch_rew;
-#pragma unroll
-        for (int j = 1; j < A; ++j) { sdet += detect_rew; scat += catch_rew; }
-        ST(HNS_ST_DETECT_REWARD) += sdet * iA;
-        const bool capture_flag = catch_rew != 0.0f;                              // :945
-        ST(HNS_ST_BLOCKED) += all_blocked ? 1.0f : 0.0f;
-        ST(HNS_ST_SUCCESS) = (capture_flag || ST(HNS_ST_SUCCESS) != 0.0f) ? 1.0f : 0.0f;
-        const float cur = (capture_flag ? 1.0f : 0.0f) * progress + (capture_flag ? 0.0f : 1.0f) * (float)c.max_episode_length;
-        if (cur < ST(HNS_ST_FIRST_CAPTURE_STEP)) ST(HNS_ST_FIRST_CAPTURE_STEP) = cur;
-        ST(HNS_ST_CATCH_REWARD) += scat * iA;
-        ST(HNS_ST_SPEED_REWARD) += sum_speed * iA;
-        ST(HNS_ST_COLLISION_CYLINDER) += sum_cc * iA;
-        ST(HNS_ST_COLLISION_DRONE) += sum_cd * iA;
-        ST(HNS_ST_COLLISION) += any_coll ? 1.0f : 0.0f;
-        ST(HNS_ST_COLLISION_WALL) += sum_cw * iA;
-        ST(HNS_ST_COLLISION_REWARD) += sum_coll * iA;
-        ST(HNS_ST_SMOOTHNESS_REWARD) += sum_smooth * iA;
-        const bool done = progress >= (float)c.max_episode_length;                // :1008-1010
-        if (done) {                                                               // :1017-1056
-            ST(HNS_ST_COLLISION) = ST(HNS_ST_COLLISION) / progress;
-            ST(HNS_ST_ACTION_ERROR_ORDER1_MEAN) = ST(HNS_ST_ACTION_ERROR_ORDER1_MEAN) / progress;
-            ST(HNS_ST_TARGET_PREDICTED_ERROR) = ST(HNS_ST_TARGET_PREDICTED_ERROR) / progress;
-            ST(HNS_ST_SMOOTHNESS_MEAN) = ST(HNS_ST_SMOOTHNESS_MEAN) / progress;
-            ST(HNS_ST_SMOOTHNESS_REWARD) = ST(HNS_ST_SMOOTHNESS_REWARD) / progress;
-            ST(HNS_ST_DISTANCE_REWARD) = ST(HNS_ST_DISTANCE_REWARD) / progress;
-            ST(HNS_ST_DETECT_REWARD) = ST(HNS_ST_DETECT_REWARD) / progress;
-            ST(HNS_ST_CATCH_REWARD) = ST(HNS_ST_CATCH_REWARD) / progress;
-            ST(HNS_ST_COLLISION_REWARD) = ST(HNS_ST_COLLISION_REWARD) / progress;
-            ST(HNS_ST_COLLISION_WALL) = ST(HNS_ST_COLLISION_WALL) / progress;
-            ST(HNS_ST_COLLISION_DRONE) = ST(HNS_ST_COLLISION_DRONE) / progress;
-            ST(HNS_ST_COLLISION_CYLINDER) = ST(HNS_ST_COLLISION_CYLINDER) / progress;
-            ST(HNS_ST_SPEED_REWARD) = ST(HNS_ST_SPEED_REWARD) / progress;
-        }
-        ST(HNS_ST_RETURN) += sum_rew * iA;
-#undef ST
-        b.done[e] = (uint8_t)done;
-        if (b.detect) b.detect[e] = (uint8_t)det_any;
-        b.progress[e] = progress;
-        if (!LAB(LAB_NOSTORE | LAB_NOST_STATS)) {
-#pragma unroll
-            for (int i = 0; i < HNS_NUM_STATS; ++i) st_f1(b.stats + (size_t)i * E + e, st[i]);
-        }
-        prof_mark(p.prof, 6);
-    }
-    prof_mark(p.prof, 7);
-    prof_mark(p.prof, 15);
-#ifdef HNS_LAB
-    if (p.prof && lane == 0 && LAB(LAB_HWID)) {                   // where the hardware put this wave (tools/wave_placement.py)
-        unsigned long long *pr = p.prof + (size_t)(blockIdx.x * (A + 1) + (tid >> 6)) * kProfSlots;
-        pr[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
-        pr[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
-        pr[12] = (unsigned long long)(tid >= NA);
-    }
-#endif
-}
-
-// Fourth design = the third with the env wave — ONE wave, issuing one instruction every 5-7 cycles — relieved of most of its serial
+// Relative to the third design (same structure) the env wave — ONE wave, issuing one instruction every 5-7 cycles — relieved of most of its serial
 // work (tools/phase_timeline.py: in the third design 5.8 us of the 14.5 us of a workgroup's life were env-wave work that the pursuer
 // waves waited for):
 //   * the line of sight evader -> pursuer at t (:1080) is not evaluated at all: it is the test the previous step (or the reset) ran on
@@ -1369,7 +996,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v3_kernel(const Params 
 //     (:791-794) is applied by the pursuers themselves (was: the env wave patched the stored rows);
 //   * everything but the pointers behind the first loads comes from a device-resident block through the scalar cache (StepArgs).
 // Three workgroup barriers.
-template <int A>
+template <int A, bool PROF>
 __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArgs ka) {
     // the block behind `rest` is never written while the kernel runs: read it as constant memory (scalar loads, placed like kernel-argument loads)
     typedef const Params __attribute__((address_space(4))) ParamsC;
@@ -1399,8 +1026,8 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         float4 last4 = reinterpret_cast<const float4 *>(ka.pid_last_rate)[ia];
         float4 thr4 = reinterpret_cast<const float4 *>(ka.throttle)[ia];
         __builtin_amdgcn_sched_barrier(0);
-        prof_mark(p.prof, 0);
-        prof_mark(p.prof, 14);
+        if constexpr (PROF) prof_mark(p.prof, 0);
+        if constexpr (PROF) prof_mark(p.prof, 14);
         const int C = c.num_cylinders, K = c.obs_max_cylinder;
         const bool with_state = c.write_critic_state && b.state_drones != nullptr;
         const LdsV3 L = lds_layout_v3(A, C, K);
@@ -1419,7 +1046,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         load_rigid(slab + lane * 13, s);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        prof_mark(p.prof, 1);
+        if constexpr (PROF) prof_mark(p.prof, 1);
         // ---- phase 1: controller, rotors, thrust vector (A1-A3) ----
         // line of sight evader -> this pursuer at t (:1080): positions, evader and cylinders are those the previous step (or the reset)
         // evaluated it on for the observation, so that result is carried in the spare fourth column of the controller record
@@ -1442,9 +1069,9 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
             float *red = sRed + tid * kRedS;
             red[R_AERR] = aerr; red[R_TD] = thr_diff;
         }
-        prof_mark(p.prof, 2);
+        if constexpr (PROF) prof_mark(p.prof, 2);
         __syncthreads();                                                            // barrier 1
-        prof_mark(p.prof, 12);
+        if constexpr (PROF) prof_mark(p.prof, 12);
         // ---- phase 2: downwash, torques, integration (A4, A5) ----
         V3 fdw = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -1490,9 +1117,9 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
             const float row[13] = {s.pos.x, s.pos.y, s.pos.z, s.q.w, s.q.x, s.q.y, s.q.z, s.lin.x, s.lin.y, s.lin.z, s.ang.x, s.ang.y, s.ang.z};
             wave_store_rows<13>(slab, b.drone_state + ((size_t)e0 * A + (tid & ~63)) * 13, row, lane);
         }
-        prof_mark(p.prof, 3);
+        if constexpr (PROF) prof_mark(p.prof, 3);
         __syncthreads();                                                            // barrier 2
-        prof_mark(p.prof, 8);
+        if constexpr (PROF) prof_mark(p.prof, 8);
         // ---- phase 3a: distance and line of sight to the evader, the k nearest cylinders, per-pursuer reward terms on S_{t+1} ----
         const float progress = sTp[kEPB * 3 + le];                                  // progress + 1, published by the env wave
         const V3 tp = {sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]};
@@ -1511,7 +1138,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         if (!LAB(LAB_NOSTORE | LAB_NOST_REC)) reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
 #pragma unroll
         for (int sidx = 0; sidx < kMaxK; ++sidx) knn_masked[sidx] = (sidx < K) ? cyl[3 * knn_idx[sidx] + 2] < 0.0f : false;   // :759,775-778
-        prof_mark(p.prof, 9);
+        if constexpr (PROF) prof_mark(p.prof, 9);
         const float act = (d > c.catch_radius) ? 1.0f : 0.0f;                     // hideandseek.py:919-995
         const float dist_rew = (-c.dist_reward_coef * d) * act;
         const bool cap_ok = (d < c.catch_radius) && !blocked;
@@ -1564,14 +1191,14 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
             red[R_COLL] = cr; red[R_SMOOTH] = sm;
             red[R_FLAGS] = __int_as_float((cap_ok ? F_CAP : 0) | (blocked ? F_BLOCKED : 0) | (det ? F_DET : 0));
         }
-        prof_mark(p.prof, 4);
+        if constexpr (PROF) prof_mark(p.prof, 4);
         __syncthreads();                                                            // barrier 3
-        prof_mark(p.prof, 5);
+        if constexpr (PROF) prof_mark(p.prof, 5);
         // ---- phase 3c: the observation rows, beside the env wave's reductions (A8 hideandseek.py:741-886) ----
         bool det_any = false;                                                       // :787-794: any pursuer sees the evader
 #pragma unroll
         for (int j = 0; j < A; ++j)
-            det_any = det_any || (__float_as_int(sRed[(le * A + j) * kRedS + R_FLAGS]) & F_DET) != 0;
+            det_any |= (__float_as_int(sRed[(le * A + j) * kRedS + R_FLAGS]) & F_DET) != 0;
         {
             const float t = progress * c.inv_max_episode_length;                  // :796
             const V3 heading = d_quat_rot_x(s.q), up = d_quat_rot_z(s.q, 1.0f);   // multirotor.py:613-614
@@ -1600,15 +1227,17 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         }
         if (!LAB(LAB_NOSTORE | LAB_NOST_OCYL)) {                                     // the k nearest cylinders (:767-778)
             float krow[kMaxK * 5];
+            const float mv = c.mask_value, ch = c.cylinder_height, cs = c.cylinder_size;   // values, not lvalues (see d_rotor)
 #pragma unroll
             for (int sidx = 0; sidx < kMaxK; ++sidx) {
                 const float *cc = cyl + 3 * ((sidx < K) ? knn_idx[sidx] : 0);
                 const bool masked = knn_masked[sidx];
-                krow[sidx * 5] = masked ? c.mask_value : s.pos.x - cc[0];
-                krow[sidx * 5 + 1] = masked ? c.mask_value : s.pos.y - cc[1];
-                krow[sidx * 5 + 2] = masked ? c.mask_value : s.pos.z - cc[2];
-                krow[sidx * 5 + 3] = masked ? c.mask_value : c.cylinder_height;
-                krow[sidx * 5 + 4] = masked ? c.mask_value : c.cylinder_size;
+                const float rx = s.pos.x - cc[0], ry = s.pos.y - cc[1], rz = s.pos.z - cc[2];   // loaded whether masked or not: no branch per value
+                krow[sidx * 5] = masked ? mv : rx;
+                krow[sidx * 5 + 1] = masked ? mv : ry;
+                krow[sidx * 5 + 2] = masked ? mv : rz;
+                krow[sidx * 5 + 3] = masked ? mv : ch;
+                krow[sidx * 5 + 4] = masked ? mv : cs;
             }
             float *g = b.obs_cylinders + ((size_t)e0 * A + (tid & ~63)) * K * 5;
             if (K == 3) {
@@ -1630,7 +1259,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
                 wave_store_rows<5, slab_rows(A)>(slab, g, r, lane);
             }
         }
-        prof_mark(p.prof, 6);
+        if constexpr (PROF) prof_mark(p.prof, 6);
     } else {
         // ================================= env wave: lane <-> env ========================================
 #ifdef HNS_LAB
@@ -1638,8 +1267,8 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
 #endif
         if (HNS_ENV_PRIO) __builtin_amdgcn_s_setprio(HNS_ENV_PRIO);   // one wave in four, but every barrier of its workgroup waits for it
         const int le = lane, e = e0 + le;
-        prof_mark(p.prof, 0);
-        prof_mark(p.prof, 14);
+        if constexpr (PROF) prof_mark(p.prof, 0);
+        if constexpr (PROF) prof_mark(p.prof, 14);
         const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.num_envs;
         const LdsV3 L = lds_layout_v3(A, C, K);
         float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red, *sEnvOut = smem + L.envout;
@@ -1681,7 +1310,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         }
         progress += 1.0f;                                                           // isaac_env.py:236
         sTp[kEPB * 3 + le] = progress;
-        prof_mark(p.prof, 1);
+        if constexpr (PROF) prof_mark(p.prof, 1);
         float st[HNS_NUM_STATS];                  // the statistics rows of these envs: needed behind barrier 1 (not earlier: the first microseconds
 #pragma unroll                                  // of the launch are HBM-bound and these 6 MB are not on the critical path)
         for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = b.stats[(size_t)i * E + e];
@@ -1696,9 +1325,9 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
             fcx += tx;
             fcy += ty;
         }
-        prof_mark(p.prof, 2);
+        if constexpr (PROF) prof_mark(p.prof, 2);
         __syncthreads();                                                            // barrier 1: positions at t, line-of-sight flags, action errors
-        prof_mark(p.prof, 12);
+        if constexpr (PROF) prof_mark(p.prof, 12);
         // the pursuers' pushes (hideandseek.py:1074-1088), ascending; then arena, then cylinders
         V3 F = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -1741,12 +1370,12 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
             st[HNS_ST_SMOOTHNESS_MEAN] += sum_td * c.inv_num_agents;
             if (max_td > st[HNS_ST_SMOOTHNESS_MAX]) st[HNS_ST_SMOOTHNESS_MAX] = max_td;
         }
-        prof_mark(p.prof, 3);
+        if constexpr (PROF) prof_mark(p.prof, 3);
         __syncthreads();                                                            // barrier 2
-        prof_mark(p.prof, 8);
-        prof_mark(p.prof, 4);
+        if constexpr (PROF) prof_mark(p.prof, 8);
+        if constexpr (PROF) prof_mark(p.prof, 4);
         __syncthreads();                                                            // barrier 3: reward terms
-        prof_mark(p.prof, 5);
+        if constexpr (PROF) prof_mark(p.prof, 5);
         // ---- phase 3b: per-env reductions, reward, done, statistics (hideandseek.py:919-1065) ----
         const float iA = c.inv_num_agents;
         bool any_cap = false, all_blocked = true, any_coll = false, det_any = false;
@@ -1825,10 +1454,10 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
 #pragma unroll
             for (int i = 0; i < HNS_NUM_STATS; ++i) st_f1(b.stats + (size_t)i * E + e, st[i]);
         }
-        prof_mark(p.prof, 6);
+        if constexpr (PROF) prof_mark(p.prof, 6);
     }
-    prof_mark(p.prof, 7);
-    prof_mark(p.prof, 15);
+    if constexpr (PROF) prof_mark(p.prof, 7);
+    if constexpr (PROF) prof_mark(p.prof, 15);
 #ifdef HNS_LAB
     if (p.prof && lane == 0 && LAB(LAB_HWID)) {                   // where the hardware put this wave (tools/wave_placement.py)
         unsigned long long *pr = p.prof + (size_t)(blockIdx.x * (A + 1) + (tid >> 6)) * kProfSlots;
@@ -1961,7 +1590,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
         } else if (c.init_mode == HNS_INIT_SCENARIO) {
             for (int k = 0; k < C; ++k) {
                 cyl[3 * k] = c.fixed_cyl_pos[k][0]; cyl[3 * k + 1] = c.fixed_cyl_pos[k][1];
-                cyl[3 * k + 2] = (k >= c.fixed_cyl_active) ? c.invalid_z : c.fixed_cyl_pos[k][2];
+                { const float iz = c.invalid_z, fz = c.fixed_cyl_pos[k][2]; cyl[3 * k + 2] = (k >= c.fixed_cyl_active) ? iz : fz; }
             }
         } else {                                                                  // hideandseek.py:576-607
             uint8_t *occ = sGrid + le * kGridStride;   // [GN*GN] occupancy, then [GN*GN] free-cell list
@@ -2291,8 +1920,7 @@ static void select_kernels(hns_env *env) {
     }
     const char *force = getenv("HNS_STEP_DESIGN");        // "1" = the first design for every shape (A/B measurements)
     const bool v3 = c.num_targets != 2 && c.num_envs % hns::kEPB == 0 && !(force && force[0] == '1');
-    if (v3 && force && force[0] == '3') env->step_fn = hns::hns_step_v3_kernel<A>;                          // "3" = the third design (A/B)
-    else if (v3) env->step_args_fn = hns::hns_step_v4_kernel<A>;
+    if (v3) { env->step_args_fn = hns::hns_step_v4_kernel<A, false>; env->step_args_prof_fn = hns::hns_step_v4_kernel<A, true>; }
     env->threads = hns::Geo<A>::T;
     env->cyl_magic = (uint32_t)(0xFFFFFFFFull / (uint32_t)(3 * c.num_cylinders) + 1ull);
     env->grid = (c.num_envs + hns::kEPB - 1) / hns::kEPB;
@@ -2364,6 +1992,11 @@ int hns_create(const hns_cfg *cfg, hns_env **out) {
     }
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(env->step_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds_step);
     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(env->reset_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds_reset);
+    if (e1 == hipSuccess && env->step_args_fn) {
+        e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(env->step_args_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds_step);
+        if (e1 == hipSuccess)
+            e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(env->step_args_prof_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds_step);
+    }
     if (e1 != hipSuccess || e2 != hipSuccess) {
         set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
         delete env;
@@ -2475,13 +2108,13 @@ static int launch(hns_env *env, bool is_step, const Params &p, hipStream_t strea
         }
         // the events ride on the dispatch itself (start / stop of THIS kernel, the timestamps a profiler reads),
         // not on separate marker packets before and after it
-        if (split) hipExtLaunchKernelGGL(env->step_args_fn, dim3(env->grid), dim3(env->threads), (uint32_t)lds, stream, ev.first, ev.second, 0, ka);
+        if (split) hipExtLaunchKernelGGL(env->prof ? env->step_args_prof_fn : env->step_args_fn, dim3(env->grid), dim3(env->threads), (uint32_t)lds, stream, ev.first, ev.second, 0, ka);
         else hipExtLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads), (uint32_t)lds, stream, ev.first, ev.second, 0, p);
         HNS_CHECK_HIP(hipGetLastError());
         env->events.push_back(ev);
         return HNS_OK;
     }
-    if (split) hipLaunchKernelGGL(env->step_args_fn, dim3(env->grid), dim3(env->threads), lds, stream, ka);
+    if (split) hipLaunchKernelGGL(env->prof ? env->step_args_prof_fn : env->step_args_fn, dim3(env->grid), dim3(env->threads), lds, stream, ka);
     else hipLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads), lds, stream, p);
     HNS_CHECK_HIP(hipGetLastError());
     return HNS_OK;
