@@ -29,7 +29,6 @@ and DGL's FPS start point are unpinned):
 """
 import ctypes as C
 import math
-from collections import deque
 
 import numpy as np
 import torch
@@ -99,30 +98,41 @@ class GenBuffer:
     def init_history(self, init_tasks):
         self._history_buffer = np.asarray(init_tasks, dtype=np.float32).reshape(-1, self.task_dim)
 
+    def _flood_rank(self):
+        """Discovery rank of every offset (dx, dy) in a 4-neighbour breadth-first flood from the origin, neighbours taken in the
+        order -x, +x, -y, +y (hideandseek_envgen.py:246-262).  The reference floods THROUGH occupied cells, so nothing blocks and
+        the flood on the bounded grid discovers the in-grid cells in the same relative order as on the open plane (every
+        shortest-path predecessor of an in-grid cell lies between it and the start).  One table serves every start cell.
+        Built ring by ring: a ring's cells are discovered in the order their first parent sits in the previous ring."""
+        n = self.num_grid
+        rank = np.full((2 * n + 1, 2 * n + 1), -1, dtype=np.int64)
+        steps = np.array([(-1, 0), (1, 0), (0, -1), (0, 1)])
+        ring, count = np.array([[0, 0]]), 1
+        rank[n, n] = 0
+        while len(ring):
+            cand = (ring[:, None, :] + steps[None, :, :]).reshape(-1, 2)          # parents in ring order, their neighbours in step order
+            cand = cand[(np.abs(cand) <= n).all(axis=1)]
+            fresh = cand[rank[cand[:, 0] + n, cand[:, 1] + n] < 0]
+            _, first = np.unique(fresh[:, 0] * (4 * n + 4) + fresh[:, 1], return_index=True)
+            ring = fresh[np.sort(first)]                                            # first appearance wins, order kept
+            rank[ring[:, 0] + n, ring[:, 1] + n] = count + np.arange(len(ring))
+            count += len(ring)
+        return rank
+
     def init_easy_cases(self):
-        """:235-277: evader on a random free cell, pursuers on the nearest free cells (BFS)."""
-        n, out = self.num_grid, []
-        free = np.argwhere(self.grid_map == 0)
-        for _ in range(self.buffer_length):
-            x, y = free[self.rng.integers(len(free))]
-            visited = np.zeros((n, n), dtype=bool)
-            visited[x, y] = True
-            queue, found = deque([(x, y)]), []
-            while queue and len(found) < self.num_agents:
-                cx, cy = queue.popleft()
-                for dx, dy in ((-1, 0), (1, 0), (0, -1), (0, 1)):
-                    nx, ny = cx + dx, cy + dy
-                    if 0 <= nx < n and 0 <= ny < n and not visited[nx, ny]:
-                        visited[nx, ny] = True
-                        if self.grid_map[nx, ny] == 0:
-                            found.append((nx, ny))
-                            if len(found) == 4:
-                                break
-                        queue.append((nx, ny))
-            out.append(found[:self.num_agents] + [(x, y)])
-        cells = np.asarray(out, dtype=np.float64)
+        """Easy starting tasks (hideandseek_envgen.py:235-277): the evader on a random free cell, the pursuers on the free cells
+        the flood from that cell reaches first.  All samples at once: rank every free cell by the flood table, keep the
+        num_agents smallest per sample."""
+        n, A, B = self.num_grid, self.num_agents, self.buffer_length
+        free = np.argwhere(self.grid_map == 0)                                     # [F, 2]
+        start = free[np.array([self.rng.integers(len(free)) for _ in range(B)])]   # one draw per sample, in sample order
+        off = free[None, :, :] - start[:, None, :]                                 # [B, F, 2]
+        rank = self._flood_rank()[off[..., 0] + n, off[..., 1] + n]                # [B, F]; the start itself has rank 0
+        rank[rank == 0] = np.iinfo(np.int64).max                                   # the evader's cell is not a pursuer's
+        nearest = np.argsort(rank, axis=1, kind="stable")[:, :A]                   # [B, A] indices into `free`, in discovery order
+        cells = np.concatenate([free[nearest], start[:, None, :]], axis=1).astype(np.float64)   # pursuers, then the evader
         xy = np.clip((cells - n // 2) * self.grid_size, -self.boundary, self.boundary)
-        z = (self.rng.random((self.buffer_length, self.num_agents + 1, 1)) * 0.2 - 0.1) + self.max_height / 2
+        z = (self.rng.random((B, A + 1, 1)) * 0.2 - 0.1) + self.max_height / 2
         return np.concatenate([xy, z], axis=-1).astype(np.float32)
 
     def insert(self, states):

@@ -68,6 +68,31 @@ def test_genbuffer_samplenearby_and_history():
     assert easy.shape == (20, 4, 3) and (np.abs(easy[..., 2] - 0.6) <= 0.1).all()
 
 
+def test_easy_cases_take_the_cells_a_flood_reaches_first():
+    """init_easy_cases ranks cells by a precomputed flood table; here the same placement from a literal queue flood per sample."""
+    from collections import deque
+    for A, seed in ((3, 1), (4, 2), (6, 3)):
+        gb = GenBuffer(A, 5, seed=seed, buffer_length=40)
+        easy = gb.init_easy_cases()
+        n, free = gb.num_grid, np.argwhere(gb.grid_map == 0)
+        rng = np.random.default_rng(seed)
+        for k in range(40):
+            sx, sy = free[rng.integers(len(free))]
+            seen = {(sx, sy)}
+            todo, got = deque([(sx, sy)]), []
+            while todo and len(got) < A:
+                cx, cy = todo.popleft()
+                for dx, dy in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+                    q = (cx + dx, cy + dy)
+                    if 0 <= q[0] < n and 0 <= q[1] < n and q not in seen:
+                        seen.add(q)
+                        todo.append(q)
+                        if gb.grid_map[q] == 0:
+                            got.append(q)
+            want = np.clip((np.array(got[:A] + [(sx, sy)], dtype=np.float64) - n // 2) * gb.grid_size, -gb.boundary, gb.boundary)
+            np.testing.assert_array_equal(easy[k, :, :2], want.astype(np.float32))
+
+
 def test_oracle_reset_from_task_vectors():
     E, A, Cn = 40, 3, 5
     cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": Cn, "min_num": 4}, "env": {"num_envs": E}})
