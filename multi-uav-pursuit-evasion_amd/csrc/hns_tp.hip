@@ -6,8 +6,8 @@
 // (omni_drones/learning/mappo.py:572-589), I = 7 + 3A, evaluated every step on a T-frame window.
 // In the reference this is a cuDNN LSTM over [E,T,I] plus ~25 elementwise launches; here it is
 //   hns_tp_pack_kernel : parameters -> matrix-core operand image (only when they changed)
-//   hns_tp_lstm_kernel : frame append + window shift + LSTM + FC + tanh + rescale
-//   hns_tp_rows_kernel : the 20+3F-value observation rows                           (HBM-bound)
+//   hns_tp_lstm_kernel : frame append + window shift + LSTM + FC + tanh + rescale, then the 20+3F-value observation rows of
+//                        the wave's envs (a second, HBM-bound kernel until round 2)
 //
 // This is the one dense contraction near the hot path: per env and timestep z[256] = W[256 x (I+64)]·[x;h].
 // It runs on the matrix cores at fp32-class accuracy with TWO-TERM fp16 SPLITS:
@@ -545,84 +545,80 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
         for (int ch = 0; ch < 4; ++ch) o = TP_MFMA(TP_A(L.wfc, ch), hh[ch], o);
     }
 #undef TP_A
-    if (valid) {
-        float *pr = p.tp.pred + (size_t)e * R;
+    // the wave's 32 predictions also go to LDS ([env][16], the parked-frame area is free by now): the rows below need all of an env's
+    // 3F values in one lane
+    float *sPred = reinterpret_cast<float *>(simg + L.bytes / 16) + (wave * 8 * NXC) * 64;
+    {
+        float *pr = p.tp.pred + (size_t)ec * R;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = 8 * (i >> 2) + 4 * hb + (i & 3);
             if (row < R) {
                 const float v = tp_tanh_s(o[i]);
                 const int comp = row % 3;
-                pr[row] = (comp < 2) ? (v * 0.5f) * p.arena_size : ((v + 1.0f) * 0.5f) * p.max_height;
+                const float val = (comp < 2) ? (v * 0.5f) * p.arena_size : ((v + 1.0f) * 0.5f) * p.max_height;
+                if (valid) pr[row] = val;
+                sPred[(lane & 31) * 16 + row] = val;
             }
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (prof && lane == 0) prof[3] = __builtin_amdgcn_s_memrealtime();
-}
-
-// ---- observation rows: [rpos_evader(3) | drone - predicted (3F) | quat4 linvel3 heading3 up3 t x4 (17)] -------------
-// hideandseek.py:844-854 (state_self, masked rpos from the step kernel's rows) and :873-880
-// (state_drones, unmasked rpos); TP_groundtruth / TP_done :838-842.  One thread per pursuer, rows
-// assembled in LDS (odd stride) and written as one contiguous slice per workgroup.
-constexpr int kRowThreads = 256;
-__global__ __launch_bounds__(kRowThreads) void hns_tp_rows_kernel(const TpParams p) {
-    extern __shared__ __align__(16) float smem[];
-    const int R = 3 * p.F, D = HNS_SELF_DIM + R;
-    const int n_agents = p.E * p.A;
-    const int first = blockIdx.x * kRowThreads, ia = first + threadIdx.x;
-    const int nrows = min(kRowThreads, n_agents - first);
-    const bool valid = ia < n_agents;
-    float o20[HNS_SELF_DIM];
-    float px = 0.f, py = 0.f, pz = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
-    int e = 0;
-    if (valid) {
-        e = ia / p.A;
-        const float4 *s4 = reinterpret_cast<const float4 *>(p.obs_self20 + (size_t)ia * HNS_SELF_DIM);
+    // ---- observation rows of this wave's envs: [rpos_evader(3) | drone - predicted (3F) | quat4 linvel3 heading3 up3 t x4 (17)] ----
+    // hideandseek.py:844-854 (state_self, masked rpos from the step kernel's rows) and :873-880 (state_drones, unmasked rpos);
+    // TP_groundtruth / TP_done :838-842.  One lane per pursuer row (32 A rows per wave, contiguous in every buffer).  Was a second
+    // kernel (10 us + a launch); here the stores of one workgroup drain under the recurrences of the others.
+    {
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));       // rows are 4-byte aligned (D = 20 + 3F floats)
+        const int A = p.A, D = HNS_SELF_DIM + R, e_w0 = blockIdx.x * kTpEnvs + wave * 32;
+        for (int r = lane; r < 32 * A; r += 64) {
+            const int el = r / A, a = r - el * A, er = e_w0 + el;
+            if (er >= p.E) continue;
+            const size_t ia = (size_t)er * A + a;
+            float o20[HNS_SELF_DIM];
+            const float4 *s4 = reinterpret_cast<const float4 *>(p.obs_self20 + ia * HNS_SELF_DIM);
 #pragma unroll
-        for (int v = 0; v < HNS_SELF_DIM / 4; ++v) {
-            const float4 q = s4[v];
-            o20[4 * v] = q.x; o20[4 * v + 1] = q.y; o20[4 * v + 2] = q.z; o20[4 * v + 3] = q.w;
-        }
-        const float *ds = p.drone_state + (size_t)ia * 13;
-        px = ds[0]; py = ds[1]; pz = ds[2];
-        tx = p.target_pos[(size_t)e * 3]; ty = p.target_pos[(size_t)e * 3 + 1]; tz = p.target_pos[(size_t)e * 3 + 2];
-        if (ia - e * p.A == 0) {
-            // CUDA scalar-division form: tensor / python_scalar multiplies by the fp32 reciprocal
-            float *gt = p.tp.groundtruth + (size_t)e * 3;
-            gt[0] = tx * (1.0f / (0.5f * p.arena_size));
-            gt[1] = ty * (1.0f / (0.5f * p.arena_size));
-            gt[2] = (tz * (1.0f / p.max_height)) * 2.0f - 1.0f;
-            p.tp.tp_done[e] = (uint8_t)(p.progress[e] <= (float)(p.max_len - p.F));
-        }
-    }
-    for (int pass = 0; pass < 2; ++pass) {               // 0: state_self, 1: state_drones
-        float *dst = pass == 0 ? p.tp.obs_self : p.tp.state_drones;
-        if (!dst) continue;
-        if (pass) __syncthreads();
-        if (valid) {
-            float *row = smem + threadIdx.x * D;
-            if (pass == 0) { row[0] = o20[0]; row[1] = o20[1]; row[2] = o20[2]; }
-            else { row[0] = px - tx; row[1] = py - ty; row[2] = pz - tz; }
-            const float *pr = p.tp.pred + (size_t)e * R;
-            for (int f = 0; f < p.F; ++f) {
-                row[3 + 3 * f] = px - pr[3 * f];
-                row[4 + 3 * f] = py - pr[3 * f + 1];
-                row[5 + 3 * f] = pz - pr[3 * f + 2];
+            for (int v = 0; v < HNS_SELF_DIM / 4; ++v) {
+                const float4 q = s4[v];
+                o20[4 * v] = q.x; o20[4 * v + 1] = q.y; o20[4 * v + 2] = q.z; o20[4 * v + 3] = q.w;
             }
+            const float *ds = p.drone_state + ia * 13, *tg = p.target_pos + (size_t)er * 3;
+            const float px = ds[0], py = ds[1], pz = ds[2], tx = tg[0], ty = tg[1], tz = tg[2];
+            if (a == 0) {
+                // CUDA scalar-division form: tensor / python_scalar multiplies by the fp32 reciprocal
+                float *gt = p.tp.groundtruth + (size_t)er * 3;
+                gt[0] = tx * (1.0f / (0.5f * p.arena_size));
+                gt[1] = ty * (1.0f / (0.5f * p.arena_size));
+                gt[2] = (tz * (1.0f / p.max_height)) * 2.0f - 1.0f;
+                p.tp.tp_done[er] = (uint8_t)(p.progress[er] <= (float)(p.max_len - p.F));
+            }
+            const float *pr = sPred + el * 16;
+            for (int pass = 0; pass < 2; ++pass) {               // 0: state_self, 1: state_drones
+                float *dst = pass == 0 ? p.tp.obs_self : p.tp.state_drones;
+                if (!dst) continue;
+                float *g = dst + ia * D;
+                const float r0 = pass == 0 ? o20[0] : px - tx, r1 = pass == 0 ? o20[1] : py - ty, r2 = pass == 0 ? o20[2] : pz - tz;
+                if (R == 15) {                                    // five predicted points: 35 floats = 8 x 16 B + 3
+                    float w[36];
+                    w[0] = r0; w[1] = r1; w[2] = r2;
 #pragma unroll
-            for (int j = 3; j < HNS_SELF_DIM; ++j) row[R + j] = o20[j];
-        }
-        __syncthreads();
-        float *g = dst + (size_t)first * D;
-        const int n = nrows * D;
-        if ((((size_t)first * D) & 3) == 0) {
-            const int n4 = n >> 2;
-            for (int i = threadIdx.x; i < n4; i += kRowThreads) reinterpret_cast<float4 *>(g)[i] = reinterpret_cast<const float4 *>(smem)[i];
-            for (int i = (n4 << 2) + threadIdx.x; i < n; i += kRowThreads) g[i] = smem[i];
-        } else {
-            for (int i = threadIdx.x; i < n; i += kRowThreads) g[i] = smem[i];
+                    for (int f = 0; f < 5; ++f) { w[3 + 3 * f] = px - pr[3 * f]; w[4 + 3 * f] = py - pr[3 * f + 1]; w[5 + 3 * f] = pz - pr[3 * f + 2]; }
+#pragma unroll
+                    for (int j = 3; j < HNS_SELF_DIM; ++j) w[15 + j] = o20[j];
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) *reinterpret_cast<f4u *>(g + 4 * v) = (f4u){w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]};
+                    g[32] = w[32]; g[33] = w[33]; g[34] = w[34];
+                } else {
+                    g[0] = r0; g[1] = r1; g[2] = r2;
+                    for (int f = 0; f < p.F; ++f) { g[3 + 3 * f] = px - pr[3 * f]; g[4 + 3 * f] = py - pr[3 * f + 1]; g[5 + 3 * f] = pz - pr[3 * f + 2]; }
+#pragma unroll
+                    for (int j = 3; j < HNS_SELF_DIM; ++j) g[R + j] = o20[j];
+                }
+            }
         }
     }
+    if (prof && lane == 0) prof[4] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace hns
@@ -735,10 +731,6 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     const int grid = (p.E + waves * 32 - 1) / (waves * 32);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), lds, s, p);
-    HNS_CHECK_HIP(hipGetLastError());
-    const int D = HNS_SELF_DIM + 3 * p.F;
-    const int rgrid = (p.E * p.A + hns::kRowThreads - 1) / hns::kRowThreads;
-    hipLaunchKernelGGL(hns::hns_tp_rows_kernel, dim3(rgrid), dim3(hns::kRowThreads), (size_t)hns::kRowThreads * D * sizeof(float), s, p);
     HNS_CHECK_HIP(hipGetLastError());
     return HNS_OK;
 }

@@ -33,6 +33,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "agent-steps/s" and "sample" in c
     assert d["tp_mode"]["value"] > 0 and d["stream_shards"]["groups"] == 2
+    tr = d["tp_mode"]["roofline"]                                                          # the predictor against the matrix-core peak
+    assert tr["bound"] == "mfma" and tr["unit"] == "TFLOP/s" and tr["peak"] == 2500.0 and 0 < tr["frac"] < 1 and d["tp_mode"]["observe_us"] > 0
     assert "env.step" in d["config"]["workload"] and d["abi_rate"]["value"] > 0        # headline through the Python class, bare ABI beside it
     assert "look-up" in r["traffic_source"] or r["traffic"] is None                       # PMC traffic is a static look-up, labelled so
     cf = d["configs"]                                                                      # every other BASELINE configuration
