@@ -960,18 +960,18 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
 #endif
 constexpr int kPub = 11;  // published per pursuer: position at t (3), thrust vector (3), position at t+1 (3), 1 / (|thrust| + 1e-6); odd stride
 struct LdsV3 { int slab, slab_stride, pub, cyl, cyl_stride, tp, red, envout, total; };
-__host__ __device__ inline LdsV3 lds_layout_v3(int A, int C, int K) {
+__host__ __device__ inline LdsV3 lds_layout_v3(int A, int C, int K, int NT = 1) {
     LdsV3 L;
     int o = 0;
-    L.slab_stride = slab_floats(A, K, 1);
+    L.slab_stride = slab_floats(A, K, NT);
     if (L.slab_stride < 64 * 13 + 4) L.slab_stride = r4(64 * 13 + 4);
     L.slab = o;  o += A * L.slab_stride;
     L.pub = o;   o += r4(kEPB * A * kPub);
     L.cyl_stride = (3 * C) | 1;
     L.cyl = o;   o += r4(kEPB * L.cyl_stride);
-    L.tp = o;    o += r4(kEPB * 4);                      // evader at t+1 (3 per env) + the step counter (1 per env)
+    L.tp = o;    o += r4(kEPB * (3 * NT + 1));               // evader(s) at t+1 ([64][3 NT], contiguous: stored as one slice) + the step counter
     L.red = o;   o += r4(kEPB * A * red_stride(1));
-    L.envout = o; o += r4(kEPB * (A > 3 ? A : 3));           // the env wave's own staging: evader velocity [64,3], rewards [64,A]
+    L.envout = o; o += r4(kEPB * (A > 3 * NT ? A : 3 * NT)); // the env wave's own staging: evader velocity [64,3 NT], rewards [64,A]
     L.total = o;
     return L;
 }
@@ -996,12 +996,12 @@ HNS_DEV void env_store_slice(const float *lds, float *g, int n, int lane) {
 //     (:791-794) is applied by the pursuers themselves (was: the env wave patched the stored rows);
 //   * everything but the pointers behind the first loads comes from a device-resident block through the scalar cache (StepArgs).
 // Three workgroup barriers.
-template <int A, bool PROF>
-__global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArgs ka) {
+template <int A, int NT, bool PROF>
+__global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_v4_kernel(const StepArgs ka) {
     // the block behind `rest` is never written while the kernel runs: read it as constant memory (scalar loads, placed like kernel-argument loads)
     typedef const Params __attribute__((address_space(4))) ParamsC;
     ParamsC &p = *(ParamsC *)ka.rest;
-    constexpr int NA = Geo<A>::NA, SD = HNS_SELF_DIM, kRedS = red_stride(1);
+    constexpr int NA = Geo<A>::NA, SD = NT == 2 ? 24 : HNS_SELF_DIM, kRedS = red_stride(1), T3 = 3 * NT;
     extern __shared__ __align__(16) float smem[];
     const auto &c = p.cfg;
     const auto &b = p.buf;
@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         if constexpr (PROF) prof_mark(p.prof, 14);
         const int C = c.num_cylinders, K = c.obs_max_cylinder;
         const bool with_state = c.write_critic_state && b.state_drones != nullptr;
-        const LdsV3 L = lds_layout_v3(A, C, K);
+        const LdsV3 L = lds_layout_v3(A, C, K, NT);
         float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red;
         float *slab = smem + L.slab + (tid >> 6) * L.slab_stride;
         const float4 ta = d_action_tanh(act4);           // needs the action only: evaluated while the rest is in flight
@@ -1121,27 +1121,40 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         __syncthreads();                                                            // barrier 2
         if constexpr (PROF) prof_mark(p.prof, 8);
         // ---- phase 3a: distance and line of sight to the evader, the k nearest cylinders, per-pursuer reward terms on S_{t+1} ----
-        const float progress = sTp[kEPB * 3 + le];                                  // progress + 1, published by the env wave
-        const V3 tp = {sTp[le * 3], sTp[le * 3 + 1], sTp[le * 3 + 2]};
+        const float progress = sTp[kEPB * T3 + le];                                 // progress + 1, published by the env wave
+        const V3 tp = {sTp[le * T3], sTp[le * T3 + 1], sTp[le * T3 + 2]};
+        V3 tpB = tp;                                                                // second evader (extension, include/hns.h)
+        if constexpr (NT == 2) tpB = V3{sTp[le * T3 + 3], sTp[le * T3 + 4], sTp[le * T3 + 5]};
         const float *cyl = sCyl + le * L.cyl_stride;
         const float rtx = s.pos.x - tp.x, rty = s.pos.y - tp.y, rtz = s.pos.z - tp.z;
         const float d = d_norm3(rtx, rty, rtz);                                     // |evader - pursuer| (hideandseek.py:921, :780)
         int knn_idx[kMaxK + 1];
         bool knn_masked[kMaxK];
-        bool blocked, unused;
+        bool blocked, blockedB;
 #ifdef HNS_LAB
-        if (LAB(LAB_NOLOS2)) { cylinder_pass<1, false>(c, C, K, s.pos, tp, tp, cyl, knn_idx, blocked, unused); } else
+        if (LAB(LAB_NOLOS2)) { cylinder_pass<NT, false>(c, C, K, s.pos, tp, tpB, cyl, knn_idx, blocked, blockedB); } else
 #endif
-        cylinder_pass<1, true>(c, C, K, s.pos, tp, tp, cyl, knn_idx, blocked, unused);
+        cylinder_pass<NT, true>(c, C, K, s.pos, tp, tpB, cyl, knn_idx, blocked, blockedB);
         const bool det = (d < c.drone_detect_radius) && !blocked;                   // :787-789
-        last4.w = blocked ? 1.0f : 0.0f;                                            // = the next step's line of sight at ITS t
+        last4.w = (float)((blocked ? 1 : 0) + (NT == 2 && blockedB ? 2 : 0));       // = the next step's line of sight at ITS t
         if (!LAB(LAB_NOSTORE | LAB_NOST_REC)) reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
 #pragma unroll
         for (int sidx = 0; sidx < kMaxK; ++sidx) knn_masked[sidx] = (sidx < K) ? cyl[3 * knn_idx[sidx] + 2] < 0.0f : false;   // :759,775-778
         if constexpr (PROF) prof_mark(p.prof, 9);
-        const float act = (d > c.catch_radius) ? 1.0f : 0.0f;                     // hideandseek.py:919-995
-        const float dist_rew = (-c.dist_reward_coef * d) * act;
-        const bool cap_ok = (d < c.catch_radius) && !blocked;
+        bool cap_ok = (d < c.catch_radius) && !blocked, all_blk = blocked, detB = false;   // hideandseek.py:919-995
+        float dn = d;
+        float r1x = 0.f, r1y = 0.f, r1z = 0.f;
+        if constexpr (NT == 2) {
+            // extension: distance term to the NEAREST evader, capture of ANY evader, `blocked` = no line of sight to either
+            r1x = s.pos.x - tpB.x; r1y = s.pos.y - tpB.y; r1z = s.pos.z - tpB.z;
+            const float d1 = d_norm3(r1x, r1y, r1z);
+            detB = (d1 < c.drone_detect_radius) && !blockedB;
+            cap_ok = cap_ok || ((d1 < c.catch_radius) && !blockedB);
+            all_blk = blocked && blockedB;
+            dn = d1 < d ? d1 : d;
+        }
+        const float act = (dn > c.catch_radius) ? 1.0f : 0.0f;
+        const float dist_rew = (-c.dist_reward_coef * dn) * act;
         // Threshold tests on norms: RN(sqrt(x)) compared with a limit is decided on x itself unless x lies within 2^-19 of
         // the squared limit; only then the correctly rounded square root is taken (same booleans as the plain form).
         bool fast = false;
@@ -1189,28 +1202,33 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
             float *red = sRed + tid * kRedS;
             red[R_DIST] = dist_rew; red[R_SPEED] = speed_rew; red[R_CC] = cc; red[R_CD] = cd; red[R_CW] = cw;
             red[R_COLL] = cr; red[R_SMOOTH] = sm;
-            red[R_FLAGS] = __int_as_float((cap_ok ? F_CAP : 0) | (blocked ? F_BLOCKED : 0) | (det ? F_DET : 0));
+            red[R_FLAGS] = __int_as_float((cap_ok ? F_CAP : 0) | (all_blk ? F_BLOCKED : 0) | (det ? F_DET : 0) | (detB ? F_DET1 : 0));
         }
         if constexpr (PROF) prof_mark(p.prof, 4);
         __syncthreads();                                                            // barrier 3
         if constexpr (PROF) prof_mark(p.prof, 5);
         // ---- phase 3c: the observation rows, beside the env wave's reductions (A8 hideandseek.py:741-886) ----
-        bool det_any = false;                                                       // :787-794: any pursuer sees the evader
+        bool det_any = false, det_any1 = false;                                     // :787-794: any pursuer sees the evader
 #pragma unroll
-        for (int j = 0; j < A; ++j)
-            det_any |= (__float_as_int(sRed[(le * A + j) * kRedS + R_FLAGS]) & F_DET) != 0;
+        for (int j = 0; j < A; ++j) {
+            const int fl = __float_as_int(sRed[(le * A + j) * kRedS + R_FLAGS]);
+            det_any |= (fl & F_DET) != 0;
+            det_any1 |= (fl & F_DET1) != 0;
+        }
         {
             const float t = progress * c.inv_max_episode_length;                  // :796
             const V3 heading = d_quat_rot_x(s.q), up = d_quat_rot_z(s.q, 1.0f);   // multirotor.py:613-614
             const float m = c.mask_value;
-            const float row[SD] = {det_any ? rtx : m, det_any ? rty : m, det_any ? rtz : m, s.q.w, s.q.x, s.q.y, s.q.z, s.lin.x, s.lin.y, s.lin.z,
-                                   heading.x, heading.y, heading.z, up.x, up.y, up.z, t, t, t, t};            // :856-863
+            float row[SD] = {det_any ? rtx : m, det_any ? rty : m, det_any ? rtz : m, s.q.w, s.q.x, s.q.y, s.q.z, s.lin.x, s.lin.y, s.lin.z,
+                             heading.x, heading.y, heading.z, up.x, up.y, up.z, t, t, t, t};                  // :856-863
+            if constexpr (NT == 2) { row[20] = det_any1 ? r1x : m; row[21] = det_any1 ? r1y : m; row[22] = det_any1 ? r1z : m; row[23] = 0.0f; }
             if (!LAB(LAB_NOSTORE | LAB_NOST_SELF)) wave_store_rows<SD, slab_rows(A)>(slab, b.obs_self + ((size_t)e0 * A + (tid & ~63)) * SD, row, lane);
             if (with_state && !LAB(LAB_NOSTORE | LAB_NOST_SELF)) {                  // :871-886 (never masked)
                 float rs[SD];
 #pragma unroll
                 for (int i = 0; i < SD; ++i) rs[i] = row[i];
                 rs[0] = rtx; rs[1] = rty; rs[2] = rtz;
+                if constexpr (NT == 2) { rs[20] = r1x; rs[21] = r1y; rs[22] = r1z; }
                 wave_store_rows<SD, slab_rows(A)>(slab, b.state_drones + ((size_t)e0 * A + (tid & ~63)) * SD, rs, lane);
             }
         }
@@ -1270,12 +1288,14 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         if constexpr (PROF) prof_mark(p.prof, 0);
         if constexpr (PROF) prof_mark(p.prof, 14);
         const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.num_envs;
-        const LdsV3 L = lds_layout_v3(A, C, K);
+        const LdsV3 L = lds_layout_v3(A, C, K, NT);
         float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red, *sEnvOut = smem + L.envout;
         float *cylw = sCyl + le * L.cyl_stride;
         // the evader at t
-        const float *gt = b.target_pos + (size_t)e * 3;
+        const float *gt = b.target_pos + (size_t)e * T3;
         const V3 tp0 = {gt[0], gt[1], gt[2]};
+        V3 tp1 = tp0;
+        if constexpr (NT == 2) tp1 = V3{gt[3], gt[4], gt[5]};
         float progress = b.progress[e];
         {   // this workgroup's cylinders are one contiguous slice [64][3C]: coalesced 4-byte loads (lane <-> consecutive floats), scattered
             // into rows of odd stride (lane = env reads its row conflict-free); index / 3C by multiply-high.  Eight cylinders (24 passes)
@@ -1309,7 +1329,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
             __builtin_amdgcn_wave_barrier();
         }
         progress += 1.0f;                                                           // isaac_env.py:236
-        sTp[kEPB * 3 + le] = progress;
+        sTp[kEPB * T3 + le] = progress;
         if constexpr (PROF) prof_mark(p.prof, 1);
         float st[HNS_NUM_STATS];                  // the statistics rows of these envs: needed behind barrier 1 (not earlier: the first microseconds
 #pragma unroll                                  // of the launch are HBM-bound and these 6 MB are not on the critical path)
@@ -1325,32 +1345,63 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
             fcx += tx;
             fcy += ty;
         }
+        V3 Fenv1 = {0.f, 0.f, 0.f};
+        float gcx = 0.f, gcy = 0.f;
+        if constexpr (NT == 2) {               // each evader runs the potential field on its own (they ignore each other)
+            bool out1 = false;
+            Fenv1 = d_prey_arena_term(c, tp1, out1);
+            out_of_arena = out_of_arena || out1;
+#pragma unroll 4
+            for (int k = 0; k < C; ++k) {
+                float tx, ty;
+                d_prey_cylinder_term(c, tp1, cylw[3 * k], cylw[3 * k + 1], cylw[3 * k + 2], tx, ty);
+                gcx += tx;
+                gcy += ty;
+            }
+        }
         if constexpr (PROF) prof_mark(p.prof, 2);
         __syncthreads();                                                            // barrier 1: positions at t, line-of-sight flags, action errors
         if constexpr (PROF) prof_mark(p.prof, 12);
         // the pursuers' pushes (hideandseek.py:1074-1088), ascending; then arena, then cylinders
-        V3 F = {0.f, 0.f, 0.f};
+        V3 F = {0.f, 0.f, 0.f}, G = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < A; ++j) {
             const float *pj = sPub + (le * A + j) * kPub;
             const V3 dp = {pj[0], pj[1], pj[2]};
-            const bool blocked_pre = pj[10] != 0.0f;                                // :1080, carried over from the previous step's observation
-            const V3 fp = d_prey_pursuer_term(c, dp, tp0, blocked_pre);
+            const int los = (int)pj[10];                                            // :1080, carried over from the previous step's observation (bit k: evader k)
+            const V3 fp = d_prey_pursuer_term(c, dp, tp0, (los & 1) != 0);
             F.x = (j == 0) ? fp.x : F.x + fp.x;
             F.y = (j == 0) ? fp.y : F.y + fp.y;
             F.z = (j == 0) ? fp.z : F.z + fp.z;
+            if constexpr (NT == 2) {
+                const V3 f1 = d_prey_pursuer_term(c, dp, tp1, (los & 2) != 0);
+                G.x = (j == 0) ? f1.x : G.x + f1.x;
+                G.y = (j == 0) ? f1.y : G.y + f1.y;
+                G.z = (j == 0) ? f1.z : G.z + f1.z;
+            }
         }
         F.x = F.x + Fenv.x; F.y = F.y + Fenv.y; F.z = F.z + Fenv.z;
         F.x = F.x + fcx; F.y = F.y + fcy; F.z = F.z + 0.0f;
         const V3 tvel = {(c.v_prey * F.x) / (__builtin_fabsf(F.x) + 1e-5f), (c.v_prey * F.y) / (__builtin_fabsf(F.y) + 1e-5f),
                          (c.v_prey * F.z) / (__builtin_fabsf(F.z) + 1e-5f)};        // per-axis speed (:741)
         const V3 tpn = {tp0.x + tvel.x * c.dt, tp0.y + tvel.y * c.dt, tp0.z + tvel.z * c.dt};
-        sTp[le * 3] = tpn.x; sTp[le * 3 + 1] = tpn.y; sTp[le * 3 + 2] = tpn.z;
+        sTp[le * T3] = tpn.x; sTp[le * T3 + 1] = tpn.y; sTp[le * T3 + 2] = tpn.z;
         { const float sf = (tpn.x + tpn.y) + tpn.z; flag_nonfinite(b.nonfinite, (sf - sf) != 0.0f, 2u); }
-        if (!LAB(LAB_NOSTORE)) {            // [64,3] slices, whole lines: the new position is already laid out in sTp
-            sEnvOut[le * 3] = tvel.x; sEnvOut[le * 3 + 1] = tvel.y; sEnvOut[le * 3 + 2] = tvel.z;
-            env_store_slice(sTp, b.target_pos + (size_t)e0 * 3, kEPB * 3, lane);
-            env_store_slice(sEnvOut, b.target_vel + (size_t)e0 * 3, kEPB * 3, lane);
+        V3 tvel1 = {0.f, 0.f, 0.f};
+        if constexpr (NT == 2) {
+            G.x = G.x + Fenv1.x; G.y = G.y + Fenv1.y; G.z = G.z + Fenv1.z;
+            G.x = G.x + gcx; G.y = G.y + gcy; G.z = G.z + 0.0f;
+            tvel1 = V3{(c.v_prey * G.x) / (__builtin_fabsf(G.x) + 1e-5f), (c.v_prey * G.y) / (__builtin_fabsf(G.y) + 1e-5f),
+                       (c.v_prey * G.z) / (__builtin_fabsf(G.z) + 1e-5f)};
+            const V3 tpn1 = {tp1.x + tvel1.x * c.dt, tp1.y + tvel1.y * c.dt, tp1.z + tvel1.z * c.dt};
+            sTp[le * T3 + 3] = tpn1.x; sTp[le * T3 + 4] = tpn1.y; sTp[le * T3 + 5] = tpn1.z;
+            { const float sf = (tpn1.x + tpn1.y) + tpn1.z; flag_nonfinite(b.nonfinite, (sf - sf) != 0.0f, 2u); }
+        }
+        if (!LAB(LAB_NOSTORE)) {            // [64,3 NT] slices, whole lines: the new position is already laid out in sTp
+            sEnvOut[le * T3] = tvel.x; sEnvOut[le * T3 + 1] = tvel.y; sEnvOut[le * T3 + 2] = tvel.z;
+            if constexpr (NT == 2) { sEnvOut[le * T3 + 3] = tvel1.x; sEnvOut[le * T3 + 4] = tvel1.y; sEnvOut[le * T3 + 5] = tvel1.z; }
+            env_store_slice(sTp, b.target_pos + (size_t)e0 * T3, kEPB * T3, lane);
+            env_store_slice(sEnvOut, b.target_vel + (size_t)e0 * T3, kEPB * T3, lane);
         }
         {   // statistics that only need phase-1 data (A10 hideandseek.py:731-733, :1097-1098, :996-997)
             float sum_ae = 0.f, sum_td = 0.f, max_td = 0.f;
@@ -1378,7 +1429,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         if constexpr (PROF) prof_mark(p.prof, 5);
         // ---- phase 3b: per-env reductions, reward, done, statistics (hideandseek.py:919-1065) ----
         const float iA = c.inv_num_agents;
-        bool any_cap = false, all_blocked = true, any_coll = false, det_any = false;
+        bool any_cap = false, all_blocked = true, any_coll = false, det_any = false, det_any1 = false;
         float sum_dist = 0, sum_speed = 0, sum_cc = 0, sum_cd = 0, sum_cw = 0, sum_coll = 0, sum_smooth = 0;
 #pragma unroll
         for (int j = 0; j < A; ++j) {
@@ -1387,6 +1438,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
             any_cap |= (fl & F_CAP) != 0;
             all_blocked &= (fl & F_BLOCKED) != 0;
             det_any |= (fl & F_DET) != 0;
+            det_any1 |= (fl & F_DET1) != 0;
             any_coll |= red[R_COLL] < 0.0f;
             if (j == 0) {
                 sum_dist = red[R_DIST]; sum_speed = red[R_SPEED]; sum_cc = red[R_CC]; sum_cd = red[R_CD]; sum_cw = red[R_CW];
@@ -1396,7 +1448,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
                 sum_coll += red[R_COLL]; sum_smooth += red[R_SMOOTH];
             }
         }
-        const float detf = det_any ? 1.0f : 0.0f;
+        const float detf = (det_any || (NT == 2 && det_any1)) ? 1.0f : 0.0f;
         const float detect_rew = c.detect_reward_coef * detf;
         const float catch_rew = c.catch_reward_coef * (any_cap ? 1.0f : 0.0f);
         float sum_rew = 0.f;
@@ -1448,7 +1500,7 @@ __global__ __launch_bounds__(Geo<A>::T, 1) void hns_step_v4_kernel(const StepArg
         ST(HNS_ST_RETURN) += sum_rew * iA;
 #undef ST
         b.done[e] = (uint8_t)done;
-        if (b.detect) b.detect[e] = (uint8_t)det_any;
+        if (b.detect) b.detect[e] = (uint8_t)((det_any ? 1 : 0) | (NT == 2 && det_any1 ? 2 : 0));      // bit k: evader k detected
         b.progress[e] = progress;
         if (!LAB(LAB_NOSTORE | LAB_NOST_STATS)) {
 #pragma unroll
@@ -1919,15 +1971,16 @@ static void select_kernels(hns_env *env) {
         env->reset_fn = hns::hns_reset_kernel<A, 1>;
     }
     const char *force = getenv("HNS_STEP_DESIGN");        // "1" = the first design for every shape (A/B measurements)
-    const bool v3 = c.num_targets != 2 && c.num_envs % hns::kEPB == 0 && !(force && force[0] == '1');
-    if (v3) { env->step_args_fn = hns::hns_step_v4_kernel<A, false>; env->step_args_prof_fn = hns::hns_step_v4_kernel<A, true>; }
+    const bool v3 = c.num_envs % hns::kEPB == 0 && !(force && force[0] == '1');
+    if (v3 && c.num_targets == 2) env->step_args_fn = env->step_args_prof_fn = hns::hns_step_v4_kernel<A, 2, false>;   // (no phase stamps with two evaders)
+    else if (v3) { env->step_args_fn = hns::hns_step_v4_kernel<A, 1, false>; env->step_args_prof_fn = hns::hns_step_v4_kernel<A, 1, true>; }
     env->threads = hns::Geo<A>::T;
     env->cyl_magic = (uint32_t)(0xFFFFFFFFull / (uint32_t)(3 * c.num_cylinders) + 1ull);
     env->grid = (c.num_envs + hns::kEPB - 1) / hns::kEPB;
     hns::Lds L = hns::lds_layout(A, c.num_cylinders, c.obs_max_cylinder, c.num_targets == 2 ? 2 : 1);
     env->lds_step = (size_t)L.total * sizeof(float);
     env->lds_reset = env->lds_step + (size_t)hns::kEPB * hns::kGridStride;   // + per-env occupancy grid / free-cell list
-    if (v3) env->lds_step = (size_t)hns::lds_layout_v3(A, c.num_cylinders, c.obs_max_cylinder).total * sizeof(float);
+    if (v3) env->lds_step = (size_t)hns::lds_layout_v3(A, c.num_cylinders, c.obs_max_cylinder, c.num_targets == 2 ? 2 : 1).total * sizeof(float);
 }
 
 
