@@ -352,6 +352,30 @@ def test_line_of_sight_flag_is_derived_state():
         assert np.array_equal(a[k], b[k], equal_nan=True), k
 
 
+def test_line_of_sight_flag_at_full_size():
+    """65 536 envs, wild actions, masked resets: after every block of steps the carried flag column equals what
+    hns_refresh_derived_state recomputes from the positions (a separate kernel, one plain test per pursuer)."""
+    E, A, C = 65536, 3, 8
+    env = make_env(E, A, C, max_len=12, cylinder={"min_num": 2})
+    env.set_seed(21)
+    env.reset()
+    gen = torch.Generator(device=env.device).manual_seed(9)
+    for block in range(4):
+        for t in range(9):
+            td = env.step(env.rand_step_input(torch.randn(E, A, 4, generator=gen, device=env.device) * (0.3, 1.0, 3.0, 30.0)[block]))
+            done = td[("next", "done")].reshape(E)
+            if bool(done.any()):
+                rtd = env.rand_step_input()
+                rtd.set("_reset", done)
+                env.reset(rtd)
+        carried = env._bufs["pid_last_rate"][..., 3].clone()
+        assert env._lib.hns_refresh_derived_state(env._env, env._stream()) == 0
+        torch.cuda.synchronize()
+        fresh = env._bufs["pid_last_rate"][..., 3]
+        assert torch.equal(carried, fresh), (block, int((carried != fresh).sum()))
+        assert 0 < int(fresh.sum()) < E * A                       # both outcomes occur
+
+
 def test_stream_shards_reproduce_the_whole_batch():
     """The batch as independent shards on separate HIP streams of one GPU (bench.py's `stream_shards` leg, the
     multi-GPU sharding applied inside a GPU): every buffer equals the corresponding slice of the one-launch batch."""

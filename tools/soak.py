@@ -27,6 +27,10 @@ for name, (task, algo) in modes.items():
     dt = time.perf_counter() - t0
     b = env._bufs
     ok = env.check_finite()
+    carried = b["pid_last_rate"][..., 3].clone()          # the carried line-of-sight flag against a fresh evaluation of the final state
+    assert env._lib.hns_refresh_derived_state(env._env, env._stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(carried, b["pid_last_rate"][..., 3]), "carried line-of-sight flag differs from a fresh evaluation"
     pos = b["drone_state"][..., :3]
     sp = b["drone_state"][..., 7:10].norm(dim=-1)
     qn = b["drone_state"][..., 3:7].norm(dim=-1)
