@@ -344,6 +344,8 @@ def main():
         env_tp = make_env(E, A, C, algo={"use_TP_net": 1})
         n = args.tp_steps
         dt_tp = timed_steps(env_tp, tds, n, 20)
+        timed_steps(env_tp, tds, 64, 4, timing=4)                 # the step kernel's own duration in this mode (events on its dispatch)
+        tp_step_us = env_tp.kernel_ms()[0] * 1e3
         T, F, I = env_tp.tp_history_step, env_tp.tp_future_step, env_tp.tp_frame_dim
         flop_env = 2.0 * (T * 4 * 64 * (I + 64) + 64 * 3 * F)          # useful FLOP of LSTM(I->64) x T + Linear(64->3F), per env and step
         # the predictor alone (frame append + LSTM + rows: hns_tp_observe), bracketed by events on the stream it is launched on
@@ -359,7 +361,7 @@ def main():
         obs_us = ev0.elapsed_time(ev1) / reps * 1e3
         tflops = flop_env * E / (obs_us * 1e-6) / 1e12
         tp_mode = {"value": round(E * A * n / dt_tp, 1), "unit": "agent-steps/s", "steps": n, "ms_per_step": round(dt_tp / n * 1e3, 5),
-                   "useful_mflop_per_env": round(flop_env / 1e6, 4), "observe_us": round(obs_us, 2),
+                   "useful_mflop_per_env": round(flop_env / 1e6, 4), "observe_us": round(obs_us, 2), "step_kernel_us": round(tp_step_us, 2),
                    "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tflops / 2500.0, 4),
                                 "note": "useful FLOP of LSTM + FC per launch of hns_tp_observe / its duration / dense f16 peak; every product is issued as three "
                                         "f16 MFMAs (hi*hi, hi*lo, lo*hi of the split operands) to hold the 1e-5 parity, so the matrix pipe does 3x this"},
