@@ -241,7 +241,7 @@ def main():
         except Exception:  # noqa: BLE001
             pass
         roofline["traffic"] = traffic
-        roofline["kernel"] = "hns_step_v4_kernel<%d,false>" % A if (args.targets == 1 and E % 64 == 0) else "hns_step_kernel<%d,%d>" % (A, args.targets)
+        roofline["kernel"] = "hns_step_v4_kernel<%d,%d,false>" % (A, args.targets) if E % 64 == 0 else "hns_step_kernel<%d,%d,false>" % (A, args.targets)
         if kernel_by_rank:
             roofline["kernel_us_by_rank"] = {"min": min(kernel_by_rank), "max": max(kernel_by_rank), "all": kernel_by_rank}
         # achievable HBM bandwidth on this box ("measure achievable with a device copy kernel and report both")
