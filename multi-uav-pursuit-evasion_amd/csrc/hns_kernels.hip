@@ -88,7 +88,7 @@ static_assert(sizeof(StepArgs) == 64, "the argument block of the step kernel is 
 #define LAB(bit) false
 #endif
 enum { LAB_NOSTORE = 1, LAB_NOP1 = 2, LAB_NOP2 = 4, LAB_NOP3A = 8, LAB_NOP3B = 16, LAB_NOLOAD = 32,
-       LAB_NOST_SELF = 64, LAB_NOST_OTH = 128, LAB_NOST_REC = 256, LAB_NOST_DS = 512, LAB_NOST_OCYL = 1024, LAB_NOST_STATS = 2048, LAB_HWID = 4096, LAB_NOLOS1 = 8192, LAB_NOLOS2 = 16384 };
+       LAB_NOST_SELF = 64, LAB_NOST_OTH = 128, LAB_NOST_REC = 256, LAB_NOST_DS = 512, LAB_NOST_OCYL = 1024, LAB_NOST_STATS = 2048, LAB_HWID = 4096, LAB_NOLOS2 = 16384 };
 
 constexpr int kProfSlots = 16;
 // lane 0 of every wave stamps s_memtime at a phase boundary (only when a buffer is attached)
@@ -1280,9 +1280,6 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_v4_kernel
         if constexpr (PROF) prof_mark(p.prof, 6);
     } else {
         // ================================= env wave: lane <-> env ========================================
-#ifdef HNS_LAB
-        if (p.lab_stagger == 3) __builtin_amdgcn_s_setprio(3); else if (p.lab_stagger == 0)
-#endif
         if (HNS_ENV_PRIO) __builtin_amdgcn_s_setprio(HNS_ENV_PRIO);   // one wave in four, but every barrier of its workgroup waits for it
         const int le = lane, e = e0 + le;
         if constexpr (PROF) prof_mark(p.prof, 0);

@@ -32,7 +32,7 @@ z = rt0.min()
 dur_c = t[..., 7] - t[..., 0]
 f = np.median(dur_c / np.maximum(rt1 - rt0, 1.0))          # shader cycles per ns
 print("shader clock ~ %.2f GHz; kernel span %.0f ns" % (f, rt1.max() - z))
-marks = [("start", 0), ("loaded", 1), ("pid done", 10), ("b0 passed", 11), ("p1 done", 2), ("b1 passed", 12), ("p2 done", 3), ("b2 passed", 8), ("obs done", 9), ("3a done", 4), ("b3 passed", 5), ("3b done", 6), ("end", 7)]
+marks = [("start", 0), ("loaded", 1), ("p1 done", 2), ("b1 passed", 12), ("p2 done", 3), ("b2 passed", 8), ("obs done", 9), ("3a done", 4), ("b3 passed", 5), ("3b done", 6), ("end", 7)]
 rounds = (np.arange(E // 64) >> 8) & 3
 print("envs", E)
 for role, sl in (("agent waves", slice(0, A)), ("env wave", slice(A, A + 1))):
