@@ -317,6 +317,32 @@ def test_steps_captured_in_a_hip_graph_replay_identically():
         assert np.array_equal(a[k], b[k], equal_nan=True), k
 
 
+def test_setters_reach_the_kernel():
+    """The step kernel reads its configuration from a device-resident block: the evader-speed curriculum and the
+    smoothness schedule must refresh it.  Same run on the oracle with the struct edited in place; bit-exact before and after."""
+    import ctypes as C
+    E, A = 128, 3
+    env = make_env(E, A, 6, max_len=50, use_deployment=1, init_smoothness_coef=1.0)
+    env.set_seed(4)
+    env.reset()
+    host = O.alloc_buffers(env.hcfg)
+    O.reset(env.hcfg, host, None, env.seed, 0)
+    g = torch.Generator().manual_seed(17)
+    for t in range(9):
+        if t == 3:
+            assert env._lib.hns_set_v_prey(env._env, C.c_float(0.7)) == 0
+            env.hcfg.v_prey = 0.7
+        if t == 6:
+            assert env._lib.hns_set_smoothness_coef(env._env, C.c_float(3.5)) == 0
+            env.hcfg.smoothness_coef = 3.5
+        action = torch.randn(E, A, 4, generator=g)
+        env.step(env.rand_step_input(action.to(env.device)))
+        O.step(env.hcfg, host, action.numpy())
+        assert_same(host, env.export_state(), f"step {t}")
+    assert (np.abs(np.abs(host["target_vel"]) - 0.7) < 0.05).mean() > 0.9          # the new speed is what the evaders fly at
+    assert (host["stats"][abi.STAT_NAMES.index("smoothness_coef")] == 3.5).all()
+
+
 def test_line_of_sight_flag_is_derived_state():
     """The step kernel does not re-evaluate the evader policy's line of sight (hideandseek.py:1080): it reads the flag the previous
     step / the reset stored in pid_last_rate[..., 3] for the same positions (include/hns.h).  (i) after resets and steps the stored
