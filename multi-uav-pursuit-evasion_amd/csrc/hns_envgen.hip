@@ -41,6 +41,70 @@ struct FpsParams {
 };
 
 
+// One round's all-to-all: reduce the workgroup's candidate, publish it as one tagged granule (slots double-buffered by round parity),
+// sweep every workgroup's granule and take the same arg-max everywhere.  Returns the winner's index (its coordinates are in sQ when
+// sQ is given), or -1 after reporting that a workgroup never showed up (every spin is bounded).
+template <int THREADS>
+HNS_DEV int fps_exchange(const FpsParams &p, gu64 *gran, int G, int g_self, int r, unsigned long long best, unsigned long long *s_best,
+                         int *s_cur, int *s_fail, float *sQ) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = p.d;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) s_best[wave] = best;
+    __syncthreads();
+    const unsigned long long tag = (unsigned long long)(r % 4095 + 1) << 52;
+    gu64 *slot = gran + (size_t)(r & 1) * G;
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < THREADS / 64; ++w) best = s_best[w] > best ? s_best[w] : best;
+        __hip_atomic_store(slot + g_self, tag | best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // sweep every workgroup's candidate (wave 0): all loads in flight at once, same arg-max everywhere
+    if (wave == 0) {
+        unsigned long long v[kFpsMaxGroups / 64];
+        bool fail = false;
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < kFpsMaxGroups / 64; ++u) {
+                const int g = u * 64 + lane;
+                v[u] = g < G ? __hip_atomic_load(slot + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+            }
+#pragma unroll
+            for (int u = 0; u < kFpsMaxGroups / 64; ++u) ok = ok && ((v[u] >> 52) == (tag >> 52));
+            if (__all(ok)) break;
+            if (++spins > kFpsSpinLimit) { fail = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        unsigned long long gb = 0;
+#pragma unroll
+        for (int u = 0; u < kFpsMaxGroups / 64; ++u) {
+            const unsigned long long c52 = v[u] & 0xFFFFFFFFFFFFFull;
+            gb = c52 > gb ? c52 : gb;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long o = __shfl_xor(gb, off);
+            gb = o > gb ? o : gb;
+        }
+        const int gi = (int)(0xFFFFFu - (unsigned)(gb & 0xFFFFFu));
+        if (lane == 0) { *s_cur = gi; if (fail) *s_fail = 1; }
+        // the winner's coordinates for the next round (immutable input: plain loads)
+        if (!fail && sQ)
+            for (int c = lane; c < d; c += 64) sQ[c] = p.points[(size_t)gi * d + c];
+    }
+    __syncthreads();
+    if (*s_fail) {                                   // a workgroup never showed up: give up loudly, never hang
+        if (tid == 0) __hip_atomic_store((gu64 *)p.scratch, 1ull + (unsigned long long)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return -1;
+    }
+    return *s_cur;
+}
+
 __global__ __launch_bounds__(kFpsThreads) void hns_fps_kernel(const FpsParams p) {
     extern __shared__ __align__(16) float s_dyn[];     // [d] the newest sample, then the staged points
     __shared__ unsigned long long s_best[kFpsThreads / 64];
@@ -98,62 +162,80 @@ __global__ __launch_bounds__(kFpsThreads) void hns_fps_kernel(const FpsParams p)
                 best = cand > best ? cand : best;
             }
         }
+        cur = fps_exchange<kFpsThreads>(p, gran, G, blockIdx.x, r, best, s_best, &s_cur, &s_fail, sQ);
+        if (cur < 0) return;
+    }
+}
+
+// XCD-local variant for the generator's own shape (at most 36 coordinates, at most 65 536 points).  The per-round exchange between 32
+// workgroups of ONE XCD costs 0.8 us against 2.6 us across the chip (tools/microbench/exchange_latency.hip) — with the same agent-scope
+// stores and loads, so the result does not depend on where the workgroups actually land, only the time does.  The points (10 MB for
+// 70 000 tasks) fit neither that XCD's LDS nor its L2: they live in registers, two per thread at 1024 threads per CU (a third one spills; exactly 36
+// coordinates: 3 pursuers + evader + 8 cylinders, the shape of BASELINE config 4; other shapes take the chip-wide kernel); the newest
+// sample's coordinates are workgroup-uniform and come in through scalar loads (`points` is immutable input).  Launched as 8 x 32 workgroups;
+// those with blockIdx % 8 != 0 — by the round-robin dispatch, the ones on the other XCDs — leave at once.
+constexpr int kFxThreads = 1024, kFxGroups = 32, kFxStride = 8, kFxPts = 2, kFxD = 36;
+
+__global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams p) {
+    if (blockIdx.x % kFxStride) return;
+    __shared__ unsigned long long s_best[kFxThreads / 64];
+    __shared__ int s_cur;
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, g_self = blockIdx.x / kFxStride;
+    const int gtid = g_self * kFxThreads + tid, stride = kFxGroups * kFxThreads;
+    gu64 *gran = (gu64 *)(p.scratch + 8);
+    typedef const float __attribute__((address_space(4))) cfloat;      // `points` is immutable while the kernel runs: constant memory
+    cfloat *qbase = (cfloat *)p.points;
+    float x[kFxPts][kFxD], dist[kFxPts];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const unsigned long long o = __shfl_xor(best, off);
-            best = o > best ? o : best;
+    for (int j = 0; j < kFxPts; ++j) {
+        dist[j] = kInf;
+        int i = gtid + j * stride;
+        i = i < p.n ? i : p.n - 1;                      // beyond the end: a copy of the last point, never a candidate (see below)
+        const float4 *row = reinterpret_cast<const float4 *>(p.points + (size_t)i * kFxD);       // rows of 144 B: nine 16-byte loads
+#pragma unroll
+        for (int c = 0; c < kFxD / 4; ++c) {
+            const float4 v = row[c];
+            x[j][4 * c] = v.x; x[j][4 * c + 1] = v.y; x[j][4 * c + 2] = v.z; x[j][4 * c + 3] = v.w;
         }
-        if (lane == 0) s_best[wave] = best;
-        __syncthreads();
-        // ---- publish this workgroup's candidate as one tagged granule (slots double-buffered by round parity) ----
-        const unsigned long long tag = (unsigned long long)(r % 4095 + 1) << 52;
-        gu64 *slot = gran + (size_t)(r & 1) * G;
-        if (tid == 0) {
+    }
+    if (tid == 0) s_fail = 0;
+    int cur = p.start;
+    __syncthreads();
+    for (int r = 0; r < p.k; ++r) {
+        if (g_self == 0 && tid == 0) p.out_idx[r] = cur;
+        if (r == p.k - 1) break;
+        // the newest sample: uniform address -> scalar loads, 12 coordinates at a time, used as scalar operands; every point's
+        // distance stays ONE sequential fmaf chain over the coordinates (= the oracle)
+        cfloat *qrow = qbase + (size_t)__builtin_amdgcn_readfirstlane(cur) * kFxD;
+        float acc[kFxPts];
 #pragma unroll
-            for (int w = 1; w < kFpsThreads / 64; ++w) best = s_best[w] > best ? s_best[w] : best;
-            __hip_atomic_store(slot + blockIdx.x, tag | best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // ---- sweep every workgroup's candidate (wave 0): all loads in flight at once, same arg-max everywhere ----
-        if (wave == 0) {
-            unsigned long long v[kFpsMaxGroups / 64];
-            bool fail = false;
-            unsigned spins = 0;
-            for (;;) {
-                bool ok = true;
+        for (int j = 0; j < kFxPts; ++j) acc[j] = 0.0f;
 #pragma unroll
-                for (int u = 0; u < kFpsMaxGroups / 64; ++u) {
-                    const int g = u * 64 + lane;
-                    v[u] = g < G ? __hip_atomic_load(slot + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+        for (int c0 = 0; c0 < kFxD; c0 += 12) {
+            float q[12];
+#pragma unroll
+            for (int c = 0; c < 12; ++c) q[c] = qrow[c0 + c];
+#pragma unroll
+            for (int j = 0; j < kFxPts; ++j)
+#pragma unroll
+                for (int c = 0; c < 12; ++c) {
+                    const float df = x[j][c0 + c] - q[c];
+                    acc[j] = HNS_FMA(df, df, acc[j]);
                 }
-#pragma unroll
-                for (int u = 0; u < kFpsMaxGroups / 64; ++u) ok = ok && ((v[u] >> 52) == (tag >> 52));
-                if (__all(ok)) break;
-                if (++spins > kFpsSpinLimit) { fail = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            unsigned long long gb = 0;
-#pragma unroll
-            for (int u = 0; u < kFpsMaxGroups / 64; ++u) {
-                const unsigned long long c52 = v[u] & 0xFFFFFFFFFFFFFull;
-                gb = c52 > gb ? c52 : gb;
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const unsigned long long o = __shfl_xor(gb, off);
-                gb = o > gb ? o : gb;
-            }
-            const int gi = (int)(0xFFFFFu - (unsigned)(gb & 0xFFFFFu));
-            if (lane == 0) { s_cur = gi; if (fail) s_fail = 1; }
-            // the winner's coordinates for the next round (immutable input: plain loads)
-            if (!fail)
-                for (int c = lane; c < d; c += 64) sQ[c] = p.points[(size_t)gi * d + c];
         }
-        __syncthreads();
-        if (s_fail) {                                   // a workgroup never showed up: give up loudly, never hang
-            if (tid == 0) __hip_atomic_store((gu64 *)p.scratch, 1ull + (unsigned long long)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
+        unsigned long long best = 0;
+#pragma unroll
+        for (int j = 0; j < kFxPts; ++j) {
+            const int i = gtid + j * stride;
+            const float m = (i == cur) ? -1.0f : (acc[j] < dist[j] ? acc[j] : dist[j]);
+            dist[j] = m;
+            const unsigned long long key = m < 0.0f ? 0ull : (unsigned long long)__float_as_uint(m) + 1ull;
+            const unsigned long long cand = (key << 20) | (unsigned long long)(0xFFFFFu - (unsigned)i);
+            if (i < p.n) best = cand > best ? cand : best;
         }
-        cur = s_cur;
+        cur = fps_exchange<kFxThreads>(p, gran, kFxGroups, g_self, r, best, s_best, &s_cur, &s_fail, nullptr);
+        if (cur < 0) return;
     }
 }
 
@@ -253,6 +335,15 @@ int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start,
     hns::FpsParams p;
     p.points = points; p.n = n; p.d = d; p.k = k; p.start = start; p.groups = groups;
     p.out_idx = out_idx; p.scratch = (unsigned long long *)scratch;
+    // the generator's own shape: the XCD-local kernel (same results; HNS_FPS_KERNEL=chip keeps the chip-wide one, for A/B measurements)
+    static const bool chip_only = [] { const char *e = getenv("HNS_FPS_KERNEL"); return e && e[0] == 'c'; }();
+    if (!chip_only && d == hns::kFxD && n >= 2048 && n <= hns::kFxGroups * hns::kFxThreads * hns::kFxPts &&
+        cus >= hns::kFxGroups * hns::kFxStride && (reinterpret_cast<uintptr_t>(points) & 15) == 0) {
+        p.groups = hns::kFxGroups; p.in_lds = 0;
+        hipLaunchKernelGGL(hns::hns_fps_xcd_kernel, dim3(hns::kFxGroups * hns::kFxStride), dim3(hns::kFxThreads), 0, s, p);
+        HNS_CHECK_HIP(hipGetLastError());
+        return HNS_OK;
+    }
     const int per_thread = (n + groups * hns::kFpsThreads - 1) / (groups * hns::kFpsThreads);
     const size_t q_floats = (size_t)((d + 3) & ~3), pts_floats = (size_t)per_thread * hns::kFpsThreads * (d + 1);
     p.in_lds = (q_floats + pts_floats) * sizeof(float) <= 144 * 1024 ? 1 : 0;
