@@ -36,6 +36,7 @@ struct FpsParams {
     const float *points;   // [n, d]
     int n, d, k, start, groups;
     int in_lds;            // the workgroup's points are staged in LDS (rows of d+1 floats: conflict-free)
+    int xcds;              // hns_fps_xcd_kernel: workgroups with blockIdx % 8 < xcds work (1 or 2 XCDs)
     int32_t *out_idx;      // [k]
     unsigned long long *scratch;   // [0]: error word; [8 ..): granules [2 parity][groups]
 };
@@ -46,7 +47,7 @@ struct FpsParams {
 // sQ is given), or -1 after reporting that a workgroup never showed up (every spin is bounded).
 template <int THREADS>
 HNS_DEV int fps_exchange(const FpsParams &p, gu64 *gran, int G, int g_self, int r, unsigned long long best, unsigned long long *s_best,
-                         int *s_cur, int *s_fail, float *sQ) {
+                         int *s_cur, int *s_fail, float *sQ, float *warm = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = p.d;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -61,6 +62,15 @@ HNS_DEV int fps_exchange(const FpsParams &p, gu64 *gran, int G, int g_self, int 
 #pragma unroll
         for (int w = 1; w < THREADS / 64; ++w) best = s_best[w] > best ? s_best[w] : best;
         __hip_atomic_store(slot + g_self, tag | best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (warm) {
+            // pull this workgroup's candidate row into the XCD's L2 while the exchange is in flight: if it wins, every workgroup of
+            // this XCD fetches its coordinates next (scalar loads, on the critical path of the round) and finds them there
+            const int ci = (int)(0xFFFFFu - (unsigned)(best & 0xFFFFFu));
+            const float4 *row = reinterpret_cast<const float4 *>(p.points + (size_t)ci * d);
+            float4 a = row[0];
+            for (int c = 1; c < d / 4; ++c) { const float4 b = row[c]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            *warm += (a.x + a.y) + (a.z + a.w);
+        }
     }
     // sweep every workgroup's candidate (wave 0): all loads in flight at once, same arg-max everywhere
     if (wave == 0) {
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(kFpsThreads) void hns_fps_kernel(const FpsParams p)
     }
 }
 
-// XCD-local variant for the generator's own shape (at most 36 coordinates, at most 65 536 points).  The per-round exchange between 32
+// XCD-local variant for the generator's own shape (36 coordinates; up to 65 536 points on one XCD, up to 131 072 on two).  The per-round exchange between 32
 // workgroups of ONE XCD costs 0.8 us against 2.6 us across the chip (tools/microbench/exchange_latency.hip) — with the same agent-scope
 // stores and loads, so the result does not depend on where the workgroups actually land, only the time does.  The points (10 MB for
 // 70 000 tasks) fit neither that XCD's LDS nor its L2: they live in registers, two per thread at 1024 threads per CU (a third one spills; exactly 36
@@ -177,12 +187,13 @@ __global__ __launch_bounds__(kFpsThreads) void hns_fps_kernel(const FpsParams p)
 constexpr int kFxThreads = 1024, kFxGroups = 32, kFxStride = 8, kFxPts = 2, kFxD = 36;
 
 __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams p) {
-    if (blockIdx.x % kFxStride) return;
+    if ((int)(blockIdx.x % kFxStride) >= p.xcds) return;
     __shared__ unsigned long long s_best[kFxThreads / 64];
     __shared__ int s_cur;
     __shared__ int s_fail;
-    const int tid = threadIdx.x, g_self = blockIdx.x / kFxStride;
-    const int gtid = g_self * kFxThreads + tid, stride = kFxGroups * kFxThreads;
+    const int G = kFxGroups * p.xcds;
+    const int tid = threadIdx.x, g_self = (blockIdx.x / kFxStride) * p.xcds + blockIdx.x % kFxStride;
+    const int gtid = g_self * kFxThreads + tid, stride = G * kFxThreads;
     gu64 *gran = (gu64 *)(p.scratch + 8);
     typedef const float __attribute__((address_space(4))) cfloat;      // `points` is immutable while the kernel runs: constant memory
     cfloat *qbase = (cfloat *)p.points;
@@ -201,6 +212,7 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
     }
     if (tid == 0) s_fail = 0;
     int cur = p.start;
+    float warm = 0.0f;                                  // sum of the rows touched to warm the L2 (kept alive by the store below)
     __syncthreads();
     for (int r = 0; r < p.k; ++r) {
         if (g_self == 0 && tid == 0) p.out_idx[r] = cur;
@@ -234,9 +246,10 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
             const unsigned long long cand = (key << 20) | (unsigned long long)(0xFFFFFu - (unsigned)i);
             if (i < p.n) best = cand > best ? cand : best;
         }
-        cur = fps_exchange<kFxThreads>(p, gran, kFxGroups, g_self, r, best, s_best, &s_cur, &s_fail, nullptr);
+        cur = fps_exchange<kFxThreads>(p, gran, G, g_self, r, best, s_best, &s_cur, &s_fail, nullptr, &warm);
         if (cur < 0) return;
     }
+    if (warm == -1.0f) p.scratch[1] = 1;               // never true (coordinates are normalised to [0, 1]): the loads above are not dead
 }
 
 // ---- samplenearby (hideandseek_envgen.py:316-370, grid check :187-207) -----------------------------
@@ -334,12 +347,14 @@ int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start,
     HNS_CHECK_HIP(hipMemsetAsync(scratch, 0, hns_fps_scratch_bytes(), s));
     hns::FpsParams p;
     p.points = points; p.n = n; p.d = d; p.k = k; p.start = start; p.groups = groups;
-    p.out_idx = out_idx; p.scratch = (unsigned long long *)scratch;
+    p.out_idx = out_idx; p.scratch = (unsigned long long *)scratch; p.xcds = 0;
     // the generator's own shape: the XCD-local kernel (same results; HNS_FPS_KERNEL=chip keeps the chip-wide one, for A/B measurements)
     static const bool chip_only = [] { const char *e = getenv("HNS_FPS_KERNEL"); return e && e[0] == 'c'; }();
-    if (!chip_only && d == hns::kFxD && n >= 2048 && n <= hns::kFxGroups * hns::kFxThreads * hns::kFxPts &&
+    const int fx_cap = hns::kFxGroups * hns::kFxThreads * hns::kFxPts;        // points one XCD's registers hold
+    if (!chip_only && d == hns::kFxD && n >= 2048 && n <= 2 * fx_cap &&
         cus >= hns::kFxGroups * hns::kFxStride && (reinterpret_cast<uintptr_t>(points) & 15) == 0) {
-        p.groups = hns::kFxGroups; p.in_lds = 0;
+        p.xcds = n <= fx_cap ? 1 : 2;                 // two XCDs: the exchange crosses the fabric once, still a quarter of the chip
+        p.groups = hns::kFxGroups * p.xcds; p.in_lds = 0;
         hipLaunchKernelGGL(hns::hns_fps_xcd_kernel, dim3(hns::kFxGroups * hns::kFxStride), dim3(hns::kFxThreads), 0, s, p);
         HNS_CHECK_HIP(hipGetLastError());
         return HNS_OK;

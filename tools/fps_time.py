@@ -4,7 +4,7 @@ import torch, hns_amd
 from hns_amd import abi
 lib = abi.load_library()
 dev = torch.device("cuda:0")
-for n, k in ((51000, 5000), (70000, 5000), (10000, 5000)):
+for n, k in ((51000, 5000), (70536, 5000), (10000, 5000)):
     p = torch.rand(n, 36, device=dev)
     out = torch.zeros(k, dtype=torch.int32, device=dev)
     scratch = torch.zeros(lib.hns_fps_scratch_bytes(), dtype=torch.uint8, device=dev)
