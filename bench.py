@@ -335,6 +335,8 @@ def main():
                            "generator_ms_task_batch_max": round(max(gen_ms), 2), "construction_and_first_reset_ms": round(first_reset_ms, 1),
                            "value_incl_generator": round(E * 3 * L * EP / total, 1),
                            "value_incl_generator_at_800_step_episodes": round(E * 3 * 800 / (800 * step_s / (L * EP) + sum(gen_ms[1:]) / max(EP - 1, 1) * 1e-3), 1),
+                           "generator_ms_task_batch_steady": round(max(gen_ms[-3:]), 2),            # the last batch: history full, everything warm
+                           "value_incl_generator_steady_at_800_step_episodes": round(E * 3 * 800 * 3 / (3 * 800 * step_s / (L * EP) + sum(gen_ms[-3:]) * 1e-3), 1),
                            "history_size": len(e4.gen_buffer)}
         del e4
 
