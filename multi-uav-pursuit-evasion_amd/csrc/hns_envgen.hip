@@ -62,14 +62,14 @@ HNS_DEV int fps_exchange(const FpsParams &p, gu64 *gran, int G, int g_self, int 
 #pragma unroll
         for (int w = 1; w < THREADS / 64; ++w) best = s_best[w] > best ? s_best[w] : best;
         __hip_atomic_store(slot + g_self, tag | best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (warm) {
+        if (warm && best != 0) {                      // (a workgroup without points has no candidate: nothing to touch)
             // pull this workgroup's candidate row into the XCD's L2 while the exchange is in flight: if it wins, every workgroup of
             // this XCD fetches its coordinates next (scalar loads, on the critical path of the round) and finds them there
             const int ci = (int)(0xFFFFFu - (unsigned)(best & 0xFFFFFu));
-            const float4 *row = reinterpret_cast<const float4 *>(p.points + (size_t)ci * d);
-            float4 a = row[0];
-            for (int c = 1; c < d / 4; ++c) { const float4 b = row[c]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-            *warm += (a.x + a.y) + (a.z + a.w);
+            const float *row = p.points + (size_t)ci * d;          // (4-byte loads: rows of other widths than 36 are not 16-byte aligned)
+            float a = row[0];
+            for (int c = 8; c < d; c += 8) a += row[c];             // one word per 32 bytes touches every line of the row
+            *warm += a + row[d - 1];
         }
     }
     // sweep every workgroup's candidate (wave 0): all loads in flight at once, same arg-max everywhere
@@ -177,15 +177,18 @@ __global__ __launch_bounds__(kFpsThreads) void hns_fps_kernel(const FpsParams p)
     }
 }
 
-// XCD-local variant for the generator's own shape (36 coordinates; up to 65 536 points on one XCD, up to 131 072 on two).  The per-round exchange between 32
+// XCD-local variant for the generator's shapes (up to 36 coordinates; up to 65 536 points on one XCD, up to 131 072 on two).  The per-round exchange between 32
 // workgroups of ONE XCD costs 0.8 us against 2.6 us across the chip (tools/microbench/exchange_latency.hip) — with the same agent-scope
 // stores and loads, so the result does not depend on where the workgroups actually land, only the time does.  The points (10 MB for
-// 70 000 tasks) fit neither that XCD's LDS nor its L2: they live in registers, two per thread at 1024 threads per CU (a third one spills; exactly 36
-// coordinates: 3 pursuers + evader + 8 cylinders, the shape of BASELINE config 4; other shapes take the chip-wide kernel); the newest
+// 70 000 tasks) fit neither that XCD's LDS nor its L2: they live in registers, two per thread at 1024 threads per CU (a third one spills; at most 36
+// coordinates = 3 pursuers + evader + 8 cylinders, the shape of BASELINE config 4; wider tasks take the chip-wide kernel); the newest
 // sample's coordinates are workgroup-uniform and come in through scalar loads (`points` is immutable input).  Launched as 8 x 32 workgroups;
 // those with blockIdx % 8 != 0 — by the round-robin dispatch, the ones on the other XCDs — leave at once.
 constexpr int kFxThreads = 1024, kFxGroups = 32, kFxStride = 8, kFxPts = 2, kFxD = 36;
 
+// FULL: exactly 36 coordinates (16-byte row loads, wide scalar loads).  Otherwise rows are zero-padded to 36 in registers: a zero
+// difference leaves the sequential fma chain unchanged, bit for bit (acc + 0 * 0 = acc for acc >= 0).
+template <bool FULL>
 __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams p) {
     if ((int)(blockIdx.x % kFxStride) >= p.xcds) return;
     __shared__ unsigned long long s_best[kFxThreads / 64];
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
     __shared__ int s_fail;
     const int G = kFxGroups * p.xcds;
     const int tid = threadIdx.x, g_self = (blockIdx.x / kFxStride) * p.xcds + blockIdx.x % kFxStride;
-    const int gtid = g_self * kFxThreads + tid, stride = G * kFxThreads;
+    const int gtid = g_self * kFxThreads + tid, stride = G * kFxThreads, d = FULL ? kFxD : p.d;
     gu64 *gran = (gu64 *)(p.scratch + 8);
     typedef const float __attribute__((address_space(4))) cfloat;      // `points` is immutable while the kernel runs: constant memory
     cfloat *qbase = (cfloat *)p.points;
@@ -203,11 +206,17 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         dist[j] = kInf;
         int i = gtid + j * stride;
         i = i < p.n ? i : p.n - 1;                      // beyond the end: a copy of the last point, never a candidate (see below)
-        const float4 *row = reinterpret_cast<const float4 *>(p.points + (size_t)i * kFxD);       // rows of 144 B: nine 16-byte loads
+        if constexpr (FULL) {
+            const float4 *row = reinterpret_cast<const float4 *>(p.points + (size_t)i * kFxD);   // rows of 144 B: nine 16-byte loads
 #pragma unroll
-        for (int c = 0; c < kFxD / 4; ++c) {
-            const float4 v = row[c];
-            x[j][4 * c] = v.x; x[j][4 * c + 1] = v.y; x[j][4 * c + 2] = v.z; x[j][4 * c + 3] = v.w;
+            for (int c = 0; c < kFxD / 4; ++c) {
+                const float4 v = row[c];
+                x[j][4 * c] = v.x; x[j][4 * c + 1] = v.y; x[j][4 * c + 2] = v.z; x[j][4 * c + 3] = v.w;
+            }
+        } else {
+            const float *row = p.points + (size_t)i * d;
+#pragma unroll
+            for (int c = 0; c < kFxD; ++c) x[j][c] = c < d ? row[c < d ? c : 0] : 0.0f;
         }
     }
     if (tid == 0) s_fail = 0;
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         if (r == p.k - 1) break;
         // the newest sample: uniform address -> scalar loads, 12 coordinates at a time, used as scalar operands; every point's
         // distance stays ONE sequential fmaf chain over the coordinates (= the oracle)
-        cfloat *qrow = qbase + (size_t)__builtin_amdgcn_readfirstlane(cur) * kFxD;
+        cfloat *qrow = qbase + (size_t)__builtin_amdgcn_readfirstlane(cur) * d;
         float acc[kFxPts];
 #pragma unroll
         for (int j = 0; j < kFxPts; ++j) acc[j] = 0.0f;
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         for (int c0 = 0; c0 < kFxD; c0 += 12) {
             float q[12];
 #pragma unroll
-            for (int c = 0; c < 12; ++c) q[c] = qrow[c0 + c];
+            for (int c = 0; c < 12; ++c) q[c] = (FULL || c0 + c < d) ? qrow[(FULL || c0 + c < d) ? c0 + c : 0] : 0.0f;
 #pragma unroll
             for (int j = 0; j < kFxPts; ++j)
 #pragma unroll
@@ -351,11 +360,12 @@ int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start,
     // the generator's own shape: the XCD-local kernel (same results; HNS_FPS_KERNEL=chip keeps the chip-wide one, for A/B measurements)
     static const bool chip_only = [] { const char *e = getenv("HNS_FPS_KERNEL"); return e && e[0] == 'c'; }();
     const int fx_cap = hns::kFxGroups * hns::kFxThreads * hns::kFxPts;        // points one XCD's registers hold
-    if (!chip_only && d == hns::kFxD && n >= 2048 && n <= 2 * fx_cap &&
+    if (!chip_only && d <= hns::kFxD && d >= 4 && n >= 2048 && n <= 2 * fx_cap &&
         cus >= hns::kFxGroups * hns::kFxStride && (reinterpret_cast<uintptr_t>(points) & 15) == 0) {
         p.xcds = n <= fx_cap ? 1 : 2;                 // two XCDs: the exchange crosses the fabric once, still a quarter of the chip
         p.groups = hns::kFxGroups * p.xcds; p.in_lds = 0;
-        hipLaunchKernelGGL(hns::hns_fps_xcd_kernel, dim3(hns::kFxGroups * hns::kFxStride), dim3(hns::kFxThreads), 0, s, p);
+        hipLaunchKernelGGL(d == hns::kFxD ? hns::hns_fps_xcd_kernel<true> : hns::hns_fps_xcd_kernel<false>, dim3(hns::kFxGroups * hns::kFxStride),
+                           dim3(hns::kFxThreads), 0, s, p);
         HNS_CHECK_HIP(hipGetLastError());
         return HNS_OK;
     }

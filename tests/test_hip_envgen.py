@@ -26,7 +26,7 @@ def _fps_hip(lib, pts, k, start):
     return out.cpu().numpy()
 
 
-@pytest.mark.parametrize("n,d,k", [(1, 3, 1), (37, 5, 37), (300, 36, 300), (5000, 36, 800), (60000, 36, 400), (65536, 36, 64), (70001, 36, 150), (131072, 36, 48), (131073, 36, 16), (200000, 12, 40)])
+@pytest.mark.parametrize("n,d,k", [(1, 3, 1), (37, 5, 37), (300, 36, 300), (5000, 36, 800), (60000, 36, 400), (65536, 36, 64), (70001, 36, 150), (131072, 36, 48), (131073, 36, 16), (30000, 27, 300), (70000, 30, 64), (4096, 5, 100), (2048, 4, 64), (200000, 12, 40)])
 def test_fps_matches_oracle(n, d, k):
     lib = abi.load_library()
     rng = np.random.default_rng(n + d)
