@@ -58,9 +58,15 @@ HNS_DEV int fps_exchange(const FpsParams &p, gu64 *gran, int G, int g_self, int 
     __syncthreads();
     const unsigned long long tag = (unsigned long long)(r % 4095 + 1) << 52;
     gu64 *slot = gran + (size_t)(r & 1) * G;
-    if (tid == 0) {
+    if (wave == 0) {                                    // the waves' candidates: one per lane, then a shuffle tree (was a serial loop on one lane)
+        best = lane < THREADS / 64 ? s_best[lane] : 0ull;
 #pragma unroll
-        for (int w = 1; w < THREADS / 64; ++w) best = s_best[w] > best ? s_best[w] : best;
+        for (int off = THREADS / 128; off >= 1; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best, off);
+            best = o > best ? o : best;
+        }
+    }
+    if (tid == 0) {
         __hip_atomic_store(slot + g_self, tag | best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (warm && best != 0) {                      // (a workgroup without points has no candidate: nothing to touch)
             // pull this workgroup's candidate row into the XCD's L2 while the exchange is in flight: if it wins, every workgroup of
