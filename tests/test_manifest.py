@@ -123,5 +123,9 @@ def test_task_yaml_for_the_unedited_train_script():
     if os.path.exists(ref_yaml):                               # the authoring container only
         import yaml
         ref, ours = yaml.safe_load(open(ref_yaml)), yaml.safe_load(open(os.path.join(root, "cfg", "task", "HideAndSeek_hip.yaml")))
-        diff = {k for k in set(ref) | set(ours) if ref.get(k) != ours.get(k)}
-        assert diff == {"name", "action_transform", "env", "publish_ctbr"}, diff
+        assert ours["defaults"][0] == "HideAndSeek"            # hydra: inherits the reference's own task file
+        assert set(ours) - {"defaults"} == {"name", "action_transform", "env", "publish_ctbr"} and "action_transform" in ref
+        # ... and what the file leaves out resolves, without hydra, to the reference file's values (the built-in defaults are those)
+        full = config.load_cfg(ref_yaml, name="HideAndSeek_hip", action_transform="none", env={"num_envs": 65536, "max_episode_length": ref["env"]["max_episode_length"]})
+        c = config.resolve_hns_cfg(full)
+        assert bytes(C.string_at(C.addressof(a), C.sizeof(abi.HnsCfg))) == bytes(C.string_at(C.addressof(c), C.sizeof(abi.HnsCfg)))
