@@ -111,3 +111,24 @@ def test_reset_distribution_matches_reference_ranges():
     used = counts[counts > 0]
     assert len(used) == 45 - 0 or len(used) >= 40
     assert used.std() / used.mean() < 0.25
+
+
+@settings(max_examples=15, deadline=None)
+@given(seed=st.integers(0, 2**31 - 1), A=st.sampled_from([1, 3, 6]), C=st.sampled_from([3, 8, 16]))
+def test_line_of_sight_column_describes_the_state_it_sits_in(seed, A, C):
+    """include/hns.h: pid_last_rate[..., 3] = the pursuer's line-of-sight flag in the state the buffers hold.  After resets
+    (full and masked) and steps it equals a fresh evaluation of the exported positions — the property the step kernel's
+    carry-over rests on; the GPU twin of this test is in test_hip_parity.py."""
+    E = 40
+    c, arrs = _env(E, A, C, seed, max_len=7)
+    rng = np.random.default_rng(seed)
+    epoch = 1
+    for t in range(16):
+        fresh = O.blocked(c, arrs["drone_state"][..., :3], arrs["target_pos"], arrs["cylinders"])
+        assert np.array_equal(arrs["pid_last_rate"][..., 3], fresh.astype(np.float32)), t
+        O.step(c, arrs, rng.standard_normal((E, A, 4)).astype(np.float32))
+        if arrs["done"].any():
+            mask = arrs["done"].copy()
+            mask[::4] = 0                                     # some done envs keep running: flags of both kinds side by side
+            O.reset(c, arrs, mask, seed, epoch)
+            epoch += 1
