@@ -301,11 +301,11 @@ struct TpGate {
             const float4 *b4 = reinterpret_cast<const float4 *>(c.bias + (2 * q + c.tj) * 32);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float4 bv = b4[v];
-                c.acc[q][4 * v] = HNS_FMA(c.acc[q][4 * v], kTpLoInv, bv.x);
-                c.acc[q][4 * v + 1] = HNS_FMA(c.acc[q][4 * v + 1], kTpLoInv, bv.y);
-                c.acc[q][4 * v + 2] = HNS_FMA(c.acc[q][4 * v + 2], kTpLoInv, bv.z);
-                c.acc[q][4 * v + 3] = HNS_FMA(c.acc[q][4 * v + 3], kTpLoInv, bv.w);
+                const float4 bv = b4[v];                      // two accumulator elements per v_pk_fma_f32 (they are consecutive registers)
+                const f32x2 lo = tp_fma_2((f32x2){c.acc[q][4 * v], c.acc[q][4 * v + 1]}, (f32x2)kTpLoInv, (f32x2){bv.x, bv.y});
+                const f32x2 hi = tp_fma_2((f32x2){c.acc[q][4 * v + 2], c.acc[q][4 * v + 3]}, (f32x2)kTpLoInv, (f32x2){bv.z, bv.w});
+                c.acc[q][4 * v] = lo[0]; c.acc[q][4 * v + 1] = lo[1];
+                c.acc[q][4 * v + 2] = hi[0]; c.acc[q][4 * v + 3] = hi[1];
             }
         }
     }
