@@ -17,17 +17,18 @@ env._lib.hns_set_phase_profile(env._env, C.c_void_p(buf.data_ptr()))
 env._tp_observe(); torch.cuda.synchronize()
 env._lib.hns_set_phase_profile(env._env, None)
 nw = (E // 256) * 8
-t = buf.cpu().numpy()[:nw, :4].astype(np.float64) * 10.0      # ns
+t = buf.cpu().numpy()[:nw, :5].astype(np.float64) * 10.0      # ns
 z = t[:, 0].min()
 t -= z
 print("waves", nw)
-for i, n in enumerate(["start", "staged", "loop end", "end"]):
+print("observation rows (stamp 4 - stamp 3, the tail that was a second kernel): median %.0f ns, max %.0f ns" % (np.median(t[:, 4] - t[:, 3]), (t[:, 4] - t[:, 3]).max()))
+for i, n in enumerate(["start", "staged", "loop end", "predictions out", "rows out"]):
     print("%-9s min %8.0f  p10 %8.0f  median %8.0f  p90 %8.0f  max %8.0f ns" % ((n,) + tuple(np.percentile(t[:, i], [0, 10, 50, 90, 100]))))
-d = t[:, 3] - t[:, 0]
+d = t[:, 4] - t[:, 0]
 print("wave lifetime: min %.0f median %.0f max %.0f ns; staging median %.0f ns" % (d.min(), np.median(d), d.max(), np.median(t[:, 1] - t[:, 0])))
-wg = t.reshape(-1, 8, 4)
-print("per-workgroup end (max over waves): p10 %.0f median %.0f p90 %.0f max %.0f" % tuple(np.percentile(wg[:, :, 3].max(1), [10, 50, 90, 100])))
-order = np.argsort(wg[:, :, 3].max(1))
+wg = t.reshape(-1, 8, 5)
+print("per-workgroup end (max over waves): p10 %.0f median %.0f p90 %.0f max %.0f" % tuple(np.percentile(wg[:, :, 4].max(1), [10, 50, 90, 100])))
+order = np.argsort(wg[:, :, 4].max(1))
 print("slowest workgroups:", order[-8:], "fastest:", order[:8])
 if "--stamps" in sys.argv:
     c = buf.cpu().numpy()[:nw, :16].astype(np.float64).reshape(-1, 8, 16)
