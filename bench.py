@@ -106,7 +106,13 @@ def main():
         dist.init_process_group(os.environ.get("HNS_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    n_dev = max(torch.cuda.device_count(), 1)
+    backend = dist.get_backend() if dist is not None else None
+    if world > 1 and backend == "nccl" and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > n_dev:
+        # RCCL needs one device per rank; folding ranks onto one GPU would also overstate n_gpus
+        raise SystemExit(f"[bench] {world} ranks but only {n_dev} GPU(s) visible: refuse to fold ranks onto one device with the nccl/RCCL "
+                         f"backend (HNS_DIST_BACKEND=gloo runs the N>1 path on fewer devices as a smoke test; n_gpus then reports the devices)")
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     coll_dev = device if (dist is not None and dist.get_backend() == "nccl") else "cpu"
@@ -207,7 +213,10 @@ def main():
 
     run(args.warmup)
     sync()
-    env.enable_kernel_timing(args.time_every)
+    # kernel-duration samples: every `time_every`-th launch carries events; short runs (the driver's --steps 20) time every
+    # launch so that the roofline never rests on fewer than min(steps, 8) samples
+    time_every = max(1, min(args.time_every, args.steps // 8))
+    env.enable_kernel_timing(time_every)
     t0 = time.perf_counter()
     run(args.steps)
     sync()
@@ -216,11 +225,14 @@ def main():
     roofline, kernel_ms = kernel_roofline(env, E, A, C, NT=args.targets)
 
     # ranks that actually took part (an all-reduce of ones), slowest rank's wall time, per-rank kernel time
-    n_ranks, kernel_by_rank = 1, None
+    n_ranks, n_devices, kernel_by_rank = 1, 1, None
     if world > 1:
         ones = torch.ones(1, device=coll_dev, dtype=torch.float64)
         dist.all_reduce(ones)
         n_ranks = int(round(float(ones.item())))
+        where = [None] * world                      # n_gpus = distinct (host, device) pairs, not ranks
+        dist.all_gather_object(where, (socket.gethostname(), local_rank))
+        n_devices = len(set(where))
         tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -328,7 +340,9 @@ def main():
         e4.enable_kernel_timing(0)
         r4, _ = kernel_roofline(e4, E, 3, 8)
         steady = sorted(gen_ms[1:])
-        configs["cfg4"] = {"workload": f"HideAndSeek_envgen, 3v1, 8 cylinders, {E} envs, episodes of {L} steps (the reference: 800), new task batch every 3 episodes",
+        configs["cfg4"] = {"workload": f"HideAndSeek_envgen, 3v1, 8 cylinders, {E} envs, episodes of {L} steps (the reference: 800), new task batch every 3 episodes, "
+                                       "R_min 0.0 / R_max 1.0 (the reference's 0.5 / 0.9 would admit no task under this bench's random policy: every task "
+                                       "enters the history here, so the trim runs at its full 5000 + E size - the generator's worst case)",
                            "value": round(E * 3 * L * EP / step_s, 1), "unit": "agent-steps/s (stepping only)", "ms_per_step": round(step_s / (L * EP) * 1e3, 5),
                            "roofline": r4, "episodes": EP, "generator_ms_per_episode": [round(x, 2) for x in gen_ms],
                            "generator_ms_per_episode_steady_median": round(steady[len(steady) // 2], 2) if steady else None,
@@ -441,14 +455,14 @@ def main():
     if rank == 0:
         out = {
             "metric": "env agent-steps/sec at 65536 envs, HideAndSeek 3v1; 1/2/4/8 GPU",
-            "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": n_ranks, "steps": args.steps,
+            "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": n_devices, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"HideAndSeek {A}v{args.targets}, {C} random cylinders + LOS/k-nearest sensing, "
                                    f"{E} envs per GPU (BASELINE configs[2]), timed through env.step(td)",
                        "num_envs_per_gpu": E, "num_agents": A, "num_targets": args.targets, "num_cylinders": C, "obs_max_cylinder": K,
                        "episode_length": args.episode, "critic_state_output": args.critic_state,
-                       "sharding": f"contiguous env slices x{n_ranks}", "world_size_launched": world,
+                       "sharding": f"contiguous env slices x{n_ranks}", "world_size_launched": world, "ranks": n_ranks,
                        "collective": "1 all-gather of 5 fp64 per 64-step rollout" if world > 1 else "none"},
             "env_frames_per_s": round(value / A, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "abi_rate": abi_rate, "configs": configs or None,

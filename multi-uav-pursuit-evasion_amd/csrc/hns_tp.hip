@@ -39,6 +39,7 @@
 // the cell update of units 0..31 is issued between the MFMAs of units 32..63 (TpCell / TpGate SIDE).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <initializer_list>
 #include <new>
 #include <string>
@@ -103,12 +104,7 @@ HNS_DEV void tp_split(float w, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)w;
     lo = (_Float16)((w - (float)hi) * kTpLoScale);
 }
-// two values at once: both conversions to fp16 are v_cvt_pk_f16_f32, the subtraction and the scaling v_pk_* (6 instead of 10 instructions)
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-HNS_DEV void tp_split2(f32x2 w, half2v &hi, half2v &lo) {
-    hi = __builtin_convertvector(w, half2v);
-    lo = __builtin_convertvector((w - __builtin_convertvector(hi, f32x2)) * kTpLoScale, half2v);
-}
 
 // ---- parameters -> operand image (run when the parameters changed) ------------------------------
 __global__ __launch_bounds__(256) void hns_tp_pack_kernel(const TpParams p, int nxc) {
@@ -185,6 +181,54 @@ HNS_DEV float tp_frame_val(const TpParams &p, int e, int k, bool det) {
     return comp == 2 ? p.cylinder_size : p.cylinders[((size_t)e * p.C + cy) * 3 + comp];
 }
 
+// ---- one pursuer's observation row: [rpos_evader(3) | drone - predicted (3F) | quat4 linvel3 heading3 up3 t x4 (17)] ----
+// hideandseek.py:844-854 (state_self, masked rpos from the step kernel's rows) and :873-880 (state_drones, unmasked rpos);
+// TP_groundtruth / TP_done :838-842.  `pr` = the env's 3F predictions (LDS).
+HNS_DEV void tp_write_row(const TpParams &p, int er, int a, const float *pr) {
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));       // rows are 4-byte aligned (D = 20 + 3F floats)
+    const int A = p.A, R = 3 * p.F, D = HNS_SELF_DIM + R;
+    const size_t ia = (size_t)er * A + a;
+    float o20[HNS_SELF_DIM];
+    const float4 *s4 = reinterpret_cast<const float4 *>(p.obs_self20 + ia * HNS_SELF_DIM);
+#pragma unroll
+    for (int v = 0; v < HNS_SELF_DIM / 4; ++v) {
+        const float4 q = s4[v];
+        o20[4 * v] = q.x; o20[4 * v + 1] = q.y; o20[4 * v + 2] = q.z; o20[4 * v + 3] = q.w;
+    }
+    const float *ds = p.drone_state + ia * 13, *tg = p.target_pos + (size_t)er * 3;
+    const float px = ds[0], py = ds[1], pz = ds[2], tx = tg[0], ty = tg[1], tz = tg[2];
+    if (a == 0) {
+        // CUDA scalar-division form: tensor / python_scalar multiplies by the fp32 reciprocal
+        float *gt = p.tp.groundtruth + (size_t)er * 3;
+        gt[0] = tx * (1.0f / (0.5f * p.arena_size));
+        gt[1] = ty * (1.0f / (0.5f * p.arena_size));
+        gt[2] = (tz * (1.0f / p.max_height)) * 2.0f - 1.0f;
+        p.tp.tp_done[er] = (uint8_t)(p.progress[er] <= (float)(p.max_len - p.F));
+    }
+    for (int pass = 0; pass < 2; ++pass) {               // 0: state_self, 1: state_drones
+        float *dst = pass == 0 ? p.tp.obs_self : p.tp.state_drones;
+        if (!dst) continue;
+        float *g = dst + ia * D;
+        const float r0 = pass == 0 ? o20[0] : px - tx, r1 = pass == 0 ? o20[1] : py - ty, r2 = pass == 0 ? o20[2] : pz - tz;
+        if (R == 15) {                                    // five predicted points: 35 floats = 8 x 16 B + 3
+            float w[36];
+            w[0] = r0; w[1] = r1; w[2] = r2;
+#pragma unroll
+            for (int f = 0; f < 5; ++f) { w[3 + 3 * f] = px - pr[3 * f]; w[4 + 3 * f] = py - pr[3 * f + 1]; w[5 + 3 * f] = pz - pr[3 * f + 2]; }
+#pragma unroll
+            for (int j = 3; j < HNS_SELF_DIM; ++j) w[15 + j] = o20[j];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) *reinterpret_cast<f4u *>(g + 4 * v) = (f4u){w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]};
+            g[32] = w[32]; g[33] = w[33]; g[34] = w[34];
+        } else {
+            g[0] = r0; g[1] = r1; g[2] = r2;
+            for (int f = 0; f < p.F; ++f) { g[3 + 3 * f] = px - pr[3 * f]; g[4 + 3 * f] = py - pr[3 * f + 1]; g[5 + 3 * f] = pz - pr[3 * f + 2]; }
+#pragma unroll
+            for (int j = 3; j < HNS_SELF_DIM; ++j) g[R + j] = o20[j];
+        }
+    }
+}
+
 #define TP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 // ---- the gate pre-activations of 32 hidden units (4 gate tiles) for one timestep ------------------
@@ -197,7 +241,50 @@ HNS_DEV float tp_frame_val(const TpParams &p, int e, int k, bool det) {
 // up with dynamically indexed register arrays in scratch memory for some shapes: 20x slower).
 // The kernel as a whole is bound by the gate nonlinearities (10 transcendental ops per unit and
 // timestep), not by this block.
-constexpr int kTpDepth = 2;
+#ifndef TP_DEPTH
+#define TP_DEPTH 2
+#endif
+constexpr int kTpDepth = TP_DEPTH;
+
+// A unit pair's values.  TP_PK = 1 keeps them as packed fp32 (v_pk_add/mul/fma_f32); the default issues two plain instructions per
+// operation: on gfx950 a packed fp32 instruction occupies a lone wave's issue for 11 cycles (two plain ones: 2 x 5.2-6), saves
+// nothing at 4 waves per SIMD either (0.177 against 2 x 0.19-0.27 instructions per cycle), and beside a running MFMA it waits for
+// the matrix pipe — one packed instruction per MFMA and wave, where plain and transcendental ones still find 2-3 issue slots
+// (tools/microbench/simd_share.hip; round 3).
+#ifndef TP_PK
+#define TP_PK 0
+#endif
+#if TP_PK
+typedef f32x2 tpv2;
+HNS_DEV tpv2 tp_v2(float a, float b) { return (f32x2){a, b}; }
+HNS_DEV tpv2 tp_add_s(tpv2 a, float s) { return a + s; }
+HNS_DEV tpv2 tp_mul_s(tpv2 a, float s) { return a * s; }
+HNS_DEV tpv2 tp_mul_2(tpv2 a, tpv2 b) { return a * b; }
+HNS_DEV tpv2 tp_sub_2(tpv2 a, tpv2 b) { return a - b; }
+HNS_DEV tpv2 tp_fma_2(tpv2 a, tpv2 b, tpv2 c) { return __builtin_elementwise_fma(a, b, c); }
+HNS_DEV tpv2 tp_fma_s(tpv2 a, float b, float c) { return __builtin_elementwise_fma(a, (f32x2)b, (f32x2)c); }
+#else
+struct tpv2 {
+    float x, y;
+    __device__ __forceinline__ float operator[](int i) const { return i ? y : x; }
+};
+HNS_DEV tpv2 tp_v2(float a, float b) { return tpv2{a, b}; }
+HNS_DEV tpv2 tp_add_s(tpv2 a, float s) { return tpv2{a.x + s, a.y + s}; }
+HNS_DEV tpv2 tp_mul_s(tpv2 a, float s) { return tpv2{a.x * s, a.y * s}; }
+HNS_DEV tpv2 tp_mul_2(tpv2 a, tpv2 b) { return tpv2{a.x * b.x, a.y * b.y}; }
+HNS_DEV tpv2 tp_sub_2(tpv2 a, tpv2 b) { return tpv2{a.x - b.x, a.y - b.y}; }
+HNS_DEV tpv2 tp_fma_2(tpv2 a, tpv2 b, tpv2 c) { return tpv2{HNS_FMA(a.x, b.x, c.x), HNS_FMA(a.y, b.y, c.y)}; }
+HNS_DEV tpv2 tp_fma_s(tpv2 a, float b, float c) { return tpv2{HNS_FMA(a.x, b, c), HNS_FMA(a.y, b, c)}; }
+#endif
+// v_exp_f32 / v_rcp_f32 on both halves of a pair (transcendentals have no packed form)
+HNS_DEV tpv2 tp_exp2_2(tpv2 v) { return tp_v2(__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])); }
+HNS_DEV tpv2 tp_rcp_2(tpv2 v) { return tp_v2(__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])); }
+// fp16 split of a pair: hi = fp16(v), lo = fp16((v - hi) 2^11)
+HNS_DEV void tp_split_v2(tpv2 w, half2v &hi, half2v &lo) {
+    hi = __builtin_convertvector((f32x2){w[0], w[1]}, half2v);
+    const tpv2 r = tp_mul_s(tp_sub_2(w, tp_v2((float)hi[0], (float)hi[1])), kTpLoScale);
+    lo = __builtin_convertvector((f32x2){r[0], r[1]}, half2v);
+}
 
 // ---- cell update of the 16 units of one tile pair (torch.nn.LSTM gate order i, f, g, o), lane-local ----
 // Cut into 40 slices (8 unit pairs x 5 stages of <= 8 VALU ops) so that the update of tile pair 0 can be
@@ -210,41 +297,50 @@ struct TpCellCtx {
     float (&h)[16];           // TJ = 0: h_t of these units, parked while tile pair 1 still reads h_{t-1}
     half8 (&hh)[4];           // TJ = 1: h_{t-1} is dead by then, h_t goes straight into the next B operands
     half8 (&hl)[4];
-    f32x2 t[5];               // the unit pair in flight: two values per register pair, so the adds / fmas / muls are v_pk_*
+    tpv2 t[5];                // the unit pair in flight
 };
-// v_exp_f32 / v_rcp_f32 on both halves of a pair (transcendentals have no packed form; measured 8 cycles each)
-HNS_DEV f32x2 tp_exp2_2(f32x2 v) { return (f32x2){__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])}; }
-HNS_DEV f32x2 tp_fma_2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-HNS_DEV f32x2 tp_rcp_2(f32x2 v) { return (f32x2){__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; }
 template <int TJ>
 struct TpCell {
     static constexpr int N = 40;
     template <int K>
     static __device__ __forceinline__ void slice(TpCellCtx &x) {
         constexpr int S = K % 5, u0 = 2 * (K / 5), u1 = u0 + 1;
-        f32x2 *t = x.t;
+        tpv2 *t = x.t;
+#ifdef TP_ABL_NOCELL                           // lab: no nonlinearities (timing of the matrix products + operand traffic alone)
+        if constexpr (S == 4) {
+            const tpv2 h = tp_mul_s(tp_v2(x.z[0][u0], x.z[3][u1]), 1e-3f);
+            if constexpr (TJ == 0) { x.h[u0] = h[0]; x.h[u1] = h[1]; }
+            else {
+                half2v a, b;
+                tp_split_v2(h, a, b);
+                x.hh[2 + (u0 >> 3)][u0 & 7] = a[0]; x.hl[2 + (u0 >> 3)][u0 & 7] = b[0];
+                x.hh[2 + (u1 >> 3)][u1 & 7] = a[1]; x.hl[2 + (u1 >> 3)][u1 & 7] = b[1];
+            }
+        }
+        return;
+#endif
         if constexpr (S == 0) {            // 1 + e_i, 1 + e_f
-            t[0] = tp_exp2_2((f32x2){x.z[0][u0], x.z[0][u1]}) + 1.0f;
-            t[1] = tp_exp2_2((f32x2){x.z[1][u0], x.z[1][u1]}) + 1.0f;
+            t[0] = tp_add_s(tp_exp2_2(tp_v2(x.z[0][u0], x.z[0][u1])), 1.0f);
+            t[1] = tp_add_s(tp_exp2_2(tp_v2(x.z[1][u0], x.z[1][u1])), 1.0f);
         } else if constexpr (S == 1) {     // 1 + e_g; i, f
-            t[2] = tp_exp2_2((f32x2){x.z[2][u0], x.z[2][u1]}) + 1.0f;
+            t[2] = tp_add_s(tp_exp2_2(tp_v2(x.z[2][u0], x.z[2][u1])), 1.0f);
             t[0] = tp_rcp_2(t[0]);
             t[1] = tp_rcp_2(t[1]);
         } else if constexpr (S == 2) {     // g = tanh; c' = f c + i g; e_c
-            const f32x2 g = tp_fma_2(tp_rcp_2(t[2]), (f32x2)2.0f, (f32x2)-1.0f);
-            const f32x2 cn = tp_fma_2(t[1], (f32x2){x.c[16 * TJ + u0], x.c[16 * TJ + u1]}, t[0] * g);
+            const tpv2 g = tp_fma_s(tp_rcp_2(t[2]), 2.0f, -1.0f);
+            const tpv2 cn = tp_fma_2(t[1], tp_v2(x.c[16 * TJ + u0], x.c[16 * TJ + u1]), tp_mul_2(t[0], g));
             x.c[16 * TJ + u0] = cn[0]; x.c[16 * TJ + u1] = cn[1];
-            t[3] = tp_exp2_2(cn * (2.0f * kNegLog2e));
+            t[3] = tp_exp2_2(tp_mul_s(cn, 2.0f * kNegLog2e));
         } else if constexpr (S == 3) {     // o; 1 + e_c
-            t[4] = tp_rcp_2(tp_exp2_2((f32x2){x.z[3][u0], x.z[3][u1]}) + 1.0f);
-            t[3] = t[3] + 1.0f;
+            t[4] = tp_rcp_2(tp_add_s(tp_exp2_2(tp_v2(x.z[3][u0], x.z[3][u1])), 1.0f));
+            t[3] = tp_add_s(t[3], 1.0f);
         } else {                           // h' = o tanh(c')
-            const f32x2 h = t[4] * tp_fma_2(tp_rcp_2(t[3]), (f32x2)2.0f, (f32x2)-1.0f);
+            const tpv2 h = tp_mul_2(t[4], tp_fma_s(tp_rcp_2(t[3]), 2.0f, -1.0f));
             if constexpr (TJ == 0) {
                 x.h[u0] = h[0]; x.h[u1] = h[1];
             } else {
                 half2v a, b;
-                tp_split2(h, a, b);
+                tp_split_v2(h, a, b);
                 x.hh[2 + (u0 >> 3)][u0 & 7] = a[0]; x.hl[2 + (u0 >> 3)][u0 & 7] = b[0];
                 x.hh[2 + (u1 >> 3)][u1 & 7] = a[1]; x.hl[2 + (u1 >> 3)][u1 & 7] = b[1];
             }
@@ -306,11 +402,18 @@ struct TpGate {
             const float4 *b4 = reinterpret_cast<const float4 *>(c.bias + (2 * q + c.tj) * 32);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float4 bv = b4[v];                      // two accumulator elements per v_pk_fma_f32 (they are consecutive registers)
-                const f32x2 lo = tp_fma_2((f32x2){c.acc[q][4 * v], c.acc[q][4 * v + 1]}, (f32x2)kTpLoInv, (f32x2){bv.x, bv.y});
-                const f32x2 hi = tp_fma_2((f32x2){c.acc[q][4 * v + 2], c.acc[q][4 * v + 3]}, (f32x2)kTpLoInv, (f32x2){bv.z, bv.w});
+                const float4 bv = b4[v];
+#if TP_PK
+                const f32x2 lo = __builtin_elementwise_fma((f32x2){c.acc[q][4 * v], c.acc[q][4 * v + 1]}, (f32x2)kTpLoInv, (f32x2){bv.x, bv.y});
+                const f32x2 hi = __builtin_elementwise_fma((f32x2){c.acc[q][4 * v + 2], c.acc[q][4 * v + 3]}, (f32x2)kTpLoInv, (f32x2){bv.z, bv.w});
                 c.acc[q][4 * v] = lo[0]; c.acc[q][4 * v + 1] = lo[1];
                 c.acc[q][4 * v + 2] = hi[0]; c.acc[q][4 * v + 3] = hi[1];
+#else
+                c.acc[q][4 * v] = HNS_FMA(c.acc[q][4 * v], kTpLoInv, bv.x);
+                c.acc[q][4 * v + 1] = HNS_FMA(c.acc[q][4 * v + 1], kTpLoInv, bv.y);
+                c.acc[q][4 * v + 2] = HNS_FMA(c.acc[q][4 * v + 2], kTpLoInv, bv.z);
+                c.acc[q][4 * v + 3] = HNS_FMA(c.acc[q][4 * v + 3], kTpLoInv, bv.w);
+#endif
             }
         }
     }
@@ -319,7 +422,12 @@ struct TpGate {
     static __device__ __forceinline__ void step(const Ctx &c) {
         if constexpr (n == NLO) scale_bias(c);
         constexpr int ci = chunk(n), q = tile(n);
+#ifdef TP_ABL_NOMFMA                           // lab: no matrix products (the accumulators take one operand register each instead)
+        c.acc[q][n % 16] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, c.a[n % RING]).x & 0x3f000000u);
+        if constexpr (false) {
+#else
         if constexpr (ci < NXC) {
+#endif
             if constexpr (vlo(n)) c.acc[q] = TP_MFMA(c.a[n % RING], c.xl[ci], c.acc[q]);
             else c.acc[q] = TP_MFMA(c.a[n % RING], c.xh[ci], c.acc[q]);
         } else {
@@ -471,6 +579,9 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
     for (int i = 0; i < 32; ++i) c[i] = 0.0f;
     float hn0[16];                          // h_t of tile pair 0's units, parked while tile pair 1 still reads h_{t-1}
 
+#ifdef TP_PHASES
+    unsigned long long ph[4] = {0, 0, 0, 0}, last = __builtin_readcyclecounter();
+#endif
     // one timestep; t = 0 (h_0 = 0: no recurrent product) is peeled so that the loop body is straight-line code
     auto timestep = [&](int t, auto with_h) {
         constexpr bool WITH_H = decltype(with_h)::value;
@@ -481,7 +592,7 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
                 half2v a, b;
-                tp_split2((f32x2){xc[8 * cx + j], xc[8 * cx + j + 1]}, a, b);
+                tp_split_v2(tp_v2(xc[8 * cx + j], xc[8 * cx + j + 1]), a, b);
                 xh[cx][j] = a[0]; xl[cx][j] = b[0];
                 xh[cx][j + 1] = a[1]; xl[cx][j + 1] = b[1];
             }
@@ -501,7 +612,14 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
         // the MFMAs of the second (not at t = 0: too few MFMAs without the recurrent product)
         f32x16 acc0[4], acc1[4];
         TpCellCtx cell0{acc0, c, hn0, hh, hl, {}}, cell1{acc1, c, hn0, hh, hl, {}};
+#ifdef TP_PHASES
+#define TP_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); if (WITH_H) ph[i] += now_ - last; last = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define TP_STAMP(i)
+#endif
+        TP_STAMP(0)                                  // 0: split / window rows of this timestep
         tp_gate_tiles<NXC, WITH_H>(acc0, aw, 0, hb, sBias, xh, xl, hh, hl);
+        TP_STAMP(1)                                  // 1: gate tiles of units 0..31
         constexpr bool SIDE = WITH_H;
         if constexpr (SIDE) {
             tp_gate_tiles<NXC, WITH_H, true>(acc1, aw, 1, hb, sBias, xh, xl, hh, hl, &cell0);
@@ -510,19 +628,24 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
             __builtin_amdgcn_sched_barrier(0);            // acc0 is dead before acc1 goes live
             tp_gate_tiles<NXC, WITH_H>(acc1, aw, 1, hb, sBias, xh, xl, hh, hl);
         }
+        TP_STAMP(2)                                  // 2: gate tiles of units 32..63 (+ the cell update of units 0..31)
         TpCell<1>::run_all(cell1);
         __builtin_amdgcn_sched_barrier(0);
+        TP_STAMP(3)                                  // 3: cell update of units 32..63
         // h_{t-1} is dead now: h_t -> B operands of the next timestep
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
             half2v a, b;
-            tp_split2((f32x2){hn0[i], hn0[i + 1]}, a, b);
+            tp_split_v2(tp_v2(hn0[i], hn0[i + 1]), a, b);
             hh[i >> 3][i & 7] = a[0]; hl[i >> 3][i & 7] = b[0];
             hh[i >> 3][(i & 7) + 1] = a[1]; hl[i >> 3][(i & 7) + 1] = b[1];
         }
     };
     timestep(0, std::false_type{});
     for (int t = 1; t < T; ++t) timestep(t, std::true_type{});
+#ifdef TP_PHASES
+    if (prof && lane == 0) { prof[5] = ph[0]; prof[6] = ph[1]; prof[7] = ph[2]; prof[8] = ph[3]; }
+#endif
 
     if (prof && lane == 0) prof[2] = __builtin_amdgcn_s_memrealtime();
     // ---- output layer on h_T: tanh(W_fc h + b), rescaled to arena units (hideandseek.py:834-836) ----
@@ -572,57 +695,421 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (prof && lane == 0) prof[3] = __builtin_amdgcn_s_memrealtime();
-    // ---- observation rows of this wave's envs: [rpos_evader(3) | drone - predicted (3F) | quat4 linvel3 heading3 up3 t x4 (17)] ----
-    // hideandseek.py:844-854 (state_self, masked rpos from the step kernel's rows) and :873-880 (state_drones, unmasked rpos);
-    // TP_groundtruth / TP_done :838-842.  One lane per pursuer row (32 A rows per wave, contiguous in every buffer).  Was a second
-    // kernel (10 us + a launch); here the stores of one workgroup drain under the recurrences of the others.
+    // ---- observation rows of this wave's envs (tp_write_row): one lane per pursuer row, 32 A rows per wave, contiguous in every
+    // buffer.  Was a second kernel (10 us + a launch); here the stores of one workgroup drain under the recurrences of the others.
     {
-        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));       // rows are 4-byte aligned (D = 20 + 3F floats)
-        const int A = p.A, D = HNS_SELF_DIM + R, e_w0 = blockIdx.x * kTpEnvs + wave * 32;
+        const int A = p.A, e_w0 = blockIdx.x * kTpEnvs + wave * 32;
         for (int r = lane; r < 32 * A; r += 64) {
             const int el = r / A, a = r - el * A, er = e_w0 + el;
-            if (er >= p.E) continue;
-            const size_t ia = (size_t)er * A + a;
-            float o20[HNS_SELF_DIM];
-            const float4 *s4 = reinterpret_cast<const float4 *>(p.obs_self20 + ia * HNS_SELF_DIM);
+            if (er < p.E) tp_write_row(p, er, a, sPred + el * 16);
+        }
+    }
+    if (prof && lane == 0) prof[4] = __builtin_amdgcn_s_memrealtime();
+}
+
+// =================================================================================================
+// Weight-stationary predictor (round 3) — hns_tp_lstm_ws_kernel
+// =================================================================================================
+// What bounds the tile kernel above (measured, tools/lab/lab_batch60-61, tools/microbench/simd_share.hip): with the
+// nonlinearities compiled out it takes 55 us, with the matrix products compiled out 94 us — the full kernel 92-97.  It is
+// bound by VALU ISSUE, not by the matrix pipe: a lone wave issues one VALU instruction per 5-6 cycles (9 transcendental),
+// two waves per SIMD cannot fill a VALU that takes one wave-instruction per 2 cycles, and its 256-register waves
+// (two accumulator sets, cell state and both operand images of h per wave) leave room for two.
+// This kernel turns the roles around so that FOUR waves fit a SIMD:
+//   * a wave owns 32 gate ROWS (the four gates of 8 hidden units) of the weight matrix for the whole kernel: its A operands
+//     (two split terms x (frame chunks + 4 recurrent chunks) x 4 registers = 40 registers for 3 pursuers) are loaded once;
+//     8 such waves = one workgroup = all 256 gate rows, serving 128 envs (4 column tiles of 32); two workgroups per CU;
+//   * the activations are the moving operand: x_t and h_{t-1} sit in LDS in B-operand order (hi and lo split terms);
+//     every wave reads the same 10 operands per column tile, issues 15 MFMAs into ONE 16-register accumulator, runs the
+//     cell update of its 8 units x 32 envs on it (lane-local again: local row 8 gate + unit, so a lane holds the four
+//     gates of four units) and publishes its slice of h_t; one workgroup barrier pair per timestep;
+//   * LDS traffic 640 KB per CU and timestep (960 KB for the tile kernel's weight image reads), 49 KB per workgroup.
+// Split terms are UNSCALED here (lo = fp16(v - fp16(v)), subnormal where it must be: v_mfma_f32_32x32x16_f16 keeps fp16
+// subnormals, checked in simd_share.hip): hi*hi, hi*lo and lo*hi accumulate into one chain that starts at the bias —
+// no scaling pass, no bias pass.  The one operand whose magnitude would make the weights' low term matter, `progress`
+// (up to max_episode_length), enters as progress/1024 against its weight column x 1024 (both exact).
+constexpr int kWsWaves = 8, kWsThreads = kWsWaves * 64, kWsEnvs = 128, kWsTiles = 4;
+#ifdef WS_NOPROG
+constexpr float kWsProgScale = 1.0f, kWsProgInv = 1.0f;
+#else
+constexpr float kWsProgScale = 1024.0f, kWsProgInv = 1.0f / 1024.0f;
+#endif
+
+struct WsImage { int a, wfc, bias, bfc, slots; };     // offsets in 16-byte slots
+__host__ __device__ constexpr WsImage ws_image(int nxc) {
+    WsImage L{};
+    int o = 0;
+    L.a = o;    o += 8 * 2 * (nxc + 4) * 64;          // [row slice][term][chunk][lane]
+    L.wfc = o;  o += 2 * 4 * 64;                      // [term][chunk][lane]
+    L.bias = o; o += 256 / 4;                         // [row slice][half][16] floats
+    L.bfc = o;  o += 32 / 4;                          // [half][16] floats
+    L.slots = o;
+    return L;
+}
+// hidden unit in k-slot sp (0..7) of lane half hb in recurrent chunk c: the first four come from row slice 2c, the others from 2c+1
+__host__ __device__ inline int ws_unit(int c, int hb, int sp) { return 16 * c + 8 * (sp >> 2) + 4 * hb + (sp & 3); }
+
+HNS_DEV void ws_split(float w, _Float16 &hi, _Float16 &lo) {
+    // `w` is made opaque first: when it is a product, hipcc folds the multiply into ONE of the two uses of fp16(w) below
+    // (v_fma_mixlo_f16: a single rounding of the exact product) and converts the fp32 product for the other (v_cvt_pk_f16_f32);
+    // where the fp32 value sits exactly between two fp16 values the two disagree by an fp16 ulp and hi + lo is no longer w
+    // (found as 1-3 envs in 512 off by 1e-5, tools/tp_debug3.py)
+    asm volatile("" : "+v"(w));
+    hi = (_Float16)w;
+    lo = (_Float16)(w - (float)hi);
+}
+
+__global__ __launch_bounds__(256) void hns_tp_pack_ws_kernel(const TpParams p, int nxc) {
+    const WsImage L = ws_image(nxc);
+    const int I = p.I, R = 3 * p.F, NC = nxc + 4;
+    const int n_a = 8 * NC * 64, n_fc = 4 * 64;
+    uint4 *img = reinterpret_cast<uint4 *>(p.tp.packed);
+    for (int sidx = blockIdx.x * blockDim.x + threadIdx.x; sidx < n_a + n_fc; sidx += gridDim.x * blockDim.x) {
+        float w[8];
+        int slot_hi, slot_lo;
+        if (sidx < n_a) {
+            const int ln = sidx & 63, g = sidx >> 6, ch = g % NC, r = g / NC;
+            const int rho = ln & 31, hb = ln >> 5, row = (rho >> 3) * kTpH + 8 * r + (rho & 7);        // torch row: gate * 64 + unit
 #pragma unroll
-            for (int v = 0; v < HNS_SELF_DIM / 4; ++v) {
-                const float4 q = s4[v];
-                o20[4 * v] = q.x; o20[4 * v + 1] = q.y; o20[4 * v + 2] = q.z; o20[4 * v + 3] = q.w;
-            }
-            const float *ds = p.drone_state + ia * 13, *tg = p.target_pos + (size_t)er * 3;
-            const float px = ds[0], py = ds[1], pz = ds[2], tx = tg[0], ty = tg[1], tz = tg[2];
-            if (a == 0) {
-                // CUDA scalar-division form: tensor / python_scalar multiplies by the fp32 reciprocal
-                float *gt = p.tp.groundtruth + (size_t)er * 3;
-                gt[0] = tx * (1.0f / (0.5f * p.arena_size));
-                gt[1] = ty * (1.0f / (0.5f * p.arena_size));
-                gt[2] = (tz * (1.0f / p.max_height)) * 2.0f - 1.0f;
-                p.tp.tp_done[er] = (uint8_t)(p.progress[er] <= (float)(p.max_len - p.F));
-            }
-            const float *pr = sPred + el * 16;
-            for (int pass = 0; pass < 2; ++pass) {               // 0: state_self, 1: state_drones
-                float *dst = pass == 0 ? p.tp.obs_self : p.tp.state_drones;
-                if (!dst) continue;
-                float *g = dst + ia * D;
-                const float r0 = pass == 0 ? o20[0] : px - tx, r1 = pass == 0 ? o20[1] : py - ty, r2 = pass == 0 ? o20[2] : pz - tz;
-                if (R == 15) {                                    // five predicted points: 35 floats = 8 x 16 B + 3
-                    float w[36];
-                    w[0] = r0; w[1] = r1; w[2] = r2;
-#pragma unroll
-                    for (int f = 0; f < 5; ++f) { w[3 + 3 * f] = px - pr[3 * f]; w[4 + 3 * f] = py - pr[3 * f + 1]; w[5 + 3 * f] = pz - pr[3 * f + 2]; }
-#pragma unroll
-                    for (int j = 3; j < HNS_SELF_DIM; ++j) w[15 + j] = o20[j];
-#pragma unroll
-                    for (int v = 0; v < 8; ++v) *reinterpret_cast<f4u *>(g + 4 * v) = (f4u){w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]};
-                    g[32] = w[32]; g[33] = w[33]; g[34] = w[34];
+            for (int j = 0; j < 8; ++j) {
+                if (ch < nxc) {
+                    const int k = 16 * ch + 8 * hb + j;
+                    w[j] = k < I ? p.tp.w_ih[row * I + k] * tp_gate_scale(row) * (k == 0 ? kWsProgScale : 1.0f) : 0.0f;
                 } else {
-                    g[0] = r0; g[1] = r1; g[2] = r2;
-                    for (int f = 0; f < p.F; ++f) { g[3 + 3 * f] = px - pr[3 * f]; g[4 + 3 * f] = py - pr[3 * f + 1]; g[5 + 3 * f] = pz - pr[3 * f + 2]; }
-#pragma unroll
-                    for (int j = 3; j < HNS_SELF_DIM; ++j) g[R + j] = o20[j];
+                    w[j] = p.tp.w_hh[row * kTpH + ws_unit(ch - nxc, hb, j)] * tp_gate_scale(row);
                 }
             }
+            slot_hi = L.a + ((r * 2 + 0) * NC + ch) * 64 + ln;
+            slot_lo = L.a + ((r * 2 + 1) * NC + ch) * 64 + ln;
+        } else {
+            const int u = sidx - n_a, ln = u & 63, c = u >> 6, row = ln & 31, hb = ln >> 5;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = row < R ? p.tp.w_fc[row * kTpH + ws_unit(c, hb, j)] * (2.0f * kNegLog2e) : 0.0f;
+            slot_hi = L.wfc + c * 64 + ln;
+            slot_lo = L.wfc + (4 + c) * 64 + ln;
+        }
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 a, b;
+            ws_split(w[j], a, b);
+            hi[j] = a; lo[j] = b;
+        }
+        img[slot_hi] = *reinterpret_cast<uint4 *>(&hi);
+        img[slot_lo] = *reinterpret_cast<uint4 *>(&lo);
+    }
+    float *bias = reinterpret_cast<float *>(img + L.bias), *bfc = reinterpret_cast<float *>(img + L.bfc);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 256 + 32; idx += gridDim.x * blockDim.x) {
+        if (idx < 256) {                                    // [slice][half][16]: register i <-> gate i>>2 of unit 8 r + 4 hb + (i&3)
+            const int i = idx & 15, hb = (idx >> 4) & 1, r = idx >> 5;
+            const int g = (i >> 2) * kTpH + 8 * r + 4 * hb + (i & 3);
+            bias[idx] = (p.tp.b_ih[g] + p.tp.b_hh[g]) * tp_gate_scale(g);
+        } else {
+            const int i = idx & 15, hb = (idx - 256) >> 4;
+            const int row = 8 * (i >> 2) + 4 * hb + (i & 3);
+            bfc[idx - 256] = row < R ? p.tp.b_fc[row] * (2.0f * kNegLog2e) : 0.0f;
+        }
+    }
+}
+
+// One column tile's matrix products in the weight-stationary kernel: op k = (A operand: split term and k-chunk of this wave's rows,
+// B operand: x or h chunk, hi or lo term, read from LDS).  Cross terms of every chunk first, then the leading terms (they read
+// the hi operands a second time), all into one accumulator that starts at the bias.
+// The B operands go through a ring of four registers, three reads ahead of the matrix pipe.  A ring slot is refilled only after
+// the NEXT op has issued: every op depends on its predecessor's accumulator, so that one has retired by then — a ds_read that
+// lands in a register an MFMA in flight still reads corrupts the operand (found in round 2 on the A side, and again here on the
+// B side: 1-3 envs in 256 off by 1e-5 while the compiler placed the reads).  BASE rotates the slots from tile to tile so that the
+// first reads of a tile, which may be issued right behind the previous tile's last MFMA, never target that MFMA's slot.
+template <int NXC, bool WITH_H>
+struct WsTile {
+    static constexpr int NX2 = 2 * NXC, NCROSS = NX2 + (WITH_H ? 8 : 0), N = NCROSS + NXC + (WITH_H ? 4 : 0);
+    static constexpr int D = 3, RING = 4;
+    static constexpr bool lead(int k) { return k >= NCROSS; }
+    static constexpr bool is_x(int k) { return k < NX2 || (lead(k) && k < NCROSS + NXC); }
+    static constexpr int chunk(int k) { return k < NX2 ? k / 2 : k < NCROSS ? (k - NX2) / 2 : k < NCROSS + NXC ? k - NCROSS : k - NCROSS - NXC; }
+    static constexpr int b_term(int k) { return lead(k) ? 0 : (k < NX2 ? k % 2 : (k - NX2) % 2); }       // cross terms: hi operand (with w2), then lo (with w1)
+    static constexpr int a_term(int k) { return lead(k) ? 0 : 1 - b_term(k); }
+    static constexpr int a_chunk(int k) { return is_x(k) ? chunk(k) : NXC + chunk(k); }
+    struct Ctx {
+        f32x16 &acc;
+        half8 (&b)[RING];
+        const half8 (&aw)[2][NXC + 4];
+        const uint4 *xb, *hp;     // x buffer of this timestep / h buffer, both + tile * 64 + lane
+    };
+    template <int k>
+    static __device__ __forceinline__ half8 load(const Ctx &c) {
+        constexpr int off = ((chunk(k) * 2 + b_term(k)) * 4) * 64;
+        return __builtin_bit_cast(half8, is_x(k) ? c.xb[off] : c.hp[off]);
+    }
+    template <int BASE, int k>
+    static __device__ __forceinline__ void pro(const Ctx &c) {
+        c.b[(k + BASE) % RING] = load<k>(c);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int BASE, int k>
+    static __device__ __forceinline__ void step(const Ctx &c) {
+        c.acc = TP_MFMA(c.aw[a_term(k)][a_chunk(k)], c.b[(k + BASE) % RING], c.acc);
+        if constexpr (k + D < N) c.b[(k + D + BASE) % RING] = load<k + D>(c);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int BASE, int... Ps, int... Ks>
+    static __device__ __forceinline__ void run_seq(const Ctx &c, std::integer_sequence<int, Ps...>, std::integer_sequence<int, Ks...>) {
+        (pro<BASE, Ps>(c), ...);
+        (step<BASE, Ks>(c), ...);
+    }
+    template <int BASE>
+    static __device__ __forceinline__ void run(const Ctx &c) {
+        run_seq<BASE>(c, std::make_integer_sequence<int, (D < N ? D : N)>{}, std::make_integer_sequence<int, N>{});
+    }
+};
+
+#ifndef WS_OCC
+#define WS_OCC 4
+#endif
+template <int NXC>
+__global__ __launch_bounds__(kWsThreads, WS_OCC) void hns_tp_lstm_ws_kernel(const TpParams p) {
+    constexpr int NC = NXC + 4;
+    constexpr WsImage L = ws_image(NXC);
+    extern __shared__ __align__(16) uint4 simg[];
+    // LDS (16-byte slots): h_{t-1} [chunk 4][term 2][tile 4][lane 64] | x [buffer 2][chunk NXC][term 2][tile 4][lane 64] | bias [64]
+    uint4 *sH = simg, *sX = simg + 2048, *sB = sX + 1024 * NXC;
+    const int tid = threadIdx.x, lane = tid & 63, r = tid >> 6, hb = lane >> 5;
+    const int I = p.I, T = p.T, R = 3 * p.F;
+    const int e0 = blockIdx.x * kWsEnvs;
+    const uint4 *img = reinterpret_cast<const uint4 *>(p.tp.packed);
+    unsigned long long *prof = p.prof ? p.prof + (size_t)(blockIdx.x * kWsWaves + r) * 16 : nullptr;
+    if (prof && lane == 0) prof[0] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- this wave's rows of the weight matrix: A operands for the whole kernel ----
+    half8 aw[2][NC];
+#pragma unroll
+    for (int term = 0; term < 2; ++term)
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            const uint4 v = img[L.a + ((r * 2 + term) * NC + ch) * 64 + lane];
+            aw[term][ch] = __builtin_bit_cast(half8, v);
+        }
+    if (tid < 64) sB[tid] = img[L.bias + tid];
+
+    // ---- frames: thread (env_l, q) owns values 4 q .. 4 q + 3 of every 16-wide chunk of env e0 + env_l ----
+    const int env_l = tid >> 2, q = tid & 3;
+    const int e = e0 + env_l;
+    const bool valid = e < p.E;
+    const int ec = valid ? e : p.E - 1;
+    const bool vec = (I & 3) == 0;                         // rows 16-byte aligned and made of whole quads
+    float *hist = p.tp.history + (size_t)ec * T * I;
+    float nf[NXC][4];                                      // the new frame
+    {
+        const bool det = p.detect[ec] != 0;
+#pragma unroll
+        for (int cx = 0; cx < NXC; ++cx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * cx + 4 * q + j;
+                nf[cx][j] = k < I ? tp_frame_val(p, ec, k, det) : 0.0f;
+            }
+    }
+    auto load_row = [&](int slot, float (&dst)[NXC][4]) {
+        const float *row = hist + (size_t)slot * I;
+#pragma unroll
+        for (int cx = 0; cx < NXC; ++cx) {
+            const int k0 = 16 * cx + 4 * q;
+            if (vec) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 < I) v = *reinterpret_cast<const float4 *>(row + k0);
+                dst[cx][0] = v.x; dst[cx][1] = v.y; dst[cx][2] = v.z; dst[cx][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[cx][j] = (k0 + j) < I ? row[k0 + j] : 0.0f;
+            }
+        }
+    };
+    // frame tt of the new window: stored to the window in HBM (raw) and to LDS as the B operand of timestep tt (split)
+    auto emit = [&](int tt, const float (&v)[NXC][4]) {
+        float *row = hist + (size_t)tt * I;
+#pragma unroll
+        for (int cx = 0; cx < NXC; ++cx) {
+            const int k0 = 16 * cx + 4 * q;
+            if (valid) {
+                if (vec) { if (k0 < I) *reinterpret_cast<float4 *>(row + k0) = make_float4(v[cx][0], v[cx][1], v[cx][2], v[cx][3]); }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (k0 + j < I) row[k0 + j] = v[cx][j];
+                }
+            }
+            typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+            half4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float w = (cx == 0 && q == 0 && j == 0) ? v[cx][j] * kWsProgInv : v[cx][j];
+                _Float16 a, b;
+                ws_split(w, a, b);
+                hi[j] = a; lo[j] = b;
+            }
+            // k-slot 4 q + j of the chunk: lane half q >> 1, bytes 8 (q & 1) .. of that lane's 16
+            const int slot = (((tt & 1) * NXC + cx) * 2 * 4 + (env_l >> 5)) * 64 + 32 * (q >> 1) + (env_l & 31);
+            reinterpret_cast<uint2 *>(sX)[(slot + 0 * 4 * 64) * 2 + (q & 1)] = __builtin_bit_cast(uint2, hi);
+            reinterpret_cast<uint2 *>(sX)[(slot + 1 * 4 * 64) * 2 + (q & 1)] = __builtin_bit_cast(uint2, lo);
+        }
+    };
+    const bool fill = (T == 1) || p.fill;
+    float xn[NXC][4];
+    {
+        if (fill) emit(0, nf);
+        else { load_row(1, xn); emit(0, xn); }
+        if (T > 1) {
+            if (fill || T == 2) {
+#pragma unroll
+                for (int cx = 0; cx < NXC; ++cx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xn[cx][j] = nf[cx][j];
+            } else load_row(2, xn);
+        }
+    }
+
+    float c[kWsTiles][4];
+#pragma unroll
+    for (int te = 0; te < kWsTiles; ++te)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[te][j] = 0.0f;
+    uint2 hnew[kWsTiles][2];
+    half8 bring[4];                                        // B-operand ring (WsTile)
+    const float4 *sBias = reinterpret_cast<const float4 *>(sB) + (r * 2 + hb) * 4;
+    if (prof && lane == 0) prof[1] = __builtin_amdgcn_s_memrealtime();
+
+    for (int t = 0; t < T; ++t) {
+        __syncthreads();                                   // x_t and h_{t-1} are in LDS
+        if (t + 1 < T) {                                   // frame t+1 -> the other x buffer (last read at timestep t-1)
+            emit(t + 1, xn);
+            if (t + 2 < T) {
+                if (fill || t + 2 == T - 1) {
+#pragma unroll
+                    for (int cx = 0; cx < NXC; ++cx)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xn[cx][j] = nf[cx][j];
+                } else load_row(t + 3, xn);
+            }
+        }
+        auto tile = [&](auto te_c) {
+            constexpr int te = decltype(te_c)::value;
+            f32x16 acc;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 b = sBias[v];
+                acc[4 * v] = b.x; acc[4 * v + 1] = b.y; acc[4 * v + 2] = b.z; acc[4 * v + 3] = b.w;
+            }
+            {
+                const uint4 *xb = sX + (t & 1) * (NXC * 2 * 4 * 64) + te * 64 + lane, *hp = sH + te * 64 + lane;
+                if (t > 0) {
+                    using W = WsTile<NXC, true>;
+                    const typename W::Ctx cx{acc, bring, aw, xb, hp};
+                    W::template run<(W::N * te) % W::RING>(cx);
+                } else {
+                    using W = WsTile<NXC, false>;
+                    const typename W::Ctx cx{acc, bring, aw, xb, hp};
+                    W::template run<(W::N * te) % W::RING>(cx);
+                }
+            }
+#ifdef WS_NOPS
+            asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
+#endif
+            // cell update of units 8 r + 4 hb + j (torch.nn.LSTM gate order i, f, g, o = accumulator registers j, 4 + j, 8 + j, 12 + j)
+            typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+            half4 hi4, lo4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float Ei = 1.0f + __builtin_amdgcn_exp2f(acc[j]);
+                const float Ef = 1.0f + __builtin_amdgcn_exp2f(acc[4 + j]);
+                const float Eg = 1.0f + __builtin_amdgcn_exp2f(acc[8 + j]);
+                const float Eo = 1.0f + __builtin_amdgcn_exp2f(acc[12 + j]);
+                const float gi = __builtin_amdgcn_rcpf(Ei), gf = __builtin_amdgcn_rcpf(Ef);
+                const float gg = HNS_FMA(__builtin_amdgcn_rcpf(Eg), 2.0f, -1.0f);
+                const float cn = HNS_FMA(gf, c[te][j], gi * gg);
+                c[te][j] = cn;
+                const float Ec = 1.0f + __builtin_amdgcn_exp2f(cn * (2.0f * kNegLog2e));
+                // h = o tanh(c') = (2 - Ec) / (Eo Ec): one reciprocal (Ec <= 1 + 2^(2.9 T) stays finite; Eo = inf gives 0)
+#ifdef WS_H2RCP
+                const float h = __builtin_amdgcn_rcpf(Eo) * HNS_FMA(__builtin_amdgcn_rcpf(Ec), 2.0f, -1.0f);
+#else
+                const float h = (2.0f - Ec) * __builtin_amdgcn_rcpf(Eo * Ec);
+#endif
+                _Float16 a, b;
+                ws_split(h, a, b);
+                hi4[j] = a; lo4[j] = b;
+#ifdef WS_DEBUG                                              // lab: one (env, unit)'s pre-activations, cell state and h per timestep
+                if (p.prof && e0 + te * 32 + (lane & 31) == WS_DEBUG_ENV && 8 * r + 4 * hb + j == WS_DEBUG_UNIT) {
+                    float *dbg = reinterpret_cast<float *>(p.prof) + 4096 + t * 8;
+                    dbg[0] = acc[j]; dbg[1] = acc[4 + j]; dbg[2] = acc[8 + j]; dbg[3] = acc[12 + j]; dbg[4] = cn; dbg[5] = h; dbg[6] = (float)a; dbg[7] = (float)b;
+                }
+#endif
+            }
+            hnew[te][0] = __builtin_bit_cast(uint2, hi4);
+            hnew[te][1] = __builtin_bit_cast(uint2, lo4);
+        };
+        tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{});
+        tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{});
+        __syncthreads();                                   // every wave has read h_{t-1}
+        // publish this slice of h_t: chunk r >> 1, k-slots 4 (r & 1) .. + 3 of both lane halves
+#pragma unroll
+        for (int te = 0; te < kWsTiles; ++te)
+#pragma unroll
+            for (int term = 0; term < 2; ++term)
+                reinterpret_cast<uint2 *>(sH)[((((r >> 1) * 2 + term) * 4 + te) * 64 + lane) * 2 + (r & 1)] = hnew[te][term];
+    }
+    __syncthreads();
+    if (prof && lane == 0) prof[2] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- output layer on h_T (waves 0..3, one column tile each): tanh(W_fc h + b), rescaled to arena units (hideandseek.py:834-836) ----
+    float *sPred = reinterpret_cast<float *>(sX);           // [env 128][16]; the x buffers are free now
+    if (r < kWsTiles) {
+        const int te = r;
+        f32x16 o;
+        {
+            const float4 *b4 = reinterpret_cast<const float4 *>(img + L.bfc) + hb * 4;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 b = b4[v];
+                o[4 * v] = b.x; o[4 * v + 1] = b.y; o[4 * v + 2] = b.z; o[4 * v + 3] = b.w;
+            }
+        }
+        half8 fh[4], fl[4], f1[4], f2[4];                   // every operand in its own register, all read before the first MFMA
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const uint4 *bh = sH + ((ch * 2) * 4 + te) * 64 + lane;
+            fh[ch] = __builtin_bit_cast(half8, bh[0]); fl[ch] = __builtin_bit_cast(half8, bh[4 * 64]);
+            f1[ch] = __builtin_bit_cast(half8, img[L.wfc + ch * 64 + lane]); f2[ch] = __builtin_bit_cast(half8, img[L.wfc + (4 + ch) * 64 + lane]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            o = TP_MFMA(f2[ch], fh[ch], o);
+            o = TP_MFMA(f1[ch], fl[ch], o);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) o = TP_MFMA(f1[ch], fh[ch], o);
+        __builtin_amdgcn_sched_barrier(0);
+        const int el = te * 32 + (lane & 31), er = e0 + el;
+        float *pr = p.tp.pred + (size_t)(er < p.E ? er : p.E - 1) * R;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 8 * (i >> 2) + 4 * hb + (i & 3);
+            if (row < R) {
+                const float v = tp_tanh_s(o[i]);
+                const int comp = row % 3;
+                const float val = (comp < 2) ? (v * 0.5f) * p.arena_size : ((v + 1.0f) * 0.5f) * p.max_height;
+                if (er < p.E) pr[row] = val;
+                sPred[el * 16 + row] = val;
+            }
+        }
+    }
+    __syncthreads();
+    if (prof && lane == 0) prof[3] = __builtin_amdgcn_s_memrealtime();
+    // ---- observation rows of the workgroup's envs ----
+    {
+        const int A = p.A;
+        for (int rr = tid; rr < kWsEnvs * A; rr += kWsThreads) {
+            const int el = rr / A, a = rr - el * A, er = e0 + el;
+            if (er < p.E) tp_write_row(p, er, a, sPred + el * 16);
         }
     }
     if (prof && lane == 0) prof[4] = __builtin_amdgcn_s_memrealtime();
@@ -636,6 +1123,14 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
 using hns::TpParams;
 
 static int tp_nxc(int I) { return (I + 15) / 16; }
+// which kernel serves a frame width: the weight-stationary one for one 16-value chunk (up to 3 pursuers, no cylinders in the
+// frame — the reference's default); HNS_TP_KERNEL=tile / ws forces one of them for A/B measurements (ws: up to 2 chunks)
+static bool tp_use_ws(int nxc) {
+    static const int mode = [] { const char *m = getenv("HNS_TP_KERNEL"); return !m ? 0 : (m[0] == 't' ? 1 : (m[0] == 'w' ? 2 : 0)); }();
+    if (mode == 1) return false;
+    if (mode == 2) return nxc <= 2;
+    return nxc == 1;
+}
 static int tp_frame_dim(const hns_cfg &c) { return 7 + 3 * c.num_agents + (c.tp_use_obstacles ? 3 * c.num_cylinders : 0); }
 
 static void tp_fill_params(const hns_env *env, TpParams &p) {
@@ -708,7 +1203,8 @@ int hns_tp_refresh(hns_env *env, void *stream) {
     if (!env->tp.bound) { hns_set_error("hns_tp_refresh: hns_tp_bind first"); return HNS_ERR_NOT_BOUND; }
     TpParams p;
     tp_fill_params(env, p);
-    hipLaunchKernelGGL(hns::hns_tp_pack_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, p, tp_nxc(p.I));
+    if (tp_use_ws(tp_nxc(p.I))) hipLaunchKernelGGL(hns::hns_tp_pack_ws_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, p, tp_nxc(p.I));
+    else hipLaunchKernelGGL(hns::hns_tp_pack_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, p, tp_nxc(p.I));
     HNS_CHECK_HIP(hipGetLastError());
     env->tp.dirty = false;
     return HNS_OK;
@@ -725,6 +1221,19 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
     tp_fill_params(env, p);
     p.fill = fill_history ? 1 : 0;
     const int nxc = tp_nxc(p.I);
+    if (tp_use_ws(nxc)) {
+        void (*wfn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_ws_kernel<1> : hns::hns_tp_lstm_ws_kernel<2>;
+        const size_t wlds = (size_t)(2048 + 1024 * nxc + 64) * 16;
+        static thread_local unsigned long long ws_attr_devs[2] = {0ull, 0ull};
+        const unsigned long long bit = 1ull << (env->device & 63);
+        if (!(ws_attr_devs[nxc - 1] & bit)) {
+            HNS_CHECK_HIP(hipFuncSetAttribute((const void *)wfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+            ws_attr_devs[nxc - 1] |= bit;
+        }
+        hipLaunchKernelGGL(wfn, dim3((p.E + hns::kWsEnvs - 1) / hns::kWsEnvs), dim3(hns::kWsThreads), wlds, (hipStream_t)stream, p);
+        HNS_CHECK_HIP(hipGetLastError());
+        return HNS_OK;
+    }
     void (*fn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_kernel<1> : nxc == 2 ? hns::hns_tp_lstm_kernel<2> : hns::hns_tp_lstm_kernel<3>;
     const int waves = hns::tp_waves(nxc);
     const size_t lds = (size_t)hns::tp_image(nxc).bytes + (size_t)waves * 8 * nxc * 64 * sizeof(float);   // image + parked new frame

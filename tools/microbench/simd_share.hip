@@ -1,0 +1,363 @@
+// How do the waves of ONE SIMD share its matrix pipe and its VALU on gfx950?  Questions behind the predictor kernel's
+// wave layout and instruction selection (csrc/hns_tp.hip):
+//   roles : one MFMA-stream wave beside 0..3 VALU-stream waves on the same SIMD, by VALU instruction kind — which kinds
+//           issue beside a running MFMA and which wait for it?  (v_fma, v_exp, v_rcp, v_pk_fma, v_pk_mul, v_pk_add, v_cvt_pk,
+//           v_mov, the cell update's mix with and without packed instructions)
+//   mixed : every wave runs the predictor's own proportion (1 MFMA : 6.5 VALU-equivalents), blocked or interleaved,
+//           1 / 2 / 4 waves per SIMD at constant work per SIMD, with and without packed instructions: wall time per MFMA.
+//   denorm: does v_mfma_f32_32x32x16_f16 keep fp16 subnormal inputs (unscaled low split terms)?
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 simd_share.hip -o simd_share && ./simd_share
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+#define REP2(x) x x
+#define REP4(x) x x x x
+#define REP8(x) REP4(x) REP4(x)
+#define REP16(x) REP8(x) REP8(x)
+
+// operands of every VALU block: %0..%2 = x0,x1,x2 ; %3 = pair p0 ; %4..%6 = y0,y1,y2 ; %7 = pair p1 ; %8 = float k ; %9 = pair kp
+#define VOPS "+v"(x0), "+v"(x1), "+v"(x2), "+v"(p0), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(p1) : "v"(k), "v"(kp)
+// 26 instructions on two register sets: 12 transcendental, 6 packed, 8 plain — the cell update's own mix
+#define MIX13(a, b, c, p)                                                                                                  \
+    "v_exp_f32 %" #a ", %" #a "\n v_exp_f32 %" #b ", %" #b "\n v_exp_f32 %" #c ", %" #c "\n"                               \
+    "v_pk_add_f32 %" #p ", %" #p ", %9\n v_add_f32 %" #c ", 1.0, %" #c "\n"                                                \
+    "v_rcp_f32 %" #a ", %" #a "\n v_rcp_f32 %" #b ", %" #b "\n v_rcp_f32 %" #c ", %" #c "\n"                               \
+    "v_pk_fma_f32 %" #p ", %" #p ", %9, %9\n v_pk_mul_f32 %" #p ", %" #p ", %9\n"                                          \
+    "v_fma_f32 %" #c ", %" #c ", %8, %8\n v_mul_f32 %" #a ", %" #a ", %8\n v_cvt_pk_f16_f32 %" #b ", %" #a ", %" #c "\n"
+#define MIX26 MIX13(0, 1, 2, 3) MIX13(4, 5, 6, 7)
+// the same arithmetic without packed fp32 instructions: every v_pk_* replaced by two plain ones (16 per set)
+#define MIX16(a, b, c)                                                                                                     \
+    "v_exp_f32 %" #a ", %" #a "\n v_exp_f32 %" #b ", %" #b "\n v_exp_f32 %" #c ", %" #c "\n"                               \
+    "v_add_f32 %" #a ", 1.0, %" #a "\n v_add_f32 %" #b ", 1.0, %" #b "\n v_add_f32 %" #c ", 1.0, %" #c "\n"                \
+    "v_rcp_f32 %" #a ", %" #a "\n v_rcp_f32 %" #b ", %" #b "\n v_rcp_f32 %" #c ", %" #c "\n"                               \
+    "v_fma_f32 %" #a ", %" #a ", %8, %8\n v_fma_f32 %" #b ", %" #b ", %8, %8\n v_mul_f32 %" #a ", %" #a ", %8\n"           \
+    "v_mul_f32 %" #b ", %" #b ", %8\n v_fma_f32 %" #c ", %" #c ", %8, %8\n v_mul_f32 %" #a ", %" #a ", %8\n"               \
+    "v_cvt_pk_f16_f32 %" #b ", %" #a ", %" #c "\n"
+#define MIX32 MIX16(0, 1, 2) MIX16(4, 5, 6)
+#define SIX(op) op(0) op(1) op(2) op(4) op(5) op(6)
+#define O_FMA(i) "v_fma_f32 %" #i ", %" #i ", %8, %8\n"
+#define O_EXP(i) "v_exp_f32 %" #i ", %" #i "\n"
+#define O_RCP(i) "v_rcp_f32 %" #i ", %" #i "\n"
+#define O_MOV(i) "v_mov_b32 %" #i ", %8\n"
+#define O_ADD(i) "v_add_f32 %" #i ", 1.0, %" #i "\n"
+#define O_CVT(i) "v_cvt_pk_f16_f32 %" #i ", %" #i ", %8\n"
+#define O_CVTF(i) "v_cvt_f32_f16 %" #i ", %" #i "\n"
+#define TWO(op) op(3) op(7)
+#define O_PKFMA(i) "v_pk_fma_f32 %" #i ", %" #i ", %9, %9\n"
+#define O_PKMUL(i) "v_pk_mul_f32 %" #i ", %" #i ", %9\n"
+#define O_PKADD(i) "v_pk_add_f32 %" #i ", %" #i ", %9\n"
+#define O_PKMULH(i) "v_pk_mul_f16 %" #i ", %" #i ", %8\n"
+
+enum { V_FMA, V_EXP, V_RCP, V_MOV, V_ADD, V_CVTPK, V_CVTF, V_PKFMA, V_PKMUL, V_PKADD, V_PKMULH, V_MIX26, V_MIX32, V_COUNT };
+static const char *kVName[V_COUNT] = {"v_fma_f32", "v_exp_f32", "v_rcp_f32", "v_mov_b32", "v_add_f32", "v_cvt_pk_f16_f32", "v_cvt_f32_f16",
+                                      "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_mul_f16", "mix (6 pk/26)", "mix (no pk, 32)"};
+static const int kVInstr[V_COUNT] = {24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 26, 32};
+
+template <int VK>
+__device__ __forceinline__ void valu_block(float &x0, float &x1, float &x2, f32x2 &p0, float &y0, float &y1, float &y2, f32x2 &p1, float k, f32x2 kp) {
+    if constexpr (VK == V_FMA) asm volatile(REP4(SIX(O_FMA)) : VOPS);
+    if constexpr (VK == V_EXP) asm volatile(REP4(SIX(O_EXP)) : VOPS);
+    if constexpr (VK == V_RCP) asm volatile(REP4(SIX(O_RCP)) : VOPS);
+    if constexpr (VK == V_MOV) asm volatile(REP4(SIX(O_MOV)) : VOPS);
+    if constexpr (VK == V_ADD) asm volatile(REP4(SIX(O_ADD)) : VOPS);
+    if constexpr (VK == V_CVTPK) asm volatile(REP4(SIX(O_CVT)) : VOPS);
+    if constexpr (VK == V_CVTF) asm volatile(REP4(SIX(O_CVTF)) : VOPS);
+    if constexpr (VK == V_PKFMA) asm volatile(REP4(REP4(TWO(O_PKFMA)) REP2(TWO(O_PKFMA))) : VOPS);
+    if constexpr (VK == V_PKMUL) asm volatile(REP4(REP4(TWO(O_PKMUL)) REP2(TWO(O_PKMUL))) : VOPS);
+    if constexpr (VK == V_PKADD) asm volatile(REP4(REP4(TWO(O_PKADD)) REP2(TWO(O_PKADD))) : VOPS);
+    if constexpr (VK == V_PKMULH) asm volatile(REP4(SIX(O_PKMULH)) : VOPS);
+    if constexpr (VK == V_MIX26) asm volatile(MIX26 : VOPS);
+    if constexpr (VK == V_MIX32) asm volatile(MIX32 : VOPS);
+}
+
+__device__ __forceinline__ unsigned hw_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
+    return v;
+}
+
+// ---- roles: slot 0..nM-1 of each SIMD runs an MFMA stream, the other slots the VALU stream VK ---------------------------
+// MF 0: 32x32x16 f16; 2: 16x16x32 f16
+template <int MF, int VK>
+__global__ __launch_bounds__(1024) void roles(float *out, long long *cyc, unsigned *hw, int iters, int nM) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = wave >> 2;
+    long long t0 = 0, t1 = 0;
+    float s = 0.f;
+    if (slot < nM) {
+        half8 a, b;
+        for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (lane + i)); b[i] = (_Float16)(0.002f * i); }
+        if constexpr (MF == 2) {
+            f32x4 acc[8];
+            for (int q = 0; q < 8; ++q) acc[q] = (f32x4)0.f;
+            t0 = __builtin_readcyclecounter();
+            for (int it = 0; it < iters; ++it)
+                asm volatile(REP4("v_mfma_f32_16x16x32_f16 %0, %8, %9, %0\n v_mfma_f32_16x16x32_f16 %1, %8, %9, %1\n v_mfma_f32_16x16x32_f16 %2, %8, %9, %2\n"
+                                  "v_mfma_f32_16x16x32_f16 %3, %8, %9, %3\n v_mfma_f32_16x16x32_f16 %4, %8, %9, %4\n v_mfma_f32_16x16x32_f16 %5, %8, %9, %5\n"
+                                  "v_mfma_f32_16x16x32_f16 %6, %8, %9, %6\n v_mfma_f32_16x16x32_f16 %7, %8, %9, %7\n")
+                             : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                             : "v"(a), "v"(b));
+            t1 = __builtin_readcyclecounter();
+            for (int q = 0; q < 8; ++q) s += acc[q][0] + acc[q][3];
+        } else {
+            f32x16 acc[4];
+            for (int q = 0; q < 4; ++q) for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+            t0 = __builtin_readcyclecounter();
+            for (int it = 0; it < iters; ++it)
+                asm volatile(REP8("v_mfma_f32_32x32x16_f16 %0, %4, %5, %0\n v_mfma_f32_32x32x16_f16 %1, %4, %5, %1\n"
+                                  "v_mfma_f32_32x32x16_f16 %2, %4, %5, %2\n v_mfma_f32_32x32x16_f16 %3, %4, %5, %3\n")
+                             : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(a), "v"(b));
+            t1 = __builtin_readcyclecounter();
+            for (int q = 0; q < 4; ++q) s += acc[q][0] + acc[q][15];
+        }
+    } else {
+        float x0 = 0.01f * lane, x1 = 0.01f * (lane + 1), x2 = 0.01f * (lane + 2), y0 = 0.02f * lane, y1 = 0.02f * (lane + 1), y2 = 0.02f * (lane + 2), k = 0.999f;
+        f32x2 p0 = {0.5f, 0.25f + lane}, p1 = {0.75f, 0.1f * lane}, kp = {0.999f, 1.001f};
+        t0 = __builtin_readcyclecounter();
+        for (int it = 0; it < iters; ++it) valu_block<VK>(x0, x1, x2, p0, y0, y1, y2, p1, k, kp);
+        t1 = __builtin_readcyclecounter();
+        s = x0 + x1 + x2 + y0 + y1 + y2 + p0[0] + p0[1] + p1[0] + p1[1];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (lane == 0) {
+        cyc[blockIdx.x * 16 + wave] = t1 - t0;
+        hw[blockIdx.x * 16 + wave] = hw_id();
+    }
+}
+
+// ---- mixed: every wave runs 32 MFMAs + 8 VALU blocks (26 with / 32 without packed instructions) per iteration -----------
+// ORDER 0: blocked (all MFMAs, then all VALU); 1: 4 MFMAs, one block, ...; 2: 1 MFMA : half a block
+// two accumulator tiles (4 waves per SIMD fit in 128 registers); the VALU block reads them, the next MFMAs read its result
+template <int ORDER, bool PK>
+__global__ __launch_bounds__(1024) void mixed(float *out, long long *cyc, int iters) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    half8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (lane + i)); b[i] = (_Float16)(0.002f * i); }
+    f32x16 acc0, acc1;
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    float x0 = 0.01f * lane, x1 = 0.01f * (lane + 1), x2 = 0.01f * (lane + 2), y0 = 0.02f * lane, y1 = 0.02f * (lane + 1), y2 = 0.02f * (lane + 2), k = 0.999f;
+    f32x2 p0 = {0.5f, 0.25f + lane}, p1 = {0.75f, 0.1f * lane}, kp = {0.999f, 1.001f};
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#define M2 "v_mfma_f32_32x32x16_f16 %0, %2, %3, %0\n v_mfma_f32_32x32x16_f16 %1, %2, %3, %1\n"
+#define M1A "v_mfma_f32_32x32x16_f16 %0, %2, %3, %0\n"
+#define M1B "v_mfma_f32_32x32x16_f16 %1, %2, %3, %1\n"
+#define MOPS "+v"(acc0), "+v"(acc1) : "v"(a), "v"(b)
+        if constexpr (ORDER == 0) {
+            asm volatile(REP16(M2) : MOPS);
+            x0 += acc0[0]; y0 += acc1[0];
+            if constexpr (PK) asm volatile(REP8(MIX26) : VOPS); else asm volatile(REP8(MIX32) : VOPS);
+            b[0] = (_Float16)x0;
+        } else if constexpr (ORDER == 1) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                asm volatile(M2 M2 : MOPS);
+                if constexpr (PK) asm volatile(MIX26 : VOPS); else asm volatile(MIX32 : VOPS);
+            }
+            x0 += acc0[0]; y0 += acc1[0];
+            b[0] = (_Float16)x0;
+        } else {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                asm volatile(M1A : MOPS);
+                if constexpr (PK) asm volatile(MIX13(0, 1, 2, 3) : VOPS); else asm volatile(MIX16(0, 1, 2) : VOPS);
+                asm volatile(M1B : MOPS);
+                if constexpr (PK) asm volatile(MIX13(4, 5, 6, 7) : VOPS); else asm volatile(MIX16(4, 5, 6) : VOPS);
+                asm volatile(M1A : MOPS);
+                asm volatile(M1B : MOPS);
+            }
+            x0 += acc0[0]; y0 += acc1[0];
+            b[0] = (_Float16)x0;
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + y0 + y1 + y2 + p0[0] + p0[1] + p1[0] + p1[1] + acc0[1] + acc1[1];
+    if (lane == 0) cyc[blockIdx.x * 16 + wave] = t1 - t0;
+}
+
+// ---- mixed16: the same proportion with v_mfma_f32_16x16x32_f16 (two 16-cycle MFMAs per 32x32x16) ---------------------------
+// ORDER 0: blocked; 1: 8 MFMAs, one block; 2: 2 MFMAs : a quarter block (4 VALU); 3: 1 MFMA : 2 VALU
+#define Q_A(a) "v_exp_f32 %" #a ", %" #a "\n v_add_f32 %" #a ", 1.0, %" #a "\n"
+#define Q_B(a) "v_rcp_f32 %" #a ", %" #a "\n v_fma_f32 %" #a ", %" #a ", %8, %8\n"
+template <int ORDER>
+__global__ __launch_bounds__(1024) void mixed16(float *out, long long *cyc, int iters) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    half8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (lane + i)); b[i] = (_Float16)(0.002f * i); }
+    f32x4 c0 = (f32x4)0.f, c1 = (f32x4)0.f, c2 = (f32x4)0.f, c3 = (f32x4)0.f;
+    float x0 = 0.01f * lane, x1 = 0.01f * (lane + 1), x2 = 0.01f * (lane + 2), y0 = 0.02f * lane, y1 = 0.02f * (lane + 1), y2 = 0.02f * (lane + 2), k = 0.999f;
+    f32x2 p0 = {0.5f, 0.25f + lane}, p1 = {0.75f, 0.1f * lane}, kp = {0.999f, 1.001f};
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#define N4 "v_mfma_f32_16x16x32_f16 %0, %4, %5, %0\n v_mfma_f32_16x16x32_f16 %1, %4, %5, %1\n v_mfma_f32_16x16x32_f16 %2, %4, %5, %2\n v_mfma_f32_16x16x32_f16 %3, %4, %5, %3\n"
+#define N1(i) "v_mfma_f32_16x16x32_f16 %" #i ", %4, %5, %" #i "\n"
+#define NOPS "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b)
+        if constexpr (ORDER == 0) {
+            asm volatile(REP16(N4) : NOPS);                                   // 64 MFMAs = 32 of the 32x32x16 kind
+            x0 += c0[0]; y0 += c1[0];
+            asm volatile(REP8(MIX32) : VOPS);
+            b[0] = (_Float16)x0;
+        } else if constexpr (ORDER == 1) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                asm volatile(N4 N4 : NOPS);
+                asm volatile(MIX32 : VOPS);
+            }
+            x0 += c0[0]; y0 += c1[0];
+            b[0] = (_Float16)x0;
+        } else if constexpr (ORDER == 2) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                asm volatile(N1(0) N1(1) : NOPS); asm volatile(Q_A(0) Q_A(1) : VOPS);
+                asm volatile(N1(2) N1(3) : NOPS); asm volatile(Q_B(0) Q_B(1) : VOPS);
+                asm volatile(N1(0) N1(1) : NOPS); asm volatile(Q_A(2) Q_A(4) : VOPS);
+                asm volatile(N1(2) N1(3) : NOPS); asm volatile(Q_B(2) Q_B(4) : VOPS);
+                asm volatile(N1(0) N1(1) : NOPS); asm volatile(Q_A(5) Q_A(6) : VOPS);
+                asm volatile(N1(2) N1(3) : NOPS); asm volatile(Q_B(5) Q_B(6) : VOPS);
+                asm volatile(N1(0) N1(1) : NOPS); asm volatile(Q_A(0) Q_B(0) : VOPS);
+                asm volatile(N1(2) N1(3) : NOPS); asm volatile(Q_A(4) Q_B(4) : VOPS);
+            }
+            x0 += c0[0]; y0 += c1[0];
+            b[0] = (_Float16)x0;
+        } else {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                asm volatile(N1(0) : NOPS); asm volatile(Q_A(0) : VOPS); asm volatile(N1(1) : NOPS); asm volatile(Q_A(1) : VOPS);
+                asm volatile(N1(2) : NOPS); asm volatile(Q_B(0) : VOPS); asm volatile(N1(3) : NOPS); asm volatile(Q_B(1) : VOPS);
+                asm volatile(N1(0) : NOPS); asm volatile(Q_A(2) : VOPS); asm volatile(N1(1) : NOPS); asm volatile(Q_A(4) : VOPS);
+                asm volatile(N1(2) : NOPS); asm volatile(Q_B(2) : VOPS); asm volatile(N1(3) : NOPS); asm volatile(Q_B(4) : VOPS);
+                asm volatile(N1(0) : NOPS); asm volatile(Q_A(5) : VOPS); asm volatile(N1(1) : NOPS); asm volatile(Q_A(6) : VOPS);
+                asm volatile(N1(2) : NOPS); asm volatile(Q_B(5) : VOPS); asm volatile(N1(3) : NOPS); asm volatile(Q_B(6) : VOPS);
+                asm volatile(N1(0) : NOPS); asm volatile(Q_A(0) : VOPS); asm volatile(N1(1) : NOPS); asm volatile(Q_B(0) : VOPS);
+                asm volatile(N1(2) : NOPS); asm volatile(Q_A(4) : VOPS); asm volatile(N1(3) : NOPS); asm volatile(Q_B(4) : VOPS);
+            }
+            x0 += c0[0]; y0 += c1[0];
+            b[0] = (_Float16)x0;
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + y0 + y1 + y2 + p0[0] + p0[1] + p1[0] + p1[1] + c0[1] + c1[1] + c2[0] + c3[0];
+    if (lane == 0) cyc[blockIdx.x * 16 + wave] = t1 - t0;
+}
+
+// ---- denorm: A = fp16 subnormals, B = 1 --------------------------------------------------------------------------------
+__global__ void denorm(float *out) {
+    const int lane = threadIdx.x;
+    half8 a, b;
+    const _Float16 tiny = (_Float16)5.9604645e-8f * (_Float16)3.0f;     // 3 x 2^-24: an fp16 subnormal
+    for (int i = 0; i < 8; ++i) { a[i] = tiny; b[i] = (_Float16)1.0f; }
+    f32x16 acc;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);      // 16 x (3 x 2^-24) = 2.861e-6 if subnormals survive
+    f32x16 acc2;
+    for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc2, 0, 0, 0);    // subnormals on the B side
+    if (lane == 0) { out[0] = acc[0]; out[1] = acc2[0]; out[2] = (float)tiny; }
+}
+
+static float *g_out; static long long *g_cyc; static unsigned *g_hw;
+static hipEvent_t g_e0, g_e1;
+constexpr int NB = 256;
+
+template <int MF, int VK>
+void run_roles() {
+    const int iters = 400;
+    static const int nMs[6] = {0, 0, 1, 1, 1, 2}, Ws[6] = {1, 4, 2, 3, 4, 4};
+    double alone1 = 0;
+    for (int cfg = 0; cfg < 6; ++cfg) {
+        const int nM = nMs[cfg], W = Ws[cfg];
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            (void)hipEventRecord(g_e0);
+            hipLaunchKernelGGL((roles<MF, VK>), dim3(NB), dim3(256 * W), 0, 0, g_out, g_cyc, g_hw, iters, nM);
+            (void)hipEventRecord(g_e1);
+            (void)hipDeviceSynchronize();
+            (void)hipEventElapsedTime(&ms, g_e0, g_e1);
+        }
+        std::vector<long long> h(NB * 16);
+        (void)hipMemcpy(h.data(), g_cyc, NB * 16 * 8, hipMemcpyDeviceToHost);
+        double m = 0, v = 0; int nm = 0, nv = 0;
+        for (int b = 0; b < NB; ++b)
+            for (int w = 0; w < 4 * W; ++w) { if ((w >> 2) < nM) { m += h[b * 16 + w]; ++nm; } else { v += h[b * 16 + w]; ++nv; } }
+        const double mc = nm ? m / nm / (iters * 32.0) : 0.0, vc = nv ? v / nv / (iters * (double)kVInstr[VK]) : 0.0;
+        const int nV = W - nM;
+        if (cfg == 0) alone1 = vc;
+        printf("roles %s %-18s M=%d V=%d : MFMA %5.1f cyc/MFMA/wave | VALU %6.2f cyc/instr/wave = %.3f instr/cyc/SIMD (x%.2f of one wave alone) | %.3f ms\n",
+               MF == 0 ? "32x32x16" : "16x16x32", kVName[VK], nM, nV, mc, vc, vc > 0 ? nV / vc : 0.0, alone1 > 0 ? vc / alone1 : 0.0, ms);
+    }
+}
+
+template <int ORDER, bool PK>
+void run_mixed() {
+    for (int W : {1, 2, 4}) {
+        const int it = 1200 / W;
+        float ms = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(g_e0);
+            hipLaunchKernelGGL((mixed<ORDER, PK>), dim3(NB), dim3(256 * W), 0, 0, g_out, g_cyc, it);
+            (void)hipEventRecord(g_e1);
+            (void)hipDeviceSynchronize();
+            (void)hipEventElapsedTime(&ms, g_e0, g_e1);
+        }
+        std::vector<long long> h(NB * 16);
+        (void)hipMemcpy(h.data(), g_cyc, NB * 16 * 8, hipMemcpyDeviceToHost);
+        double mx = 0, av = 0; int n = 0;
+        for (int b = 0; b < NB; ++b) for (int w = 0; w < 4 * W; ++w) { mx = std::max(mx, (double)h[b * 16 + w]); av += h[b * 16 + w]; ++n; }
+        av /= n;
+        printf("mixed order %d %s W=%d : slowest wave %.1f SIMD cycles per MFMA (+%s VALU) [mean wave %.1f] | %.3f ms = %.1f ns per MFMA per SIMD\n",
+               ORDER, PK ? "pk   " : "no-pk", W, mx / (W * it * 32.0), PK ? "6.5" : "8", av / (W * it * 32.0), ms, ms * 1e6 / (W * it * 32.0));
+    }
+}
+
+template <int ORDER>
+void run_mixed16() {
+    for (int W : {1, 2, 4}) {
+        const int it = 1200 / W;
+        float ms = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(g_e0);
+            hipLaunchKernelGGL((mixed16<ORDER>), dim3(NB), dim3(256 * W), 0, 0, g_out, g_cyc, it);
+            (void)hipEventRecord(g_e1);
+            (void)hipDeviceSynchronize();
+            (void)hipEventElapsedTime(&ms, g_e0, g_e1);
+        }
+        std::vector<long long> h(NB * 16);
+        (void)hipMemcpy(h.data(), g_cyc, NB * 16 * 8, hipMemcpyDeviceToHost);
+        double mx = 0, av = 0; int n = 0;
+        for (int b = 0; b < NB; ++b) for (int w = 0; w < 4 * W; ++w) { mx = std::max(mx, (double)h[b * 16 + w]); av += h[b * 16 + w]; ++n; }
+        av /= n;
+        printf("mixed16 order %d no-pk W=%d : slowest wave %.1f SIMD cycles per TWO 16x16x32 (+8 VALU) [mean wave %.1f] | %.3f ms = %.1f ns per pair per SIMD\n",
+               ORDER, W, mx / (W * it * 32.0), av / (W * it * 32.0), ms, ms * 1e6 / (W * it * 32.0));
+    }
+}
+
+int main(int argc, char **argv) {
+    const bool full = argc > 1 && !strcmp(argv[1], "--full");
+    (void)hipMalloc(&g_out, NB * 1024 * 4); (void)hipMalloc(&g_cyc, NB * 16 * 8); (void)hipMalloc(&g_hw, NB * 16 * 4);
+    (void)hipEventCreate(&g_e0); (void)hipEventCreate(&g_e1);
+
+    denorm<<<1, 64>>>(g_out);
+    float d[3]; (void)hipMemcpy(d, g_out, 12, hipMemcpyDeviceToHost);
+    printf("denorm: A-side %.4e  B-side %.4e  (kept if 2.8610e-06; tiny = %.4e)\n", d[0], d[1], d[2]);
+
+    if (full) {
+        run_roles<0, V_FMA>(); run_roles<0, V_EXP>(); run_roles<0, V_RCP>(); run_roles<0, V_MOV>(); run_roles<0, V_ADD>();
+        run_roles<0, V_CVTPK>(); run_roles<0, V_CVTF>(); run_roles<0, V_PKFMA>(); run_roles<0, V_PKMUL>(); run_roles<0, V_PKADD>(); run_roles<0, V_PKMULH>();
+        run_roles<0, V_MIX26>(); run_roles<0, V_MIX32>();
+        run_roles<2, V_FMA>(); run_roles<2, V_PKFMA>(); run_roles<2, V_MIX26>(); run_roles<2, V_MIX32>();
+    }
+    run_roles<2, V_EXP>(); run_roles<2, V_ADD>();
+
+    run_mixed<0, true>(); run_mixed<0, false>();
+    run_mixed<1, true>(); run_mixed<1, false>();
+    run_mixed<2, true>(); run_mixed<2, false>();
+    run_mixed16<0>(); run_mixed16<1>(); run_mixed16<2>(); run_mixed16<3>();
+    return 0;
+}

@@ -30,6 +30,12 @@ wg = t.reshape(-1, 8, 5)
 print("per-workgroup end (max over waves): p10 %.0f median %.0f p90 %.0f max %.0f" % tuple(np.percentile(wg[:, :, 4].max(1), [10, 50, 90, 100])))
 order = np.argsort(wg[:, :, 4].max(1))
 print("slowest workgroups:", order[-8:], "fastest:", order[:8])
+if "--phases" in sys.argv:     # -DTP_PHASES build: cycles per phase summed over the timesteps with a recurrent product
+    c = buf.cpu().numpy()[:nw, 5:9].astype(np.float64).reshape(-1, 8, 4) / 9.0
+    names = ["rows + frame split", "gate tiles, units 0..31", "gate tiles, units 32..63 (+ cell update 0..31)", "cell update 32..63"]
+    for grp, name in ((slice(0, 4), "waves 0-3 (older)"), (slice(4, 8), "waves 4-7 (younger)")):
+        g = c[:, grp]
+        print(name + ": " + "; ".join("%s %.0f" % (n, g[..., i].mean()) for i, n in enumerate(names)) + "; timestep %.0f cycles" % g.sum(-1).mean())
 if "--stamps" in sys.argv:
     c = buf.cpu().numpy()[:nw, :16].astype(np.float64).reshape(-1, 8, 16)
     for grp, name in ((slice(0, 4), "waves 0-3"), (slice(4, 8), "waves 4-7")):
