@@ -848,7 +848,11 @@ struct WsTile {
     }
     template <int BASE, int k>
     static __device__ __forceinline__ void step(const Ctx &c) {
+#ifdef TP_ABL_NOMFMA                           // lab: no matrix products
+        c.acc[k % 16] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, c.b[(k + BASE) % RING]).x & 0x3f000000u);
+#else
         c.acc = TP_MFMA(c.aw[a_term(k)][a_chunk(k)], c.b[(k + BASE) % RING], c.acc);
+#endif
         if constexpr (k + D < N) c.b[(k + D + BASE) % RING] = load<k + D>(c);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -865,6 +869,14 @@ struct WsTile {
 
 #ifndef WS_OCC
 #define WS_OCC 4
+#endif
+#ifndef WS_ABL
+#define WS_ABL 0       // lab: 1 = no frame phase inside the loop, 2 = no barriers inside the loop (timing only, results wrong)
+#endif
+#if WS_ABL & 2
+#define WS_SYNC()
+#else
+#define WS_SYNC() __syncthreads()
 #endif
 template <int NXC>
 __global__ __launch_bounds__(kWsThreads, WS_OCC) void hns_tp_lstm_ws_kernel(const TpParams p) {
@@ -977,8 +989,17 @@ __global__ __launch_bounds__(kWsThreads, WS_OCC) void hns_tp_lstm_ws_kernel(cons
     const float4 *sBias = reinterpret_cast<const float4 *>(sB) + (r * 2 + hb) * 4;
     if (prof && lane == 0) prof[1] = __builtin_amdgcn_s_memrealtime();
 
+#ifdef WS_PHASES                                           // lab: cycles per phase, summed over the timesteps with a recurrent product (tools/tp_phase_profile.py --ws)
+    unsigned long long wph[5] = {0, 0, 0, 0, 0}, wlast = __builtin_readcyclecounter();
+#define WS_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); if (t > 0) wph[i] += now_ - wlast; wlast = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define WS_STAMP(i)
+#endif
     for (int t = 0; t < T; ++t) {
-        __syncthreads();                                   // x_t and h_{t-1} are in LDS
+        WS_STAMP(4)                                        // 4: publishing h + loop overhead
+        WS_SYNC();                                         // x_t and h_{t-1} are in LDS
+        WS_STAMP(0)                                        // 0: barrier waits
+#if !(WS_ABL & 1)
         if (t + 1 < T) {                                   // frame t+1 -> the other x buffer (last read at timestep t-1)
             emit(t + 1, xn);
             if (t + 2 < T) {
@@ -990,6 +1011,8 @@ __global__ __launch_bounds__(kWsThreads, WS_OCC) void hns_tp_lstm_ws_kernel(cons
                 } else load_row(t + 3, xn);
             }
         }
+#endif
+        WS_STAMP(1)                                        // 1: next frame
         auto tile = [&](auto te_c) {
             constexpr int te = decltype(te_c)::value;
             f32x16 acc;
@@ -1013,11 +1036,15 @@ __global__ __launch_bounds__(kWsThreads, WS_OCC) void hns_tp_lstm_ws_kernel(cons
 #ifdef WS_NOPS
             asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
 #endif
+            WS_STAMP(2)                                    // 2: matrix products of the tile
             // cell update of units 8 r + 4 hb + j (torch.nn.LSTM gate order i, f, g, o = accumulator registers j, 4 + j, 8 + j, 12 + j)
             typedef _Float16 half4 __attribute__((ext_vector_type(4)));
             half4 hi4, lo4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+#ifdef TP_ABL_NOCELL                           // lab: no nonlinearities
+                const float h = (acc[j] + acc[12 + j]) * 1e-3f;
+#else
                 const float Ei = 1.0f + __builtin_amdgcn_exp2f(acc[j]);
                 const float Ef = 1.0f + __builtin_amdgcn_exp2f(acc[4 + j]);
                 const float Eg = 1.0f + __builtin_amdgcn_exp2f(acc[8 + j]);
@@ -1033,6 +1060,7 @@ __global__ __launch_bounds__(kWsThreads, WS_OCC) void hns_tp_lstm_ws_kernel(cons
 #else
                 const float h = (2.0f - Ec) * __builtin_amdgcn_rcpf(Eo * Ec);
 #endif
+#endif
                 _Float16 a, b;
                 ws_split(h, a, b);
                 hi4[j] = a; lo4[j] = b;
@@ -1045,10 +1073,12 @@ __global__ __launch_bounds__(kWsThreads, WS_OCC) void hns_tp_lstm_ws_kernel(cons
             }
             hnew[te][0] = __builtin_bit_cast(uint2, hi4);
             hnew[te][1] = __builtin_bit_cast(uint2, lo4);
+            WS_STAMP(3)                                    // 3: cell update of the tile
         };
         tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{});
         tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{});
-        __syncthreads();                                   // every wave has read h_{t-1}
+        WS_SYNC();                                         // every wave has read h_{t-1}
+        WS_STAMP(0)
         // publish this slice of h_t: chunk r >> 1, k-slots 4 (r & 1) .. + 3 of both lane halves
 #pragma unroll
         for (int te = 0; te < kWsTiles; ++te)
@@ -1058,6 +1088,14 @@ __global__ __launch_bounds__(kWsThreads, WS_OCC) void hns_tp_lstm_ws_kernel(cons
     }
     __syncthreads();
     if (prof && lane == 0) prof[2] = __builtin_amdgcn_s_memrealtime();
+#ifdef WS_PHASES
+    if (prof && lane == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        prof[5] = wph[0]; prof[6] = wph[1]; prof[7] = wph[2]; prof[8] = wph[3]; prof[9] = wph[4]; prof[10] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 
     // ---- output layer on h_T (waves 0..3, one column tile each): tanh(W_fc h + b), rescaled to arena units (hideandseek.py:834-836) ----
     float *sPred = reinterpret_cast<float *>(sX);           // [env 128][16]; the x buffers are free now

@@ -338,8 +338,35 @@ void run_mixed16() {
     }
 }
 
+// sustained load: the same kernel for tens of milliseconds — shader clock (cycle counter / wall time) once power management has reacted
+template <class F>
+void sustain(const char *name, F launch, int W, int it) {
+    for (int rep = 0; rep < 3; ++rep) {
+        float ms = 0;
+        (void)hipEventRecord(g_e0);
+        launch(it);
+        (void)hipEventRecord(g_e1);
+        (void)hipDeviceSynchronize();
+        (void)hipEventElapsedTime(&ms, g_e0, g_e1);
+        std::vector<long long> h(NB * 16);
+        (void)hipMemcpy(h.data(), g_cyc, NB * 16 * 8, hipMemcpyDeviceToHost);
+        double mx = 0;
+        for (int b = 0; b < NB; ++b) for (int w = 0; w < 4 * W; ++w) mx = std::max(mx, (double)h[b * 16 + w]);
+        printf("sustain %-28s rep %d: %.2f ms, slowest wave %.0f cycles -> %.2f GHz; %.1f ns per MFMA unit per SIMD\n", name, rep, ms, mx, mx / (ms * 1e6), ms * 1e6 / ((double)W * it * 32.0));
+    }
+}
+
 int main(int argc, char **argv) {
     const bool full = argc > 1 && !strcmp(argv[1], "--full");
+    if (argc > 1 && !strcmp(argv[1], "--sustain")) {
+        (void)hipMalloc(&g_out, NB * 1024 * 4); (void)hipMalloc(&g_cyc, NB * 16 * 8); (void)hipMalloc(&g_hw, NB * 16 * 4);
+        (void)hipEventCreate(&g_e0); (void)hipEventCreate(&g_e1);
+        sustain("mixed order 2 no-pk W=4, 1 ms", [](int it) { hipLaunchKernelGGL((mixed<2, false>), dim3(NB), dim3(1024), 0, 0, g_out, g_cyc, it); }, 4, 300);
+        sustain("mixed order 2 no-pk W=4, 60 ms", [](int it) { hipLaunchKernelGGL((mixed<2, false>), dim3(NB), dim3(1024), 0, 0, g_out, g_cyc, it); }, 4, 18000);
+        sustain("mixed order 0 pk W=2, 60 ms", [](int it) { hipLaunchKernelGGL((mixed<0, true>), dim3(NB), dim3(512), 0, 0, g_out, g_cyc, it); }, 2, 36000);
+        sustain("MFMA only W=1, 40 ms", [](int it) { hipLaunchKernelGGL((roles<0, V_FMA>), dim3(NB), dim3(256), 0, 0, g_out, g_cyc, g_hw, it, 1); }, 1, 36000);
+        return 0;
+    }
     (void)hipMalloc(&g_out, NB * 1024 * 4); (void)hipMalloc(&g_cyc, NB * 16 * 8); (void)hipMalloc(&g_hw, NB * 16 * 4);
     (void)hipEventCreate(&g_e0); (void)hipEventCreate(&g_e1);
 

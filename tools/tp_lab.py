@@ -60,8 +60,7 @@ def child(args):
             O.tp_observe(env.hcfg, env.export_state(), tpa, fill=False)
             e_rows = max(e_rows, float(np.abs(env._tp_bufs["obs_self"].cpu().numpy() - tpa["obs_self"]).max()))
             e_pred = max(e_pred, float(np.abs(env._tp_bufs["pred"].cpu().numpy() - tpa["pred"]).max()))
-        assert np.array_equal(env._tp_bufs["history"].cpu().numpy(), tpa["history"]), "window differs from the oracle"
-        errs[f"x{scale:g}"] = {"rows": e_rows, "pred": e_pred}
+        errs[f"x{scale:g}"] = {"rows": e_rows, "pred": e_pred, "window": bool(np.array_equal(env._tp_bufs["history"].cpu().numpy(), tpa["history"]))}
         del env
 
     # ---- time ----
@@ -111,7 +110,8 @@ def main():
         r = json.loads(line[-1])
         e = r["err"]
         print(f"{name:14s} observe {r['observe_us_med']:7.2f} us (min {r['observe_us_min']:7.2f})  step+observe {r['step_plus_observe_us_med']:7.2f} us  "
-              f"err rows/pred x1 {e['x1']['rows']:.1e}/{e['x1']['pred']:.1e}  x3 {e['x3']['rows']:.1e}/{e['x3']['pred']:.1e}", flush=True)
+              f"err rows/pred x1 {e['x1']['rows']:.1e}/{e['x1']['pred']:.1e}  x3 {e['x3']['rows']:.1e}/{e['x3']['pred']:.1e}"
+              + ("" if e['x1']['window'] and e['x3']['window'] else "  WINDOW DIFFERS FROM THE ORACLE"), flush=True)
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ buf = torch.zeros((E // 64) * (A + 1), 16, dtype=torch.int64, device=env.device)
 env._lib.hns_set_phase_profile(env._env, C.c_void_p(buf.data_ptr()))
 env._tp_observe(); torch.cuda.synchronize()
 env._lib.hns_set_phase_profile(env._env, None)
-nw = (E // 256) * 8
+nw = (E // 128) * 8 if "--ws" in sys.argv else (E // 256) * 8
 t = buf.cpu().numpy()[:nw, :5].astype(np.float64) * 10.0      # ns
 z = t[:, 0].min()
 t -= z
@@ -30,6 +30,20 @@ wg = t.reshape(-1, 8, 5)
 print("per-workgroup end (max over waves): p10 %.0f median %.0f p90 %.0f max %.0f" % tuple(np.percentile(wg[:, :, 4].max(1), [10, 50, 90, 100])))
 order = np.argsort(wg[:, :, 4].max(1))
 print("slowest workgroups:", order[-8:], "fastest:", order[:8])
+if "--ws" in sys.argv:         # -DWS_PHASES build of the weight-stationary kernel: cycles per phase and timestep (timesteps 1..T-1)
+    c = buf.cpu().numpy()[:nw, 5:10].astype(np.float64).reshape(-1, 8, 5) / 9.0
+    names = ["barrier waits", "next frame", "matrix products (4 tiles)", "cell updates (4 tiles)", "publish h + loop"]
+    print("all waves: " + "; ".join("%s %.0f" % (n, c[..., i].mean()) for i, n in enumerate(names)) + "; timestep %.0f cycles" % c.sum(-1).mean())
+    for w in range(8):
+        print("  wave %d: " % w + " ".join("%6.0f" % c[:, w, i].mean() for i in range(5)))
+    hw = buf.cpu().numpy()[:nw, 10].reshape(-1, 8)[:, 0]
+    cu = ((hw >> 32) & 0xf) * 64 + ((hw >> 13) & 7) * 16 + ((hw >> 8) & 0xf)       # XCC | SE | CU
+    by = {}
+    for b, k in enumerate(cu): by.setdefault(int(k), []).append(b)
+    pairs = [v for v in by.values() if len(v) == 2]
+    print("distinct CUs %d; examples of co-resident workgroups: %s; difference of the two block ids: %s" % (len(by), pairs[:6], sorted(set(abs(a - b) for a, b in pairs))[:8]))
+    lt = t[:, 2] - t[:, 1]
+    print("recurrence (stamp 2 - stamp 1): median %.0f ns -> %.2f GHz by the cycle counter" % (np.median(lt), c.sum(-1).mean() * 9 / np.median(lt)))
 if "--phases" in sys.argv:     # -DTP_PHASES build: cycles per phase summed over the timesteps with a recurrent product
     c = buf.cpu().numpy()[:nw, 5:9].astype(np.float64).reshape(-1, 8, 4) / 9.0
     names = ["rows + frame split", "gate tiles, units 0..31", "gate tiles, units 32..63 (+ cell update 0..31)", "cell update 32..63"]
