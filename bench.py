@@ -13,7 +13,9 @@ Prints ONE JSON line (rank 0):
   * `roofline`: the step kernel, measured live — every 32nd launch of the timed region carries dispatch-bound hipEvents
     (hns_enable_timing), per-rank min/max in `kernel_us_by_rank`; `traffic` is a LOOK-UP of the committed PMC profile;
   * `configs`: the other BASELINE configurations (cfg2 4 096 envs / no cylinders, cfg4 envgen with the generator's cost
-    per episode, cfg5_shard 6v2 / 16 cylinders — one GPU's shard), each with its own ms_per_step and roofline fraction;
+    per episode, cfg5_shard 6v2 / 16 cylinders — one GPU's shard), each with its own ms_per_step and roofline fraction, and
+    `beyond_l3`: the headline shape at 262 144 and 1 048 576 envs (0.4 / 1.6 GB touched per step: past the 256 MiB Infinity Cache);
+  * `n_gpus`: distinct (host, device) pairs the ranks ran on (`config.ranks` = ranks); the RCCL backend refuses ranks > devices;
   * `tp_mode`: step + trajectory predictor (the reference's default `use_TP_net: 1`);
   * `cpu_baseline` (N = 1 only): the CPU oracle — test infrastructure, never the product — on a bounded sample.
 """
@@ -309,9 +311,32 @@ def main():
         dt = timed_steps(e5, td5, n, 30, timing=8)
         r5, _ = kernel_roofline(e5, E, 6, 16, NT=2)
         assert e5.check_finite()
+        if r5 is not None:
+            try:
+                tj5 = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"hns_step_kernel<6>|E{E}|C16|k3|critic_state_off|NT2", {})
+                r5["traffic"] = tj5.get("traffic_bytes_per_launch")
+                r5["traffic_source"] = tj5.get("source", "profiles/traffic.json") + " (static look-up of the committed rocprofv3 PMC passes)"
+            except Exception:  # noqa: BLE001
+                pass
         configs["cfg5_shard"] = {"workload": f"HideAndSeek 6v2 (extension), 16 cylinders, {E} envs = one GPU's shard of the 8 x 65 536 job",
                                  "value": round(E * 6 * n / dt, 1), "unit": "agent-steps/s", "ms_per_step": round(dt / n * 1e3, 5), "steps": n, "roofline": r5}
         del e5
+        # beyond the 256 MiB Infinity Cache: the headline batch touches ~105 MB per step, which the last-level cache can hold between
+        # launches; these two batches touch 0.42 GB and 1.7 GB per step, so every byte comes from / goes to HBM
+        beyond = {}
+        for eb in ((262144, 1048576) if E >= 65536 else ()):          # (not at the reduced sizes of the contract test)
+            nb = max(40, n // 4)
+            ebv = make_env(eb, A, C)
+            _, tdb = action_ring(eb, A, 13, R=2)
+            dtb = timed_steps(ebv, tdb, nb, 10, timing=4)
+            rb, _ = kernel_roofline(ebv, eb, A, C)
+            assert ebv.check_finite()
+            beyond[str(eb)] = {"workload": f"HideAndSeek {A}v1, {C} cylinders, {eb} envs ({algorithmic_bytes_per_env(A, C, K) * eb / 1e6:.0f} MB algorithmic per step)",
+                               "value": round(eb * A * nb / dtb, 1), "unit": "agent-steps/s", "ms_per_step": round(dtb / nb * 1e3, 5), "steps": nb, "roofline": rb}
+            del ebv, tdb
+            torch.cuda.empty_cache()
+        if beyond:
+            configs["beyond_l3"] = beyond
         # cfg4: HideAndSeek_envgen — steps + the Adaptive Environment Generator at every episode boundary
         from hns_amd.envgen import HideAndSeek_envgen
         L, EP = args.envgen_episode_length, args.envgen_episodes

@@ -21,7 +21,13 @@
  * Conventions: plain C types only; every `float*`/`uint8_t*` in hns_buffers is a DEVICE
  * pointer owned by the caller (e.g. torch tensors) that must stay valid while bound;
  * functions return 0 on success and a negative hns_status on error, never throw, never
- * allocate device memory after hns_create, never synchronise the stream.  Quaternions are
+ * allocate device memory after hns_create, never synchronise a stream or the device (three documented exceptions: hns_bind's FIRST
+ * call does one blocking 1 KB upload; hns_step_kernel_ms waits for its last sample; a configuration setter waits only if eight
+ * earlier changes are still queued).  hns_step / hns_reset / hns_tp_observe / the setters are legal inside a stream capture.
+ * The configuration setters (hns_set_v_prey, hns_set_smoothness_coef, hns_set_phase_profile) and a repeated hns_bind change a
+ * device-resident parameter block with ONE stream-ordered copy enqueued on the stream of the latest hns_step / hns_reset call
+ * (the null stream before the first): launches already enqueued there keep the old values, later launches and graph replays on
+ * that stream see the new ones.  The HIP device current at the call must be the env's.  Quaternions are
  * (w,x,y,z) (omni_drones/utils/torch.py:62,125).  All tensors are C-contiguous fp32 unless noted.
  */
 #ifndef HNS_H_
@@ -261,7 +267,7 @@ int hns_raycast(hns_env *env, int num_rays, float max_range, float *out, void *s
  * + Linear(64 -> 3F) + tanh) evaluated on a T-frame history, I = 7 + 3A (+ 3C with cfg.tp_use_obstacles):
  *   frame = [progress, evader pos (masked), evader vel (masked), pursuer positions]   (:815-820)
  *           + [x, y, cylinder_size] of every cylinder slot with task.use_obstacles     (:808-816)
- * I <= 32 (two 16-wide operand chunks): up to 7 pursuers, or e.g. 3 pursuers + 5 cylinder slots.
+ * I <= 48 (three 16-wide operand chunks): up to 7 pursuers, or 3 pursuers + 8 cylinder slots.
  * The parameters are the caller's tensors in PyTorch layouts (the learner trains them,
  * scripts/train.py:180).  They are converted into a matrix-core operand image (`packed`) by
  * hns_tp_refresh: call it after every parameter update (hns_tp_bind schedules one).

@@ -36,7 +36,16 @@ struct hns_env {
     void (*reset_fn)(const hns::Params) = nullptr;
     void (*step_args_fn)(const hns::StepArgs) = nullptr;   // step kernel taking the split argument block (else step_fn)
     void (*step_args_prof_fn)(const hns::StepArgs) = nullptr;   // ... compiled with the per-wave phase stamps (hns_set_phase_profile)
-    hns::Params *params_dev = nullptr, *params_host = nullptr;   // device copy of the step launch's Params + its pinned host image
+    // device copy of the step launch's Params (allocated by hns_create) and what feeds it: a ring of pinned host images, one
+    // stream-ordered hipMemcpyAsync per change on `last_stream` (the stream of the latest step / reset / observe call)
+    static constexpr int kParamRing = 8;
+    hns::Params *params_dev = nullptr, *params_host = nullptr;   // params_host: the image last enqueued (ordinary memory, for comparison)
+    hns::Params *params_ring = nullptr;                          // pinned, [kParamRing]
+    hipEvent_t ring_events[kParamRing] = {};                     // recorded behind each slot's copy
+    bool ring_pending[kParamRing] = {};
+    int ring_next = 0;
+    std::vector<hns::Params *> captured_images;                  // pinned images a stream capture took (they must outlive the graph)
+    hipStream_t last_stream = nullptr;
     bool params_valid = false;
     unsigned long long *prof = nullptr;
     uint32_t cyl_magic = 0;

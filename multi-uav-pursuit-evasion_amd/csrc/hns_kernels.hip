@@ -1982,6 +1982,7 @@ static void select_kernels(hns_env *env) {
 
 
 static int upload_step_params(hns_env *env);
+static int alloc_step_params(hns_env *env);
 
 extern "C" {
 
@@ -2052,6 +2053,7 @@ int hns_create(const hns_cfg *cfg, hns_env **out) {
         delete env;
         return HNS_ERR_DEVICE;
     }
+    if (alloc_step_params(env) != HNS_OK) { hns_destroy(env); return HNS_ERR_DEVICE; }
     *out = env;
     return HNS_OK;
 }
@@ -2061,6 +2063,9 @@ void hns_destroy(hns_env *env) {
     for (auto &p : env->events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &p : env->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (env->params_dev) (void)hipFree(env->params_dev);
+    if (env->params_ring) (void)hipHostFree(env->params_ring);
+    for (auto *img : env->captured_images) (void)hipHostFree(img);
+    for (auto &ev : env->ring_events) if (ev) (void)hipEventDestroy(ev);
     delete env->params_host;
     delete env;
 }
@@ -2111,22 +2116,53 @@ static void fill_step_params(const hns_env *env, Params &p) {
 #endif
 }
 
-// Device copy of that block for the step kernel that reads it through `StepArgs::rest`.  Called where the block changes (bind, the
-// configuration setters, the profiling buffer), never from a steady-state step: it synchronises the device — launches in
-// flight still read the old block — and must not run inside a stream capture.
+// Device copy of that block for the step kernel that reads it through `StepArgs::rest`: one allocation in hns_create, refreshed
+// where the block changes (bind, the configuration setters, the profiling buffer), never from a steady-state step.
+static int alloc_step_params(hns_env *env) {
+    HNS_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&env->params_dev), sizeof(Params)));
+    HNS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&env->params_ring), sizeof(Params) * hns_env::kParamRing, hipHostMallocDefault));
+    for (auto &ev : env->ring_events) HNS_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    env->params_host = new Params;
+    return HNS_OK;
+}
+
+// A change travels as ONE stream-ordered copy of the block from a pinned image, enqueued on the stream of the latest step / reset
+// call: launches already enqueued there keep the old values, later ones see the new ones; no device synchronisation, no allocation,
+// legal inside a stream capture (the image a capture takes is then kept for the graph's lifetime).  The very first upload (hns_bind
+// before any launch) is a plain blocking copy: nothing reads the block yet.
 static int upload_step_params(hns_env *env) {
     if (!env->step_args_fn || !env->bound) return HNS_OK;
-    if (!env->params_dev) {
-        HNS_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&env->params_dev), sizeof(Params)));
-        env->params_host = new Params;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != env->device) {
+        set_error("the current HIP device is not the one this env was created on (hipSetDevice first)");
+        return HNS_ERR_DEVICE;
     }
     Params q;
     fill_step_params(env, q);
     if (env->params_valid && memcmp(&q, env->params_host, sizeof(Params)) == 0) return HNS_OK;
-    HNS_CHECK_HIP(hipDeviceSynchronize());
     memcpy(env->params_host, &q, sizeof(Params));
-    HNS_CHECK_HIP(hipMemcpy(env->params_dev, env->params_host, sizeof(Params), hipMemcpyHostToDevice));
-    env->params_valid = true;
+    if (!env->params_valid) {
+        HNS_CHECK_HIP(hipMemcpy(env->params_dev, env->params_host, sizeof(Params), hipMemcpyHostToDevice));
+        env->params_valid = true;
+        return HNS_OK;
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(env->last_stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone) {
+        Params *img = nullptr;
+        HNS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&img), sizeof(Params), hipHostMallocDefault));
+        memcpy(img, &q, sizeof(Params));
+        env->captured_images.push_back(img);
+        HNS_CHECK_HIP(hipMemcpyAsync(env->params_dev, img, sizeof(Params), hipMemcpyHostToDevice, env->last_stream));
+        return HNS_OK;
+    }
+    const int slot = env->ring_next;
+    env->ring_next = (slot + 1) % hns_env::kParamRing;
+    if (env->ring_pending[slot]) HNS_CHECK_HIP(hipEventSynchronize(env->ring_events[slot]));   // only when kParamRing changes are in flight at once
+    memcpy(env->params_ring + slot, &q, sizeof(Params));
+    HNS_CHECK_HIP(hipMemcpyAsync(env->params_dev, env->params_ring + slot, sizeof(Params), hipMemcpyHostToDevice, env->last_stream));
+    HNS_CHECK_HIP(hipEventRecord(env->ring_events[slot], env->last_stream));
+    env->ring_pending[slot] = true;
     return HNS_OK;
 }
 
@@ -2136,6 +2172,7 @@ static int launch(hns_env *env, bool is_step, const Params &p, hipStream_t strea
         set_error("hns_step / hns_reset: the current HIP device is not the one this env was created on");
         return HNS_ERR_DEVICE;
     }
+    env->last_stream = stream;
     std::pair<hipEvent_t, hipEvent_t> ev{};
     const bool time_it = is_step && env->timing > 0 && (env->step_count++ % (uint64_t)env->timing) == 0;
     auto fn = is_step ? env->step_fn : env->reset_fn;

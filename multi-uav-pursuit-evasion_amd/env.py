@@ -121,7 +121,16 @@ class _PlainEnvBase:
 
     def step(self, tensordict):
         out = self._step(tensordict)
-        tensordict.set("next", out["next"])
+        # EnvBase.step: tensordict.update(tensordict_out) — `next` (replaced as a whole: the same persistent tree every step) and the
+        # transform's keys (merged into what the caller's tensordict already holds under `stats` / `info`)
+        for k, v in dict.items(out):
+            cur = tensordict.get(k)
+            if cur is v:
+                continue
+            if k == "next" or cur is None or not isinstance(v, dict):
+                tensordict.set(k, v)
+            else:
+                cur.update(v)
         return tensordict
 
     def train(self, mode=True):
@@ -255,12 +264,12 @@ class HideAndSeek(_EnvBase):
         self.observation_spec = composite_spec({
             "agents": {"observation": obs, "state": state, "TP": tp},
             "stats": {k: unbounded_spec((E, 1), dev) for k in abi.STAT_NAMES},
-            "info": {"drone_state": unbounded_spec((E, A, 13), dev), "prev_action": bounded_spec(-1.0, 1.0, (E, A, 4), dev)}})
-        self.action_spec = composite_spec({"agents": {"action": bounded_spec(-1.0, 1.0, (E, A, 4), dev)}})
-        self.reward_spec = composite_spec({"agents": {"reward": unbounded_spec((E, A, 1), dev)}})
-        if not USING_REAL_TORCHRL:                                # torchrl derives these two itself
+            "info": {"drone_state": unbounded_spec((E, A, 13), dev), "prev_action": bounded_spec(-1.0, 1.0, (E, A, 4), dev)}}, (E,))
+        self.action_spec = composite_spec({"agents": {"action": bounded_spec(-1.0, 1.0, (E, A, 4), dev)}}, (E,))
+        self.reward_spec = composite_spec({"agents": {"reward": unbounded_spec((E, A, 1), dev)}}, (E,))
+        if not USING_REAL_TORCHRL:                                # torchrl derives these two itself (input_spec["_action_spec"], a bool done_spec)
             self.done_spec = bool_spec((E, 1), dev)
-            self.input_spec = composite_spec({"_action_spec": self.action_spec})
+            self.input_spec = composite_spec({"_action_spec": self.action_spec}, (E,))
         self.agent_spec = {"drone": AgentSpec("drone", A, _env=self)}
 
     # ---- besides reset / step / set_seed / train / eval, which the base class provides --------------------------------
@@ -303,7 +312,7 @@ class HideAndSeek(_EnvBase):
     # ---- isaac_env.py:210-225 -----------------------------------------------------------------------------
     def _reset(self, tensordict=None, **kwargs):
         mask_t = None
-        if tensordict is not None and tensordict.get("_reset") is not None:
+        if tensordict is not None and "_reset" in tensordict.keys():     # (tensordict 0.1.x: get() without a default raises on a missing key)
             mask_t = tensordict.get("_reset").reshape(self.num_envs).to(torch.uint8).contiguous()
         last_stats = self.stats.clone()
         ptr = C.c_void_p(mask_t.data_ptr()) if mask_t is not None else None
@@ -343,20 +352,6 @@ class HideAndSeek(_EnvBase):
         self._action_keepalive = action
         self._since_full_reset += 1
         self._state_version += 1
-        # what PIDRateController._inv_call leaves on the caller's tensordict (transforms.py:438-457); hideandseek.py:726-731 reads
-        # the first two back — here they are views of the buffers the kernel just updated
-        # (the entries are the same persistent tensors every step: a tensordict that already carries them — a collector steps
-        #  the same one again and again, return_same_td — is not touched again)
-        if getattr(tensordict, "_hns_transform_keys", None) is not self:
-            tensordict.set(("stats", "action_error_order1"), self._bufs["action_error"])
-            tensordict.set(("info", "prev_action"), self._bufs["prev_action"])
-            if self.publish_ctbr:
-                tensordict.set("ctbr", self._bufs["ctbr"])
-                tensordict.set("target_rate", self._bufs["target_rate"][..., :3])
-            try:
-                object.__setattr__(tensordict, "_hns_transform_keys", self)
-            except Exception:  # noqa: BLE001  (a tensordict class without instance attributes: set the keys every step)
-                pass
         b = self._bufs
         # hideandseek.py:1012-1015 — evader-speed curriculum; v_prey starts at its 1.3 cap with the
         # reference's defaults, in which case no host sync is ever needed
@@ -377,7 +372,14 @@ class HideAndSeek(_EnvBase):
             nxt = self._obs_tensordict()
             nxt.set(("agents", "reward"), b["reward"].unsqueeze(-1))
             nxt.set("done", b["done"].view(torch.bool).unsqueeze(-1))
-            self._next_cache = TensorDict({"next": nxt}, self.batch_size)
+            # beside `next`: what PIDRateController._inv_call leaves on the stepped tensordict (transforms.py:438-457; hideandseek.py:726-731
+            # reads the first two back) — views of the buffers the kernel just updated.  They travel in the RETURNED tree, which the base
+            # class merges into the caller's: torchrl locks the input tensordict while `_step` runs, new keys cannot be set on it.
+            out = {"next": nxt, "stats": {"action_error_order1": b["action_error"]}, "info": {"prev_action": b["prev_action"]}}
+            if self.publish_ctbr:
+                out["ctbr"] = b["ctbr"]
+                out["target_rate"] = b["target_rate"][..., :3]
+            self._next_cache = TensorDict(out, self.batch_size)
         return self._next_cache
 
     def _obs_tensordict(self):

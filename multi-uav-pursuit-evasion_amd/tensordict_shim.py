@@ -238,14 +238,17 @@ def bool_spec(shape, device=None):
     return TensorSpec(shape, dtype=torch.bool, device=device)
 
 
-def composite_spec(d):
+def composite_spec(d, shape=()):
+    """`shape` = the batch part every entry starts with: torchrl's EnvBase setters reject a composite whose shape differs from the env's
+    batch_size (the reference builds per-env specs and `.expand(num_envs)`s them, hideandseek.py:327-433 — same result)."""
     if USING_REAL_TORCHRL:
-        return _RealComposite({k: (composite_spec(v) if isinstance(v, dict) and not isinstance(v, _RealComposite) else v) for k, v in d.items()})
-    return CompositeSpec(d)
+        return _RealComposite({k: (composite_spec(v, shape) if isinstance(v, dict) and not isinstance(v, _RealComposite) else v) for k, v in d.items()},
+                              shape=torch.Size(shape))
+    return CompositeSpec({k: (composite_spec(v, shape) if isinstance(v, dict) and not isinstance(v, CompositeSpec) else v) for k, v in d.items()}, shape)
 
 
 def spec_tree(spec):
     """{key: {...} | [shape, dtype]} of a (real or stand-in) spec tree — what the manifest test compares."""
-    if hasattr(spec, "items") and not hasattr(spec, "dtype"):
+    if isinstance(spec, (dict, CompositeSpec)) or (USING_REAL_TORCHRL and isinstance(spec, _RealComposite)):
         return {k: spec_tree(v) for k, v in spec.items()}
     return [list(spec.shape), str(spec.dtype).replace("torch.", "")]

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Child process of tests/test_torchrl_branch.py: HideAndSeek as a (stand-in) torchrl EnvBase under TransformedEnv + SyncDataCollector,
+wired as scripts/train.py:165-205 wires the reference's env; the collected rollouts are replayed on the CPU oracle."""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [HERE, ROOT, os.path.join(ROOT, "oracle")]
+
+import numpy as np
+import torch
+import hns_amd  # noqa: F401
+from hns_amd import config, tensordict_shim
+assert tensordict_shim.USING_REAL_TORCHRL and tensordict_shim.USING_REAL_TENSORDICT, "the stand-in packages were not picked up"
+from hns_amd.env import HideAndSeek
+from tensordict import TensorDict
+from torchrl.envs import Compose, EnvBase, TransformedEnv
+from torchrl.collectors import SyncDataCollector
+import hns_oracle as O
+
+use_tp = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+E, A, L, T = 256, 3, 12, 8
+cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": 5, "min_num": 3}, "env": {"num_envs": E, "max_episode_length": L}},
+                      algo={"use_TP_net": use_tp, "train_every": T})
+base_env = HideAndSeek(cfg, headless=True)
+assert isinstance(base_env, EnvBase) and tuple(base_env.batch_size) == (E,)
+assert tuple(base_env.observation_spec.shape) == (E,) and tuple(base_env.input_spec["_action_spec"].shape) == (E,)
+assert tuple(base_env.observation_spec[("agents", "observation", "state_self")].shape) == (E, A, 1, 35 if use_tp else 20)
+env = TransformedEnv(base_env, Compose()).train()            # action_transform: none (cfg/task/HideAndSeek_hip.yaml)
+env.set_seed(0)
+agent_spec = env.agent_spec["drone"]                          # reached through the wrapper, as train.py:176 does
+assert agent_spec.n == A
+
+gen = torch.Generator(device=base_env.device).manual_seed(5)
+
+
+def policy(td):
+    td.set(("agents", "action"), torch.randn(E, A, 4, generator=gen, device=base_env.device))
+    return td
+
+
+frames_per_batch = env.num_envs * int(cfg.algo.train_every)
+collector = SyncDataCollector(env, policy=policy, frames_per_batch=frames_per_batch, total_frames=frames_per_batch * 4,
+                              device=cfg.sim.device, return_same_td=True)
+# the oracle follows: full reset, then every collected action; masked resets where the collector issued them
+host = O.alloc_buffers(base_env.hcfg)
+O.reset(base_env.hcfg, host, None, base_env.seed, 0)
+epoch, n_resets, first = 1, 0, None
+for i, data in enumerate(collector):
+    assert tuple(data.batch_size) == (E, T)
+    if first is None:
+        first = data
+    assert data is first                                          # return_same_td
+    rew, done = data.get(("next", "agents", "reward")), data.get(("next", "done"))
+    assert tuple(rew.shape) == (E, T, A, 1) and tuple(done.shape) == (E, T, 1) and done.dtype == torch.bool
+    assert tuple(data.get(("next", "agents", "observation", "state_self")).shape) == (E, T, A, 1, 35 if use_tp else 20)
+    assert tuple(data.get(("stats", "action_error_order1")).shape) == (E, T, A) and tuple(data.get(("info", "prev_action")).shape) == (E, T, A, 4)
+    assert "_reset" not in data.keys()
+    acts = data.get(("agents", "action")).cpu().numpy()
+    for t in range(T):
+        O.step(base_env.hcfg, host, np.ascontiguousarray(acts[:, t]))
+        assert np.array_equal(host["reward"], rew[:, t, :, 0].cpu().numpy()), f"rollout {i} step {t}: reward differs from the oracle"
+        assert np.array_equal(host["done"].astype(bool), done[:, t, 0].cpu().numpy())
+        if host["done"].any():
+            O.reset(base_env.hcfg, host, host["done"].copy(), base_env.seed, epoch)
+            epoch += 1
+            n_resets += 1
+dev = base_env.export_state()
+for k in ("drone_state", "target_pos", "progress", "stats"):
+    assert np.array_equal(host[k], dev[k], equal_nan=True), f"{k} differs from the oracle after the rollouts"
+# reset(td) with a tensordict that carries no `_reset` (tensordict 0.1.x: get() raises on a missing key)
+td = env.reset(TensorDict({}, [E], device=base_env.device))
+assert not td.get("done").any()
+print(json.dumps({"rollouts": i + 1, "frames": (i + 1) * E * T, "masked_resets": n_resets, "use_tp": use_tp}))

@@ -29,7 +29,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(d["value"] - 4096 * 3 * 64 / (d["ms_per_step"] * 1e-3 * 64)) / d["value"] < 1e-3
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["kernel_us"] > 0 and r["samples"] >= 1
+    assert r["kernel_us"] > 0 and r["samples"] >= 8                                       # short runs time every launch
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "agent-steps/s" and "sample" in c
     assert d["tp_mode"]["value"] > 0 and d["stream_shards"]["groups"] == 2
@@ -55,7 +55,8 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout            # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["sharding"].endswith("x2") and "all-gather" in d["config"]["collective"]
+    # n_gpus counts DEVICES (both ranks share cuda:0 here); the rank count is reported beside it
+    assert d["n_gpus"] == 1 and d["config"]["ranks"] == 2 and d["config"]["sharding"].endswith("x2") and "all-gather" in d["config"]["collective"]
     assert abs(d["value"] - 2 * 4096 * 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3      # whole-job aggregate
     assert d["cpu_baseline"] is None              # rank 0 at N = 1 only
 
@@ -72,7 +73,19 @@ def test_bench_launches_its_own_ranks():
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["world_size_launched"] == 2
+    assert d["n_gpus"] == 1 and d["config"]["ranks"] == 2 and d["config"]["world_size_launched"] == 2
     k = d["roofline"]["kernel_us_by_rank"]
     assert len(k["all"]) == 2 and 0 < k["min"] <= k["max"]
     assert abs(d["value"] - 2 * 4096 * 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+
+
+@pytest.mark.gpu
+def test_bench_refuses_to_fold_rccl_ranks_onto_one_gpu():
+    """With the RCCL backend two ranks need two devices: on a 1-GPU box the launch fails loudly instead of reporting n_gpus 2."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HNS_DIST_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "2", "--envs", "4096"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "refuse to fold" in (out.stderr + out.stdout)

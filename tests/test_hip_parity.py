@@ -343,6 +343,38 @@ def test_setters_reach_the_kernel():
     assert (host["stats"][abi.STAT_NAMES.index("smoothness_coef")] == 3.5).all()
 
 
+def test_setter_between_graph_replays():
+    """hns_step captured into a HIP graph; hns_set_v_prey between two replays (the curriculum hook, hideandseek.py:1012-1015).  The
+    setter enqueues one stream-ordered copy of the parameter block on the stream of the latest step — no device synchronisation, no
+    allocation (include/hns.h) — so the replay that follows flies the new speed and the one before it the old; both against the oracle."""
+    import ctypes as C
+    E, A = 128, 3
+    env = make_env(E, A, 6, max_len=50)
+    env.set_seed(9)
+    env.reset()
+    host = O.alloc_buffers(env.hcfg)
+    O.reset(env.hcfg, host, None, env.seed, 0)
+    act = torch.randn(E, A, 4, generator=torch.Generator().manual_seed(23)).to(env.device)
+    stream = torch.cuda.Stream(env.device)
+    sp, ap = C.c_void_p(stream.cuda_stream), C.c_void_p(act.data_ptr())
+    with torch.cuda.stream(stream):
+        assert env._lib.hns_step(env._env, ap, sp) == 0, env._lib.hns_last_error()          # warm-up on the capture stream
+        O.step(env.hcfg, host, act.cpu().numpy())
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            assert env._lib.hns_step(env._env, ap, sp) == 0, env._lib.hns_last_error()
+        for rep in range(6):
+            if rep == 3:
+                assert env._lib.hns_set_v_prey(env._env, C.c_float(0.6)) == 0, env._lib.hns_last_error()   # no synchronisation before or after
+                env.hcfg.v_prey = 0.6
+            graph.replay()
+            O.step(env.hcfg, host, act.cpu().numpy())
+        stream.synchronize()
+    assert_same(host, env.export_state(), "after six replays")
+    assert (np.abs(np.abs(host["target_vel"]) - 0.6) < 0.05).mean() > 0.9
+
+
 def test_line_of_sight_flag_is_derived_state():
     """The step kernel does not re-evaluate the evader policy's line of sight (hideandseek.py:1080): it reads the flag the previous
     step / the reset stored in pid_last_rate[..., 3] for the same positions (include/hns.h).  (i) after resets and steps the stored

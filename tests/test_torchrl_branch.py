@@ -1,0 +1,61 @@
+"""The branch of hns_amd that subclasses torchrl's EnvBase (taken when `torchrl` / `tensordict` import) — executed against
+tests/fake_torchrl, stand-ins that enforce what torchrl 0.1.1 / tensordict 0.1.2 enforce (the real packages cannot be installed
+in the build image).  Reference wiring: omni_drones/envs/isaac_env.py:47-57,210-240, scripts/train.py:165-205,
+omni_drones/utils/torchrl/collector.py:33-87."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "fake_torchrl")
+
+
+def test_stand_ins_enforce_the_contract():
+    """CPU: the checks themselves — a spec without the batch shape, a missing key without default, a new key on a locked tensordict."""
+    code = r"""
+import sys; sys.path.insert(0, %r)
+import torch
+from tensordict import TensorDict
+from torchrl.data import CompositeSpec, UnboundedContinuousTensorSpec
+from torchrl.envs import EnvBase
+class E(EnvBase):
+    def _set_seed(self, s): pass
+e = E(device="cpu", batch_size=[4])
+try:
+    e.observation_spec = CompositeSpec({"o": UnboundedContinuousTensorSpec((4, 3))})       # composite shape () != batch (4,)
+    raise SystemExit("spec without the batch shape was accepted")
+except ValueError:
+    pass
+e.observation_spec = CompositeSpec({"o": UnboundedContinuousTensorSpec((4, 3))}, shape=[4])
+td = TensorDict({"a": torch.zeros(4, 2)}, [4])
+try:
+    td.get("_reset"); raise SystemExit("missing key returned something")
+except KeyError:
+    pass
+assert td.get("_reset", None) is None
+td.lock_()
+try:
+    td.set("b", torch.zeros(4)); raise SystemExit("locked tensordict took a new key")
+except RuntimeError:
+    pass
+try:
+    TensorDict({"a": torch.zeros(3, 2)}, [4]); raise SystemExit("wrong batch size accepted")
+except RuntimeError:
+    pass
+print("ok")
+""" % FAKE
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_tp", [0, 1])
+def test_env_under_transformed_env_and_collector(use_tp):
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    out = subprocess.run([sys.executable, os.path.join(FAKE, "run_collector.py"), str(use_tp)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["rollouts"] == 4 and r["masked_resets"] >= 2 and r["use_tp"] == use_tp
