@@ -480,9 +480,11 @@ class HideAndSeek(_EnvBase):
         torch.cuda.synchronize(self.device)
         return {k: v.detach().cpu().numpy().copy() for k, v in self._bufs.items()}
 
-    def import_state(self, arrays):
+    def import_state(self, arrays, check=False):
         for k, v in arrays.items():
             self._bufs[k].copy_(torch.as_tensor(v).to(self.device).view(self._bufs[k].shape))
+        if check and not all(bool(torch.isfinite(self._bufs[k]).all()) for k in arrays if self._bufs[k].dtype.is_floating_point):
+            raise HnsError("import_state: non-finite values in the imported state")
         # the line-of-sight column of pid_last_rate is derived from the positions just written (include/hns.h)
         self._check(self._lib.hns_refresh_derived_state(self._env, self._stream()), "hns_refresh_derived_state")
         self._needs_reset = False
@@ -519,10 +521,19 @@ class HideAndSeek(_EnvBase):
     def load_state(self, path):
         import numpy as np
         z = np.load(path)
-        for k in self._bufs:
+        # derived / optional outputs may be absent from a snapshot written by an older build or without `publish_ctbr`: the sticky
+        # failure word restarts at zero, the transform's extra outputs are rewritten by the next step
+        optional = ("nonfinite", "ctbr", "target_rate")
+        fields = [k for k in self._bufs if k in z.files or k not in optional]
+        for k in fields:
+            if k not in z.files:
+                raise KeyError(f"snapshot has no field {k}")
             if tuple(z[k].shape) != tuple(self._bufs[k].shape):
                 raise ValueError(f"snapshot field {k} has shape {z[k].shape}, env expects {tuple(self._bufs[k].shape)}")
-        self.import_state({k: z[k] for k in self._bufs})
+        for k in optional:
+            if k in self._bufs and k not in z.files:
+                self._bufs[k].zero_()
+        self.import_state({k: z[k] for k in fields})
         self.seed, epoch, self._since_full_reset, self.update_epoch = (int(x) for x in z["_meta"])
         self._check(self._lib.hns_set_reset_epoch(self._env, C.c_uint32(epoch)), "hns_set_reset_epoch")
         self.v_prey = float(z["_v_prey"])
@@ -533,9 +544,11 @@ class HideAndSeek(_EnvBase):
             self._tp_filled = bool(int(z["_tp_filled"]))
 
     def check_finite(self, clear=False, deep=False):
-        """Failure detection: True iff no step since the word was last cleared produced a non-finite pursuer state, evader
+        """Failure detection: True iff no STEP since the word was last cleared produced a non-finite pursuer state, evader
         position or reward.  The step kernel ORs one sticky device word (hns_buffers.nonfinite); this reads that word —
-        one 4-byte read-back, no reduction over the buffers.  `deep=True` also reduces every float buffer (diagnostics)."""
+        one 4-byte read-back, no reduction over the buffers.  Non-finite values that enter another way (import_state / load_state,
+        a reset, the observation buffers) are caught one step later at the earliest — they propagate into the state the step checks —
+        or at once with `deep=True`, which reduces every float buffer (what the soak tools and `import_state(..., check=True)` use)."""
         word = int(self._bufs["nonfinite"].item())
         if clear:
             self._bufs["nonfinite"].zero_()

@@ -126,11 +126,44 @@ class GenBuffer:
         n, A, B = self.num_grid, self.num_agents, self.buffer_length
         free = np.argwhere(self.grid_map == 0)                                     # [F, 2]
         start = free[np.array([self.rng.integers(len(free)) for _ in range(B)])]   # one draw per sample, in sample order
+        if A > 4:
+            return self._easy_cases_literal(start)
         off = free[None, :, :] - start[:, None, :]                                 # [B, F, 2]
         rank = self._flood_rank()[off[..., 0] + n, off[..., 1] + n]                # [B, F]; the start itself has rank 0
         rank[rank == 0] = np.iinfo(np.int64).max                                   # the evader's cell is not a pursuer's
         nearest = np.argsort(rank, axis=1, kind="stable")[:, :A]                   # [B, A] indices into `free`, in discovery order
         cells = np.concatenate([free[nearest], start[:, None, :]], axis=1).astype(np.float64)   # pursuers, then the evader
+        xy = np.clip((cells - n // 2) * self.grid_size, -self.boundary, self.boundary)
+        z = (self.rng.random((B, A + 1, 1)) * 0.2 - 0.1) + self.max_height / 2
+        return np.concatenate([xy, z], axis=-1).astype(np.float32)
+
+    def _easy_cases_literal(self, start):
+        """More than four pursuers: the reference's queue flood as written (hideandseek_envgen.py:246-262), because of what its
+        `if len(found) == 4: break` does there — the fourth free cell found is never enqueued and the remaining neighbours of the
+        cell being expanded are skipped, which changes which cells the fifth and later pursuers get near the arena rim.  (Up to
+        four pursuers the flood ends at that `break` and the rank table above gives the same cells.)"""
+        from collections import deque
+        n, A, B = self.num_grid, self.num_agents, self.buffer_length
+        cells = np.zeros((B, A + 1, 2), dtype=np.float64)
+        for k in range(B):
+            x, y = int(start[k, 0]), int(start[k, 1])
+            visited = np.zeros((n, n), dtype=bool)
+            queue = deque([(x, y)])
+            visited[x, y] = True
+            found = []
+            while queue and len(found) < A:
+                cx, cy = queue.popleft()
+                for dx, dy in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+                    nx, ny = cx + dx, cy + dy
+                    if 0 <= nx < n and 0 <= ny < n and not visited[nx, ny]:
+                        visited[nx, ny] = True
+                        if self.grid_map[nx, ny] == 0:
+                            found.append((nx, ny))
+                            if len(found) == 4:
+                                break
+                        queue.append((nx, ny))
+            cells[k, :A] = found[:A]
+            cells[k, A] = (x, y)
         xy = np.clip((cells - n // 2) * self.grid_size, -self.boundary, self.boundary)
         z = (self.rng.random((B, A + 1, 1)) * 0.2 - 0.1) + self.max_height / 2
         return np.concatenate([xy, z], axis=-1).astype(np.float32)

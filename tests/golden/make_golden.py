@@ -731,8 +731,9 @@ PHYS = dict(dt=DT, g=9.81, mass=CF["mass"], inertia=[CF["inertia"]["xx"], CF["in
             lin_damp=0.2, ang_damp=0.2, v_max=TASK["v_drone"] * (1.0 - 1e-6), w_max=1000.0, ground=1)
 
 
-def gen_episode(tag, E, A, C, T, seed, max_len, action_scale=0.5, task=None, n_active=None):
-    """Closed loop: every stage is reference code except the integrator (A5 spec above)."""
+def gen_episode(tag, E, A, C, T, seed, max_len, action_scale=0.5, task=None, n_active=None, keep=None):
+    """Closed loop: every stage is reference code except the integrator (A5 spec above).
+    `keep`: store only these per-step records (the 100-step free-running fixtures)."""
     g = torch.Generator().manual_seed(seed)
     env = ShimEnv(E, A, C, task, max_len=max_len)
     tr = ShimTransform()
@@ -798,7 +799,7 @@ def gen_episode(tag, E, A, C, T, seed, max_len, action_scale=0.5, task=None, n_a
                          reward=out[("agents", "reward")], done=out["done"]).items():
             rec[k].append(v.clone())
     save(f"g_episode_{tag}", **{"init_" + k: v for k, v in init.items()},
-         **{k: torch.stack(v) for k, v in rec.items()},
+         **{k: torch.stack(v) for k, v in rec.items() if keep is None or k in keep},
          meta=np.array([E, A, C, T, max_len], dtype=np.int64))
 
 
@@ -815,6 +816,10 @@ if __name__ == "__main__":
     gen_episode("a3c8", E=24, A=3, C=8, T=40, seed=20241001, max_len=60)
     gen_episode("a3c5", E=24, A=3, C=5, T=30, seed=20241002, max_len=60, n_active=0)
     gen_episode("a6c16", E=12, A=6, C=16, T=20, seed=20241003, max_len=60)
+    # S_1 .. S_100 free running: the same closed loop, 100 steps, only what a free-running comparison reads
+    FREE = ("action", "pos", "rot", "vel", "tpos", "tvel", "progress", "reward", "done", "state_self")
+    gen_episode("free_a3c8", E=16, A=3, C=8, T=100, seed=20250301, max_len=120, keep=FREE)
+    gen_episode("free_a6c16", E=8, A=6, C=16, T=100, seed=20250302, max_len=120, keep=FREE)
 
 
 # --------------------------------------------------------------------------------------

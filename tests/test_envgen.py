@@ -69,9 +69,11 @@ def test_genbuffer_samplenearby_and_history():
 
 
 def test_easy_cases_take_the_cells_a_flood_reaches_first():
-    """init_easy_cases ranks cells by a precomputed flood table; here the same placement from a literal queue flood per sample."""
+    """init_easy_cases ranks cells by a precomputed flood table (up to four pursuers) or floods literally (more); here the reference's
+    queue flood as written, hideandseek_envgen.py:246-262, including its `if len(found) == 4: break` (the fourth cell found is not
+    enqueued, the rest of that expansion is skipped)."""
     from collections import deque
-    for A, seed in ((3, 1), (4, 2), (6, 3)):
+    for A, seed in ((3, 1), (4, 2), (6, 3), (7, 4)):
         gb = GenBuffer(A, 5, seed=seed, buffer_length=40)
         easy = gb.init_easy_cases()
         n, free = gb.num_grid, np.argwhere(gb.grid_map == 0)
@@ -86,9 +88,11 @@ def test_easy_cases_take_the_cells_a_flood_reaches_first():
                     q = (cx + dx, cy + dy)
                     if 0 <= q[0] < n and 0 <= q[1] < n and q not in seen:
                         seen.add(q)
-                        todo.append(q)
                         if gb.grid_map[q] == 0:
                             got.append(q)
+                            if len(got) == 4:
+                                break
+                        todo.append(q)
             want = np.clip((np.array(got[:A] + [(sx, sy)], dtype=np.float64) - n // 2) * gb.grid_size, -gb.boundary, gb.boundary)
             np.testing.assert_array_equal(easy[k, :, :2], want.astype(np.float32))
 

@@ -246,6 +246,17 @@ def test_snapshot_resume_is_bit_exact(tmp_path):
     st["drone_state"][0, 0, 0] = np.nan
     a.import_state(st)
     assert not a.check_finite(deep=True)            # injected, not stepped: only the buffer scan sees it
+    with pytest.raises(Exception):
+        a.import_state(st, check=True)
+    a.step(a.rand_step_input(acts[0].to(a.device)))
+    assert not a.check_finite()                     # ... and one step later the sticky word has it
+    # a snapshot from before the failure word existed (no `nonfinite` field) still loads; the word restarts at zero
+    z = dict(np.load(str(tmp_path / "snap.npz")))
+    z.pop("nonfinite")
+    np.savez_compressed(str(tmp_path / "old.npz"), **z)
+    c = make_env(200, 3, 8, max_len=7)
+    c.load_state(str(tmp_path / "old.npz"))
+    assert c.check_finite() and np.array_equal(c.export_state()["drone_state"], z["drone_state"])
 
 
 def test_set_state_get_state_round_trip():
