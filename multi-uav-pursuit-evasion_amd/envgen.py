@@ -336,6 +336,16 @@ class HideAndSeek_envgen(HideAndSeek):
         self.num_unif = self.num_envs
         A, Cn, E = self.num_agents, self.num_cylinders, self.num_envs
         self.gen_buffer = DeviceGenBuffer(self, seed=int(cfg.get("seed", 0)))
+        # task.global_gen_buffer: one history for the whole data-parallel job, owned by rank 0 (the reference's semantics under
+        # sharding, sharding.GlobalGenBuffer); default: every rank keeps its own
+        self.global_gen_buffer = False
+        if int(t.get("global_gen_buffer", 0)):
+            import torch.distributed as dist
+            from . import sharding
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                self.gen_buffer = sharding.GlobalGenBuffer(self.gen_buffer, int(t.get("num_envs_total", 0)) or None)
+                self.global_gen_buffer = True
+        self._env_offset = int(env_index_offset)
         if self.use_init_easy:                                                # :485-495
             easy = GenBuffer(A, Cn, arena_size=float(t.arena_size), cylinder_size=float(t.cylinder.size),
                              max_height=float(t.max_height), seed=int(cfg.get("seed", 0))).init_easy_cases()
@@ -381,7 +391,7 @@ class HideAndSeek_envgen(HideAndSeek):
             return super()._reset(tensordict, **kwargs)
         import time
         mask_t = None
-        if tensordict is not None and tensordict.get("_reset") is not None:
+        if tensordict is not None and "_reset" in tensordict.keys():
             mask_t = tensordict.get("_reset").reshape(self.num_envs).to(torch.uint8).contiguous()
         last_stats = self.stats.clone()
         E = self.num_envs
@@ -390,6 +400,8 @@ class HideAndSeek_envgen(HideAndSeek):
         if self.update_iter == 0:
             hist = len(self.gen_buffer)
             num_buffer = min(hist, int(E * (1 - self.ratio_unif)))
+            if self.global_gen_buffer:
+                num_buffer = self.gen_buffer.buffer_share(E, self._env_offset, self.ratio_unif)
             self.num_unif = E - num_buffer
             if num_buffer > 0:
                 self.gen_buffer.samplenearby_into(self._tasks_dev[self.num_unif:], self.expand_cylinders, self.expand_step)
@@ -437,7 +449,12 @@ class HideAndSeek_envgen(HideAndSeek):
         else:
             ex["success_buffer"].zero_()
             ex["success_unif"].copy_(success)
-        if float(success.mean()) > self.success_threshold:
+        if self.global_gen_buffer:
+            from . import sharding
+            mean_success = sharding.global_mean(success)
+        else:
+            mean_success = float(success.mean())
+        if mean_success > self.success_threshold:
             self.ratio_unif = 1.0
         self.gen_buffer.insert_weights(success)
         self.update_iter += 1
@@ -454,7 +471,7 @@ class HideAndSeek_envgen(HideAndSeek):
                 ex[f"success_cylinders_{i}"].fill_(float(both[1, i] / both[0, i]) if both[0, i] > 0 else 0.0)
             keep = (w <= self.R_max) & (w >= self.R_min)
             kept = self.gen_buffer._state_buffer[keep]
-            self.gen_buffer.insert_history(kept)
+            self.gen_buffer.insert_history(kept)              # (global mode: every rank takes part, also with nothing to add)
             ex["add_history"].fill_(float(kept.shape[0]))
         ex["history_buffer"].fill_(float(len(self.gen_buffer)))
         ex["ratio_unif"].fill_(self.ratio_unif)

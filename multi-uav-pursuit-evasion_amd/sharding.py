@@ -67,6 +67,92 @@ def normalise_advantages(adv, success=None, eps=1e-7):
     return (adv - mean.to(adv.dtype)) / std.clamp(min=eps).to(adv.dtype), rate
 
 
+def _coll_tensor(t):
+    """A tensor the active backend can move: device tensors for RCCL, host tensors for gloo."""
+    return t.contiguous() if dist.get_backend() == "nccl" else t.cpu().contiguous()
+
+
+def global_mean(values):
+    """Mean over the WHOLE sharded batch (one all-reduce of [sum, count])."""
+    v = values.reshape(-1).double()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(v.mean())
+    acc = _coll_tensor(torch.stack([v.sum(), torch.tensor(float(v.numel()), dtype=torch.float64, device=v.device)]))
+    dist.all_reduce(acc)
+    return float(acc[0] / acc[1])
+
+
+class GlobalGenBuffer:
+    """ONE task history for a data-parallel run, as the reference's single process has it (hideandseek_envgen.py:209-233):
+    rank 0 owns the 5000-entry history.  When a task batch has been evaluated every rank hands the tasks it keeps to rank 0
+    (one gather, variable length, padded), rank 0 appends them and runs the farthest-point trim once, and the trimmed history
+    (<= 5000 x task_dim fp32 = 0.7 MB) goes back to every rank in one broadcast; each rank then perturbs ITS share of the next
+    batch from that common history with its own Philox stream.  Wraps a GenBuffer (numpy, CPU tests) or a DeviceGenBuffer.
+    Traffic per task batch over xGMI: <= 65 536 x 144 B = 9.4 MB into rank 0 per rank in the worst case (every task kept), 0.7 MB out.
+    Without it (the default) every rank keeps its own 5000-entry history: W histories of the shard's tasks — cheaper, no exchange,
+    but 8 x 5000 remembered tasks instead of 5000 and no task crosses shards."""
+
+    def __init__(self, inner, num_envs_total=None):
+        object.__setattr__(self, "inner", inner)
+        object.__setattr__(self, "num_envs_total", num_envs_total)
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+    def __setattr__(self, name, value):
+        setattr(self.inner, name, value)
+
+    def __len__(self):
+        return self._n()
+
+    def _n(self):
+        return int(self.inner._history.shape[0]) if hasattr(self.inner, "_history") else int(self.inner._history_buffer.shape[0])
+
+    def _history_tensor(self):
+        h = getattr(self.inner, "_history", None)
+        return h if h is not None else torch.as_tensor(self.inner._history_buffer)
+
+    def insert_history(self, states):
+        world, rank = dist.get_world_size(), dist.get_rank()
+        D = self.inner.task_dim
+        dev = getattr(self.inner, "_history", torch.zeros(0)).device if hasattr(self.inner, "_history") else torch.device("cpu")
+        kept = torch.as_tensor(states, dtype=torch.float32).reshape(-1, D).to(dev)
+        # 1. how many tasks every rank keeps, then the tasks themselves, padded to the longest (gather to rank 0)
+        n_local = _coll_tensor(torch.tensor([kept.shape[0]], dtype=torch.int64, device=dev))
+        counts = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(counts, n_local)
+        counts = [int(c.item()) for c in counts]
+        longest = max(counts)
+        n_hist = _coll_tensor(torch.zeros(1, dtype=torch.int64, device=dev))
+        if longest > 0:
+            pad = torch.zeros(longest, D, dtype=torch.float32, device=dev)
+            pad[:kept.shape[0]] = kept
+            pad = _coll_tensor(pad)
+            parts = [torch.zeros_like(pad) for _ in range(world)] if rank == 0 else None
+            dist.gather(pad, parts, dst=0)
+            if rank == 0:
+                allkept = torch.cat([p[:c] for p, c in zip(parts, counts)]).to(dev)
+                self.inner.insert_history(allkept if hasattr(self.inner, "_history") else allkept.cpu().numpy())
+        # 2. the trimmed history back to everybody
+        if rank == 0:
+            n_hist[0] = self._n()
+        dist.broadcast(n_hist, src=0)
+        n = int(n_hist.item())
+        hist = _coll_tensor(self._history_tensor().to(dev).float()) if rank == 0 else _coll_tensor(torch.zeros(n, D, dtype=torch.float32, device=dev))
+        if n > 0:
+            dist.broadcast(hist, src=0)
+            if rank != 0:
+                self.inner.init_history(hist.cpu().numpy())
+
+    def buffer_share(self, num_envs_local, env_offset, ratio_unif):
+        """How many of this rank's envs take a perturbed history task: the reference's min(len(history), int(E (1 - ratio_unif)))
+        (hideandseek_envgen.py:881-883) with E the WHOLE batch, split over the ranks in proportion to their env ranges."""
+        total = self.num_envs_total or num_envs_local * dist.get_world_size()
+        nb = min(self._n(), int(total * (1 - ratio_unif)))
+        lo, hi = env_offset * nb // total, (env_offset + num_envs_local) * nb // total
+        return hi - lo
+
+
 class GlobalSuccessRate:
     """`env.success_rate_fn` for a shard of a data-parallel run: the success rate over the WHOLE batch, as the reference's
     `stats["success"].mean()` sees it (hideandseek.py:1012-1015), so that every shard raises the evader's speed at the

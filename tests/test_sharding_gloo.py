@@ -91,3 +91,116 @@ def test_two_rank_shards_equal_single_process():
     np.testing.assert_allclose(got, ref.numpy(), rtol=2e-5, atol=2e-6)
     rate = float(full["stats"][abi.STAT_NAMES.index("success")].mean())
     assert abs(outs[0][7] - rate) < 1e-12 and abs(outs[1][7] - rate) < 1e-12
+
+
+# ---- one task history for the whole job (sharding.GlobalGenBuffer; reference semantics, hideandseek_envgen.py:209-233) ----------
+def _genbuf_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import hns_amd  # noqa: F401
+    from hns_amd import sharding
+    from hns_amd.envgen import GenBuffer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gb = sharding.GlobalGenBuffer(GenBuffer(3, 5, seed=11, buffer_length=60), num_envs_total=200)
+    rng = np.random.default_rng(100 + rank)
+    hists = []
+    for rnd in range(3):
+        # rank 0 keeps 25 / 0 / 50 tasks, rank 1 keeps 40 / 30 / 45: an empty contribution and an overflow of the 60-entry history
+        n = [[25, 0, 50], [40, 30, 45]][rank][rnd]
+        gb.insert_history(rng.random((n, gb.task_dim)).astype(np.float32))
+        hists.append(np.array(gb.inner._history_buffer, copy=True))
+    share = gb.buffer_share(100, 100 * rank, 0.3)
+    mean = sharding.global_mean(torch.full((100,), float(rank)))
+    q.put((rank, hists, share, mean))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_global_gen_buffer_two_ranks():
+    """Both ranks end every round with the SAME history, and it is the one a single process gets from the concatenated
+    contributions (rank 0 does the appending and the farthest-point trim); the perturbed share of the next batch splits
+    min(len(history), int(E_total (1 - ratio_unif))) over the ranks."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_genbuf_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from hns_amd.envgen import GenBuffer
+    single = GenBuffer(3, 5, seed=11, buffer_length=60)            # rank 0's generator state (same seed)
+    r0, r1 = np.random.default_rng(100), np.random.default_rng(101)
+    for rnd, (n0, n1) in enumerate([(25, 40), (0, 30), (50, 45)]):
+        both = np.concatenate([r0.random((n0, single.task_dim)).astype(np.float32), r1.random((n1, single.task_dim)).astype(np.float32)])
+        single.insert_history(both)
+        np.testing.assert_array_equal(outs[0][1][rnd], single._history_buffer)
+        np.testing.assert_array_equal(outs[1][1][rnd], single._history_buffer)
+    assert len(single._history_buffer) == 60
+    assert outs[0][2] + outs[1][2] == min(60, int(200 * 0.7)) and abs(outs[0][2] - outs[1][2]) <= 1
+    assert outs[0][3] == outs[1][3] == 0.5
+
+
+def _envgen_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import hns_amd  # noqa: F401
+    from hns_amd import config, sharding
+    from hns_amd.envgen import HideAndSeek_envgen
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    E, L = 192, 5
+    cfg = config.make_cfg({"name": "HideAndSeek_envgen", "num_agents": 3, "cylinder": {"max_num": 5, "min_num": 0},
+                           "use_particle_generator": 1, "ratio_unif": 0.3, "eval_iter": 2, "R_min": 0.0, "R_max": 1.0,
+                           "global_gen_buffer": 1, "num_envs_total": E * world,
+                           "env": {"num_envs": E, "max_episode_length": L}})
+    env = HideAndSeek_envgen(cfg, headless=True, env_index_offset=rank * E)
+    assert env.global_gen_buffer and isinstance(env.gen_buffer, sharding.GlobalGenBuffer)
+    env.set_seed(3)
+    td = env.reset()
+    g = torch.Generator(device=env.device).manual_seed(rank)
+    sizes, shares = [], []
+    for ep in range(6):
+        done = None
+        while done is None or not bool(done.any()):
+            td = env.step(env.rand_step_input(torch.randn(E, 3, 4, generator=g, device=env.device)))
+            done = td[("next", "done")]
+        r = env.rand_step_input()
+        r.set("_reset", done.squeeze(-1))
+        env.reset(r)
+        sizes.append(len(env.gen_buffer))
+        shares.append(E - env.num_unif)
+    q.put((rank, sizes, shares, env.gen_buffer._history_buffer))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_envgen_global_history_two_ranks_one_gpu():
+    """HideAndSeek_envgen with task.global_gen_buffer on two ranks (gloo; both on cuda:0): the device-resident buffers behind
+    sharding.GlobalGenBuffer.  After every task batch the two ranks hold the same history, it grows by what BOTH kept, and the
+    perturbed share of a batch is min(len(history), int(E_total 0.7)) split over the ranks."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_envgen_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=500) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, s0, sh0, h0), (_, s1, sh1, h1) = outs
+    assert s0 == s1 and np.array_equal(h0, h1)                       # one history
+    assert s0[1] == 2 * 192 and s0[3] == 4 * 192 and s0[5] == 6 * 192   # eval_iter = 2: every second episode both shards' 192 tasks enter
+    assert sh0[0] == sh1[0] == 0                                      # empty history: uniform tasks only
+    assert sh0[-1] + sh1[-1] == min(s0[-2], int(2 * 192 * 0.7))
