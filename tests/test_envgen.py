@@ -196,6 +196,34 @@ def test_envgen_history_trim_on_gpu():
 
 
 @pytest.mark.gpu
+def test_envgen_whole_env_at_65536_envs():
+    """BASELINE config 4 at its stated size as a whole env (the farthest-point trim alone is covered up to 200 000 points in
+    test_hip_envgen.py): three task batches, 70 536 -> 5000 trims, perturbed batches, every buffer finite."""
+    from hns_amd.envgen import HideAndSeek_envgen, GenBuffer
+    E, L = 65536, 3
+    env = HideAndSeek_envgen(config.make_cfg({"name": "HideAndSeek_envgen", "num_agents": 3, "eval_iter": 1, "R_min": 0.0, "R_max": 1.0, "ratio_unif": 0.3,
+                                              "use_particle_generator": 1, "cylinder": {"max_num": 8, "min_num": 8},
+                                              "env": {"num_envs": E, "max_episode_length": L}}))
+    env.set_seed(4)
+    env.reset()
+    rows = {r.tobytes() for r in env.all_tasks}
+    for ep in range(3):
+        for t in range(L):
+            td = env.step(env.rand_step_input())
+        assert bool(td[("next", "done")].all())
+        rtd = env.rand_step_input()
+        rtd.set("_reset", td[("next", "done")].squeeze(-1))
+        env.reset(rtd)
+        hist = env.gen_buffer._history_buffer
+        assert hist.shape == (5000, 36) and len(np.unique(hist, axis=0)) == 5000
+        if ep == 0:
+            assert all(r.tobytes() in rows for r in hist)                 # the trim selects among the tasks that were run
+        assert env.num_unif == E - 5000                                   # min(len(history), int(E 0.7)) perturbed tasks
+        assert GenBuffer(3, 8).sanity_ok(env.all_tasks[env.num_unif:]).mean() > 0.95
+    assert env.check_finite(deep=True) and float(env.stats["history_buffer"][0]) == 5000
+
+
+@pytest.mark.gpu
 def test_envgen_with_trajectory_predictor_on_gpu():
     """Both reference defaults together (use_particle_generator + use_TP_net): the reset's observation pass runs
     the predictor too, so the 35-value rows handed out by reset() belong to the NEW placement."""
