@@ -76,7 +76,8 @@ struct Params {
 struct StepArgs {               // 64 B
     const float *action;
     float *prev_action, *drone_state, *pid_integ, *pid_last_rate, *throttle;
-    const float *cylinders;
+    const float *cylinders;     // 16-byte aligned; the low four bits carry num_cylinders - 1 (the 64-byte block has no room for another word,
+                                // and the two-evader kernel's first loads need the count before the parameter block is warm)
     const Params *rest;         // device copy of the launch's Params (action = null), kept by the env handle
 };
 static_assert(sizeof(StepArgs) == 64, "the argument block of the step kernel is sized for the fast launch path");
@@ -959,7 +960,8 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
 #define HNS_ENV_PRIO 2
 #endif
 constexpr int kPub = 11;  // published per pursuer: position at t (3), thrust vector (3), position at t+1 (3), 1 / (|thrust| + 1e-6); odd stride
-struct LdsV3 { int slab, slab_stride, pub, cyl, cyl_stride, tp, red, envout, total; };
+struct LdsV3 { int slab, slab_stride, pub, cyl, cyl_stride, tp, red, envout, term, total; };
+constexpr int kTermStride = 2 * HNS_MAX_CYLINDERS + 1;   // per env: (tx, ty) of every cylinder's push on the second evader; odd stride
 __host__ __device__ inline LdsV3 lds_layout_v3(int A, int C, int K, int NT = 1) {
     LdsV3 L;
     int o = 0;
@@ -970,8 +972,9 @@ __host__ __device__ inline LdsV3 lds_layout_v3(int A, int C, int K, int NT = 1) 
     L.cyl_stride = (3 * C) | 1;
     L.cyl = o;   o += r4(kEPB * L.cyl_stride);
     L.tp = o;    o += r4(kEPB * (3 * NT + 1));               // evader(s) at t+1 ([64][3 NT], contiguous: stored as one slice) + the step counter
-    L.red = o;   o += r4(kEPB * A * red_stride(1));
+    L.red = o;   o += r4(kEPB * A * red_stride(NT));
     L.envout = o; o += r4(kEPB * (A > 3 * NT ? A : 3 * NT)); // the env wave's own staging: evader velocity [64,3 NT], rewards [64,A]
+    L.term = o;  if (NT == 2) o += r4(kEPB * kTermStride);    // two evaders: the pursuer lanes' share of the evader policy (below)
     L.total = o;
     return L;
 }
@@ -1001,7 +1004,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_v4_kernel
     // the block behind `rest` is never written while the kernel runs: read it as constant memory (scalar loads, placed like kernel-argument loads)
     typedef const Params __attribute__((address_space(4))) ParamsC;
     ParamsC &p = *(ParamsC *)ka.rest;
-    constexpr int NA = Geo<A>::NA, SD = NT == 2 ? 24 : HNS_SELF_DIM, kRedS = red_stride(1), T3 = 3 * NT;
+    constexpr int NA = Geo<A>::NA, SD = NT == 2 ? 24 : HNS_SELF_DIM, kRedS = red_stride(NT), T3 = 3 * NT;
     extern __shared__ __align__(16) float smem[];
     const auto &c = p.cfg;
     const auto &b = p.buf;
@@ -1025,6 +1028,29 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_v4_kernel
         float4 integ4 = reinterpret_cast<const float4 *>(ka.pid_integ)[ia];
         float4 last4 = reinterpret_cast<const float4 *>(ka.pid_last_rate)[ia];
         float4 thr4 = reinterpret_cast<const float4 *>(ka.throttle)[ia];
+        // (two evaders, see below: this wave's cylinder passes and this pursuer's cylinders — through the kernel argument, issued with the
+        //  first loads; the count of cylinders is only known from the parameter block, so the loads cover HNS_MAX_CYLINDERS slots of the
+        //  workgroup's OWN range and are clamped to it)
+        constexpr int kStage = NT == 2 ? (3 * HNS_MAX_CYLINDERS + A - 1) / A : 1, kOwnCyl = NT == 2 ? (HNS_MAX_CYLINDERS + A - 1) / A : 1;
+        float stage_v[kStage], own_c[kOwnCyl][3];
+        if constexpr (NT == 2) {
+            const uintptr_t cw = reinterpret_cast<uintptr_t>(ka.cylinders);
+            const int Cq = (int)(cw & 15) + 1;
+            const float *cyl0 = reinterpret_cast<const float *>(cw & ~(uintptr_t)15);
+            const float *gc = cyl0 + (size_t)e0 * Cq * 3 + lane;
+#pragma unroll
+            for (int i = 0; i < kStage; ++i) {
+                const int pass = (tid >> 6) + i * A;
+                stage_v[i] = pass < 3 * Cq ? gc[pass * 64] : 0.0f;
+            }
+            const float *gcy = cyl0 + (size_t)(e0 + le) * Cq * 3;
+#pragma unroll
+            for (int i = 0; i < kOwnCyl; ++i) {
+                const int k = a + i * A;
+                const int kc = k < Cq ? k : 0;
+                own_c[i][0] = gcy[3 * kc]; own_c[i][1] = gcy[3 * kc + 1]; own_c[i][2] = gcy[3 * kc + 2];
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PROF) prof_mark(p.prof, 0);
         if constexpr (PROF) prof_mark(p.prof, 14);
@@ -1033,6 +1059,24 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_v4_kernel
         const LdsV3 L = lds_layout_v3(A, C, K, NT);
         float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red;
         float *slab = smem + L.slab + (tid >> 6) * L.slab_stride;
+        // Two evaders: ONE env wave running both potential fields (2 x (C cylinders + A pursuers) terms, one instruction per 5-7
+        // cycles) and staging 3 C x 64 cylinder values kept the A pursuer waves waiting for ~9 k of a workgroup's 44 k cycles
+        // (tools/phase_profile.py --targets=2, round 3).  The pursuer lanes take over what does not need the env wave's order:
+        //   * wave w stages the cylinder passes w, w + A, ... for phase 3 (the env wave reads ITS cylinders straight from memory);
+        //   * every pursuer evaluates its own push on both evaders (hideandseek.py:1074-1088) and pursuer a the second evader's
+        //     cylinder terms of cylinders a, a + A, ... (:1114-1136); the env wave only adds them up, in the reference's order.
+        // Two evaders: ONE env wave running both potential fields (2 x (C cylinders + A pursuers) terms, one instruction per 5-7
+        // cycles) and staging 3 C x 64 cylinder values kept the A pursuer waves waiting for ~9 k of a workgroup's 44 k cycles
+        // (tools/phase_profile.py --targets=2, round 3).  The pursuer lanes take over what does not need the env wave's order:
+        //   * wave w stages the cylinder passes w, w + A, ... for phase 3 (the env wave reads ITS cylinders straight from memory);
+        //   * every pursuer evaluates its own push on both evaders (hideandseek.py:1074-1088) and pursuer a the second evader's
+        //     cylinder terms of cylinders a, a + A, ... (:1114-1136); the env wave only adds them up, in the reference's order.
+        V3 etp0 = {0.f, 0.f, 0.f}, etp1 = {0.f, 0.f, 0.f};
+        if constexpr (NT == 2) {
+            const float *gt = b.target_pos + (size_t)(e0 + le) * T3;
+            etp0 = V3{gt[0], gt[1], gt[2]};
+            etp1 = V3{gt[3], gt[4], gt[5]};
+        }
         const float4 ta = d_action_tanh(act4);           // needs the action only: evaluated while the rest is in flight
         // own rows through the private slab
         {
@@ -1068,6 +1112,33 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_v4_kernel
             pub[10] = los_t;
             float *red = sRed + tid * kRedS;
             red[R_AERR] = aerr; red[R_TD] = thr_diff;
+            if constexpr (NT == 2) {
+                const int los = (int)los_t;                                          // bit k: line of sight to evader k blocked at t
+                const V3 f0 = d_prey_pursuer_term(c, s.pos, etp0, (los & 1) != 0);
+                const V3 f1 = d_prey_pursuer_term(c, s.pos, etp1, (los & 2) != 0);
+                red[R_FX] = f0.x; red[R_FY] = f0.y; red[R_FZ] = f0.z;
+                red[R_F1X] = f1.x; red[R_F1X + 1] = f1.y; red[R_F1X + 2] = f1.z;
+                float *term = smem + L.term + le * kTermStride;
+#pragma unroll
+                for (int i = 0; i < kOwnCyl; ++i) {
+                    const int k = a + i * A;
+                    if (k < C) {
+                        float tx, ty;
+                        d_prey_cylinder_term(c, etp1, own_c[i][0], own_c[i][1], own_c[i][2], tx, ty);
+                        term[2 * k] = tx; term[2 * k + 1] = ty;
+                    }
+                }
+                const int c3 = 3 * C;
+#pragma unroll
+                for (int i = 0; i < kStage; ++i) {
+                    const int pass = (tid >> 6) + i * A;
+                    if (pass < c3) {
+                        const int idx = pass * 64 + lane;
+                        const int row = (int)__umulhi((unsigned)idx, p.cyl_magic), col = idx - row * c3;
+                        sCyl[row * L.cyl_stride + col] = stage_v[i];
+                    }
+                }
+            }
         }
         if constexpr (PROF) prof_mark(p.prof, 2);
         __syncthreads();                                                            // barrier 1
@@ -1294,7 +1365,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_v4_kernel
         V3 tp1 = tp0;
         if constexpr (NT == 2) tp1 = V3{gt[3], gt[4], gt[5]};
         float progress = b.progress[e];
-        {   // this workgroup's cylinders are one contiguous slice [64][3C]: coalesced 4-byte loads (lane <-> consecutive floats), scattered
+        if constexpr (NT == 1) {   // this workgroup's cylinders are one contiguous slice [64][3C]: coalesced 4-byte loads (lane <-> consecutive floats), scattered
             // into rows of odd stride (lane = env reads its row conflict-free); index / 3C by multiply-high.  Eight cylinders (24 passes)
             // at a time with every load issued before the first LDS write: one memory round trip per chunk.
             const float *gc = b.cylinders + (size_t)e0 * C * 3 + lane;
@@ -1325,36 +1396,62 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_v4_kernel
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        // (two evaders: the pursuer waves stage the cylinders for phase 3; this wave reads its envs' cylinders from memory below)
         progress += 1.0f;                                                           // isaac_env.py:236
         sTp[kEPB * T3 + le] = progress;
         if constexpr (PROF) prof_mark(p.prof, 1);
         float st[HNS_NUM_STATS];                  // the statistics rows of these envs: needed behind barrier 1 (not earlier: the first microseconds
-#pragma unroll                                  // of the launch are HBM-bound and these 6 MB are not on the critical path)
-        for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = b.stats[(size_t)i * E + e];
+        if constexpr (NT == 1) {                  // of the launch are HBM-bound and these 6 MB are not on the critical path)
+#pragma unroll
+            for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = b.stats[(size_t)i * E + e];
+        }
         // A6: arena + cylinder terms of the potential field (hideandseek.py:1090-1136)
         bool out_of_arena = false;
         const V3 Fenv = d_prey_arena_term(c, tp0, out_of_arena);
         float fcx = 0.f, fcy = 0.f;
+        if constexpr (NT == 2) {
+            // this wave's own cylinders straight from memory: lane = env reads its row of 3 C floats, 16 bytes at a time when the row is made of whole
+            // quads (every lane of a load instruction in another cache line, but 12 instructions instead of 48)
+            const float *cylg = b.cylinders + (size_t)e * C * 3;
+            if ((C & 3) == 0) {
+                const float4 *g4 = reinterpret_cast<const float4 *>(cylg);
+                for (int k0 = 0; k0 < C; k0 += 4) {
+                    const float4 q0 = g4[3 * (k0 >> 2)], q1 = g4[3 * (k0 >> 2) + 1], q2 = g4[3 * (k0 >> 2) + 2];
+                    const float v[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float tx, ty;
+                        d_prey_cylinder_term(c, tp0, v[3 * i], v[3 * i + 1], v[3 * i + 2], tx, ty);
+                        fcx += tx;
+                        fcy += ty;
+                    }
+                }
+            } else {
+                for (int k = 0; k < C; ++k) {
+                    float tx, ty;
+                    d_prey_cylinder_term(c, tp0, cylg[3 * k], cylg[3 * k + 1], cylg[3 * k + 2], tx, ty);
+                    fcx += tx;
+                    fcy += ty;
+                }
+            }
+        } else {
 #pragma unroll 4
-        for (int k = 0; k < C; ++k) {
-            float tx, ty;
-            d_prey_cylinder_term(c, tp0, cylw[3 * k], cylw[3 * k + 1], cylw[3 * k + 2], tx, ty);
-            fcx += tx;
-            fcy += ty;
+            for (int k = 0; k < C; ++k) {
+                float tx, ty;
+                d_prey_cylinder_term(c, tp0, cylw[3 * k], cylw[3 * k + 1], cylw[3 * k + 2], tx, ty);
+                fcx += tx;
+                fcy += ty;
+            }
         }
         V3 Fenv1 = {0.f, 0.f, 0.f};
         float gcx = 0.f, gcy = 0.f;
         if constexpr (NT == 2) {               // each evader runs the potential field on its own (they ignore each other)
             bool out1 = false;
             Fenv1 = d_prey_arena_term(c, tp1, out1);
-            out_of_arena = out_of_arena || out1;
-#pragma unroll 4
-            for (int k = 0; k < C; ++k) {
-                float tx, ty;
-                d_prey_cylinder_term(c, tp1, cylw[3 * k], cylw[3 * k + 1], cylw[3 * k + 2], tx, ty);
-                gcx += tx;
-                gcy += ty;
-            }
+            out_of_arena = out_of_arena || out1;               // (its cylinder terms come from the pursuer lanes, summed behind barrier 1)
+            // the statistics rows only now: loads return in order, and the cylinder rows above must not queue behind 6 MB from HBM
+#pragma unroll
+            for (int i = 0; i < HNS_NUM_STATS; ++i) st[i] = b.stats[(size_t)i * E + e];
         }
         if constexpr (PROF) prof_mark(p.prof, 2);
         __syncthreads();                                                            // barrier 1: positions at t, line-of-sight flags, action errors
@@ -1363,18 +1460,30 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_v4_kernel
         V3 F = {0.f, 0.f, 0.f}, G = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < A; ++j) {
-            const float *pj = sPub + (le * A + j) * kPub;
-            const V3 dp = {pj[0], pj[1], pj[2]};
-            const int los = (int)pj[10];                                            // :1080, carried over from the previous step's observation (bit k: evader k)
-            const V3 fp = d_prey_pursuer_term(c, dp, tp0, (los & 1) != 0);
-            F.x = (j == 0) ? fp.x : F.x + fp.x;
-            F.y = (j == 0) ? fp.y : F.y + fp.y;
-            F.z = (j == 0) ? fp.z : F.z + fp.z;
-            if constexpr (NT == 2) {
-                const V3 f1 = d_prey_pursuer_term(c, dp, tp1, (los & 2) != 0);
-                G.x = (j == 0) ? f1.x : G.x + f1.x;
-                G.y = (j == 0) ? f1.y : G.y + f1.y;
-                G.z = (j == 0) ? f1.z : G.z + f1.z;
+            if constexpr (NT == 2) {                                                // evaluated by the pursuer's own lane, same arithmetic
+                const float *red = sRed + (le * A + j) * kRedS;
+                F.x = (j == 0) ? red[R_FX] : F.x + red[R_FX];
+                F.y = (j == 0) ? red[R_FY] : F.y + red[R_FY];
+                F.z = (j == 0) ? red[R_FZ] : F.z + red[R_FZ];
+                G.x = (j == 0) ? red[R_F1X] : G.x + red[R_F1X];
+                G.y = (j == 0) ? red[R_F1X + 1] : G.y + red[R_F1X + 1];
+                G.z = (j == 0) ? red[R_F1X + 2] : G.z + red[R_F1X + 2];
+            } else {
+                const float *pj = sPub + (le * A + j) * kPub;
+                const V3 dp = {pj[0], pj[1], pj[2]};
+                const int los = (int)pj[10];                                        // :1080, carried over from the previous step's observation (bit k: evader k)
+                const V3 fp = d_prey_pursuer_term(c, dp, tp0, (los & 1) != 0);
+                F.x = (j == 0) ? fp.x : F.x + fp.x;
+                F.y = (j == 0) ? fp.y : F.y + fp.y;
+                F.z = (j == 0) ? fp.z : F.z + fp.z;
+            }
+        }
+        if constexpr (NT == 2) {
+            const float *term = smem + L.term + le * kTermStride;
+#pragma unroll 4
+            for (int k = 0; k < C; ++k) {
+                gcx += term[2 * k];
+                gcy += term[2 * k + 1];
             }
         }
         F.x = F.x + Fenv.x; F.y = F.y + Fenv.y; F.z = F.z + Fenv.z;
@@ -1969,7 +2078,7 @@ static void select_kernels(hns_env *env) {
     }
     const char *force = getenv("HNS_STEP_DESIGN");        // "1" = the first design for every shape (A/B measurements)
     const bool v3 = c.num_envs % hns::kEPB == 0 && !(force && force[0] == '1');
-    if (v3 && c.num_targets == 2) env->step_args_fn = env->step_args_prof_fn = hns::hns_step_v4_kernel<A, 2, false>;   // (no phase stamps with two evaders)
+    if (v3 && c.num_targets == 2) { env->step_args_fn = hns::hns_step_v4_kernel<A, 2, false>; env->step_args_prof_fn = hns::hns_step_v4_kernel<A, 2, true>; }
     else if (v3) { env->step_args_fn = hns::hns_step_v4_kernel<A, 1, false>; env->step_args_prof_fn = hns::hns_step_v4_kernel<A, 1, true>; }
     env->threads = hns::Geo<A>::T;
     env->cyl_magic = (uint32_t)(0xFFFFFFFFull / (uint32_t)(3 * c.num_cylinders) + 1ull);
@@ -2185,7 +2294,7 @@ static int launch(hns_env *env, bool is_step, const Params &p, hipStream_t strea
 #endif
         if (!env->params_valid) { set_error("hns_step: the device copy of the launch parameters is missing (bind first)"); return HNS_ERR_NOT_BOUND; }
         ka = hns::StepArgs{p.action, p.buf.prev_action, p.buf.drone_state, p.buf.pid_integ, p.buf.pid_last_rate, p.buf.throttle,
-                           p.buf.cylinders, env->params_dev};
+                           reinterpret_cast<const float *>(reinterpret_cast<uintptr_t>(p.buf.cylinders) | (uintptr_t)((env->cfg.num_cylinders - 1) & 15)), env->params_dev};
     }
     if (time_it) {
         if (!env->pool.empty()) { ev = env->pool.back(); env->pool.pop_back(); }

@@ -11,8 +11,12 @@ import hns_amd
 from hns_amd import config
 from hns_amd.env import HideAndSeek
 
-E, A, Cn = 65536, 3, 8
-cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": Cn, "min_num": Cn}, "env": {"num_envs": E}})
+E, A, Cn, NT = 65536, 3, 8, 1
+for a in sys.argv[1:]:                                   # e.g. --agents=6 --cylinders=16 --targets=2 (BASELINE config 5's shard)
+    if a.startswith("--agents="): A = int(a.split("=")[1])
+    if a.startswith("--cylinders="): Cn = int(a.split("=")[1])
+    if a.startswith("--targets="): NT = int(a.split("=")[1])
+cfg = config.make_cfg({"num_agents": A, "num_targets": NT, "cylinder": {"max_num": Cn, "min_num": Cn}, "env": {"num_envs": E}})
 env = HideAndSeek(cfg, write_critic_state="--critic-state" in sys.argv)
 env.reset()
 nw = (E // 64) * (A + 1)
@@ -43,6 +47,9 @@ print("agent detail: pid(1->10) %.0f rotor(10->11) %.0f los+term(11->2) %.0f | d
       % (seg(1, 10), seg(10, 11), seg(11, 2), seg(2, 12), seg(12, 13), seg(13, 3)))
 print("agent detail: b2+pub+b3(3->8) %.0f obs(8->9) %.0f reward(9->4) %.0f" % (seg(3, 8), seg(8, 9), seg(9, 4)))
 
+ev = t16[:, A, :]
+print("env detail: pre-b1 work (0->2) %.0f  b1 wait (2->12) %.0f  post-b1 work (12->3) %.0f | agents: b1 wait (2->12) %.0f" % (
+    (ev[..., 2] - ev[..., 0]).mean(), (ev[..., 12] - ev[..., 2]).mean(), (ev[..., 3] - ev[..., 12]).mean(), seg(2, 12)))
 rt0, rt1 = t16[..., 14].astype(np.float64) * 10.0, t16[..., 15].astype(np.float64) * 10.0   # ns
 z = rt0.min()
 print("global clock (ns): first start 0, last start %.0f, first end %.0f, last end %.0f" % (rt0.max() - z, rt1.min() - z, rt1.max() - z))
