@@ -216,10 +216,10 @@ def main():
     run(args.warmup)
     sync()
     # kernel-duration samples: every `time_every`-th launch of the timed region carries dispatch-bound events.  An event-bracketed
-    # dispatch costs the host ~6 us more than a plain one (measured: the driver's 20-step command with every second launch
-    # timed read 23.2 us per step against 20.3), so a short region carries at most four of them, and the sample is then topped
-    # up to 16 with launches timed right AFTER the region (same env, same state stream, outside the wall time)
-    time_every = max(1, min(args.time_every, args.steps // 4))
+    # dispatch costs the host ~6 us more than a plain one (measured: the driver's 20-step command read 23.2 us per step with every
+    # second launch timed, 22.2 with every fifth, 20.3 with one), so a region shorter than `--time-every` carries ONE of them, and
+    # the sample is then topped up to 16 with launches timed right AFTER the region (same env, same state stream, outside the wall time)
+    time_every = max(1, min(args.time_every, args.steps))
     env.enable_kernel_timing(time_every)
     t0 = time.perf_counter()
     run(args.steps)
