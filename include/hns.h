@@ -267,7 +267,7 @@ int hns_raycast(hns_env *env, int num_rays, float max_range, float *out, void *s
  * + Linear(64 -> 3F) + tanh) evaluated on a T-frame history, I = 7 + 3A (+ 3C with cfg.tp_use_obstacles):
  *   frame = [progress, evader pos (masked), evader vel (masked), pursuer positions]   (:815-820)
  *           + [x, y, cylinder_size] of every cylinder slot with task.use_obstacles     (:808-816)
- * I <= 48 (three 16-wide operand chunks): up to 7 pursuers, or 3 pursuers + 8 cylinder slots.
+ * I <= 80 (five 16-wide operand chunks): every shape the step kernels take (7 pursuers + 16 cylinder slots = 76 values).
  * The parameters are the caller's tensors in PyTorch layouts (the learner trains them,
  * scripts/train.py:180).  They are converted into a matrix-core operand image (`packed`) by
  * hns_tp_refresh: call it after every parameter update (hns_tp_bind schedules one).

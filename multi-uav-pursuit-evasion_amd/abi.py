@@ -142,7 +142,8 @@ HNS_OK, HNS_ERR_INVALID_ARG, HNS_ERR_NOT_BOUND, HNS_ERR_DEVICE, HNS_ERR_NO_DEVIC
 
 # ---- trajectory predictor (include/hns.h: hns_tp_buffers) ------------------------------------------------
 HNS_TP_HIDDEN = 64
-TP_PACKED_BYTES = 16 * (2 * 8 * 4 * 64 + 2 * 8 * 3 * 64 + 2 * 4 * 64 + 8 * 2 * 16 // 4 + 2 * 16 // 4)   # hns_tp_packed_bytes(): three frame chunks
+TP_PACKED_BYTES = 16 * max(2 * 8 * 4 * 64 + 2 * 8 * 3 * 64 + 2 * 4 * 64 + 8 * 2 * 16 // 4 + 2 * 16 // 4,   # hns_tp_packed_bytes(): the tile kernel's image at three frame chunks
+                           8 * 2 * (5 + 4) * 64 + 2 * 4 * 64 + 256 // 4 + 32 // 4)                          # and the weight-stationary kernel's at five
 TP_WEIGHT_FIELDS = ["w_ih", "w_hh", "b_ih", "b_hh", "w_fc", "b_fc"]
 TP_BUFFER_FIELDS = TP_WEIGHT_FIELDS + ["packed", "history", "pred", "obs_self", "state_drones", "groundtruth", "tp_done"]
 # hns_tp_buffers weight field -> TP_net.state_dict() key (learning/mappo.py:572-589)

@@ -230,9 +230,9 @@ def _f32(x):
 def resolve_hns_cfg(cfg, num_envs=None, env_index_offset=0, drone_params=None, write_critic_state=True):
     t = cfg.task
     use_obst = int(cfg.algo.get("use_TP_net", 0)) and int(t.get("use_obstacles", 0))
-    if int(cfg.algo.get("use_TP_net", 0)) and abi.tp_frame_dim(int(t.num_agents), int(t.cylinder.max_num), use_obst) > 48:
-        raise NotImplementedError("TP_net frame wider than 48 values (7 + 3 num_agents + 3 cylinder.max_num with "
-                                  "task.use_obstacles=1) is not built: the HIP predictor holds three 16-wide operand chunks")
+    if int(cfg.algo.get("use_TP_net", 0)) and abi.tp_frame_dim(int(t.num_agents), int(t.cylinder.max_num), use_obst) > 80:
+        raise NotImplementedError("TP_net frame wider than 80 values (7 + 3 num_agents + 3 cylinder.max_num with "
+                                  "task.use_obstacles=1) is not built: the HIP predictor holds five 16-wide operand chunks")
     if t.get("drone_model", "Crazyflie").lower() != "crazyflie":
         raise NotImplementedError("only drone_model=Crazyflie is on the hot path")
     if not t.get("time_encoding", True):

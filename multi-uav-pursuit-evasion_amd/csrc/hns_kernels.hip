@@ -33,7 +33,8 @@
 namespace hns {
 
 constexpr int kEPB = 64;   // envs per workgroup = lanes of the env wave
-constexpr int kMaxK = 4;   // top-k insertion network width (obs_max_cylinder <= 4)
+constexpr int kMaxK = 4;   // top-k insertion network width of the step kernels (obs_max_cylinder <= 4: the reference's default is 3)
+constexpr int kWideK = 16;  // the same network for every k the cylinder count allows: first-design step kernel + reset kernel, no staging of the k-nearest rows
 // per-agent scalars handed to the env wave: 8 live values at any time (odd stride: conflict-free), 11 with a second evader
 __host__ __device__ constexpr int red_stride(int NT) { return NT == 2 ? 11 : 9; }
 enum { R_AERR = 0, R_TD, R_DIST, R_SPEED, R_CC, R_CD, R_CW, R_COLL,
@@ -113,6 +114,7 @@ __host__ __device__ constexpr int slab_rows(int A) { return A > 4 ? 32 : 64; }
 __host__ __device__ inline int slab_floats(int A, int K, int NT) {
     const int rows = slab_rows(A);
     int m = rows * (NT == 2 ? 24 : HNS_SELF_DIM);
+    if (K > kMaxK) K = 0;                       // wide selections are stored by their threads, not staged
     if (rows * K * 5 > m) m = rows * K * 5;
     if (rows * (A - 1) * 3 > m) m = rows * (A - 1) * 3;
     return r4(m);
@@ -127,7 +129,7 @@ __host__ __device__ inline Lds lds_layout(int A, int C, int K, int NT = 1) {
     L.red = o;   o += r4(kEPB * A * red_stride(NT));
     // obs_cylinders staging [64*A][K*5] (reset kernel, ragged tiles) / one wave-private slab per agent wave (step kernel):
     // the slab holds the widest of a wave's three output slices (64 rows of state_self / k-nearest rows / state_others)
-    const int rows = kEPB * A * K * 5, slabs = A * slab_floats(A, K, NT);
+    const int rows = K > kMaxK ? 0 : kEPB * A * K * 5, slabs = A * slab_floats(A, K, NT);
     L.ocyl = o;  o += r4(rows > slabs ? rows : slabs);
     L.total = o;
     return L;
@@ -291,10 +293,10 @@ HNS_DEV void wave_store_rows(float *__restrict__ slab, float *__restrict__ gslic
 // Fast path: 32-bit keys = squared-distance bits with the cylinder index in the 4 low mantissa
 // bits (non-negative floats order like unsigned ints), kept sorted by a branch-free min/max
 // insertion network.  The 2^-19 truncation is covered by the 2^-16 gap test below.
-template <int NT, bool LOS, class Cfg>
+template <int NT, bool LOS, int KM = kMaxK, class Cfg>
 HNS_DEV void cylinder_pass(const Cfg &c, int C, int K, const V3 &pos, const V3 &tp, const V3 &tpB, const float *cyl,
-                           int bi[kMaxK + 1], bool &any_block, bool &any_block1) {
-    constexpr int kTrack = kMaxK + 1;           // one more than k: guards the k-th/(k+1)-th boundary
+                           int bi[KM + 1], bool &any_block, bool &any_block1) {
+    constexpr int kTrack = KM + 1;              // one more than k: guards the k-th/(k+1)-th boundary
     uint32_t key[kTrack];
 #pragma unroll
     for (int i = 0; i < kTrack; ++i) key[i] = 0x7F80000Fu;             // +inf | 15
@@ -327,17 +329,17 @@ HNS_DEV void cylinder_pass(const Cfg &c, int C, int K, const V3 &pos, const V3 &
     for (int i = 0; i < kTrack; ++i) { bd[i] = __uint_as_float(key[i] & 0xFFFFFFF0u); bi[i] = (int)(key[i] & 15u); }
     bool order_safe = bd[0] > 1e-5f;
 #pragma unroll
-    for (int i = 0; i < kMaxK; ++i)
+    for (int i = 0; i < KM; ++i)
         if (i < K) order_safe = order_safe && (bd[i + 1] > bd[i] * 1.0000152587890625f);   // 1 + 2^-16
     if (!order_safe) {                          // rare: exact (distance - size) keys, as the reference sorts
 #pragma unroll
         for (int i = 0; i < kTrack; ++i) { bd[i] = kInf; bi[i] = 0; }
         for (int k = 0; k < C; ++k) {
             float md = d_norm3(pos.x - cyl[3 * k], pos.y - cyl[3 * k + 1], pos.z - cyl[3 * k + 2]) - c.cylinder_size;
-            if (md < bd[kMaxK - 1]) {
-                bd[kMaxK - 1] = md; bi[kMaxK - 1] = k;
+            if (md < bd[KM - 1]) {
+                bd[KM - 1] = md; bi[KM - 1] = k;
 #pragma unroll
-                for (int i = kMaxK - 1; i > 0; --i) {
+                for (int i = KM - 1; i > 0; --i) {
                     if (bd[i] < bd[i - 1]) {
                         float td = bd[i]; bd[i] = bd[i - 1]; bd[i - 1] = td;
                         int ti = bi[i]; bi[i] = bi[i - 1]; bi[i - 1] = ti;
@@ -357,11 +359,13 @@ HNS_DEV void cylinder_pass(const Cfg &c, int C, int K, const V3 &pos, const V3 &
 // the relative position of the second evader + one zero; line of sight / detection per evader.
 // STAGED (step kernel, full tiles): every output slice goes through the wave's slab (wave_store_rows); `sOCyl` is then
 // the slab of this wave and gOth / gSelf / gState / gOCyl are still the THREAD's rows (the wave's slice starts `lane` rows earlier).
-template <int A, int NT, bool STAGED = false, int PS = 13, class Cfg = hns_cfg>
+// KM > kMaxK (wide selections): the k-nearest rows go straight from the thread to its row of `gOCyl` (never staged).
+template <int A, int NT, bool STAGED = false, int PS = 13, int KM = kMaxK, class Cfg = hns_cfg>
 HNS_DEV void agent_obs(const Cfg &c, int C, int K, int le, int a, const Rigid &s, const V3 &tp, const V3 &tpB, float progress,
                        const float *cyl, const float *sDS, float *gOth, float *sOCyl, float *gSelf, float *gState,
-                       bool &blocked, bool &det, bool &blockedB, bool &detB, int knn_idx[kMaxK], bool knn_masked[kMaxK], bool st = true, bool st_oth = true,
+                       bool &blocked, bool &det, bool &blockedB, bool &detB, int knn_idx[KM], bool knn_masked[KM], bool st = true, bool st_oth = true,
                        float *gOCyl = nullptr, float *dist_out = nullptr, bool st_ocyl = true) {
+    static_assert(!(STAGED && KM > kMaxK), "wide k-nearest selections are not staged");
     constexpr int SDW = NT == 2 ? 24 : HNS_SELF_DIM;
     const int lane = threadIdx.x & 63;
     float rtx = s.pos.x - tp.x, rty = s.pos.y - tp.y, rtz = s.pos.z - tp.z;
@@ -422,19 +426,19 @@ HNS_DEV void agent_obs(const Cfg &c, int C, int K, int le, int a, const Rigid &s
             for (int i = 0; i < (A - 1) * 3; ++i) gOth[i] = o[i];
         }
     }
-    int bi[kMaxK + 1];
+    int bi[KM + 1];
     bool any_block, any_block1;
-    cylinder_pass<NT, true>(c, C, K, s.pos, tp, tpB, cyl, bi, any_block, any_block1);
+    cylinder_pass<NT, true, KM>(c, C, K, s.pos, tp, tpB, cyl, bi, any_block, any_block1);
     blocked = any_block;
     det = (dist < c.drone_detect_radius) && !blocked;                 // :787-789
     if constexpr (NT == 2) {
         blockedB = any_block1;
         detB = (dist1 < c.drone_detect_radius) && !any_block1;
     }
-    float *oc = sOCyl + (le * A + a) * K * 5;
-    float krow[kMaxK * 5];
+    float *oc = KM > kMaxK ? gOCyl : sOCyl + (le * A + a) * K * 5;
+    float krow[STAGED ? kMaxK * 5 : 1];
 #pragma unroll
-    for (int sidx = 0; sidx < kMaxK; ++sidx) {
+    for (int sidx = 0; sidx < KM; ++sidx) {
         if (sidx < K) {
             const float *cc = cyl + 3 * bi[sidx];
             bool masked = cc[2] < 0.0f;                                // :759,775-778
@@ -480,8 +484,9 @@ HNS_DEV void agent_obs(const Cfg &c, int C, int K, int le, int a, const Rigid &s
 //  shape drop from two per CU to one)
 // FULL: the batch is a whole number of 64-env tiles (E % 64 == 0) — no lane is ever idle, so every `valid` test and
 // every default value behind it is compiled out; the generic instantiation serves ragged batches.
-template <int A, int NT, bool FULL>
-__global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(const Params p) {
+template <int A, int NT, bool FULL, int KM = kMaxK>
+__global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void hns_step_kernel(const Params p) {
+    static_assert(!(FULL && KM > kMaxK), "wide k-nearest selections: the generic (unstaged) instantiation");
     constexpr int T = Geo<A>::T, NA = Geo<A>::NA;
     constexpr int SD = NT == 2 ? 24 : HNS_SELF_DIM;      // floats per state_self / state_drones row
     constexpr int kRedS = red_stride(NT);
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
             prev4 = reinterpret_cast<const float4 *>(b.prev_action)[ia];
         }
     }
-    const bool full = FULL ? true : nenv == kEPB;
+    const bool full = FULL ? true : (KM == kMaxK && nenv == kEPB);
     if (LAB(LAB_NOLOAD)) {
     } else if (full) {
         coop_copy_full<T, kEPB * A * 13>(sDS, b.drone_state + (size_t)e0 * A * 13);
@@ -764,9 +769,13 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         V3 tpB = tp;
         if constexpr (NT == 2) tpB = {sTp[le * 3 * NT + 3], sTp[le * 3 * NT + 4], sTp[le * 3 * NT + 5]};
         bool blocked, det, blockedB = false, detB = false;
-        int knn_idx[kMaxK];
-        bool knn_masked[kMaxK];
-        if (full)    // every output slice of the wave through its private slab: whole cache lines per store instruction
+        int knn_idx[KM];
+        bool knn_masked[KM];
+        if constexpr (KM > kMaxK)
+            agent_obs<A, NT, false, 13, KM>(c, C, K, le, a, s, tp, tpB, progress, cyl, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * SD,
+                                            with_state ? b.state_drones + ia * SD : nullptr, blocked, det, blockedB, detB, knn_idx, knn_masked, true, true,
+                                            b.obs_cylinders + ia * K * 5);
+        else if (full)    // every output slice of the wave through its private slab: whole cache lines per store instruction
             agent_obs<A, NT, true>(c, C, K, le, a, s, tp, tpB, progress, cyl, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl + (tid >> 6) * slab_floats(A, K, NT),
                                    b.obs_self + ia * SD, with_state ? b.state_drones + ia * SD : nullptr, blocked, det, blockedB, detB, knn_idx, knn_masked,
                                    !LAB(LAB_NOSTORE | LAB_NOST_SELF), !LAB(LAB_NOSTORE | LAB_NOST_OTH), b.obs_cylinders + ia * K * 5);
@@ -795,7 +804,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         float speed_rew = -c.speed_coef * ((sp > c.v_drone) ? 1.0f : 0.0f);
         float cc = 0.f, cd = 0.f;
 #pragma unroll
-        for (int sidx = 0; sidx < kMaxK; ++sidx) {
+        for (int sidx = 0; sidx < KM; ++sidx) {
             if (sidx < K) {
                 const float *cy = cyl + 3 * knn_idx[sidx];
                 float rx = s.pos.x - cy[0], ry = s.pos.y - cy[1];
@@ -934,7 +943,7 @@ __global__ __launch_bounds__(Geo<A>::T, NT == 2 ? 4 : 1) void hns_step_kernel(co
         }
     }
     prof_mark(p.prof, 6);
-    if (!full) {                // ragged last tile: the k-nearest rows were staged per workgroup, store the slice now
+    if (KM == kMaxK && !full) { // ragged last tile: the k-nearest rows were staged per workgroup, store the slice now
         __syncthreads();
         if (!LAB(LAB_NOSTORE | LAB_NOST_OCYL)) coop_s2g<T>(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5);
     }
@@ -1645,8 +1654,9 @@ __global__ __launch_bounds__(256) void hns_refresh_los_kernel(const hns_cfg c, c
 // (isaac_env.py:221).  The env wave regenerates the state of the masked envs into LDS with a
 // Philox stream, then the agent waves run the same agent_obs as the step kernel.
 // =================================================================================================
-template <int A, int NT>
+template <int A, int NT, int KM = kMaxK>
 __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
+    // KM > kMaxK: wide k-nearest selections, rows stored by their threads (see agent_obs)
     constexpr int T = Geo<A>::T, NA = Geo<A>::NA;
     constexpr int SD = NT == 2 ? 24 : HNS_SELF_DIM;
     extern __shared__ __align__(16) float smem[];
@@ -1799,10 +1809,11 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
         if constexpr (NT == 2) tpB = {sTp[le * 3 * NT + 3], sTp[le * 3 * NT + 4], sTp[le * 3 * NT + 5]};
         const size_t ia = (size_t)e0 * A + tid;
         bool blocked, det, blockedB = false, detB = false;
-        int knn_idx[kMaxK];
-        bool knn_masked[kMaxK];
-        agent_obs<A, NT>(c, C, K, le, a, s, tp, tpB, 0.0f, sCyl + le * L.cyl_stride, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * SD,
-                         with_state ? b.state_drones + ia * SD : nullptr, blocked, det, blockedB, detB, knn_idx, knn_masked);
+        int knn_idx[KM];
+        bool knn_masked[KM];
+        agent_obs<A, NT, false, 13, KM>(c, C, K, le, a, s, tp, tpB, 0.0f, sCyl + le * L.cyl_stride, sDS, b.obs_others + ia * (A - 1) * 3, sOCyl, b.obs_self + ia * SD,
+                                        with_state ? b.state_drones + ia * SD : nullptr, blocked, det, blockedB, detB, knn_idx, knn_masked, true, true,
+                                        b.obs_cylinders + ia * K * 5);
         b.pid_last_rate[ia * 4 + 3] = (float)((blocked ? 1 : 0) + (blockedB ? 2 : 0));   // line of sight of the new state (the env wave zeroed the record above)
         if (det) sDet[le] = 1;
         if (NT == 2 && detB) sDet1[le] = 1;
@@ -1824,7 +1835,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
     coop_s2g_masked<T>(b.drone_state + (size_t)e0 * A * 13, sDS, nenv * A * 13, A * 13, sMask);
     coop_cyl<T, false>(sCyl, b.cylinders + (size_t)e0 * C * 3, nenv, 3 * C, L.cyl_stride, p.cyl_magic, sMask);
     coop_s2g_masked<T>(b.target_pos + (size_t)e0 * 3 * NT, sTp, nenv * 3 * NT, 3 * NT, sMask);
-    coop_s2g_masked<T>(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5, A * K * 5, sMask);
+    if constexpr (KM == kMaxK) coop_s2g_masked<T>(b.obs_cylinders + (size_t)e0 * A * K * 5, sOCyl, nenv * A * K * 5, A * K * 5, sMask);
 }
 
 // =================================================================================================
@@ -2076,8 +2087,13 @@ static void select_kernels(hns_env *env) {
         env->step_fn = (c.num_envs % hns::kEPB == 0) ? hns::hns_step_kernel<A, 1, true> : hns::hns_step_kernel<A, 1, false>;
         env->reset_fn = hns::hns_reset_kernel<A, 1>;
     }
+    const bool wide = c.obs_max_cylinder > hns::kMaxK;     // k-nearest selections beyond the step kernels' network: the first design, unstaged rows
+    if (wide) {
+        if (c.num_targets == 2) { env->step_fn = hns::hns_step_kernel<A, 2, false, hns::kWideK>; env->reset_fn = hns::hns_reset_kernel<A, 2, hns::kWideK>; }
+        else { env->step_fn = hns::hns_step_kernel<A, 1, false, hns::kWideK>; env->reset_fn = hns::hns_reset_kernel<A, 1, hns::kWideK>; }
+    }
     const char *force = getenv("HNS_STEP_DESIGN");        // "1" = the first design for every shape (A/B measurements)
-    const bool v3 = c.num_envs % hns::kEPB == 0 && !(force && force[0] == '1');
+    const bool v3 = c.num_envs % hns::kEPB == 0 && !(force && force[0] == '1') && !wide;
     if (v3 && c.num_targets == 2) { env->step_args_fn = hns::hns_step_v4_kernel<A, 2, false>; env->step_args_prof_fn = hns::hns_step_v4_kernel<A, 2, true>; }
     else if (v3) { env->step_args_fn = hns::hns_step_v4_kernel<A, 1, false>; env->step_args_prof_fn = hns::hns_step_v4_kernel<A, 1, true>; }
     env->threads = hns::Geo<A>::T;
@@ -2109,10 +2125,6 @@ int hns_create(const hns_cfg *cfg, hns_env **out) {
         return HNS_ERR_INVALID_ARG;
     }
     if (cfg->num_targets < 0 || cfg->num_targets > hns::kMaxT) { set_error("hns_create: num_targets must be 0, 1 or 2"); return HNS_ERR_INVALID_ARG; }
-    if (cfg->obs_max_cylinder > hns::kMaxK) {
-        set_error("hns_create: obs_max_cylinder > 4 is not supported by the HIP kernels");
-        return HNS_ERR_INVALID_ARG;
-    }
     if (cfg->grid_num < 1 || cfg->grid_num > 16) { set_error("hns_create: grid_num out of range"); return HNS_ERR_INVALID_ARG; }
     if (cfg->init_mode != HNS_INIT_SCENARIO) {
         int half = cfg->grid_num / 2, free_cells = 0;

@@ -61,6 +61,7 @@ constexpr int kTpH = HNS_TP_HIDDEN;
 __host__ __device__ constexpr int tp_waves(int nxc) { return nxc <= 2 ? 8 : 6; }
 constexpr int kTpWaves = 8;                 // the widest workgroup (host-side sizing of the diagnostics buffer)
 constexpr int kTpMaxRows = 32;              // 3F <= 32: one M tile for the output layer
+constexpr int kTpMaxChunks = 5;             // 16-value chunks of a frame: 7 + 3 * 7 pursuers + 3 * 16 cylinders = 76 values
 constexpr float kTpLoScale = 2048.0f;       // 2^11: the low split term, kept in fp16's normal range
 constexpr float kTpLoInv = 1.0f / 2048.0f;
 
@@ -878,8 +879,9 @@ struct WsTile {
 #else
 #define WS_SYNC() __syncthreads()
 #endif
+// frames of three and more chunks hold 56-72 registers of weights per lane and 83-116 KB of LDS: one workgroup per CU, two waves per SIMD
 template <int NXC>
-__global__ __launch_bounds__(kWsThreads, WS_OCC) void hns_tp_lstm_ws_kernel(const TpParams p) {
+__global__ __launch_bounds__(kWsThreads, NXC <= 2 ? WS_OCC : 2) void hns_tp_lstm_ws_kernel(const TpParams p) {
     constexpr int NC = NXC + 4;
     constexpr WsImage L = ws_image(NXC);
     extern __shared__ __align__(16) uint4 simg[];
@@ -1162,11 +1164,13 @@ using hns::TpParams;
 
 static int tp_nxc(int I) { return (I + 15) / 16; }
 // which kernel serves a frame width: the weight-stationary one for one 16-value chunk (up to 3 pursuers, no cylinders in the
-// frame — the reference's default); HNS_TP_KERNEL=tile / ws forces one of them for A/B measurements (ws: up to 2 chunks)
+// frame — the reference's default) and for four or five (6-7 pursuers with 12-16 cylinders in the frame: the tile kernel's LDS-resident
+// weight image does not fit beyond three chunks); HNS_TP_KERNEL=tile / ws forces one of them where both exist (A/B measurements)
 static bool tp_use_ws(int nxc) {
     static const int mode = [] { const char *m = getenv("HNS_TP_KERNEL"); return !m ? 0 : (m[0] == 't' ? 1 : (m[0] == 'w' ? 2 : 0)); }();
+    if (nxc > 3) return true;
     if (mode == 1) return false;
-    if (mode == 2) return nxc <= 2;
+    if (mode == 2) return true;
     return nxc == 1;
 }
 static int tp_frame_dim(const hns_cfg &c) { return 7 + 3 * c.num_agents + (c.tp_use_obstacles ? 3 * c.num_cylinders : 0); }
@@ -1193,7 +1197,10 @@ static void tp_fill_params(const hns_env *env, TpParams &p) {
 
 extern "C" {
 
-size_t hns_tp_packed_bytes(void) { return (size_t)hns::tp_image(3).bytes; }       // the widest frame (three 16-value chunks)
+size_t hns_tp_packed_bytes(void) {                                                 // the larger of the two kernels' images at their widest frames
+    const size_t a = (size_t)hns::tp_image(3).bytes, b = (size_t)hns::ws_image(hns::kTpMaxChunks).slots * 16;
+    return a > b ? a : b;
+}
 
 int hns_tp_bind(hns_env *env, const hns_tp_buffers *b, int32_t history_step, int32_t future_step) {
     if (!env || !b) { hns_set_error("hns_tp_bind: null argument"); return HNS_ERR_INVALID_ARG; }
@@ -1219,8 +1226,8 @@ int hns_tp_bind(hns_env *env, const hns_tp_buffers *b, int32_t history_step, int
         }
     if ((reinterpret_cast<uintptr_t>(b->packed) & 15) != 0) { hns_set_error("hns_tp_bind: packed must be 16-byte aligned"); return HNS_ERR_INVALID_ARG; }
     if (env->cfg.num_targets == 2) { hns_set_error("hns_tp_bind: the predictor's frame holds one evader (num_targets = 2 is not supported)"); return HNS_ERR_CONFIG; }
-    if (tp_nxc(tp_frame_dim(env->cfg)) > 3) {
-        hns_set_error("hns_tp_bind: frame wider than 48 values (7 + 3 num_agents + 3 num_cylinders with tp_use_obstacles)");
+    if (tp_nxc(tp_frame_dim(env->cfg)) > hns::kTpMaxChunks) {
+        hns_set_error("hns_tp_bind: frame wider than 80 values (7 + 3 num_agents + 3 num_cylinders with tp_use_obstacles)");
         return HNS_ERR_CONFIG;
     }
     if (env->cfg.max_episode_length > 60000) {
@@ -1260,9 +1267,10 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
     p.fill = fill_history ? 1 : 0;
     const int nxc = tp_nxc(p.I);
     if (tp_use_ws(nxc)) {
-        void (*wfn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_ws_kernel<1> : hns::hns_tp_lstm_ws_kernel<2>;
+        void (*wfn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_ws_kernel<1> : nxc == 2 ? hns::hns_tp_lstm_ws_kernel<2> : nxc == 3 ? hns::hns_tp_lstm_ws_kernel<3>
+                                      : nxc == 4 ? hns::hns_tp_lstm_ws_kernel<4> : hns::hns_tp_lstm_ws_kernel<5>;
         const size_t wlds = (size_t)(2048 + 1024 * nxc + 64) * 16;
-        static thread_local unsigned long long ws_attr_devs[2] = {0ull, 0ull};
+        static thread_local unsigned long long ws_attr_devs[hns::kTpMaxChunks] = {};
         const unsigned long long bit = 1ull << (env->device & 63);
         if (!(ws_attr_devs[nxc - 1] & bit)) {
             HNS_CHECK_HIP(hipFuncSetAttribute((const void *)wfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));

@@ -74,8 +74,8 @@ def test_config_schema_and_validation(tmp_path):
     assert config.resolve_hns_cfg(config.make_cfg({"use_obstacles": 1}, algo={"use_TP_net": 1})).tp_use_obstacles == 1   # 7+9+15 = 31 values
     assert config.resolve_hns_cfg(config.make_cfg({"use_obstacles": 1})).tp_use_obstacles == 0                           # only read with TP_net
     assert config.resolve_hns_cfg(config.make_cfg({"use_obstacles": 1, "cylinder": {"max_num": 8}}, algo={"use_TP_net": 1})).tp_use_obstacles == 1   # 40 values: three chunks
-    with pytest.raises(NotImplementedError):                                 # 7 + 9 + 48 = 64 > 48 values per frame
-        config.resolve_hns_cfg(config.make_cfg({"use_obstacles": 1, "cylinder": {"max_num": 16}}, algo={"use_TP_net": 1}))
+    wide = config.resolve_hns_cfg(config.make_cfg({"num_agents": 7, "use_obstacles": 1, "cylinder": {"max_num": 16}}, algo={"use_TP_net": 1}))
+    assert wide.tp_use_obstacles == 1 and abi.tp_frame_dim(7, 16, 1) == 76  # the widest frame the shapes allow: five 16-value chunks
     with pytest.raises(ValueError):
         config.resolve_hns_cfg(config.make_cfg({"cylinder": {"max_num": 40}}))
     sc = config.resolve_hns_cfg(config.make_cfg({"use_random_cylinder": 0, "scenario_flag": "wall"}))

@@ -42,10 +42,16 @@ CASES = [
     dict(E=1, A=3, C=5),                                     # a single env
     dict(E=33, A=7, C=16, K=4, cylinder={"min_num": 16}),    # every limit of the ABI at once (HNS_MAX_AGENTS / _CYLINDERS, k = 4)
     dict(E=65536, A=3, C=8, cylinder={"min_num": 8}),        # BASELINE config 3 at full size, every buffer bit for bit
+    # obs_max_cylinder beyond the step kernels' 4-wide selection network (the reference sorts any k, hideandseek.py:767-773)
+    dict(E=128, A=3, C=8, K=5),                              # whole tiles
+    dict(E=200, A=3, C=8, K=8, cylinder={"min_num": 2}),     # k = every slot, most of them inactive in some envs
+    dict(E=70, A=6, C=16, K=16, cylinder={"min_num": 16}),
+    dict(E=129, A=7, C=16, K=11),
+    dict(E=96, A=4, C=12, K=7, num_targets=2),               # with the two-evader extension
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: f"E{c['E']}A{c['A']}C{c['C']}")
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"E{c['E']}A{c['A']}C{c['C']}" + (f"K{c['K']}" if c.get("K", 3) > 4 else ""))
 def test_step_and_reset_bit_exact(case):
     case = dict(case)
     O.set_threads(8 if case["E"] > 4096 else 1)
@@ -180,8 +186,8 @@ def test_error_paths():
         env.step(env.rand_step_input(torch.zeros(64, 2, 4, device=env.device)))
     with pytest.raises(RuntimeError):
         env.to("cpu")
-    with pytest.raises(HnsError):
-        make_env(64, 3, 8, K=5)                                # obs_max_cylinder > 4 unsupported by the kernels
+    with pytest.raises(ValueError):
+        make_env(64, 3, 8, K=9)                                # obs_max_cylinder > cylinder.max_num
     assert HideAndSeek.REGISTRY["hideandseek"] is HideAndSeek
     # the C ABI refuses host memory at bind time instead of faulting in the kernel
     import ctypes as C

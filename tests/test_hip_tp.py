@@ -40,11 +40,13 @@ def _host_tp(env):
 
 
 @pytest.mark.parametrize("E,A,obst", [(48, 3, 0), (300, 1, 0), (257, 2, 0), (1000, 4, 0), (130, 6, 0), (65536, 3, 0),
-                                      (200, 3, 1), (70, 1, 1)])     # obst: task.use_obstacles, cylinders in the frame
+                                      (200, 3, 1), (70, 1, 1),      # obst: task.use_obstacles, cylinders in the frame
+                                      (300, 6, 12), (260, 6, 16), (129, 7, 16)])   # obst > 1: that many cylinder slots: frames of 61, 73 and 76 values
 def test_tp_observe_matches_oracle(E, A, obst):
     O.set_threads(16 if E > 4096 else 1)                    # (65536, 3): BASELINE config 3 at full size
-    env = _env(E, A, critic_input="state", use_obstacles=obst)
-    assert env._tp_bufs["history"].shape == (E, 10, 7 + 3 * A + 15 * obst)
+    Cn = obst if obst > 1 else 5
+    env = _env(E, A, Cn=Cn, critic_input="state", use_obstacles=min(obst, 1))
+    assert env._tp_bufs["history"].shape == (E, 10, 7 + 3 * A + 3 * Cn * min(obst, 1))
     torch.manual_seed(E + A)
     with torch.no_grad():
         for prm in env.TP.parameters():                     # larger than the default init: gates leave the linear range

@@ -13,7 +13,7 @@ def main():
     for r in cur.execute(
             "select s.kernel_name,count(*),avg(d.end-d.start),min(d.end-d.start),max(d.end-d.start),sum(d.end-d.start) "
             "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id "
-            "where s.kernel_name like ? group by s.kernel_name order by 6 desc limit 12", (like,)):
+            "where s.kernel_name like ? group by s.kernel_name order by 6 desc limit 24", (like,)):
         print(f"{r[0][:70]},{r[1]},{r[2]:.0f},{r[3]},{r[4]},{r[5]}")
     rows = list(cur.execute(
         "select s.kernel_name,p.name,count(*),avg(e.value),count(distinct d.id) from rocpd_pmc_event e "
