@@ -879,9 +879,10 @@ struct WsTile {
 #else
 #define WS_SYNC() __syncthreads()
 #endif
-// frames of three and more chunks hold 56-72 registers of weights per lane and 83-116 KB of LDS: one workgroup per CU, two waves per SIMD
+// frames of two and more chunks hold 48-72 registers of weights per lane (two chunks under the 128-register cap of four waves per SIMD spill into
+// the hot loop: 186 us against 133 us for THREE chunks without the cap) and 66-116 KB of LDS: one workgroup per CU, two waves per SIMD
 template <int NXC>
-__global__ __launch_bounds__(kWsThreads, NXC <= 2 ? WS_OCC : 2) void hns_tp_lstm_ws_kernel(const TpParams p) {
+__global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : 2) void hns_tp_lstm_ws_kernel(const TpParams p) {
     constexpr int NC = NXC + 4;
     constexpr WsImage L = ws_image(NXC);
     extern __shared__ __align__(16) uint4 simg[];
@@ -1171,7 +1172,7 @@ static bool tp_use_ws(int nxc) {
     if (nxc > 3) return true;
     if (mode == 1) return false;
     if (mode == 2) return true;
-    return nxc == 1;
+    return nxc != 2;                 // three chunks: 133 us against the tile kernel's 242 (tools/lab/lab_batch84.sh); two: the tile kernel's 122-127 us
 }
 static int tp_frame_dim(const hns_cfg &c) { return 7 + 3 * c.num_agents + (c.tp_use_obstacles ? 3 * c.num_cylinders : 0); }
 

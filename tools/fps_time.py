@@ -4,7 +4,7 @@ import torch, hns_amd
 from hns_amd import abi
 lib = abi.load_library()
 dev = torch.device("cuda:0")
-for n, k, d in ((51000, 5000, 36), (70536, 5000, 36), (10000, 5000, 36), (69632, 5000, 27), (69632, 5000, 30)):
+for n, k, d in ((51000, 5000, 36), (65536, 5000, 36), (70536, 5000, 36), (10000, 5000, 36), (69632, 5000, 27), (69632, 5000, 30)):
     p = torch.rand(n, d, device=dev)
     out = torch.zeros(k, dtype=torch.int32, device=dev)
     scratch = torch.zeros(lib.hns_fps_scratch_bytes(), dtype=torch.uint8, device=dev)
