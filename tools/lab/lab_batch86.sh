@@ -1,0 +1,4 @@
+#!/bin/bash
+# round 3, batch 86: seeded sweep over the configuration space, HIP against the oracle
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout 1200 python -m pytest tests/test_hip_fuzz.py -q 2>&1 | tail -40
