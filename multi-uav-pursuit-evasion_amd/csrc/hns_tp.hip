@@ -678,7 +678,10 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
 #undef TP_A
     // the wave's 32 predictions also go to LDS ([env][16], the parked-frame area is free by now): the rows below need all of an env's
     // 3F values in one lane
-    float *sPred = reinterpret_cast<float *>(simg + L.bytes / 16) + (wave * 8 * NXC) * 64;
+    // the predictions of this wave's 32 envs, 16 values apart (five predicted points, the reference's horizon) or 32 apart (3F > 16: up to ten points).
+    // 32 x 32 values fit the wave's parked-frame slot from two chunks on; with one chunk they take a slot of their own behind all parked frames
+    const int ps = R > 16 ? 32 : 16;
+    float *sPred = reinterpret_cast<float *>(simg + L.bytes / 16) + ((NXC == 1 && R > 16) ? kTpWaves * 8 * 64 + wave * 1024 : (wave * 8 * NXC) * 64);
     {
         float *pr = p.tp.pred + (size_t)ec * R;
 #pragma unroll
@@ -689,7 +692,7 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
                 const int comp = row % 3;
                 const float val = (comp < 2) ? (v * 0.5f) * p.arena_size : ((v + 1.0f) * 0.5f) * p.max_height;
                 if (valid) pr[row] = val;
-                sPred[(lane & 31) * 16 + row] = val;
+                sPred[(lane & 31) * ps + row] = val;
             }
         }
     }
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
         const int A = p.A, e_w0 = blockIdx.x * kTpEnvs + wave * 32;
         for (int r = lane; r < 32 * A; r += 64) {
             const int el = r / A, a = r - el * A, er = e_w0 + el;
-            if (er < p.E) tp_write_row(p, er, a, sPred + el * 16);
+            if (er < p.E) tp_write_row(p, er, a, sPred + el * ps);
         }
     }
     if (prof && lane == 0) prof[4] = __builtin_amdgcn_s_memrealtime();
@@ -1101,7 +1104,8 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : 2) void hns_tp_lstm
 #endif
 
     // ---- output layer on h_T (waves 0..3, one column tile each): tanh(W_fc h + b), rescaled to arena units (hideandseek.py:834-836) ----
-    float *sPred = reinterpret_cast<float *>(sX);           // [env 128][16]; the x buffers are free now
+    float *sPred = reinterpret_cast<float *>(sX);           // [env 128][16], or [env 128][32] with more than five predicted points (3F > 16): 16 KB,
+    const int ps = R > 16 ? 32 : 16;                        // the size of ONE chunk's x buffers, which are free now
     if (r < kWsTiles) {
         const int te = r;
         f32x16 o;
@@ -1139,7 +1143,7 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : 2) void hns_tp_lstm
                 const int comp = row % 3;
                 const float val = (comp < 2) ? (v * 0.5f) * p.arena_size : ((v + 1.0f) * 0.5f) * p.max_height;
                 if (er < p.E) pr[row] = val;
-                sPred[el * 16 + row] = val;
+                sPred[el * ps + row] = val;
             }
         }
     }
@@ -1150,7 +1154,7 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : 2) void hns_tp_lstm
         const int A = p.A;
         for (int rr = tid; rr < kWsEnvs * A; rr += kWsThreads) {
             const int el = rr / A, a = rr - el * A, er = e0 + el;
-            if (er < p.E) tp_write_row(p, er, a, sPred + el * 16);
+            if (er < p.E) tp_write_row(p, er, a, sPred + el * ps);
         }
     }
     if (prof && lane == 0) prof[4] = __builtin_amdgcn_s_memrealtime();
@@ -1283,12 +1287,14 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
     }
     void (*fn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_kernel<1> : nxc == 2 ? hns::hns_tp_lstm_kernel<2> : hns::hns_tp_lstm_kernel<3>;
     const int waves = hns::tp_waves(nxc);
-    const size_t lds = (size_t)hns::tp_image(nxc).bytes + (size_t)waves * 8 * nxc * 64 * sizeof(float);   // image + parked new frame
+    const size_t lds = (size_t)hns::tp_image(nxc).bytes + (size_t)waves * 8 * nxc * 64 * sizeof(float)    // image + parked new frame
+                       + ((nxc == 1 && 3 * p.F > 16) ? (size_t)waves * 1024 * sizeof(float) : 0);              // + the predictions of more than five points
     // the attribute is per device: remembered per (frame width, device), so envs on two GPUs driven from one thread both get it
     static thread_local unsigned long long attr_devs[3] = {0ull, 0ull, 0ull};
     const unsigned long long dev_bit = 1ull << (env->device & 63);
     if (!(attr_devs[nxc - 1] & dev_bit)) {
-        HNS_CHECK_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const size_t lds_cap = (size_t)hns::tp_image(nxc).bytes + (size_t)waves * (8 * nxc * 64 + (nxc == 1 ? 1024 : 0)) * sizeof(float);   // the largest this kernel asks for
+        HNS_CHECK_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
         attr_devs[nxc - 1] |= dev_bit;
     }
     hipStream_t s = (hipStream_t)stream;

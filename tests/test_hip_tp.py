@@ -238,3 +238,52 @@ def test_tp_saturated_gates_stay_finite():
         host = env.export_state()
         O.tp_observe(env.hcfg, host, tpa, fill=False)
     assert np.abs(tpa["pred"]).max() > 0.3
+
+
+def _draw_tp_case(seed):
+    r = np.random.RandomState(7000 + seed)
+    A = int(r.randint(1, 8))
+    obst = int(r.rand() < 0.5)
+    Cn = int(r.randint(1, 17))
+    E = int(r.choice([1, 31, 64, 100, 128, 129, 192, 257, 384, 500]))
+    task = {"num_agents": A, "use_obstacles": obst, "cylinder": {"max_num": Cn, "min_num": int(r.randint(0, Cn + 1)), "obs_max_cylinder": min(3, Cn)},
+            "env": {"num_envs": E, "max_episode_length": int(r.choice([8, 40, 800]))}, "history_step": int(r.randint(1, 17)),
+            "future_predcition_step": int(r.randint(1, 11)), "drone_detect_radius": float(r.choice([0.7, 100.0]))}
+    return task, E, A, float(r.choice([1.0, 2.0, 3.0]))
+
+
+@pytest.mark.parametrize("seed", list(range(60)))
+def test_tp_random_configuration_matches_oracle(seed):
+    """Seeded sweep over frame widths (1-5 operand chunks, both kernels), window lengths, horizons and batch sizes: window, ground
+    truth and flags exact, predictions and rows within 1e-5 of the oracle's fp32 LSTM."""
+    task, E, A, scale = _draw_tp_case(seed)
+    for _ in range(20):
+        try:
+            cfg = config.make_cfg(task, algo={"use_TP_net": 1})
+            config.resolve_hns_cfg(cfg)
+            break
+        except ValueError:                                  # the placement grid does not hold the bodies: fewer cylinder slots
+            task["cylinder"]["max_num"] = max(1, task["cylinder"]["max_num"] - 2)
+            task["cylinder"]["min_num"] = min(task["cylinder"]["min_num"], task["cylinder"]["max_num"])
+            task["cylinder"]["obs_max_cylinder"] = min(3, task["cylinder"]["max_num"])
+    O.set_threads(1)
+    env = HideAndSeek(cfg)
+    env.set_seed(seed)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        for prm in env.TP.parameters():
+            prm.mul_(scale)
+    env.reset()
+    tpa = _host_tp(env)
+    tpa["history"][:] = 0
+    O.tp_observe(env.hcfg, env.export_state(), tpa, fill=True)
+    for t in range(12):
+        dev = {k: v.cpu().numpy() for k, v in env._tp_bufs.items()}
+        what = f"seed {seed} {task} call {t}"
+        assert np.array_equal(dev["history"], tpa["history"]), what
+        assert np.array_equal(dev["groundtruth"], tpa["groundtruth"]), what
+        assert np.array_equal(dev["tp_done"], tpa["tp_done"]), what
+        np.testing.assert_allclose(dev["pred"], tpa["pred"], rtol=0, atol=TOL, err_msg=what)
+        np.testing.assert_allclose(dev["obs_self"], tpa["obs_self"], rtol=0, atol=TOL, err_msg=what)
+        env.step(env.rand_step_input(torch.randn(E, A, 4, device=env.device)))
+        O.tp_observe(env.hcfg, env.export_state(), tpa, fill=False)
