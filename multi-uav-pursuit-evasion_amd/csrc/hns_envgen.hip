@@ -379,10 +379,10 @@ int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start,
     const size_t q_floats = (size_t)((d + 3) & ~3), pts_floats = (size_t)per_thread * hns::kFpsThreads * (d + 1);
     p.in_lds = (q_floats + pts_floats) * sizeof(float) <= 144 * 1024 ? 1 : 0;
     const size_t lds = (q_floats + (p.in_lds ? pts_floats : 0)) * sizeof(float);
-    static thread_local size_t lds_attr = 0;
-    if (lds > lds_attr) {
+    static thread_local unsigned long long lds_attr_devs = 0ull;       // the attribute is per device: remembered per device of this thread
+    if (!(lds_attr_devs & (1ull << (dev & 63)))) {
         HNS_CHECK_HIP(hipFuncSetAttribute((const void *)hns::hns_fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 1024));
-        lds_attr = 145 * 1024;
+        lds_attr_devs |= 1ull << (dev & 63);
     }
     hipLaunchKernelGGL(hns::hns_fps_kernel, dim3(groups), dim3(hns::kFpsThreads), lds, s, p);
     HNS_CHECK_HIP(hipGetLastError());

@@ -63,3 +63,64 @@ def test_perturb_tasks_matches_oracle(A, Cn, expand):
     assert rc == 0, env._lib.hns_last_error()
     ref = O.perturb_tasks(env.hcfg, hist.cpu().numpy(), n_tasks, expand, 0.1, seed=99)
     assert np.array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fps_random_shapes_match_oracle(seed):
+    """Seeded sweep: point counts around the kernels' hand-over sizes, every width up to 48 coordinates, duplicates, any start."""
+    r = np.random.RandomState(300 + seed)
+    n = int(r.choice([2, 63, 64, 65, 1000, 4097, 30000, 65535, 65537, 90000]))
+    d = int(r.randint(1, 49))
+    k = int(min(n, r.choice([1, 2, 17, 100, 300])))
+    pts = r.rand(n, d).astype(np.float32)
+    if seed % 3 == 0:
+        pts[r.randint(0, n, size=n // 4)] = pts[r.randint(0, n)]      # duplicates: ties -> lower index, chosen points leave the pool
+    start = int(r.randint(0, n))
+    lib = abi.load_library()
+    got = _fps_hip(lib, pts, k, start)
+    assert np.array_equal(got, O.fps(pts, k, start)), f"seed {seed}: n={n} d={d} k={k} start={start}"
+    assert len(set(got.tolist())) == k
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_perturb_and_task_reset_random_shapes_match_oracle(seed):
+    """Seeded sweep over pursuers / cylinder slots / cylinder size: hns_perturb_tasks and hns_reset_tasks bit-identical to the oracle."""
+    r = np.random.RandomState(500 + seed)
+    for _ in range(50):
+        A, Cn = int(r.randint(1, 8)), int(r.randint(1, 17))
+        task = {"num_agents": A, "cylinder": {"max_num": Cn, "min_num": int(r.randint(0, Cn + 1)), "obs_max_cylinder": int(r.randint(1, min(Cn, 6) + 1)),
+                                              "size": float(r.choice([0.075, 0.1, 0.12]))},
+                "env": {"num_envs": int(r.choice([64, 100, 256])), "max_episode_length": 20}}
+        try:
+            config.resolve_hns_cfg(config.make_cfg(task))
+            break
+        except ValueError:
+            continue
+    E = task["env"]["num_envs"]
+    env = HideAndSeek(config.make_cfg(task))
+    env.set_seed(seed)
+    env.reset()
+    b = env._bufs
+    hist = torch.cat([b["drone_state"][..., :3].reshape(E, -1), b["target_pos"], b["cylinders"].reshape(E, -1)], dim=1).contiguous()
+    n_tasks, expand, noise = int(r.choice([1, 77, 1000])), int(r.rand() < 0.5), float(r.choice([0.05, 0.1, 0.3]))
+    out = torch.zeros(n_tasks, hist.shape[1], device=env.device)
+    rc = env._lib.hns_perturb_tasks(env._env, hist.data_ptr(), E, out.data_ptr(), n_tasks, expand, C.c_float(noise), C.c_uint64(seed), env._stream())
+    assert rc == 0, env._lib.hns_last_error()
+    ref = O.perturb_tasks(env.hcfg, hist.cpu().numpy(), n_tasks, expand, noise, seed=seed)
+    assert np.array_equal(out.cpu().numpy(), ref), f"seed {seed} {task}"
+    # place the first E perturbed tasks (cycled) on the envs from `task_first` on: hns_reset_tasks against the oracle
+    tasks = np.ascontiguousarray(ref[np.arange(E) % n_tasks])
+    first = int(r.choice([0, E // 3, E]))
+    tdev = torch.from_numpy(tasks).to(env.device)
+    mask = (r.rand(E) < 0.7)
+    mdev = torch.from_numpy(mask.astype(np.uint8)).to(env.device)
+    host = env.export_state()
+    epoch = env.reset_epoch
+    rc = env._lib.hns_reset_tasks(env._env, C.c_void_p(mdev.data_ptr()), C.c_void_p(tdev.data_ptr()), C.c_int32(first), C.c_uint64(env.seed), env._stream())
+    assert rc == 0, env._lib.hns_last_error()
+    O.reset_tasks(env.hcfg, host, mask.astype(np.uint8), env.seed, epoch, tasks, first)
+    st = env.export_state()
+    for k in host:
+        if k == "state_drones" and not host[k].size:
+            continue
+        np.testing.assert_array_equal(host[k], st[k], err_msg=f"seed {seed} {task}: {k}")

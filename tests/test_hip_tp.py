@@ -287,3 +287,9 @@ def test_tp_random_configuration_matches_oracle(seed):
         np.testing.assert_allclose(dev["obs_self"], tpa["obs_self"], rtol=0, atol=TOL, err_msg=what)
         env.step(env.rand_step_input(torch.randn(E, A, 4, device=env.device)))
         O.tp_observe(env.hcfg, env.export_state(), tpa, fill=False)
+        done = env._bufs["done"].bool()
+        if bool(done.any()) and t % 3 != 2:                  # masked reset: the window is not reset per env, the new frame is appended (hideandseek.py:825-830)
+            td = env.rand_step_input()
+            td.set("_reset", done.clone())
+            env.reset(td)
+            O.tp_observe(env.hcfg, env.export_state(), tpa, fill=False)
