@@ -87,3 +87,36 @@ def test_random_configuration_is_bit_exact(seed):
             O.reset(env.hcfg, host, mask, env.seed, epoch)
             same(f"reset after step {t}")
     same("end")
+
+
+@pytest.mark.parametrize("seed", SEEDS[::6])
+def test_random_configuration_snapshot_resume(seed, tmp_path):
+    """save_state / load_state into a fresh env of the same (random) configuration: the continuation — steps and masked resets —
+    is bit-identical to the env that never stopped."""
+    from hns_amd.env import HideAndSeek
+    task, E, A = draw_case(seed)
+    cfg = config.make_cfg(task)
+    a = HideAndSeek(cfg, headless=True, write_critic_state=bool(seed % 2))
+    a.set_seed(seed)
+    a.reset()
+    g = torch.Generator().manual_seed(seed)
+    acts = [torch.randn(E, A, 4, generator=g) * 0.6 for _ in range(14)]
+
+    def run(env, lo, hi):
+        for t in range(lo, hi):
+            td = env.step(env.rand_step_input(acts[t].to(env.device)))
+            done = td[("next", "done")].squeeze(-1)
+            if bool(done.any()):
+                r = env.rand_step_input()
+                r.set("_reset", done.clone())
+                env.reset(r)
+
+    run(a, 0, 6)
+    a.save_state(str(tmp_path / "s.npz"))
+    b = HideAndSeek(cfg, headless=True, write_critic_state=bool(seed % 2))
+    b.load_state(str(tmp_path / "s.npz"))
+    run(a, 6, 14)
+    run(b, 6, 14)
+    sa, sb = a.export_state(), b.export_state()
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=f"seed {seed} {task}: {k}")
