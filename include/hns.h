@@ -250,7 +250,8 @@ int hns_reset(hns_env *env, const uint8_t *reset_mask, uint64_t seed, void *stre
 
 /* envgen reset (hideandseek_envgen.py:875-902): like hns_reset, but the masked envs with index >=
  * task_first take their placement from `tasks` (device pointer, [E, 3A+3+3C] rows = drone positions,
- * evader position, cylinder positions — the reference's task vector) instead of sampling it;
+ * evader position, cylinder positions — the reference's task vector; [E, 3A+6+3C] with both evaders'
+ * positions in the two-evader extension) instead of sampling it;
  * orientations are still drawn from the Philox stream.  Envs < task_first reset as in hns_reset. */
 int hns_reset_tasks(hns_env *env, const uint8_t *reset_mask, const float *tasks, int32_t task_first, uint64_t seed,
                     void *stream);
@@ -312,7 +313,8 @@ int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start,
 /* samplenearby (:316-370) with the grid sanity check (:187-207): tasks_out[t] = a random history entry,
  * pursuers / evader jittered by U(-1,1)*expand_step per coordinate (cylinders by {-1,0,1} cells when
  * expand_cylinders), clipped to the task bounds (:320-333); up to 10 attempts, then the entry itself.
- * history [n_hist, 3(A+1+C)], tasks_out [n_tasks, 3(A+1+C)]: device pointers; Philox stream (seed, task). */
+ * history [n_hist, 3(A+1+C)], tasks_out [n_tasks, 3(A+1+C)] (3(A+2+C) with two evaders, both jittered like
+ * pursuers): device pointers; Philox stream (seed, task). */
 int hns_perturb_tasks(hns_env *env, const float *history, int32_t n_hist, float *tasks_out, int32_t n_tasks,
                       int32_t expand_cylinders, float expand_step, uint64_t seed, void *stream);
 

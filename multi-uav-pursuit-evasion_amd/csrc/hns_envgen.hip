@@ -283,13 +283,14 @@ HNS_DEV int envgen_cell(double x, double grid_size, int num_grid) {
     return g < 0 ? 0 : (g > num_grid - 1 ? num_grid - 1 : g);
 }
 
-constexpr int kMaxBodies = HNS_MAX_AGENTS + 1 + HNS_MAX_CYLINDERS;
+constexpr int kMaxBodies = HNS_MAX_AGENTS + 2 + HNS_MAX_CYLINDERS;      // pursuers, one or two evaders, cylinder slots
 
 __global__ __launch_bounds__(256) void hns_perturb_kernel(const PerturbParams p) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= p.n_tasks) return;
     const hns_cfg &c = p.cfg;
-    const int A = c.num_agents, Cn = c.num_cylinders, nb = A + 1 + Cn, TD = 3 * nb, GN = c.grid_num, half = GN / 2;
+    // task vector: [pursuers | evader (two with the two-evader extension) | cylinder slots], three coordinates each
+    const int A = c.num_agents, Cn = c.num_cylinders, NM = A + (c.num_targets == 2 ? 2 : 1), nb = NM + Cn, TD = 3 * nb, GN = c.grid_num, half = GN / 2;
     // the reference divides by the Python double 2*cylinder_size (0.2), not by its fp32 rounding: recover the
     // decimal the YAML holds (6 places) so that bodies exactly on a cell edge fall into the same cell
     const double gs = __builtin_rint((double)c.grid_size * 1e6) / 1e6;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void hns_perturb_kernel(const PerturbParams p)
         bool ok = true;
         for (int b = 0; b < nb; ++b) {
             float v[3] = {origin[3 * b], origin[3 * b + 1], origin[3 * b + 2]};
-            if (b <= A) {
+            if (b < NM) {
                 for (int j = 0; j < 3; ++j) v[j] += (rng.uniform() * 2.0f - 1.0f) * p.expand_step;
                 v[0] = d_clamp(v[0], -bxy, bxy); v[1] = d_clamp(v[1], -bxy, bxy);
                 v[2] = d_clamp(v[2], c.max_height - 0.1f, c.max_height + 0.1f);
@@ -392,10 +393,6 @@ int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start,
 int hns_perturb_tasks(hns_env *env, const float *history, int32_t n_hist, float *tasks_out, int32_t n_tasks, int32_t expand_cylinders,
                       float expand_step, uint64_t seed, void *stream) {
     if (!env || !history || !tasks_out || n_hist < 1 || n_tasks < 0) { hns_set_error("hns_perturb_tasks: bad argument"); return HNS_ERR_INVALID_ARG; }
-    if (env->cfg.num_targets == 2) {
-        hns_set_error("hns_perturb_tasks: the task generator is built for one evader (num_targets = 2, the two-evader extension, runs without it)");
-        return HNS_ERR_CONFIG;
-    }
     if (n_tasks == 0) return HNS_OK;
     hns::PerturbParams p;
     p.cfg = env->cfg;

@@ -68,7 +68,7 @@ struct Params {
     uint32_t seed_lo, seed_hi, epoch;
     unsigned long long *prof;   // optional per-wave phase timestamps (diagnostics), else null
     uint32_t cyl_magic;         // ceil(2^32 / (3*C)): index / (3*C) as a multiply-high
-    const float *tasks;         // reset: optional [E, 3A+3+3C] task vectors (envgen), else null
+    const float *tasks;         // reset: optional [E, 3A+3NT+3C] task vectors (envgen: pursuers | evader(s) | cylinder slots), else null
     int32_t task_first;         // envs >= task_first take their placement from `tasks`
     uint32_t lab_stagger;
     uint32_t lab;               // ablation switches of the measurement build (-DHNS_LAB, tools/step_lab.py); unused otherwise
@@ -2362,10 +2362,6 @@ int hns_reset_tasks(hns_env *env, const uint8_t *reset_mask, const float *tasks,
     if (!env || !tasks) { set_error("hns_reset_tasks: null argument"); return HNS_ERR_INVALID_ARG; }
     if (!env->bound) { set_error("hns_reset_tasks: buffers not bound"); return HNS_ERR_NOT_BOUND; }
     if (task_first < 0 || task_first > env->cfg.num_envs) { set_error("hns_reset_tasks: task_first out of range"); return HNS_ERR_INVALID_ARG; }
-    if (env->cfg.num_targets == 2) {
-        set_error("hns_reset_tasks: task vectors hold one evader (num_targets = 2, the two-evader extension, resets with hns_reset only)");
-        return HNS_ERR_CONFIG;
-    }
     Params p;
     p.cfg = env->cfg;
     p.buf = env->buf;

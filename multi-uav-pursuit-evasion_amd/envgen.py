@@ -57,9 +57,10 @@ class GenBuffer:
     """hideandseek_envgen.py:209-377."""
 
     def __init__(self, num_agents, num_cylinders, device="cpu", arena_size=0.9, cylinder_size=0.1, max_height=1.2,
-                 buffer_length=5000, seed=0):
+                 buffer_length=5000, seed=0, num_targets=1):
         self.num_agents, self.num_cylinders, self.device = num_agents, num_cylinders, device
-        self.task_dim = 3 * num_agents + 3 + 3 * num_cylinders       # reference: 18 + 3A (C = 5)
+        self.num_targets = int(num_targets)                           # 2: the two-evader extension — [pursuers | evader 0 | evader 1 | cylinders]
+        self.task_dim = 3 * num_agents + 3 * self.num_targets + 3 * num_cylinders       # reference: 18 + 3A (C = 5)
         self._state_buffer = np.zeros((0, 1), dtype=np.float32)
         self._history_buffer = np.zeros((0, self.task_dim), dtype=np.float32)
         self._weight_buffer = np.zeros((0, 1), dtype=np.float32)
@@ -86,7 +87,7 @@ class GenBuffer:
         """:187-207 vectorised: every object sits in its own free cell of the disc."""
         A, Cn = self.num_agents, self.num_cylinders
         n = tasks.shape[0]
-        xyz = tasks.reshape(n, A + 1 + Cn, 3)
+        xyz = tasks.reshape(n, A + self.num_targets + Cn, 3)
         g = self.to_grid(xyz[..., :2])
         cell = g[..., 0] * self.num_grid + g[..., 1]
         free = self.grid_map.reshape(-1)[cell] == 0
@@ -123,6 +124,8 @@ class GenBuffer:
         """Easy starting tasks (hideandseek_envgen.py:235-277): the evader on a random free cell, the pursuers on the free cells
         the flood from that cell reaches first.  All samples at once: rank every free cell by the flood table, keep the
         num_agents smallest per sample."""
+        if self.num_targets != 1:
+            raise NotImplementedError("use_init_easy places one evader (the reference's flood, hideandseek_envgen.py:235-277)")
         n, A, B = self.num_grid, self.num_agents, self.buffer_length
         free = np.argwhere(self.grid_map == 0)                                     # [F, 2]
         start = free[np.array([self.rng.integers(len(free)) for _ in range(B)])]   # one draw per sample, in sample order
@@ -200,7 +203,7 @@ class GenBuffer:
         bxy = self.arena_size / math.sqrt(2.0) - 0.1
         drone = [[-bxy, bxy], [-bxy, bxy], [self.max_height - 0.1, self.max_height + 0.1]]
         cyl = [[-cb, cb], [-cb, cb], [-20.0, self.max_height / 2]]
-        return np.array(drone * (self.num_agents + 1) + cyl * self.num_cylinders)
+        return np.array(drone * (self.num_agents + self.num_targets) + cyl * self.num_cylinders)
 
     def samplenearby(self, num_tasks, expand_cylinders, expand_step):
         """:316-370, vectorised: perturb, clip, sanity-check, retry the failures (<= 10 rounds)."""
@@ -244,8 +247,8 @@ class DeviceGenBuffer:
 
     def __init__(self, env, buffer_length=5000, seed=0):
         self.env, self.lib, self.device = env, env._lib, env.device
-        self.num_agents, self.num_cylinders = env.num_agents, env.num_cylinders
-        self.task_dim = 3 * self.num_agents + 3 + 3 * self.num_cylinders
+        self.num_agents, self.num_cylinders, self.num_targets = env.num_agents, env.num_cylinders, env.num_targets
+        self.task_dim = 3 * self.num_agents + 3 * self.num_targets + 3 * self.num_cylinders
         self.buffer_length, self.eps, self.update_method = buffer_length, 1e-5, "fps"
         self._history = torch.zeros(0, self.task_dim, device=self.device)
         self._state_buffer = torch.zeros(0, self.task_dim, device=self.device)
@@ -322,8 +325,6 @@ class DeviceGenBuffer:
 class HideAndSeek_envgen(HideAndSeek):
     def __init__(self, cfg, headless=True, env_index_offset=0, write_critic_state=None):
         super().__init__(cfg, headless, env_index_offset, write_critic_state)
-        if self.num_targets != 1:
-            raise NotImplementedError("HideAndSeek_envgen with num_targets=2 is not built (task vectors hold one evader)")
         t = cfg.task
         self.use_particle_generator = int(t.get("use_particle_generator", 1))
         self.ratio_unif = float(t.get("ratio_unif", 0.3))
@@ -348,7 +349,7 @@ class HideAndSeek_envgen(HideAndSeek):
         self._env_offset = int(env_index_offset)
         if self.use_init_easy:                                                # :485-495
             easy = GenBuffer(A, Cn, arena_size=float(t.arena_size), cylinder_size=float(t.cylinder.size),
-                             max_height=float(t.max_height), seed=int(cfg.get("seed", 0))).init_easy_cases()
+                             max_height=float(t.max_height), seed=int(cfg.get("seed", 0)), num_targets=self.num_targets).init_easy_cases()
             cyl = np.tile(np.array([0.0, 0.0, -20.0], np.float32), (easy.shape[0], Cn, 1))
             self.gen_buffer.init_history(np.concatenate([easy.reshape(easy.shape[0], -1), cyl.reshape(easy.shape[0], -1)], axis=1))
         self.task_dim = self.gen_buffer.task_dim
@@ -419,7 +420,7 @@ class HideAndSeek_envgen(HideAndSeek):
                                                   C.c_int32(self.num_unif), C.c_uint64(self.seed), self._stream()), "hns_reset_tasks")
             # the uniform tasks were sampled on the device: read the placement back as task vectors
             b = self._bufs
-            placed = torch.cat([b["drone_state"][..., :3].reshape(E, -1), b["target_pos"], b["cylinders"].reshape(E, -1)], dim=1)
+            placed = torch.cat([b["drone_state"][..., :3].reshape(E, -1), b["target_pos"].reshape(E, -1), b["cylinders"].reshape(E, -1)], dim=1)
             self._tasks_dev[:self.num_unif].copy_(placed[:self.num_unif])
             self.gen_buffer.insert(self._tasks_dev)
         else:

@@ -1275,8 +1275,8 @@ static int o_envgen_cell(double x, double grid_size, int num_grid) {
 
 /* the grid sanity check alone (hideandseek_envgen.py:187-207): every body in its own free cell of the disc */
 void hns_oracle_tasks_sane(const hns_cfg *c, const float *tasks, int n, uint8_t *out) {
-    const int A = c->num_agents, Cn = c->num_cylinders, nb = A + 1 + Cn, TD = 3 * nb, GN = c->grid_num, half = GN / 2;
-    int cells[HNS_MAX_AGENTS + 1 + HNS_MAX_CYLINDERS];
+    const int A = c->num_agents, Cn = c->num_cylinders, NM = A + (c->num_targets == 2 ? 2 : 1), nb = NM + Cn, TD = 3 * nb, GN = c->grid_num, half = GN / 2;   /* [pursuers | evader(s) | cylinder slots] */
+    int cells[HNS_MAX_AGENTS + 2 + HNS_MAX_CYLINDERS];
     for (int t = 0; t < n; ++t) {
         const float *v = tasks + (size_t)t * TD;
         int ok = 1;
@@ -1295,11 +1295,11 @@ void hns_oracle_tasks_sane(const hns_cfg *c, const float *tasks, int n, uint8_t 
 
 int hns_oracle_perturb_tasks(const hns_cfg *c, const float *history, int n_hist, float *tasks_out, int n_tasks,
                              int expand_cylinders, float expand_step, uint64_t seed) {
-    const int A = c->num_agents, Cn = c->num_cylinders, nb = A + 1 + Cn, TD = 3 * nb, GN = c->grid_num, half = GN / 2;
+    const int A = c->num_agents, Cn = c->num_cylinders, NM = A + (c->num_targets == 2 ? 2 : 1), nb = NM + Cn, TD = 3 * nb, GN = c->grid_num, half = GN / 2;   /* [pursuers | evader(s) | cylinder slots] */
     const double gs = o_envgen_grid_size(c);
     const float cb = (float)((int)(c->arena_size / c->grid_size)) * c->grid_size;
     const float bxy = c->arena_size / 1.41421356237309515f - 0.1f;
-    int cells[HNS_MAX_AGENTS + 1 + HNS_MAX_CYLINDERS];
+    int cells[HNS_MAX_AGENTS + 2 + HNS_MAX_CYLINDERS];
     for (int t = 0; t < n_tasks; ++t) {
         o_rng rng = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)t, 0x9E3779B9u, 0u, {0, 0, 0, 0}, 0};
         float *out = tasks_out + (size_t)t * TD;
@@ -1312,7 +1312,7 @@ int hns_oracle_perturb_tasks(const hns_cfg *c, const float *history, int n_hist,
             int ok = 1;
             for (int b = 0; b < nb; ++b) {
                 float v[3] = {origin[3 * b], origin[3 * b + 1], origin[3 * b + 2]};
-                if (b <= A) {
+                if (b < NM) {
                     for (int j = 0; j < 3; ++j) v[j] += (o_uniform(&rng) * 2.0f - 1.0f) * expand_step;
                     v[0] = o_clamp(v[0], -bxy, bxy); v[1] = o_clamp(v[1], -bxy, bxy);
                     v[2] = o_clamp(v[2], c->max_height - 0.1f, c->max_height + 0.1f);

@@ -33,9 +33,10 @@ def _valid_tasks(gb, n, rng):
     A, Cn = gb.num_agents, gb.num_cylinders
     out = []
     for _ in range(n):
-        cells = free[rng.permutation(len(free))[:A + 1 + Cn]]
+        NM = A + getattr(gb, "num_targets", 1)
+        cells = free[rng.permutation(len(free))[:NM + Cn]]
         xy = (cells - gb.num_grid // 2) * gb.grid_size
-        z = np.concatenate([np.full(A + 1, 1.2), np.where(np.arange(Cn) < 3, 0.6, -20.0)])
+        z = np.concatenate([np.full(NM, 1.2), np.where(np.arange(Cn) < 3, 0.6, -20.0)])
         out.append(np.concatenate([xy, z[:, None]], axis=1).reshape(-1))
     return np.asarray(out, dtype=np.float32)
 
@@ -264,6 +265,36 @@ def test_grid_sanity_check_matches_reference(golden):
     c = config.resolve_hns_cfg(config.make_cfg({"num_agents": A, "cylinder": {"max_num": Cn, "min_num": 2}, "env": {"num_envs": 8}}))
     assert np.array_equal(O.tasks_sane(c, g["tasks"]), g["ok"])
     assert 0.05 < g["ok"].mean() < 0.95
+
+
+def test_two_evader_task_vectors():
+    """Two-evader extension: task vectors [pursuers | evader 0 | evader 1 | cylinder slots] through the host GenBuffer, the oracle's sanity
+    check, perturbation and task reset."""
+    import hns_oracle as O
+    E, A, Cn = 48, 4, 6
+    c = config.resolve_hns_cfg(config.make_cfg({"num_agents": A, "num_targets": 2, "cylinder": {"max_num": Cn, "min_num": 3}, "env": {"num_envs": E}}))
+    gb = GenBuffer(A, Cn, seed=1, num_targets=2, buffer_length=64)
+    assert gb.task_dim == 3 * (A + 2 + Cn) and gb.task_bounds().shape == (gb.task_dim, 2)
+    tasks = _valid_tasks(gb, E, np.random.default_rng(2))
+    assert gb.sanity_ok(tasks).all() and O.tasks_sane(c, tasks).all()
+    clash = tasks.copy()
+    clash[:, 3 * (A + 1):3 * (A + 1) + 2] = clash[:, 3 * A:3 * A + 2]                  # the second evader on the first one's cell
+    assert not gb.sanity_ok(clash).any() and not O.tasks_sane(c, clash).any()
+    gb.init_history(tasks)
+    near = gb.samplenearby(200, expand_cylinders=1, expand_step=0.1)
+    assert near.shape == (200, gb.task_dim) and gb.sanity_ok(near).all()
+    pert = O.perturb_tasks(c, tasks, 300, 1, 0.1, seed=3)
+    assert pert.shape == (300, gb.task_dim) and gb.sanity_ok(pert).mean() > 0.9 and np.array_equal(gb.sanity_ok(pert), O.tasks_sane(c, pert).astype(bool))
+    moved = np.abs(pert.reshape(300, -1, 3)[:, :A + 2] - 1.0).max() > 0                 # both evaders are jittered like pursuers
+    assert moved
+    arrs = O.alloc_buffers(c)
+    O.reset_tasks(c, arrs, None, 5, 0, tasks, 0)
+    t3 = tasks.reshape(E, A + 2 + Cn, 3)
+    np.testing.assert_array_equal(arrs["drone_state"][:, :, :3], t3[:, :A])
+    np.testing.assert_array_equal(arrs["target_pos"], t3[:, A:A + 2])
+    np.testing.assert_array_equal(arrs["cylinders"], t3[:, A + 2:])
+    with pytest.raises(NotImplementedError):
+        gb.init_easy_cases()
 
 
 # ---- device-side generator pieces (SURVEY §8 N3): oracle restatements -----------------------------------

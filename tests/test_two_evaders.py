@@ -153,7 +153,7 @@ def test_hip_two_evaders_lazy_state_and_bench_shape():
 @pytest.mark.gpu
 def test_two_evaders_full_shard_properties_and_rejections():
     """Config 5's shard (6v2, 16 cylinders, 65 536 envs): size-independent properties over 40 steps, determinism, and the
-    combinations the extension does not support fail loudly instead of silently (predictor, task generator)."""
+    combination the extension does not support fails loudly instead of silently (predictor)."""
     import ctypes as C
     from hns_amd.env import HideAndSeek, HnsError
     E, A, Cn = 65536, 6, 16
@@ -179,9 +179,46 @@ def test_two_evaders_full_shard_properties_and_rejections():
     assert np.array_equal(a["obs_self"][..., 3:7], q) and (a["obs_self"][..., 23] == 0).all()
     tp = a["target_pos"]
     assert tp.shape == (E, 2, 3) and np.isfinite(tp).all()
-    # rejections
-    assert e1._lib.hns_reset_tasks(e1._env, None, C.c_void_p(e1._bufs["target_pos"].data_ptr()), 0, C.c_uint64(0), None) == abi.HNS_ERR_CONFIG
-    assert b"one evader" in e1._lib.hns_last_error()
+    # rejection: the predictor's frame holds one evader
     with pytest.raises(NotImplementedError):
         config.make_cfg({"num_agents": A, "num_targets": 2, "cylinder": {"max_num": Cn, "min_num": Cn}, "env": {"num_envs": 64}}, algo={"use_TP_net": 1}) and \
             HideAndSeek(config.make_cfg({"num_agents": A, "num_targets": 2, "cylinder": {"max_num": Cn, "min_num": Cn}, "env": {"num_envs": 64}}, algo={"use_TP_net": 1}))
+
+
+@pytest.mark.gpu
+def test_two_evaders_with_the_task_generator():
+    """HideAndSeek_envgen with two evaders: task vectors [pursuers | evader 0 | evader 1 | cylinder slots]; every env sits on its task,
+    the task reset and the perturbation equal the oracle's, the history fills and is trimmed."""
+    import ctypes as C
+    from hns_amd.envgen import HideAndSeek_envgen
+    E, L, A, Cn = 6144, 4, 3, 6
+    cfg = config.make_cfg({"name": "HideAndSeek_envgen", "num_agents": A, "num_targets": 2, "ratio_unif": 0.3, "eval_iter": 1, "R_min": 0.0, "R_max": 1.0,
+                           "use_particle_generator": 1, "expand_cylinders": 1, "cylinder": {"max_num": Cn, "min_num": 3},
+                           "env": {"num_envs": E, "max_episode_length": L}})
+    env = HideAndSeek_envgen(cfg)
+    env.set_seed(2)
+    env.reset()
+    assert env.task_dim == 3 * A + 6 + 3 * Cn and env.all_tasks.shape == (E, env.task_dim)
+    g = torch.Generator(device=env.device).manual_seed(0)
+    for ep in range(3):
+        for t in range(L):
+            td = env.step(env.rand_step_input(torch.randn(E, A, 4, generator=g, device=env.device)))
+        rtd = env.rand_step_input()
+        rtd.set("_reset", td[("next", "done")].squeeze(-1))
+        epoch = env.reset_epoch
+        env.reset(rtd)
+        st = env.export_state()
+        placed = np.concatenate([st["drone_state"][..., :3].reshape(E, -1), st["target_pos"].reshape(E, -1), st["cylinders"].reshape(E, -1)], axis=1)
+        np.testing.assert_array_equal(placed, env.all_tasks)
+        host = O.alloc_buffers(env.hcfg)
+        O.reset_tasks(env.hcfg, host, None, env.seed, epoch, env.all_tasks, env.num_unif)
+        for k in ("drone_state", "target_pos", "cylinders", "obs_self", "obs_others", "obs_cylinders", "throttle"):
+            np.testing.assert_array_equal(host[k][env.num_unif:], st[k][env.num_unif:], err_msg=k)       # the envs placed from perturbed history tasks
+    assert len(env.gen_buffer) == 5000                                             # 3 x 6144 kept tasks, trimmed by hns_fps (45 coordinates: the chip-wide kernel)
+    hist = env.gen_buffer._history
+    out = torch.zeros(500, env.task_dim, device=env.device)
+    assert env._lib.hns_perturb_tasks(env._env, hist.data_ptr(), 5000, out.data_ptr(), 500, 1, C.c_float(0.1), C.c_uint64(7), env._stream()) == 0
+    ref = O.perturb_tasks(env.hcfg, hist.cpu().numpy(), 500, 1, 0.1, seed=7)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    sane = O.tasks_sane(env.hcfg, ref) if hasattr(O, "tasks_sane") else None
+    assert sane is None or sane.mean() > 0.7                                       # the fallback (a stored task as it is — uniform placements may share a cell) is the exception
