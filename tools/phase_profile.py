@@ -16,6 +16,7 @@ for a in sys.argv[1:]:                                   # e.g. --agents=6 --cyl
     if a.startswith("--agents="): A = int(a.split("=")[1])
     if a.startswith("--cylinders="): Cn = int(a.split("=")[1])
     if a.startswith("--targets="): NT = int(a.split("=")[1])
+    if a.startswith("--envs="): E = int(a.split("=")[1])
 cfg = config.make_cfg({"num_agents": A, "num_targets": NT, "cylinder": {"max_num": Cn, "min_num": Cn}, "env": {"num_envs": E}})
 env = HideAndSeek(cfg, write_critic_state="--critic-state" in sys.argv)
 env.reset()
@@ -55,4 +56,4 @@ z = rt0.min()
 print("global clock (ns): first start 0, last start %.0f, first end %.0f, last end %.0f" % (rt0.max() - z, rt1.min() - z, rt1.max() - z))
 print("per-block duration (ns): median %.0f p10 %.0f p90 %.0f" % tuple(np.percentile((rt1.max(1) - rt0.min(1)), [50, 10, 90])))
 order = np.argsort(rt0.min(1))
-print("start time of blocks by dispatch rank (ns): ", [int(rt0.min(1)[order[i]] - z) for i in (0, 255, 256, 511, 512, 767, 768, 1023)])
+print("start time of blocks by dispatch rank (ns): ", [int(rt0.min(1)[order[i]] - z) for i in (0, 255, 256, 511, 512, 767, 768, 1023) if i < len(order)])
