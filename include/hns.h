@@ -156,7 +156,9 @@ typedef struct hns_cfg {
  * evader captured by any pursuer; `blocked` counts steps in which no pursuer sees either evader.  Shapes:
  * target_pos / target_vel [E,2,3]; obs_self / state_drones rows have 24 values = the reference's 20, the
  * relative position of evader 1, one zero; detect[e] is a bit mask (bit k = evader k detected); task vectors
- * are [drones | evader 0 | evader 1 | cylinders].  hns_tp_* (one evader in the frame) is not available.
+ * are [drones | evader 0 | evader 1 | cylinders].  The predictor (hns_tp_*) runs the SAME network once per evader: unit u = 2 e + j
+ * sees evader j's position / velocity under detection bit j; history / pred / groundtruth / tp_done are [2E, ...] (unit-major), the rows
+ * have 24 + 6F values = [the reference's 20 + 3F row for evader 0 | relative position of evader 1, 0 | drone - predicted evader 1 (3F)].
  */
 /* Device buffers, caller-owned.  Shapes in brackets; E,A,C,k as in hns_cfg. */
 typedef struct hns_buffers {

@@ -160,13 +160,17 @@ def tp_frame_dim(A, C=0, use_obstacles=False):
     return 7 + 3 * A + (3 * C if use_obstacles else 0)
 
 
-def tp_buffer_shapes(E, A, T, F, I=None):
-    I, D = (7 + 3 * A if I is None else I), HNS_SELF_DIM + 3 * F
+def tp_buffer_shapes(E, A, T, F, I=None, num_targets=1):
+    """Two evaders (extension): the predictor runs once per (env, evader) unit — window, prediction, ground truth and done flag are
+    [E * 2, ...] (unit 2 e + j), rows carry both predictions (24 + 6F values)."""
+    NT = 2 if num_targets == 2 else 1
+    I, D = (7 + 3 * A if I is None else I), self_dim(NT) + 3 * F * NT
+    U = E * NT
     return {"w_ih": ((4 * HNS_TP_HIDDEN, I), "float32"), "w_hh": ((4 * HNS_TP_HIDDEN, HNS_TP_HIDDEN), "float32"),
             "b_ih": ((4 * HNS_TP_HIDDEN,), "float32"), "b_hh": ((4 * HNS_TP_HIDDEN,), "float32"),
             "w_fc": ((3 * F, HNS_TP_HIDDEN), "float32"), "b_fc": ((3 * F,), "float32"),
-            "packed": ((TP_PACKED_BYTES,), "uint8"), "history": ((E, T, I), "float32"), "pred": ((E, F, 3), "float32"), "obs_self": ((E, A, D), "float32"),
-            "state_drones": ((E, A, D), "float32"), "groundtruth": ((E, 3), "float32"), "tp_done": ((E,), "uint8")}
+            "packed": ((TP_PACKED_BYTES,), "uint8"), "history": ((U, T, I), "float32"), "pred": ((U, F, 3), "float32"), "obs_self": ((E, A, D), "float32"),
+            "state_drones": ((E, A, D), "float32"), "groundtruth": ((U, 3), "float32"), "tp_done": ((U,), "uint8")}
 
 
 _LIB = None

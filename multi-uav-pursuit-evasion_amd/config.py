@@ -256,8 +256,6 @@ def resolve_hns_cfg(cfg, num_envs=None, env_index_offset=0, drone_params=None, w
     NT = int(t.get("num_targets", 1))
     if NT not in (1, 2):
         raise ValueError("task.num_targets must be 1 (the reference) or 2 (extension)")
-    if NT == 2 and int(cfg.algo.get("use_TP_net", 0)):
-        raise NotImplementedError("num_targets=2 with algo.use_TP_net=1: the predictor's frame holds one evader")
     c.num_targets = NT
     c.tp_use_obstacles = 1 if use_obst else 0
     c.max_episode_length = int(cfg.env.max_episode_length)

@@ -69,7 +69,8 @@ struct TpParams {
     hns_tp_buffers tp;
     const float *drone_state, *target_pos, *target_vel, *progress, *obs_self20, *cylinders;
     const uint8_t *detect;
-    int E, A, C, I, T, F, fill, max_len;
+    int E, A, C, I, T, F, fill, max_len;     // E counts the predictor's UNITS: envs, or (env, evader) pairs with two evaders (unit 2 e + j)
+    int NT;                                  // evaders per env (1 or 2)
     float mask_value, arena_size, max_height, cylinder_size;
     unsigned long long *prof;   // diagnostics (hns_set_phase_profile): per-wave stamps of the 100 MHz clock
 };
@@ -172,20 +173,55 @@ HNS_DEV float tp_tanh(float x) { return tp_tanh_s(x * (2.0f * kNegLog2e)); }
 // component k of the frame [progress, evader pos (masked), evader vel (masked), pursuer positions]
 // (hideandseek.py:815-820; the mask is broadcast_detect, :791-803), followed with task.use_obstacles by
 // [x, y, cylinder_size] of every cylinder slot (:808-816; I = 7 + 3A + 3C then)
-HNS_DEV float tp_frame_val(const TpParams &p, int e, int k, bool det) {
+// Two evaders (extension): the SAME network runs once per evader — unit u = 2 e + j sees evader j's position / velocity (target_pos / target_vel
+// are [E,2,3] = [units,3]) under evader j's detection bit, beside env e's progress, pursuers and cylinders.
+HNS_DEV int tp_env(const TpParams &p, int u) { return p.NT == 2 ? u >> 1 : u; }
+HNS_DEV bool tp_det(const TpParams &p, int u) { return p.NT == 2 ? ((p.detect[u >> 1] >> (u & 1)) & 1) != 0 : p.detect[u] != 0; }
+HNS_DEV float tp_frame_val(const TpParams &p, int u, int k, bool det) {
+    const int e = tp_env(p, u);
     if (k == 0) return p.progress[e];
-    if (k < 4) return det ? p.target_pos[(size_t)e * 3 + (k - 1)] : p.mask_value;
-    if (k < 7) return det ? p.target_vel[(size_t)e * 3 + (k - 4)] : p.mask_value;
+    if (k < 4) return det ? p.target_pos[(size_t)u * 3 + (k - 1)] : p.mask_value;
+    if (k < 7) return det ? p.target_vel[(size_t)u * 3 + (k - 4)] : p.mask_value;
     const int j = k - 7, a = j / 3;
     if (a < p.A) return p.drone_state[((size_t)e * p.A + a) * 13 + (j - 3 * a)];
     const int jc = j - 3 * p.A, cy = jc / 3, comp = jc - 3 * cy;
     return comp == 2 ? p.cylinder_size : p.cylinders[((size_t)e * p.C + cy) * 3 + comp];
 }
 
+// Two evaders: rows of 24 + 6F values = [the reference's 20 + 3F row for evader 0 | rpos of evader 1 (3) | 0 | drone - predicted evader 1 (3F)];
+// groundtruth / tp_done per unit.  Not tuned (plain stores): the shape is an extension.
+HNS_DEV void tp_write_row2(const TpParams &p, int ev, int a, const float *pr0, const float *pr1) {
+    const int A = p.A, R = 3 * p.F, SD = 24, D = SD + 2 * R;
+    const size_t ia = (size_t)ev * A + a;
+    const float *o24 = p.obs_self20 + ia * SD, *ds = p.drone_state + ia * 13, *tg = p.target_pos + (size_t)ev * 6;
+    const float px = ds[0], py = ds[1], pz = ds[2];
+    if (a == 0) {
+        for (int j = 0; j < 2; ++j) {
+            float *gt = p.tp.groundtruth + ((size_t)ev * 2 + j) * 3;
+            gt[0] = tg[3 * j] * (1.0f / (0.5f * p.arena_size));
+            gt[1] = tg[3 * j + 1] * (1.0f / (0.5f * p.arena_size));
+            gt[2] = (tg[3 * j + 2] * (1.0f / p.max_height)) * 2.0f - 1.0f;
+            p.tp.tp_done[(size_t)ev * 2 + j] = (uint8_t)(p.progress[ev] <= (float)(p.max_len - p.F));
+        }
+    }
+    for (int pass = 0; pass < 2; ++pass) {               // 0: state_self (masked rpos from the step kernel's rows), 1: state_drones (unmasked)
+        float *dst = pass == 0 ? p.tp.obs_self : p.tp.state_drones;
+        if (!dst) continue;
+        float *g = dst + ia * D;
+        g[0] = pass == 0 ? o24[0] : px - tg[0]; g[1] = pass == 0 ? o24[1] : py - tg[1]; g[2] = pass == 0 ? o24[2] : pz - tg[2];
+        for (int f = 0; f < p.F; ++f) { g[3 + 3 * f] = px - pr0[3 * f]; g[4 + 3 * f] = py - pr0[3 * f + 1]; g[5 + 3 * f] = pz - pr0[3 * f + 2]; }
+        for (int j = 3; j < HNS_SELF_DIM; ++j) g[R + j] = o24[j];
+        g[R + 20] = pass == 0 ? o24[20] : px - tg[3]; g[R + 21] = pass == 0 ? o24[21] : py - tg[4]; g[R + 22] = pass == 0 ? o24[22] : pz - tg[5];
+        g[R + 23] = o24[23];
+        for (int f = 0; f < p.F; ++f) { g[R + 24 + 3 * f] = px - pr1[3 * f]; g[R + 25 + 3 * f] = py - pr1[3 * f + 1]; g[R + 26 + 3 * f] = pz - pr1[3 * f + 2]; }
+    }
+}
+
 // ---- one pursuer's observation row: [rpos_evader(3) | drone - predicted (3F) | quat4 linvel3 heading3 up3 t x4 (17)] ----
 // hideandseek.py:844-854 (state_self, masked rpos from the step kernel's rows) and :873-880 (state_drones, unmasked rpos);
 // TP_groundtruth / TP_done :838-842.  `pr` = the env's 3F predictions (LDS).
-HNS_DEV void tp_write_row(const TpParams &p, int er, int a, const float *pr) {
+HNS_DEV void tp_write_row(const TpParams &p, int er, int a, const float *pr, const float *pr1) {
+    if (p.NT == 2) { tp_write_row2(p, er, a, pr, pr1); return; }
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));       // rows are 4-byte aligned (D = 20 + 3F floats)
     const int A = p.A, R = 3 * p.F, D = HNS_SELF_DIM + R;
     const size_t ia = (size_t)er * A + a;
@@ -493,7 +529,7 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
     // parked in LDS (read once, as x_{T-1}): [wave][value][lane], conflict-free
     float *sXn = reinterpret_cast<float *>(simg + L.bytes / 16) + (wave * 8 * NXC) * 64 + lane;
     {
-        const bool det = p.detect[ec] != 0;
+        const bool det = tp_det(p, ec);
 #pragma unroll
         for (int cx = 0; cx < NXC; ++cx)
 #pragma unroll
@@ -702,10 +738,11 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
     // ---- observation rows of this wave's envs (tp_write_row): one lane per pursuer row, 32 A rows per wave, contiguous in every
     // buffer.  Was a second kernel (10 us + a launch); here the stores of one workgroup drain under the recurrences of the others.
     {
-        const int A = p.A, e_w0 = blockIdx.x * kTpEnvs + wave * 32;
-        for (int r = lane; r < 32 * A; r += 64) {
-            const int el = r / A, a = r - el * A, er = e_w0 + el;
-            if (er < p.E) tp_write_row(p, er, a, sPred + el * ps);
+        // (two evaders: the wave's 32 units are 16 envs, units 2 el and 2 el + 1 hold an env's two predictions)
+        const int A = p.A, NT = p.NT, ev_w0 = (blockIdx.x * kTpEnvs + wave * 32) / NT;
+        for (int r = lane; r < (32 / NT) * A; r += 64) {
+            const int el = r / A, a = r - el * A, ev = ev_w0 + el;
+            if (ev * NT < p.E) tp_write_row(p, ev, a, sPred + (el * NT) * ps, sPred + (el * NT + NT - 1) * ps);
         }
     }
     if (prof && lane == 0) prof[4] = __builtin_amdgcn_s_memrealtime();
@@ -918,7 +955,7 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : 2) void hns_tp_lstm
     float *hist = p.tp.history + (size_t)ec * T * I;
     float nf[NXC][4];                                      // the new frame
     {
-        const bool det = p.detect[ec] != 0;
+        const bool det = tp_det(p, ec);
 #pragma unroll
         for (int cx = 0; cx < NXC; ++cx)
 #pragma unroll
@@ -1151,10 +1188,10 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : 2) void hns_tp_lstm
     if (prof && lane == 0) prof[3] = __builtin_amdgcn_s_memrealtime();
     // ---- observation rows of the workgroup's envs ----
     {
-        const int A = p.A;
-        for (int rr = tid; rr < kWsEnvs * A; rr += kWsThreads) {
-            const int el = rr / A, a = rr - el * A, er = e0 + el;
-            if (er < p.E) tp_write_row(p, er, a, sPred + el * ps);
+        const int A = p.A, NT = p.NT, ev0 = e0 / NT;        // (two evaders: the workgroup's 128 units are 64 envs)
+        for (int rr = tid; rr < (kWsEnvs / NT) * A; rr += kWsThreads) {
+            const int el = rr / A, a = rr - el * A, ev = ev0 + el;
+            if (ev * NT < p.E) tp_write_row(p, ev, a, sPred + (el * NT) * ps, sPred + (el * NT + NT - 1) * ps);
         }
     }
     if (prof && lane == 0) prof[4] = __builtin_amdgcn_s_memrealtime();
@@ -1190,7 +1227,8 @@ static void tp_fill_params(const hns_env *env, TpParams &p) {
     p.obs_self20 = env->buf.obs_self;
     p.detect = env->buf.detect;
     p.cylinders = env->buf.cylinders;
-    p.E = c.num_envs; p.A = c.num_agents; p.C = c.num_cylinders;
+    p.NT = c.num_targets == 2 ? 2 : 1;
+    p.E = c.num_envs * p.NT; p.A = c.num_agents; p.C = c.num_cylinders;
     p.I = tp_frame_dim(c);
     p.cylinder_size = c.cylinder_size;
     p.T = env->tp.history_step; p.F = env->tp.future_step;
@@ -1230,7 +1268,6 @@ int hns_tp_bind(hns_env *env, const hns_tp_buffers *b, int32_t history_step, int
             return HNS_ERR_INVALID_ARG;
         }
     if ((reinterpret_cast<uintptr_t>(b->packed) & 15) != 0) { hns_set_error("hns_tp_bind: packed must be 16-byte aligned"); return HNS_ERR_INVALID_ARG; }
-    if (env->cfg.num_targets == 2) { hns_set_error("hns_tp_bind: the predictor's frame holds one evader (num_targets = 2 is not supported)"); return HNS_ERR_CONFIG; }
     if (tp_nxc(tp_frame_dim(env->cfg)) > hns::kTpMaxChunks) {
         hns_set_error("hns_tp_bind: frame wider than 80 values (7 + 3 num_agents + 3 num_cylinders with tp_use_obstacles)");
         return HNS_ERR_CONFIG;

@@ -221,7 +221,7 @@ class HideAndSeek(_EnvBase):
             self.TP = TPNet(self.tp_frame_dim, 3 * self.tp_future_step, self.tp_future_step,
                             int(t.get("window_step", 1))).to(self.device)                       # hideandseek.py:315-318
             self._tp_bufs = {}
-            for name, (shape, dt) in abi.tp_buffer_shapes(E, A, self.tp_history_step, self.tp_future_step, self.tp_frame_dim).items():
+            for name, (shape, dt) in abi.tp_buffer_shapes(E, A, self.tp_history_step, self.tp_future_step, self.tp_frame_dim, self.num_targets).items():
                 if name not in abi.TP_WEIGHT_FIELDS:
                     self._tp_bufs[name] = torch.zeros(shape, dtype=getattr(torch, dt), device=self.device)
             self._tp_weight_ptrs = None
@@ -251,7 +251,8 @@ class HideAndSeek(_EnvBase):
         A, K, E, dev = self.num_agents, self.obs_max_cylinder, self.num_envs, self.device
         t = self.cfg.task
         F = int(t.get("future_predcition_step", 5))
-        D = abi.self_dim(self.num_targets) + (3 * F if self.use_TP_net else 0)      # 20 or 35 (24: two evaders)
+        NT = self.num_targets
+        D = abi.self_dim(NT) + (3 * F * NT if self.use_TP_net else 0)               # 20 or 35 (two evaders: 24 or 24 + 6F)
         obs = {"state_self": unbounded_spec((E, A, 1, D), dev), "cylinders": unbounded_spec((E, A, K, 5), dev)}
         if A > 1:
             obs["state_others"] = unbounded_spec((E, A, A - 1, 3), dev)
@@ -259,8 +260,8 @@ class HideAndSeek(_EnvBase):
         state = {"state_drones": unbounded_spec((E, A, D), dev), "cylinders": unbounded_spec((E, K, 5), dev)}
         # the TP entry is part of the spec whether or not the predictor is used (:358-374)
         frame = abi.tp_frame_dim(A, self.num_cylinders, int(t.get("use_obstacles", 0)))
-        tp = {"TP_input": unbounded_spec((E, int(t.get("history_step", 10)), frame), dev),
-              "TP_groundtruth": unbounded_spec((E, 1, 3), dev), "TP_done": unbounded_spec((E, 1, 3), dev)}
+        tp = {"TP_input": unbounded_spec((E, int(t.get("history_step", 10)), frame) if NT == 1 else (E, NT, int(t.get("history_step", 10)), frame), dev),
+              "TP_groundtruth": unbounded_spec((E, 1, 3) if NT == 1 else (E, NT, 3), dev), "TP_done": unbounded_spec((E, 1, 3), dev)}
         self.observation_spec = composite_spec({
             "agents": {"observation": obs, "state": state, "TP": tp},
             "stats": {k: unbounded_spec((E, 1), dev) for k in abi.STAT_NAMES},
@@ -394,6 +395,10 @@ class HideAndSeek(_EnvBase):
             else:
                 state = _LazyState(self, {"cylinders": b["obs_cylinders"]}, self.batch_size)
             tp = {"TP_input": tb["history"], "TP_groundtruth": tb["groundtruth"], "TP_done": tb["tp_done"].view(torch.bool).unsqueeze(-1)}
+            if self.num_targets == 2:            # extension: one window / ground truth per (env, evader); the done flag is the env's
+                E = self.num_envs
+                tp = {"TP_input": tb["history"].view(E, 2, *tb["history"].shape[1:]), "TP_groundtruth": tb["groundtruth"].view(E, 2, 3),
+                      "TP_done": tb["tp_done"].view(torch.bool).view(E, 2)[:, :1]}
             return TensorDict({"agents": {"observation": obs, "state": state, "TP": tp}, "stats": self.stats, "info": self.info},
                               self.batch_size)
         obs = {"state_self": b["obs_self"].unsqueeze(2), "cylinders": b["obs_cylinders"]}
@@ -414,7 +419,8 @@ class HideAndSeek(_EnvBase):
             self._state_buf = torch.empty_like(rest)
         if self.num_targets == 2:                                                    # extension: both relative positions unmasked
             rpos = b["drone_state"][..., None, 0:3] - b["target_pos"].unsqueeze(1)   # [E,A,2,3]
-            return torch.cat([rpos[:, :, 0], rest[..., 3:20], rpos[:, :, 1], rest[..., 23:]], dim=-1, out=self._state_buf)
+            R = 3 * self.tp_future_step if self.use_TP_net else 0                    # evader 0's predictions sit behind its relative position
+            return torch.cat([rpos[:, :, 0], rest[..., 3:R + 20], rpos[:, :, 1], rest[..., R + 23:]], dim=-1, out=self._state_buf)
         rpos = b["drone_state"][..., 0:3] - b["target_pos"].unsqueeze(1)
         return torch.cat([rpos, rest[..., 3:]], dim=-1, out=self._state_buf)
 

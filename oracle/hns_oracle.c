@@ -1151,18 +1151,23 @@ static inline float o_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_buffers *tp, int T, int F, int fill) {
     const int E = c->num_envs, A = c->num_agents, Cn = c->tp_use_obstacles ? c->num_cylinders : 0;
-    const int I = 7 + 3 * A + 3 * Cn, H = HNS_TP_HIDDEN, R = 3 * F, D = HNS_SELF_DIM + R;
+    const int NT = c->num_targets == 2 ? 2 : 1, SD = NT == 2 ? 24 : HNS_SELF_DIM;
+    const int I = 7 + 3 * A + 3 * Cn, H = HNS_TP_HIDDEN, R = 3 * F, D = SD + NT * R;
     if (T < 1 || T > 16 || R > 32 || !b->detect) return HNS_ERR_INVALID_ARG;
     if (A > HNS_MAX_AGENTS || Cn > HNS_MAX_CYLINDERS) return HNS_ERR_INVALID_ARG;
 #pragma omp parallel for schedule(static) num_threads(g_step_threads)
     for (int e = 0; e < E; ++e) {
+      /* two evaders (extension, not in the reference): the same network once per evader — unit u = 2 e + j sees evader j under its
+       * own detection bit; window, prediction, ground truth and done flag per unit */
+      for (int jt = 0; jt < NT; ++jt) {
+        const size_t u = (size_t)e * NT + jt;
         /* frame (:815-820) and window (:825-831) */
         float frame[7 + 3 * HNS_MAX_AGENTS + 3 * HNS_MAX_CYLINDERS];
-        const int det = b->detect[e] != 0;
+        const int det = NT == 2 ? (b->detect[e] >> jt) & 1 : b->detect[e] != 0;
         frame[0] = b->progress[e];
         for (int j = 0; j < 3; ++j) {
-            frame[1 + j] = det ? b->target_pos[(size_t)e * 3 + j] : c->mask_value;
-            frame[4 + j] = det ? b->target_vel[(size_t)e * 3 + j] : c->mask_value;
+            frame[1 + j] = det ? b->target_pos[u * 3 + j] : c->mask_value;
+            frame[4 + j] = det ? b->target_vel[u * 3 + j] : c->mask_value;
         }
         for (int a = 0; a < A; ++a)
             for (int j = 0; j < 3; ++j) frame[7 + 3 * a + j] = b->drone_state[((size_t)e * A + a) * 13 + j];
@@ -1171,7 +1176,7 @@ int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_b
             frame[7 + 3 * A + 3 * k + 1] = b->cylinders[((size_t)e * c->num_cylinders + k) * 3 + 1];
             frame[7 + 3 * A + 3 * k + 2] = c->cylinder_size;
         }
-        float *hist = tp->history + (size_t)e * T * I;
+        float *hist = tp->history + u * T * I;
         if (fill) {
             for (int t = 0; t < T; ++t) memcpy(hist + (size_t)t * I, frame, sizeof(float) * (size_t)I);
         } else {
@@ -1180,27 +1185,27 @@ int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_b
         }
         /* LSTM */
         float h[HNS_TP_HIDDEN], cs[HNS_TP_HIDDEN], hn[HNS_TP_HIDDEN];
-        for (int u = 0; u < H; ++u) { h[u] = 0.0f; cs[u] = 0.0f; }
+        for (int v = 0; v < H; ++v) { h[v] = 0.0f; cs[v] = 0.0f; }
         for (int t = 0; t < T; ++t) {
             const float *x = hist + (size_t)t * I;
-            for (int u = 0; u < H; ++u) {
+            for (int v = 0; v < H; ++v) {
                 float z[4];
                 for (int q = 0; q < 4; ++q) {
-                    const int g = q * H + u;
+                    const int g = q * H + v;
                     float acc = tp->b_ih[g] + tp->b_hh[g];
                     for (int k = 0; k < I; ++k) acc = O_FMA(tp->w_ih[(size_t)g * I + k], x[k], acc);
                     for (int k = 0; k < H; ++k) acc = O_FMA(tp->w_hh[(size_t)g * H + k], h[k], acc);
                     z[q] = acc;
                 }
                 const float ig = o_sigmoid(z[0]), fg = o_sigmoid(z[1]), gg = tanhf(z[2]), og = o_sigmoid(z[3]);
-                const float cn = O_FMA(fg, cs[u], ig * gg);
-                cs[u] = cn;
-                hn[u] = og * tanhf(cn);
+                const float cn = O_FMA(fg, cs[v], ig * gg);
+                cs[v] = cn;
+                hn[v] = og * tanhf(cn);
             }
             memcpy(h, hn, sizeof(h));
         }
         /* output layer + rescale (:834-836) */
-        float *pr = tp->pred + (size_t)e * R;
+        float *pr = tp->pred + u * R;
         for (int r = 0; r < R; ++r) {
             float acc = tp->b_fc[r];
             for (int k = 0; k < H; ++k) acc = O_FMA(tp->w_fc[(size_t)r * H + k], h[k], acc);
@@ -1208,15 +1213,17 @@ int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_b
             pr[r] = (r % 3 < 2) ? (v * 0.5f) * c->arena_size : ((v + 1.0f) * 0.5f) * c->max_height;
         }
         /* TP_groundtruth / TP_done (:838-842) */
-        const float *tpos = b->target_pos + (size_t)e * 3;
-        tp->groundtruth[(size_t)e * 3] = tpos[0] * (1.0f / (0.5f * c->arena_size));
-        tp->groundtruth[(size_t)e * 3 + 1] = tpos[1] * (1.0f / (0.5f * c->arena_size));
-        tp->groundtruth[(size_t)e * 3 + 2] = (tpos[2] * (1.0f / c->max_height)) * 2.0f - 1.0f;
-        tp->tp_done[e] = (uint8_t)(b->progress[e] <= (float)(c->max_episode_length - F));
-        /* rows (:844-854, :873-880) */
+        const float *tpos = b->target_pos + u * 3;
+        tp->groundtruth[u * 3] = tpos[0] * (1.0f / (0.5f * c->arena_size));
+        tp->groundtruth[u * 3 + 1] = tpos[1] * (1.0f / (0.5f * c->arena_size));
+        tp->groundtruth[u * 3 + 2] = (tpos[2] * (1.0f / c->max_height)) * 2.0f - 1.0f;
+        tp->tp_done[u] = (uint8_t)(b->progress[e] <= (float)(c->max_episode_length - F));
+      }
+        /* rows (:844-854, :873-880); two evaders: [the reference's row for evader 0 | rpos of evader 1, 0 | drone - predicted evader 1] */
+        const float *tpos = b->target_pos + (size_t)e * NT * 3, *pr = tp->pred + (size_t)e * NT * R;
         for (int a = 0; a < A; ++a) {
             const size_t ia = (size_t)e * A + a;
-            const float *o20 = b->obs_self + ia * HNS_SELF_DIM, *ds = b->drone_state + ia * 13;
+            const float *o20 = b->obs_self + ia * SD, *ds = b->drone_state + ia * 13;
             for (int pass = 0; pass < 2; ++pass) {
                 float *dst = pass == 0 ? tp->obs_self : tp->state_drones;
                 if (!dst) continue;
@@ -1225,6 +1232,12 @@ int hns_oracle_tp_observe(const hns_cfg *c, const hns_buffers *b, const hns_tp_b
                 for (int f = 0; f < F; ++f)
                     for (int j = 0; j < 3; ++j) row[3 + 3 * f + j] = ds[j] - pr[3 * f + j];
                 for (int j = 3; j < HNS_SELF_DIM; ++j) row[R + j] = o20[j];
+                if (NT == 2) {
+                    for (int j = 0; j < 3; ++j) row[R + 20 + j] = pass == 0 ? o20[20 + j] : ds[j] - tpos[3 + j];
+                    row[R + 23] = o20[23];
+                    for (int f = 0; f < F; ++f)
+                        for (int j = 0; j < 3; ++j) row[R + 24 + 3 * f + j] = ds[j] - pr[R + 3 * f + j];
+                }
             }
         }
     }
