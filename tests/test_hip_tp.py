@@ -246,7 +246,7 @@ def _draw_tp_case(seed):
     obst = int(r.rand() < 0.5)
     Cn = int(r.randint(1, 17))
     E = int(r.choice([1, 31, 64, 100, 128, 129, 192, 257, 384, 500]))
-    task = {"num_agents": A, "use_obstacles": obst, "cylinder": {"max_num": Cn, "min_num": int(r.randint(0, Cn + 1)), "obs_max_cylinder": min(3, Cn)},
+    task = {"num_agents": A, "num_targets": 2 if r.rand() < 0.3 else 1, "use_obstacles": obst, "cylinder": {"max_num": Cn, "min_num": int(r.randint(0, Cn + 1)), "obs_max_cylinder": min(3, Cn)},
             "env": {"num_envs": E, "max_episode_length": int(r.choice([8, 40, 800]))}, "history_step": int(r.randint(1, 17)),
             "future_predcition_step": int(r.randint(1, 11)), "drone_detect_radius": float(r.choice([0.7, 100.0]))}
     return task, E, A, float(r.choice([1.0, 2.0, 3.0]))
