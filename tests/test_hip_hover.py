@@ -64,5 +64,5 @@ def test_hover_matches_reference_golden(golden):
         out = env.export_state()
         np.testing.assert_allclose(out["drone_state"][..., 0:3], g["pos"][t], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(out["obs"], g["obs"][t], rtol=1e-5, atol=1e-5)
-        np.testing.assert_allclose(out["reward"], g["reward"][t][..., 0], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(out["reward"], g["reward"][t][..., 0], rtol=1e-5, atol=2e-6)
         assert (out["done"].astype(bool) == g["done"][t][:, 0]).all()

@@ -117,12 +117,14 @@ def test_step_matches_reference_golden(golden, tag):
         np.testing.assert_allclose(out["drone_state"][..., 0:3], g["pos"][t], **kw)
         np.testing.assert_allclose(out["drone_state"][..., 3:7], g["rot"][t], **kw)
         np.testing.assert_allclose(out["drone_state"][..., 7:10], g["vel"][t][..., :3], **kw)
+        np.testing.assert_allclose(out["drone_state"][..., 10:13], g["vel"][t][..., 3:], rtol=1e-5, atol=3e-5)   # body rates: torque / 1.4e-5 kg m^2
+        np.testing.assert_allclose(out["throttle"], g["throttle"][t], **kw)
         np.testing.assert_allclose(out["target_pos"], g["tpos"][t][:, 0], **kw)
         np.testing.assert_allclose(out["obs_self"], g["state_self"][t][:, :, 0], **kw)
         np.testing.assert_allclose(out["obs_others"], g["state_others"][t], **kw)
         np.testing.assert_allclose(out["obs_cylinders"], g["cylinders"][t], **kw)
         np.testing.assert_allclose(out["state_drones"], g["state_drones"][t], **kw)
-        np.testing.assert_allclose(out["reward"], g["reward"][t][..., 0], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(out["reward"], g["reward"][t][..., 0], rtol=1e-5, atol=1e-6)
         assert (out["done"].astype(bool) == g["done"][t][:, 0]).all()
 
 

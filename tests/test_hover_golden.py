@@ -39,7 +39,7 @@ def test_hover_step_teacher_forced(golden):
         np.testing.assert_allclose(arrs["drone_state"][..., 3:7], g["rot"][t], **kw)
         np.testing.assert_allclose(arrs["drone_state"][..., 7:10], g["vel"][t][..., :3], **kw)
         np.testing.assert_allclose(arrs["obs"], g["obs"][t], **kw)
-        np.testing.assert_allclose(arrs["reward"], g["reward"][t][..., 0], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(arrs["reward"], g["reward"][t][..., 0], rtol=1e-5, atol=2e-6)
         assert (arrs["done"].astype(bool) == g["done"][t][:, 0]).all()
         ref = g["stats"][t].T
         for i, name in enumerate(abi.HOVER_STAT_NAMES):

@@ -139,7 +139,7 @@ def test_evader_policy(golden):
         c = hcfg(A=A, C=C, target_detect_radius=float(g[f"{tag}_detect_radius"]))
         force, vel, ooa = O.prey(c, g[f"{tag}_drone_pos"], g[f"{tag}_target_pos"], g[f"{tag}_cyl"])
         ref_f = g[f"{tag}_force"][:, 0]
-        close(force, ref_f, rtol=1e-4, atol=1e-4)
+        close(force, ref_f, rtol=1e-5, atol=2e-6)          # forces reach 1e5 next to a wall: measured 9.4e-7 relative, 1.4e-6 absolute below 1
         ref_v = g[f"{tag}_vel"][:, 0]
         # per-axis +-v_prey quirk (hideandseek.py:741): compare where the force is not ~0
         ok = np.abs(ref_f) > 1e-2
