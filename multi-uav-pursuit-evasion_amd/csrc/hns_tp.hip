@@ -861,10 +861,13 @@ __global__ __launch_bounds__(256) void hns_tp_pack_ws_kernel(const TpParams p, i
 // lands in a register an MFMA in flight still reads corrupts the operand (found in round 2 on the A side, and again here on the
 // B side: 1-3 envs in 256 off by 1e-5 while the compiler placed the reads).  BASE rotates the slots from tile to tile so that the
 // first reads of a tile, which may be issued right behind the previous tile's last MFMA, never target that MFMA's slot.
+#ifndef WS_D2
+#define WS_D2 3          // lab: read-ahead distance of the operand ring in the two-chunk instantiation
+#endif
 template <int NXC, bool WITH_H>
 struct WsTile {
     static constexpr int NX2 = 2 * NXC, NCROSS = NX2 + (WITH_H ? 8 : 0), N = NCROSS + NXC + (WITH_H ? 4 : 0);
-    static constexpr int D = 3, RING = 4;
+    static constexpr int D = NXC == 2 ? WS_D2 : 3, RING = D + 1;
     static constexpr bool lead(int k) { return k >= NCROSS; }
     static constexpr bool is_x(int k) { return k < NX2 || (lead(k) && k < NCROSS + NXC); }
     static constexpr int chunk(int k) { return k < NX2 ? k / 2 : k < NCROSS ? (k - NX2) / 2 : k < NCROSS + NXC ? k - NCROSS : k - NCROSS - NXC; }
@@ -911,6 +914,9 @@ struct WsTile {
 #ifndef WS_OCC
 #define WS_OCC 4
 #endif
+#ifndef WS_OCC2
+#define WS_OCC2 2      // lab: waves per SIMD the two-chunk instantiation is compiled for (4 = the 128-register cap: spills)
+#endif
 #ifndef WS_ABL
 #define WS_ABL 0       // lab: 1 = no frame phase inside the loop, 2 = no barriers inside the loop (timing only, results wrong)
 #endif
@@ -922,7 +928,7 @@ struct WsTile {
 // frames of two and more chunks hold 48-72 registers of weights per lane (two chunks under the 128-register cap of four waves per SIMD spill into
 // the hot loop: 186 us against 133 us for THREE chunks without the cap) and 66-116 KB of LDS: one workgroup per CU, two waves per SIMD
 template <int NXC>
-__global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : 2) void hns_tp_lstm_ws_kernel(const TpParams p) {
+__global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : NXC == 2 ? WS_OCC2 : 2) void hns_tp_lstm_ws_kernel(const TpParams p) {
     constexpr int NC = NXC + 4;
     constexpr WsImage L = ws_image(NXC);
     extern __shared__ __align__(16) uint4 simg[];
@@ -1028,7 +1034,7 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : 2) void hns_tp_lstm
 #pragma unroll
         for (int j = 0; j < 4; ++j) c[te][j] = 0.0f;
     uint2 hnew[kWsTiles][2];
-    half8 bring[4];                                        // B-operand ring (WsTile)
+    half8 bring[WsTile<NXC, true>::RING];                  // B-operand ring (WsTile)
     const float4 *sBias = reinterpret_cast<const float4 *>(sB) + (r * 2 + hb) * 4;
     if (prof && lane == 0) prof[1] = __builtin_amdgcn_s_memrealtime();
 
