@@ -546,3 +546,37 @@ def test_nonfinite_word_is_set_by_the_step_kernel():
     env.import_state(host)
     env.step(env.rand_step_input(act.to(env.device)))
     assert env.nonfinite_bits() & 2 and env.nonfinite_bits() & 4
+
+
+@pytest.mark.parametrize("A,NT,Cn,L,steps", [(3, 1, 8, 800, 1650), (6, 2, 16, 300, 640)], ids=["cfg3", "cfg5_shard"])
+def test_full_size_episodes_bit_exact(A, NT, Cn, L, steps):
+    """BASELINE configs 3 and 5 (one GPU's shard) at their full size over whole episodes: 65 536 envs, the reference's 800-step episodes
+    (300 for the two-evader shard), the episode boundary crossed twice and the done envs reset each time — every buffer bit for bit against
+    the oracle around the boundaries and at the end."""
+    import os
+    E = 65536
+    O.set_threads(min(32, os.cpu_count() or 8))
+    env = make_env(E, A, Cn, max_len=L, cylinder={"min_num": Cn}, num_targets=NT)
+    env.set_seed(99)
+    env.reset()
+    host = O.alloc_buffers(env.hcfg)
+    O.reset(env.hcfg, host, None, env.seed, 0)
+    g = torch.Generator(device=env.device).manual_seed(5)
+    resets = 0
+    for t in range(steps):
+        action = torch.randn(E, A, 4, generator=g, device=env.device) * 0.8
+        env.step(env.rand_step_input(action))
+        O.step(env.hcfg, host, action.cpu().numpy())
+        if t % L in (L - 2, L - 1) or t == steps - 1:
+            assert_same(host, env.export_state(), f"step {t}")
+        if host["done"].any():
+            mask = host["done"].copy()
+            td = env.rand_step_input()
+            td.set("_reset", torch.as_tensor(mask.astype(bool), device=env.device))
+            epoch = env.reset_epoch
+            env.reset(td)
+            O.reset(env.hcfg, host, mask, env.seed, epoch)
+            assert_same(host, env.export_state(), f"reset after step {t}")
+            resets += 1
+    assert resets >= 2 and host["stats"].any()
+    O.set_threads(1)
