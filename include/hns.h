@@ -284,12 +284,13 @@ typedef struct hns_tp_buffers {
     const float *w_fc;        /* [3F, 64]    fc.weight */
     const float *b_fc;        /* [3F]        fc.bias */
     void *packed;             /* [hns_tp_packed_bytes()] scratch, 16-byte aligned: operand image of the parameters */
-    float *history;           /* [E,T,I]  state: the sliding window == agents.TP.TP_input, oldest frame first */
-    float *pred;              /* [E,F,3]  out: predicted evader positions, arena units (hideandseek.py:834-836) */
-    float *obs_self;          /* [E,A,20+3F] out: agents.observation.state_self rows (:846-854) */
-    float *state_drones;      /* [E,A,20+3F] out, nullable: agents.state.state_drones (:873-880) */
-    float *groundtruth;       /* [E,3]    out: agents.TP.TP_groundtruth (:839-842) */
-    uint8_t *tp_done;         /* [E]      out: agents.TP.TP_done (:838) */
+    /* U = E units, or 2E with num_targets = 2 (unit 2 e + j = evader j of env e: the two-evader extension above) */
+    float *history;           /* [U,T,I]  state: the sliding window == agents.TP.TP_input, oldest frame first */
+    float *pred;              /* [U,F,3]  out: predicted evader positions, arena units (hideandseek.py:834-836) */
+    float *obs_self;          /* [E,A,20+3F] out: agents.observation.state_self rows (:846-854); [E,A,24+6F] with two evaders */
+    float *state_drones;      /* [E,A,20+3F] out, nullable: agents.state.state_drones (:873-880); [E,A,24+6F] with two evaders */
+    float *groundtruth;       /* [U,3]    out: agents.TP.TP_groundtruth (:839-842) */
+    uint8_t *tp_done;         /* [U]      out: agents.TP.TP_done (:838) */
 } hns_tp_buffers;
 size_t hns_tp_packed_bytes(void);
 /* history_step T in [1,16], future_step F in [1,10]; max_episode_length <= 60000 (fp16-split operands). */
