@@ -6,6 +6,7 @@ products as two-term fp16 splits on the matrix cores and its sigmoid/tanh on the
 unit; the oracle is plain fp32 + libm).  HIP vs the reference golden (its own TP_net, 14 consecutive calls) within 1e-5, and
 the env class against a plain-torch fp32 LSTM."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -252,7 +253,7 @@ def _draw_tp_case(seed):
     return task, E, A, float(r.choice([1.0, 2.0, 3.0]))
 
 
-@pytest.mark.parametrize("seed", list(range(60)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("HNS_FUZZ_TP_SEEDS", 60)))))
 def test_tp_random_configuration_matches_oracle(seed):
     """Seeded sweep over frame widths (1-5 operand chunks, both kernels), window lengths, horizons and batch sizes: window, ground
     truth and flags exact, predictions and rows within 1e-5 of the oracle's fp32 LSTM."""
