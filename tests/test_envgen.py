@@ -341,3 +341,54 @@ def test_oracle_perturb_tasks_properties():
     dxy = (moved[:, None, 3 * (A + 1):] - hist[None, :, 3 * (A + 1):]).reshape(500, len(hist), Cn, 3)[..., :2]
     cells = np.abs(dxy / 0.2 - np.rint(dxy / 0.2)).max((-1, -2)).min(1)
     assert (cells < 1e-4).all() and gb.sanity_ok(moved).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_envgen_random_configurations_on_gpu(seed):
+    """Seeded sweep over the generator's configuration space (pursuers, slots, one or two evaders, batch size, eval_iter, ratio_unif, cylinder
+    expansion, easy initial cases): every env sits on its task vector after every reset, the envs placed from history tasks equal the oracle's
+    task reset bit for bit, the history never exceeds its length, the statistics stay finite and consistent."""
+    from hns_amd.envgen import HideAndSeek_envgen
+    r = np.random.RandomState(900 + seed)
+    for _ in range(50):
+        A, Cn, NT = int(r.randint(1, 7)), int(r.randint(2, 11)), 2 if r.rand() < 0.35 else 1
+        E = int(r.choice([192, 1000, 6144]))
+        task = {"name": "HideAndSeek_envgen", "num_agents": A, "num_targets": NT, "ratio_unif": float(r.choice([0.0, 0.3, 0.7])), "eval_iter": int(r.randint(1, 4)),
+                "R_min": float(r.choice([0.0, 0.2])), "R_max": 1.0, "use_particle_generator": 1, "expand_cylinders": int(r.rand() < 0.5),
+                "expand_step": float(r.choice([0.05, 0.1])), "use_init_easy": int(NT == 1 and r.rand() < 0.4), "catch_radius": float(r.choice([0.3, 0.6])),
+                "cylinder": {"max_num": Cn, "min_num": int(r.randint(0, Cn + 1)), "size": float(r.choice([0.1, 0.12]))},
+                "env": {"num_envs": E, "max_episode_length": int(r.randint(3, 7))}}
+        try:
+            config.resolve_hns_cfg(config.make_cfg(task))
+            break
+        except ValueError:
+            continue
+    L = task["env"]["max_episode_length"]
+    env = HideAndSeek_envgen(config.make_cfg(task))
+    env.set_seed(seed)
+    env.reset()
+    assert env.all_tasks.shape == (E, 3 * A + 3 * NT + 3 * Cn)
+    g = torch.Generator(device=env.device).manual_seed(seed)
+    for ep in range(2 * task["eval_iter"] + 1):
+        for t in range(L):
+            td = env.step(env.rand_step_input(torch.randn(E, A, 4, generator=g, device=env.device) * 0.5))
+        assert bool(td[("next", "done")].all())
+        rtd = env.rand_step_input()
+        rtd.set("_reset", td[("next", "done")].squeeze(-1))
+        epoch = env.reset_epoch
+        env.reset(rtd)
+        st = env.export_state()
+        placed = np.concatenate([st["drone_state"][..., :3].reshape(E, -1), st["target_pos"].reshape(E, -1), st["cylinders"].reshape(E, -1)], axis=1)
+        np.testing.assert_array_equal(placed, env.all_tasks, err_msg=f"seed {seed} {task} episode {ep}")
+        host = O.alloc_buffers(env.hcfg)
+        O.reset_tasks(env.hcfg, host, None, env.seed, epoch, env.all_tasks, env.num_unif)
+        for k in ("drone_state", "target_pos", "cylinders", "obs_self", "obs_others", "obs_cylinders", "throttle"):
+            np.testing.assert_array_equal(host[k][env.num_unif:], st[k][env.num_unif:], err_msg=f"seed {seed} {task} episode {ep}: {k}")
+        assert len(env.gen_buffer) <= env.gen_buffer.buffer_length and 0 <= env.num_unif <= E
+        for k in ("success_buffer", "success_unif", "history_buffer", "ratio_unif"):
+            # as in the reference, success_unif is the mean of an EMPTY slice (NaN) in an episode without uniform tasks (hideandseek_envgen.py:1241-1243)
+            ok = torch.isfinite(env.stats[k]).all() or (k == "success_unif" and task["ratio_unif"] == 0.0 and torch.isnan(env.stats[k]).all())
+            assert bool(ok), k
+        assert float(env.stats["history_buffer"][0]) == len(env.gen_buffer)
+    assert env.check_finite()                                  # the state buffers (the logging statistic above is not one of them)
