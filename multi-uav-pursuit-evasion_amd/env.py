@@ -132,7 +132,7 @@ class _PlainEnvBase:
         # transform's keys (merged into what the caller's tensordict already holds under `stats` / `info`).  The returned tree and its
         # leaves are persistent (views of the buffers the kernel rewrites in place), so a tensordict that already went through this
         # merge and still holds that tree needs nothing (a collector that reuses its tensordicts, return_same_td: ~5 us of Python per step)
-        if getattr(tensordict, "_hns_merged", None) is out and dict.get(tensordict, "next") is dict.get(out, "next"):
+        if getattr(tensordict, "_hns_merged", None) is out and self._still_merged(tensordict, out):
             return tensordict
         for k, v in dict.items(out):
             cur = tensordict.get(k)
@@ -147,6 +147,20 @@ class _PlainEnvBase:
         except AttributeError:                    # a foreign tensordict type: merged every step
             pass
         return tensordict
+
+    @staticmethod
+    def _still_merged(tensordict, out):
+        """Every entry of the returned tree is still the object the caller's tensordict holds (nobody replaced `next`, `stats`, ... since)."""
+        for k, v in dict.items(out):
+            cur = dict.get(tensordict, k)
+            if cur is v:
+                continue
+            if k == "next" or not isinstance(v, dict) or not isinstance(cur, dict):
+                return False
+            for kk, vv in dict.items(v):
+                if dict.get(cur, kk) is not vv:
+                    return False
+        return True
 
     def train(self, mode=True):
         self.training = mode

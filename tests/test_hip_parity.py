@@ -580,3 +580,25 @@ def test_full_size_episodes_bit_exact(A, NT, Cn, L, steps):
             resets += 1
     assert resets >= 2 and host["stats"].any()
     O.set_threads(1)
+
+
+def test_step_merge_shortcut_notices_replaced_entries():
+    """env.step merges its persistent output tree into the caller's tensordict once; a reused tensordict is left alone while it still
+    holds that tree — and merged again as soon as the caller replaced any of the entries."""
+    env = make_env(64, 3, 5)
+    env.reset()
+    td = env.rand_step_input()
+    out = env.step(td)
+    assert out is td and td.get(("stats", "action_error_order1")) is env._bufs["action_error"]
+    nxt = td.get("next")
+    td.set(("agents", "action"), torch.zeros(64, 3, 4, device=env.device))
+    env.step(td)
+    assert td.get("next") is nxt                                           # untouched: the same persistent tree
+    td.set("stats", {"something_else": torch.zeros(64, 1, device=env.device)})      # the caller replaces an entry ...
+    env.step(td)
+    assert td.get(("stats", "action_error_order1")) is env._bufs["action_error"]    # ... the next step puts the transform's key back
+    td.set("next", {"x": torch.zeros(64, device=env.device)})
+    env.step(td)
+    assert td.get("next") is nxt
+    fresh = env.rand_step_input()
+    assert env.step(fresh).get("next") is nxt and fresh.get(("info", "prev_action")) is env._bufs["prev_action"]
