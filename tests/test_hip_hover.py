@@ -66,3 +66,35 @@ def test_hover_matches_reference_golden(golden):
         np.testing.assert_allclose(out["obs"], g["obs"][t], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(out["reward"], g["reward"][t][..., 0], rtol=1e-5, atol=2e-6)
         assert (out["done"].astype(bool) == g["done"][t][:, 0]).all()
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_hover_random_batches_bit_exact(seed):
+    """Seeded sweep: batch sizes (ragged against the 64-thread workgroups), episode lengths, action scales; masked resets at the
+    episode boundary; every buffer bit for bit against the oracle."""
+    from hns_amd.env import HideAndSeek
+    r = np.random.RandomState(70 + seed)
+    E, L = int(r.choice([1, 16, 63, 65, 300, 1024])), int(r.randint(4, 15))
+    cfg = config.make_hover_cfg({"env": {"num_envs": E, "max_episode_length": L}})
+    env = HideAndSeek.REGISTRY[cfg.task.name](cfg, headless=True)
+    env.set_seed(seed)
+    env.reset()
+    host = O.alloc_hover_buffers(env.hcfg)
+    O.hover_reset(env.hcfg, env.hover_cfg, host, None, seed, 0)
+    g = torch.Generator().manual_seed(seed)
+    epoch = 1
+    for t in range(3 * L):
+        action = torch.randn(E, 1, 4, generator=g) * float(r.choice([0.3, 1.0, 3.0]))
+        td = env.step(env.rand_step_input(action.to(env.device)))
+        O.hover_step(env.hcfg, env.hover_cfg, host, action.numpy())
+        if host["done"].any():
+            mask = host["done"].copy()
+            rtd = env.rand_step_input()
+            rtd.set("_reset", torch.as_tensor(mask.astype(bool), device=env.device))
+            env.reset(rtd)
+            O.hover_reset(env.hcfg, env.hover_cfg, host, mask, seed, epoch)
+            epoch += 1
+        if t % L == L - 1 or t == 3 * L - 1:
+            dev = env.export_state()
+            for k in host:
+                np.testing.assert_array_equal(host[k], dev[k], err_msg=f"seed {seed} E={E} L={L} step {t}: {k}")

@@ -53,3 +53,32 @@ def test_raycast_hip_equals_oracle():
         ref = O.raycast(env.hcfg, host, N, 1.5)
         np.testing.assert_array_equal(dev, ref)
         assert dev.shape == (333, A, N) and (dev >= 0).all() and (dev <= 1.5).all() and (dev < 1.5).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_raycast_random_shapes_hip_equals_oracle(seed):
+    """Seeded sweep: pursuers, cylinder slots (most of them inactive in some envs), ray counts, ranges, batch sizes, one or two evaders."""
+    import torch
+    from hns_amd.env import HideAndSeek
+    r = np.random.RandomState(40 + seed)
+    for _ in range(50):
+        A, C = int(r.randint(1, 8)), int(r.randint(1, 17))
+        task = {"num_agents": A, "num_targets": 2 if r.rand() < 0.25 else 1, "cylinder": {"max_num": C, "min_num": int(r.randint(0, C + 1)), "obs_max_cylinder": 1},
+                "env": {"num_envs": int(r.choice([1, 63, 64, 200, 1000]))}}
+        try:
+            config.resolve_hns_cfg(config.make_cfg(task))
+            break
+        except ValueError:
+            continue
+    env = HideAndSeek(config.make_cfg(task))
+    env.set_seed(seed)
+    env.reset()
+    E = env.num_envs
+    for _ in range(int(r.randint(0, 8))):
+        env.step(env.rand_step_input(torch.randn(E, A, 4, device=env.device)))
+    N, rng_max = int(r.choice([1, 3, 8, 16, 33, 64])), float(r.choice([0.2, 1.5, 5.0]))
+    dev = env.raycast(N, rng_max).cpu().numpy()
+    ref = O.raycast(env.hcfg, env.export_state(), N, rng_max)
+    np.testing.assert_array_equal(dev, ref, err_msg=f"seed {seed} {task} rays {N} range {rng_max}")
+    assert dev.shape == (E, A, N) and (dev >= 0).all() and (dev <= rng_max).all()
