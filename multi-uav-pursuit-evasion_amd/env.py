@@ -351,6 +351,12 @@ class HideAndSeek(_EnvBase):
         self._reset_mask_keepalive = mask_t
         self._state_version += 1
         self._note_reset(mask_t)
+        if self._needs_reset and mask_t is None:
+            # first reset of this env: run the torch side of a MASKED reset once (mask conversion, the read-back of max(progress)) — the first
+            # launch of a torch kernel in a process loads its code object (15-20 ms for this handful on a fresh box), better paid here than
+            # at the first episode boundary of a rollout
+            torch.zeros(self.num_envs, 1, dtype=torch.bool, device=self.device).reshape(self.num_envs).to(torch.uint8).contiguous()
+            int(self.progress_buf.max().item())
         self._needs_reset = False
         if self.use_TP_net:
             self._tp_observe()
