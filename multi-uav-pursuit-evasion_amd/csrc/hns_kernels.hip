@@ -2509,6 +2509,17 @@ int hns_set_phase_profile(hns_env *env, unsigned long long *device_buf) {
 int hns_enable_timing(hns_env *env, int on) {
     if (!env) return HNS_ERR_INVALID_ARG;
     env->timing = on < 0 ? 0 : on;
+    if (env->timing > 0) {
+        // event pairs for the first timed launches are made HERE, not inside the region the caller is about to time
+        // (only when the caller's current device is the env's, as for a launch; otherwise they are made at the first timed launch)
+        int dev = -1;
+        while (hipGetDevice(&dev) == hipSuccess && dev == env->device && env->pool.size() < 16) {
+            std::pair<hipEvent_t, hipEvent_t> ev;
+            HNS_CHECK_HIP(hipEventCreate(&ev.first));
+            HNS_CHECK_HIP(hipEventCreate(&ev.second));
+            env->pool.push_back(ev);
+        }
+    }
     return HNS_OK;
 }
 
