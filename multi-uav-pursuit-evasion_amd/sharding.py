@@ -160,12 +160,20 @@ class GlobalSuccessRate:
     episodes are 800 steps, rollouts 64; until the first rollout it falls back to the local shard."""
 
     def __init__(self):
-        self.rate = None
+        self._table = None
 
     def update(self, table):
-        tot = table.sum(0)
-        if float(tot[4]) > 0:
-            self.rate = float(tot[3] / tot[4])
+        """Keep the gathered moments; nothing is read back here (a `.item()` per rollout would drain the launch queue every 64 steps —
+        the rate is only needed while the curriculum is active, at episode ends)."""
+        self._table = table
+
+    @property
+    def rate(self):
+        if self._table is None:
+            return None
+        tot = self._table.sum(0)
+        return float(tot[3] / tot[4]) if float(tot[4]) > 0 else None
 
     def __call__(self, env):
-        return self.rate if self.rate is not None else float(env.stats["success"].mean())
+        r = self.rate
+        return r if r is not None else float(env.stats["success"].mean())
