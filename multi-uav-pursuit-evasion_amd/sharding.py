@@ -40,6 +40,11 @@ def allgather_moments(local):
     """The rollout's single collective: every rank gets the [world, MOMENT_DIM] table."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local.unsqueeze(0)
+    return _allgather(local)
+
+
+def _allgather(local):
+    """The collective itself (also called directly by the one-rank RCCL test on a single GPU)."""
     src = local.contiguous() if dist.get_backend() == "nccl" else local.cpu()   # gloo (CPU tests) gathers host tensors
     parts = [torch.empty_like(src) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, src)

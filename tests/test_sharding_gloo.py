@@ -204,3 +204,41 @@ def test_envgen_global_history_two_ranks_one_gpu():
     assert s0[1] == 2 * 192 and s0[3] == 4 * 192 and s0[5] == 6 * 192   # eval_iter = 2: every second episode both shards' 192 tasks enter
     assert sh0[0] == sh1[0] == 0                                      # empty history: uniform tasks only
     assert sh0[-1] + sh1[-1] == min(s0[-2], int(2 * 192 * 0.7))
+
+
+@pytest.mark.gpu
+def test_rccl_backend_runs_the_moment_collective_on_one_gpu(tmp_path):
+    """The backend the multi-GPU run uses ("nccl" = RCCL on ROCm) with the one rank a single-GPU box allows: the process group
+    initialises, the moment all-gather and the [sum, count] all-reduce run on device tensors, the normalised advantages equal torch's."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+import torch.distributed as dist
+import hns_amd
+from hns_amd import sharding
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29713")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+adv = torch.randn(64, 128, 3, 1, device="cuda:0")
+suc = (torch.rand(128, 1, device="cuda:0") > 0.5).float()
+table = sharding._allgather(sharding.local_moments(adv, suc))            # the collective itself, not the world_size == 1 shortcut
+assert table.shape == (1, sharding.MOMENT_DIM) and table.is_cuda
+mean, std = sharding.global_mean_std(table)
+ref = (adv - adv.mean()) / adv.std().clip(1e-7)
+got = (adv - mean.float()) / std.clamp(min=1e-7).float()
+assert torch.allclose(got, ref, atol=1e-5), float((got - ref).abs().max())
+acc = sharding._coll_tensor(torch.stack([suc.double().sum(), torch.tensor(float(suc.numel()), dtype=torch.float64, device="cuda:0")]))
+dist.all_reduce(acc)
+assert abs(float(acc[0] / acc[1]) - float(suc.mean())) < 1e-12
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok")
+"""
+    import os
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
