@@ -125,3 +125,39 @@ def test_random_configuration_snapshot_resume(seed, tmp_path):
     sa, sb = a.export_state(), b.export_state()
     for k in sa:
         np.testing.assert_array_equal(sa[k], sb[k], err_msg=f"seed {seed} {task}: {k}")
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_configuration_at_full_batch_size(seed):
+    """The random configurations of the sweep at BASELINE's batch size (65 536 envs; every other seed 16 384 + 37: a ragged tail):
+    8 steps and a masked reset, every buffer bit for bit."""
+    from hns_amd.env import HideAndSeek
+    task, _, A = draw_case(5000 + seed)
+    E = 65536 if seed % 2 == 0 else 16384 + 37
+    task = dict(task, env={"num_envs": E, "max_episode_length": 5})
+    O.set_threads(min(32, os.cpu_count() or 8))
+    env = HideAndSeek(config.make_cfg(task), headless=True, write_critic_state=bool(seed % 2))
+    env.set_seed(seed)
+    env.reset()
+    host = O.alloc_buffers(env.hcfg)
+    O.reset(env.hcfg, host, None, env.seed, 0)
+    g = torch.Generator(device=env.device).manual_seed(seed)
+    for t in range(8):
+        action = torch.randn(E, A, 4, generator=g, device=env.device) * 0.7
+        env.hcfg.v_prey = env.v_prey
+        env.step(env.rand_step_input(action))
+        O.step(env.hcfg, host, action.cpu().numpy())
+        if host["done"].any():
+            mask = host["done"].copy()
+            mask[::3] = 0
+            td = env.rand_step_input()
+            td.set("_reset", torch.as_tensor(mask.astype(bool), device=env.device))
+            epoch = env.reset_epoch
+            env.reset(td)
+            O.reset(env.hcfg, host, mask, env.seed, epoch)
+    dev = env.export_state()
+    for k in host:
+        if k == "state_drones" and not host[k].size:
+            continue
+        np.testing.assert_array_equal(host[k], dev[k], err_msg=f"seed {seed} {task}: buffer {k}")
+    O.set_threads(1)
