@@ -602,3 +602,35 @@ def test_step_merge_shortcut_notices_replaced_entries():
     assert td.get("next") is nxt
     fresh = env.rand_step_input()
     assert env.step(fresh).get("next") is nxt and fresh.get(("info", "prev_action")) is env._bufs["prev_action"]
+
+
+def test_create_destroy_cycles_do_not_leak():
+    """300 envs created, stepped and closed one after the other (every tenth with the predictor, every fifteenth with the task generator): device
+    memory free before and after differs by less than the allocator's slack; the handle's own allocations (parameter block, pinned ring,
+    events) go with hns_destroy."""
+    import gc
+    from hns_amd.env import HideAndSeek
+    from hns_amd.envgen import HideAndSeek_envgen
+    def cycle(i):
+        task = {"num_agents": 1 + i % 6, "cylinder": {"max_num": 3 + i % 9, "min_num": 2}, "env": {"num_envs": 64 + 64 * (i % 5), "max_episode_length": 8}}
+        if i % 15 == 14:
+            env = HideAndSeek_envgen(config.make_cfg(dict(task, name="HideAndSeek_envgen", use_particle_generator=1)))
+        else:
+            env = HideAndSeek(config.make_cfg(task, algo={"use_TP_net": int(i % 10 == 9)}), headless=True)
+        env.reset()
+        for _ in range(3):
+            env.step(env.rand_step_input())
+        env.enable_kernel_timing(1)
+        env.step(env.rand_step_input())
+        env.kernel_ms()
+        env.close()
+        del env
+    for i in range(30):                                    # warm the allocator and every code path first
+        cycle(i)
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(300):
+        cycle(i)
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 * 1024 * 1024, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 300 create / destroy cycles"
