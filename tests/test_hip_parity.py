@@ -634,3 +634,46 @@ def test_create_destroy_cycles_do_not_leak():
     gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 * 1024 * 1024, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 300 create / destroy cycles"
+
+
+def test_two_caller_threads_with_their_own_envs():
+    """SURVEY §8(b) threading: one caller thread per env instance.  Two threads drive two envs (different shapes, own streams, one with the
+    predictor) at the same time — ctypes releases the GIL inside every call; each ends bit-identical to the same env driven alone."""
+    import threading
+    from hns_amd.env import HideAndSeek
+    specs = [({"num_agents": 3, "cylinder": {"max_num": 8, "min_num": 4}, "env": {"num_envs": 4096, "max_episode_length": 30}}, {}),
+             ({"num_agents": 5, "num_targets": 2, "cylinder": {"max_num": 12, "min_num": 6}, "env": {"num_envs": 1000, "max_episode_length": 25}}, {"use_TP_net": 1})]
+
+    def drive(i, out, stream):
+        task, algo = specs[i]
+        with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
+            env = HideAndSeek(config.make_cfg(task, algo=algo), headless=True)
+            env.set_seed(40 + i)
+            env.reset()
+            g = torch.Generator(device=env.device).manual_seed(i)
+            E, A = env.num_envs, env.num_agents
+            for t in range(80):
+                td = env.step(env.rand_step_input(torch.randn(E, A, 4, generator=g, device=env.device)))
+                done = td[("next", "done")].squeeze(-1)
+                if t % 25 == 24 and bool(done.any()):
+                    r = env.rand_step_input()
+                    r.set("_reset", done.clone())
+                    env.reset(r)
+            torch.cuda.current_stream().synchronize()
+            out[i] = env.export_state()
+            if env.use_TP_net:
+                out[i]["tp_rows"] = env._tp_bufs["obs_self"].cpu().numpy()
+
+    alone, together = {}, {}
+    for i in range(2):
+        drive(i, alone, None)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    threads = [threading.Thread(target=drive, args=(i, together, streams[i])) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for i in range(2):
+        assert set(alone[i]) == set(together[i])
+        for k in alone[i]:
+            np.testing.assert_array_equal(alone[i][k], together[i][k], err_msg=f"env {i}: {k}")
