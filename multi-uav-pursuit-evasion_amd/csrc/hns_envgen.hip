@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kFpsThreads) void hns_fps_kernel(const FpsParams p)
     __shared__ unsigned long long s_best[kFpsThreads / 64];
     __shared__ int s_cur;
     __shared__ int s_fail;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int G = p.groups, gtid = blockIdx.x * kFpsThreads + tid, stride = G * kFpsThreads;
     gu64 *gran = (gu64 *)(p.scratch + 8);
     float dist[kFpsMaxPerThread];

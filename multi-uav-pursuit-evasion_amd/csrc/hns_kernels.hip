@@ -2181,8 +2181,8 @@ int hns_create(const hns_cfg *cfg, hns_env **out) {
 
 void hns_destroy(hns_env *env) {
     if (!env) return;
-    for (auto &p : env->events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-    for (auto &p : env->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (auto &p : env->events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &p : env->pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (env->params_dev) (void)hipFree(env->params_dev);
     if (env->params_ring) (void)hipHostFree(env->params_ring);
     for (auto *img : env->captured_images) (void)hipHostFree(img);

@@ -59,7 +59,6 @@ constexpr int kTpH = HNS_TP_HIDDEN;
 // waves per workgroup: 8 (2 per SIMD, 256 envs) while the operand image + the parked frames fit the CU's 160 KB of LDS with them;
 // three frame chunks (33..48 values) need 123 KB of image, so that shape runs 6 waves (192 envs) per workgroup
 __host__ __device__ constexpr int tp_waves(int nxc) { return nxc <= 2 ? 8 : 6; }
-constexpr int kTpWaves = 8;                 // the widest workgroup (host-side sizing of the diagnostics buffer)
 constexpr int kTpMaxRows = 32;              // 3F <= 32: one M tile for the output layer
 constexpr int kTpMaxChunks = 5;             // 16-value chunks of a frame: 7 + 3 * 7 pursuers + 3 * 16 cylinders = 76 values
 constexpr float kTpLoScale = 2048.0f;       // 2^11: the low split term, kept in fp16's normal range
@@ -166,9 +165,7 @@ __global__ __launch_bounds__(256) void hns_tp_pack_kernel(const TpParams p, int 
 // gate nonlinearities on the transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp each); the oracle
 // uses libm, the parity tolerance is the north star's 1e-5
 // arguments come pre-scaled from the matrix product: zs = -z log2 e (sigmoid), zt = -2 z log2 e (tanh)
-HNS_DEV float tp_sigmoid_s(float zs) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zs)); }
 HNS_DEV float tp_tanh_s(float zt) { return HNS_FMA(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zt)), -1.0f); }
-HNS_DEV float tp_tanh(float x) { return tp_tanh_s(x * (2.0f * kNegLog2e)); }
 
 // component k of the frame [progress, evader pos (masked), evader vel (masked), pursuer positions]
 // (hideandseek.py:815-820; the mask is broadcast_detect, :791-803), followed with task.use_obstacles by
@@ -519,11 +516,11 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
 
     const int wave = tid >> 6, lane = tid & 63, hb = lane >> 5;
     const int e = blockIdx.x * kTpEnvs + wave * 32 + (lane & 31);
-    if (blockIdx.x * kTpEnvs + wave * 32 >= p.E) return;          // whole wave out of range
+    if ((int)blockIdx.x * kTpEnvs + wave * 32 >= p.E) return;     // whole wave out of range
     const bool valid = e < p.E;
     const int ec = valid ? e : p.E - 1;                           // clamped: loads stay in bounds, stores are guarded
     const float *sBias = reinterpret_cast<const float *>(simg + L.bias), *sBfc = reinterpret_cast<const float *>(simg + L.bfc);
-    constexpr int N_HH = 8 * 4 * 64, N_IH = 8 * NXC * 64, N_FC = 4 * 64;
+    constexpr int N_FC = 4 * 64;
 
     // this lane's part of a frame: k = 16 cx + 8 hb + j
     // parked in LDS (read once, as x_{T-1}): [wave][value][lane], conflict-free

@@ -648,6 +648,11 @@ def test_two_caller_threads_with_their_own_envs():
         task, algo = specs[i]
         with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
             env = HideAndSeek(config.make_cfg(task, algo=algo), headless=True)
+            if env.use_TP_net:                              # nn.Module's default init draws from torch's GLOBAL generator (whose order two threads do
+                gw = torch.Generator().manual_seed(7 + i)   # not fix): give the predictor its parameters from a generator of this env's own
+                with torch.no_grad():
+                    for prm in env.TP.parameters():
+                        prm.copy_((torch.randn(prm.shape, generator=gw) * 0.15).to(env.device))
             env.set_seed(40 + i)
             env.reset()
             g = torch.Generator(device=env.device).manual_seed(i)
