@@ -357,6 +357,12 @@ def resolve_hns_cfg(cfg, num_envs=None, env_index_offset=0, drone_params=None, w
             raise ValueError("fixed scenarios place at most 4 drones")
         if len(cyl) > Cn:
             raise ValueError(f"scenario {t.scenario_flag!r} needs cylinder.max_num >= {len(cyl)}")
+        if len({tuple(dpos[a]) for a in range(A)}) < A:
+            import warnings
+            # kept as the reference has it (hideandseek.py:673-679: `passage` lists its second drone twice) — with all four drones the pair's
+            # separation is 0 and the downwash term 0 / 0: NaN states from the first step on, there as here
+            warnings.warn(f"scenario {t.scenario_flag!r} places two of its {A} drones on the same point (as the reference does): the state turns NaN",
+                          RuntimeWarning, stacklevel=2)
         for a in range(A):
             c.fixed_drone_pos[a][:] = dpos[a]
         c.fixed_target_pos[:] = tpos
