@@ -10,8 +10,11 @@ north_star).  `python bench.py --gpus N` launches its own N ranks when it was no
 
 Prints ONE JSON line (rank 0):
   * `value` / `ms_per_step`: the timed `env.step` loop; `abi_rate`: the same steps through the bare C ABI;
-  * `roofline`: the step kernel, measured live — every 32nd launch of the timed region carries dispatch-bound hipEvents
-    (hns_enable_timing), per-rank min/max in `kernel_us_by_rank`; `traffic` is a LOOK-UP of the committed PMC profile;
+  * `roofline`: the step kernel, measured live over the timed region itself — ONE hipEvent pair around it on the step stream
+    (hns_region_begin / hns_region_end), `kernel_us` = max(that device time, the region's wall time) / steps, so `achieved` never
+    exceeds bytes / ms_per_step; dispatch-bound events of sampled launches (`kernel_us_dispatch_events`, long regions only) and of 16
+    launches AFTER the region (`kernel_us_post_region`) are separate fields; per-rank values in `kernel_us_by_rank`; `traffic` is a
+    LOOK-UP of the committed PMC profile; `device_copy_GBs` is the library's float4 copy kernel on the same box;
   * `configs`: the other BASELINE configurations (cfg2 4 096 envs / no cylinders, cfg4 envgen with the generator's cost
     per episode, cfg5_shard 6v2 / 16 cylinders — one GPU's shard), each with its own ms_per_step and roofline fraction, and
     `beyond_l3`: the headline shape at 262 144 and 1 048 576 envs (0.4 / 1.6 GB touched per step: past the 256 MiB Infinity Cache);
@@ -200,35 +203,39 @@ def main():
         acts = [torch.randn(E, A, 4, generator=gen, device=device) for _ in range(R)]
         return acts, [TensorDict({"agents": {"action": a}}, [E]) for a in acts]
 
-    def kernel_roofline(env, E, A, C, NT=1, K=3):
-        """Roofline object of the step kernel from the launches timed since hns_enable_timing."""
-        kernel_ms, n = env.kernel_ms()
-        if kernel_ms <= 0:
-            return None, kernel_ms
+    def roofline_obj(kernel_ms, E, A, C, NT=1, K=3, source="region"):
+        """Roofline object of the step kernel: algorithmic bytes per launch / its duration."""
+        if kernel_ms is None or kernel_ms <= 0:
+            return None
         b_env = algorithmic_bytes_per_env(A, C, K, NT=NT)
         achieved = b_env * E / (kernel_ms * 1e-3) / 1e9
+        src = {"region": "one hipEvent pair around the timed region on the step stream (hns_region_begin / hns_region_end) / steps: the step kernel "
+                         "including the gap to its successor (and whatever else the region launches: the episode-boundary resets)",
+               "dispatch": "start / stop events bound to sampled dispatches (hns_enable_timing): the kernel alone"}[source]
         return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "kernel_us": round(kernel_ms * 1e3, 2), "samples": n, "bytes_per_launch": b_env * E, "bytes_per_env": b_env}, kernel_ms
+                "kernel_us": round(kernel_ms * 1e3, 2), "kernel_us_source": src, "bytes_per_launch": b_env * E, "bytes_per_env": b_env}
 
     def timed_steps(env, tds, n, warm, reset_every=None, timing=0):
-        """n `env.step` calls (with the episode-boundary reset when given); returns wall seconds."""
+        """n `env.step` calls (with the episode-boundary reset when given); returns (wall seconds, device ms between one event pair around them)."""
         done_td = TensorDict({}, [env.num_envs])
         for i in range(warm):
             env.step(tds[i % len(tds)])
         torch.cuda.synchronize(device)
         if timing:
             env.enable_kernel_timing(timing)
+        env.region_begin()
         t0 = time.perf_counter()
         for i in range(n):
             env.step(tds[i % len(tds)])
             if reset_every and (i + 1) % reset_every == 0:
                 done_td.set("_reset", env._bufs["done"])
                 env.reset(done_td)
+        env.region_end()
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         if timing:
             env.enable_kernel_timing(0)
-        return dt
+        return dt, env.region_ms()
 
     # ======================= headline: cfg3 through env.step =====================================================
     E, A, C, K = args.envs, args.agents, args.cylinders, 3
@@ -246,6 +253,8 @@ def main():
     rate_hook = sharding.GlobalSuccessRate()
     env.success_rate_fn = rate_hook
 
+    coll_events, coll_host_us = [], []
+
     def run(n):
         for _ in range(n):
             i = progress["t"]
@@ -256,8 +265,21 @@ def main():
                 env.reset(reset_td)
             if world > 1 and (i + 1) % rollout == 0:
                 # per-rollout moments for advantage normalisation (learning/mappo.py:391-396 made data-parallel) + the success
-                # rate of the curriculum (hideandseek.py:1012-1015): ONE all-gather of 5 fp64 values per rank over RCCL/xGMI
-                rate_hook.update(sharding.allgather_moments(sharding.local_moments(reward, success)))
+                # rate of the curriculum (hideandseek.py:1012-1015): ONE all-gather of 5 fp64 values per rank over RCCL/xGMI.
+                # Its cost is timed where it is paid: device time between two events on the step stream for RCCL (the collective
+                # runs on RCCL's stream, the step stream waits for it), host time of the call for gloo (host tensors)
+                loc = sharding.local_moments(reward, success)
+                if coll_dev == "cpu":
+                    c0 = time.perf_counter()
+                    table = sharding.allgather_moments(loc)
+                    coll_host_us.append((time.perf_counter() - c0) * 1e6)
+                else:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                    table = sharding.allgather_moments(loc)
+                    ev[1].record()
+                    coll_events.append(ev)
+                rate_hook.update(table)
 
     # the episode-boundary path (masked reset: mask conversion, statistics clone, one read-back of max(progress)) runs a handful of torch
     # kernels whose FIRST launch in a process loads their code objects — 15-20 ms on a fresh box, which landed inside the timed region
@@ -273,35 +295,52 @@ def main():
     env.kernel_ms()
     run(args.warmup - min(1, args.warmup))
     sync()
-    # kernel-duration samples: every `time_every`-th launch of the timed region carries dispatch-bound events.  An event-bracketed
-    # dispatch costs the host ~6 us more than a plain one (measured: the driver's 20-step command read 23.2 us per step with every
-    # second launch timed, 22.2 with every fifth, 20.3 with one), so a region shorter than `--time-every` carries ONE of them, and
-    # the sample is then topped up to 16 with launches timed right AFTER the region (same env, same state stream, outside the wall time)
-    time_every = max(1, min(args.time_every, args.steps))
-    env.enable_kernel_timing(time_every)
+    # The roofline's kernel time is ONE hipEvent pair around the whole timed region, recorded on the stream the steps are launched on
+    # (hns_region_begin / hns_region_end): device time / steps = the step kernel including the gap to its successor, with no host cost
+    # per launch.  It can never be shorter than bytes / ms_per_step allows.  Dispatch-bound events (the kernel alone, what rocprofv3
+    # reports) ride on every `time_every`-th launch only in regions long enough to hold eight of them — an event-bracketed dispatch
+    # costs the host ~6 us — and are reported beside it (`kernel_us_dispatch_events`); 16 more are taken right AFTER the region
+    # (`kernel_us_post_region`: same env, same state stream, outside every timed quantity).
+    time_every = max(1, args.time_every)
+    in_region_events = args.steps >= 8 * time_every
+    if in_region_events:
+        env.enable_kernel_timing(time_every)
+    env.region_begin()
     t0 = time.perf_counter()
     run(args.steps)
+    env.region_end()
     sync()
     elapsed = time.perf_counter() - t0
     env.enable_kernel_timing(0)
-    in_ms, in_n = env.kernel_ms()
-    extra_ms, extra_n = 0.0, 0
-    if 0 < in_n < 8:
-        env.enable_kernel_timing(1)
-        for i in range(16 - in_n):
-            env.step(tds[i % R])
-        torch.cuda.synchronize(device)
-        env.enable_kernel_timing(0)
-        extra_ms, extra_n = env.kernel_ms()
-    kernel_ms = (in_ms * in_n + extra_ms * extra_n) / max(in_n + extra_n, 1) if in_n > 0 else in_ms
-    roofline = None
-    if kernel_ms > 0:
-        b_env = algorithmic_bytes_per_env(A, C, K, NT=args.targets)
-        achieved = b_env * E / (kernel_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "kernel_us": round(kernel_ms * 1e3, 2), "samples": in_n + extra_n, "samples_in_timed_region": in_n,
-                    "kernel_us_in_timed_region": round(in_ms * 1e3, 2), "bytes_per_launch": b_env * E, "bytes_per_env": b_env}
+    region_ms = env.region_ms()
+    in_ms, in_n = env.kernel_ms() if in_region_events else (-1.0, 0)
+    env.enable_kernel_timing(1)
+    for i in range(16):
+        env.step(tds[i % R])
+    torch.cuda.synchronize(device)
+    env.enable_kernel_timing(0)
+    post_ms, post_n = env.kernel_ms()
+    # The duration the roofline is priced on: the device time of the region per step, but never less than the wall clock of the same
+    # region per step — the kernel runs once per step, so bytes / ms_per_step bounds what it can have sustained (successive launches
+    # overlap by ~0.5 us: the next kernel's first waves start while the last ones of its predecessor drain, which is why an ISOLATED
+    # dispatch, as rocprofv3 and the dispatch-bound events time it, reads a little longer than either)
+    kernel_ms = max(region_ms, elapsed * 1e3) / args.steps if region_ms > 0 else -1.0
+    roofline = roofline_obj(kernel_ms, E, A, C, NT=args.targets, K=K)
+    if roofline is not None:
+        roofline["kernel_us_source"] = "max(device time between ONE hipEvent pair around the timed region on the step stream, wall time of that region) / steps"
+        roofline["region_ms"] = round(region_ms, 4)
+        roofline["region_wall_ms"] = round(elapsed * 1e3, 4)
+        roofline["kernel_us_dispatch_events"] = round(in_ms * 1e3, 2) if in_n > 0 else None
+        roofline["dispatch_event_samples_in_region"] = in_n
+        roofline["kernel_us_post_region"] = round(post_ms * 1e3, 2) if post_n > 0 else None
+        roofline["post_region_samples"] = post_n
 
+    coll_us = coll_host_us[-(args.steps // rollout):] if coll_host_us else [a.elapsed_time(b) * 1e3 for a, b in coll_events[-(args.steps // rollout):]]
+    collective = None
+    if coll_us:
+        collective = {"per_rollout_us_mean": round(sum(coll_us) / len(coll_us), 1), "per_rollout_us_max": round(max(coll_us), 1), "rollouts": len(coll_us),
+                      "rollout_steps": rollout, "what": "local moments (3 tiny reductions) + ONE all-gather of 5 fp64 per rank; " +
+                      ("host time of the call (gloo, host tensors)" if coll_host_us else "device time between two events on the step stream (RCCL)")}
     # ranks that actually took part (an all-reduce of ones), slowest rank's wall time, per-rank kernel time
     n_ranks, n_devices, kernel_by_rank = 1, 1, None
     if world > 1:
@@ -331,33 +370,24 @@ def main():
         except Exception:  # noqa: BLE001
             pass
         if args.traffic_live and world == 1:
-            live = live_traffic(args, "hns_step_v4_kernel" if E % 64 == 0 else "hns_step_kernel")
+            live = live_traffic(args, "hns_step_v4_kernel")
             if live is not None:
                 traffic = live["traffic_bytes_per_launch"]
                 roofline["traffic_source"] = "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two separate passes of this run's workload (FETCH_SIZE KiB x 2 on gfx950 + WRITE_SIZE KiB)"
                 roofline["traffic_detail"] = live
         roofline["traffic"] = traffic
-        roofline["kernel"] = "hns_step_v4_kernel<%d,%d,false>" % (A, args.targets) if E % 64 == 0 else "hns_step_kernel<%d,%d,false>" % (A, args.targets)
+        roofline["kernel"] = "hns_step_v4_kernel<%d,%d,%s,4,false>" % (A, args.targets, "false" if E % 64 == 0 else "true")
         if kernel_by_rank:
             roofline["kernel_us_by_rank"] = {"min": min(kernel_by_rank), "max": max(kernel_by_rank), "all": kernel_by_rank}
-        # achievable HBM bandwidth on this box ("measure achievable with a device copy kernel and report both")
+        # achievable HBM bandwidth on this box ("measure achievable with a device copy kernel and report both"): the library's
+        # float4 copy kernel (hns_copy_f4; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy), 256 MB read + 256 MB written per pass
         try:
-            src = torch.empty(256 * 1024 * 1024 // 4, dtype=torch.float32, device=device).normal_()
-            dst = torch.empty_like(src)
-            for _ in range(3):
-                dst.copy_(src)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                dst.copy_(src)
-            e1.record()
-            torch.cuda.synchronize(device)
-            copy_gbs = round(20 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-            del src, dst
+            copy_gbs = round(env.device_copy_GBs(256, 20), 1)
             roofline["device_copy_GBs"] = copy_gbs
+            roofline["device_copy_kernel"] = "hns_copy_f4_kernel (float4 per lane, four pieces per thread), 2 x 256 MiB per pass"
             roofline["frac_of_device_copy"] = round(roofline["achieved"] / copy_gbs, 4)
-        except Exception:  # noqa: BLE001
-            pass
+        except Exception as ex:  # noqa: BLE001
+            roofline["device_copy_error"] = str(ex)[:200]
 
     single = world == 1
     # secondary: the same steps through the bare C ABI (what the Python class adds is the difference)
@@ -381,8 +411,8 @@ def main():
         # cfg2: 4 096 envs, the default 5 cylinder slots all inactive (BASELINE configs[1]; bytes per env 1 497)
         e2 = make_env(4096, 3, 5, task={"cylinder": {"fixed_num": 0, "min_num": 0}})
         _, td2 = action_ring(4096, 3, 7)
-        dt = timed_steps(e2, td2, n, 50, timing=8)
-        r2, _ = kernel_roofline(e2, 4096, 3, 5)
+        dt, rms = timed_steps(e2, td2, n, 50)
+        r2 = roofline_obj(rms / n, 4096, 3, 5)
         configs["cfg2"] = {"workload": "HideAndSeek 3v1, 5 cylinder slots all inactive, 4 096 envs", "value": round(4096 * 3 * n / dt, 1), "unit": "agent-steps/s",
                            "ms_per_step": round(dt / n * 1e3, 5), "steps": n, "roofline": r2,
                            "note": "64 workgroups on 256 CUs: one launch is a single workgroup's latency, not a bandwidth figure"}
@@ -390,8 +420,8 @@ def main():
         # cfg5's per-GPU shard: 6 pursuers / 2 evaders / 16 cylinders / 65 536 envs (the two-evader extension)
         e5 = make_env(E, 6, 16, NT=2)
         _, td5 = action_ring(E, 6, 9)
-        dt = timed_steps(e5, td5, n, 30, timing=8)
-        r5, _ = kernel_roofline(e5, E, 6, 16, NT=2)
+        dt, rms = timed_steps(e5, td5, n, 30)
+        r5 = roofline_obj(rms / n, E, 6, 16, NT=2)
         assert e5.check_finite()
         if r5 is not None:
             try:
@@ -410,8 +440,8 @@ def main():
             nb = max(40, n // 4)
             ebv = make_env(eb, A, C)
             _, tdb = action_ring(eb, A, 13, R=2)
-            dtb = timed_steps(ebv, tdb, nb, 10, timing=4)
-            rb, _ = kernel_roofline(ebv, eb, A, C)
+            dtb, rmsb = timed_steps(ebv, tdb, nb, 10)
+            rb = roofline_obj(rmsb / nb, eb, A, C)
             assert ebv.check_finite()
             beyond[str(eb)] = {"workload": f"HideAndSeek {A}v1, {C} cylinders, {eb} envs ({algorithmic_bytes_per_env(A, C, K) * eb / 1e6:.0f} MB algorithmic per step)",
                                "value": round(eb * A * nb / dtb, 1), "unit": "agent-steps/s", "ms_per_step": round(dtb / nb * 1e3, 5), "steps": nb, "roofline": rb}
@@ -451,7 +481,7 @@ def main():
                 ep_ms.append((time.perf_counter() - ts) * 1e3)
             total = time.perf_counter() - t_all
             e4.enable_kernel_timing(0)
-            r4, _ = kernel_roofline(e4, E, 3, 8)
+            r4 = roofline_obj(e4.kernel_ms()[0], E, 3, 8, source="dispatch")
             steady = sorted(gen_ms[1:])
             # steady state = the last three episodes (one task batch: history full, everything warm); an episode of the reference's
             # 800 steps costs 800 x the measured step time + that episode's measured non-step time
@@ -478,7 +508,7 @@ def main():
     if args.tp_steps > 0 and single and args.targets == 1:
         env_tp = make_env(E, A, C, algo={"use_TP_net": 1})
         n = args.tp_steps
-        dt_tp = timed_steps(env_tp, tds, n, 20)
+        dt_tp, _ = timed_steps(env_tp, tds, n, 20)
         timed_steps(env_tp, tds, 64, 4, timing=4)                 # the step kernel's own duration in this mode (events on its dispatch)
         tp_step_us = env_tp.kernel_ms()[0] * 1e3
         T, F, I = env_tp.tp_history_step, env_tp.tp_future_step, env_tp.tp_frame_dim
@@ -583,6 +613,7 @@ def main():
                        "episode_length": args.episode, "critic_state_output": args.critic_state,
                        "sharding": f"contiguous env slices x{n_ranks}", "world_size_launched": world, "ranks": n_ranks,
                        "collective": "1 all-gather of 5 fp64 per 64-step rollout" if world > 1 else "none"},
+            "collective_us": collective,
             "env_frames_per_s": round(value / A, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "abi_rate": abi_rate, "configs": configs or None,
             "tp_mode": tp_mode, "stream_shards": streams_mode,

@@ -23,9 +23,9 @@
  * functions return 0 on success and a negative hns_status on error, never throw, never
  * allocate device memory after hns_create, never synchronise a stream or the device (three documented exceptions: hns_bind's FIRST
  * call does one blocking 1 KB upload; hns_step_kernel_ms waits for its last sample; a configuration setter waits only if eight
- * earlier changes are still queued).  hns_step / hns_reset / hns_tp_observe / the setters are legal inside a stream capture.
+ * earlier changes are still queued).  hns_step / hns_reset / hns_tp_observe / the setters are legal inside a stream capture (a configuration change made inside a capture takes one of 16 pinned images made by hns_create and keeps it for the env's lifetime; HNS_ERR_CONFIG once they are used up).
  * The configuration setters (hns_set_v_prey, hns_set_smoothness_coef, hns_set_phase_profile) and a repeated hns_bind change a
- * device-resident parameter block with ONE stream-ordered copy enqueued on the stream of the latest hns_step / hns_reset call
+ * device-resident parameter block with ONE stream-ordered copy enqueued on the stream of the latest hns_step / hns_reset / hns_tp_observe call
  * (the null stream before the first): launches already enqueued there keep the old values, later launches and graph replays on
  * that stream see the new ones.  The HIP device current at the call must be the env's.  Quaternions are
  * (w,x,y,z) (omni_drones/utils/torch.py:62,125).  All tensors are C-contiguous fp32 unless noted.
@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HNS_ABI_VERSION 3
+#define HNS_ABI_VERSION 4
 #define HNS_MAX_AGENTS 7    /* pursuers per env: a workgroup is 64 envs = A pursuer waves + one env wave (<= 512 threads) */
 #define HNS_MAX_CYLINDERS 16
 #define HNS_NUM_STATS 24    /* hideandseek.py:400-425 */
@@ -146,6 +146,12 @@ typedef struct hns_cfg {
     int32_t fixed_cyl_active;  /* HNS_INIT_SCENARIO: number of active cylinders */
     int32_t tp_use_obstacles;  /* task.use_obstacles: the predictor's frame also holds [x, y, cylinder_size] of every cylinder slot
                                   (hideandseek.py:808-816); 0 = the reference's default */
+    int32_t pid_reset_on_reset;/* 0 = the reference: `_reset_idx` (hideandseek.py:609-723) never touches the body-rate controller; its integrator and
+                                  last body rate are cleared only through `reset_pid` at the next step (buffers.reset_pid).  1 = hns_reset also zeroes
+                                  pid_integ / pid_last_rate of the envs it resets (a fresh controller per episode; rounds 1-3 of this build) */
+    int32_t reset_extra_step;  /* 1 = the reference: `_reset_idx` ends with one `sim.step()` of the WHOLE scene (hideandseek.py:722-723) — every drone of
+                                  every env (reset or not) integrates one dt with no rotor force (gravity + damping), every evader moves one dt with
+                                  the velocity it holds; then the observation of all envs is recomputed (isaac_env.py:221).  0 = no extra step */
 } hns_cfg;
 
 /*
@@ -192,6 +198,11 @@ typedef struct hns_buffers {
     /* optional outputs (nullable): the two extra keys PIDRateController._inv_call leaves on the tensordict (transforms.py:456-457) */
     float *ctbr;           /* [E,A,4]        controller output (roll, pitch, yaw command, thrust), lee_position_controller.py:548 */
     float *target_rate;    /* [E,A,4]        target body rate in deg/s (x, y, z, 0), transforms.py:447 */
+    /* optional INPUT of hns_step (nullable): `reset_pid = tensordict['done']` (transforms.py:449-454 -> lee_position_controller.py:497-502) —
+     * envs whose byte is non-zero start the step with pid_integ = pid_last_rate = 0.  It is read at the very beginning of the step and may ALIAS
+     * `done` (written at its very end): the step then consumes the `done` its predecessor (or a reset, which clears it) left — what the root `done`
+     * of a stepped tensordict holds in the reference's collector / rollout loops.  NULL = never reset through the step. */
+    const uint8_t *reset_pid; /* [E] */
 } hns_buffers;
 
 /*
@@ -346,6 +357,15 @@ int hns_refresh_derived_state(hns_env *env, void *stream);
  * of the sampled launches since the last call (synchronises on the last sample); <0 if none. */
 int hns_enable_timing(hns_env *env, int every_n);
 float hns_step_kernel_ms(hns_env *env, int *num_launches);
+/* Region timing (bench.py's roofline): ONE start event recorded on `stream` by hns_region_begin, one stop event by hns_region_end — no
+ * per-launch host cost in between; hns_region_ms waits for the stop event and returns the device time between the two (ms; <0 without a
+ * complete pair).  Divided by the launches in between it is the step kernel's duration INCLUDING the gap to its successor. */
+int hns_region_begin(hns_env *env, void *stream);
+int hns_region_end(hns_env *env, void *stream);
+float hns_region_ms(hns_env *env);
+/* Measurement yardstick (SURVEY §8d "achievable with a device copy kernel"): dst[i] = src[i] over `bytes` (a multiple of 16, both 16-byte
+ * aligned device pointers) as 16-byte loads / stores, one float4 per thread and pass.  Not part of the environment. */
+int hns_copy_f4(void *dst, const void *src, size_t bytes, void *stream);
 
 /* Diagnostics: attach a device buffer of [num_waves, 16] uint64 (num_waves = ceil(E/64)*(A+1)); lane 0
  * of every wave of the step kernel then stamps the shader clock at up to 16 phase boundaries (NULL detaches). */

@@ -6,7 +6,7 @@ been built (`python -c "import __graft_entry__ as g; g.build()"`).
 import ctypes as C
 import os
 
-HNS_ABI_VERSION = 3
+HNS_ABI_VERSION = 4
 HNS_MAX_AGENTS = 7
 HNS_MAX_CYLINDERS = 16
 HNS_NUM_STATS = 24
@@ -55,6 +55,7 @@ class HnsCfg(C.Structure):
         ("target_xy_hi", _f * 2), ("z_lo", _f), ("z_hi", _f), ("rpy_lo", _f * 3), ("rpy_hi", _f * 3),
         ("fixed_drone_pos", (_f * 3) * (HNS_MAX_AGENTS + 1)), ("fixed_target_pos", _f * 3),
         ("fixed_cyl_pos", (_f * 3) * HNS_MAX_CYLINDERS), ("fixed_cyl_active", _i), ("tp_use_obstacles", _i),
+        ("pid_reset_on_reset", _i), ("reset_extra_step", _i),
     ]
 
     def copy(self):
@@ -68,9 +69,11 @@ _fp = C.c_void_p  # device (or, for the oracle, host) pointers travel as integer
 BUFFER_FIELDS = [
     "drone_state", "throttle", "pid_integ", "pid_last_rate", "prev_action", "target_pos",
     "target_vel", "cylinders", "progress", "stats", "obs_self", "obs_others", "obs_cylinders",
-    "state_drones", "reward", "action_error", "done", "detect", "nonfinite", "ctbr", "target_rate",
+    "state_drones", "reward", "action_error", "done", "detect", "nonfinite", "ctbr", "target_rate", "reset_pid",
 ]
-OPTIONAL_BUFFER_FIELDS = ("ctbr", "target_rate")     # bound only with task.publish_ctbr (transforms.py:456-457); NULL otherwise
+# nullable fields: ctbr / target_rate are bound only with task.publish_ctbr (transforms.py:456-457); reset_pid is an INPUT that may alias
+# `done` (include/hns.h) and is never allocated by buffer_shapes
+OPTIONAL_BUFFER_FIELDS = ("ctbr", "target_rate", "reset_pid")
 
 
 class HnsBuffers(C.Structure):
@@ -178,7 +181,7 @@ LIB_NAME = "libhns.so"
 
 
 def library_path():
-    """In-tree libhns.so; HNS_LIBRARY names another build of the same ABI (measurement builds, tools/step_lab.py)."""
+    """In-tree libhns.so; HNS_LIBRARY names another build of the same ABI (A/B measurement builds, tools/build_variant.sh)."""
     return os.environ.get("HNS_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 
@@ -220,6 +223,14 @@ def load_library():
     lib.hns_enable_timing.restype = C.c_int
     lib.hns_step_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.hns_step_kernel_ms.restype = C.c_float
+    lib.hns_region_begin.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hns_region_begin.restype = C.c_int
+    lib.hns_region_end.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hns_region_end.restype = C.c_int
+    lib.hns_region_ms.argtypes = [C.c_void_p]
+    lib.hns_region_ms.restype = C.c_float
+    lib.hns_copy_f4.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.hns_copy_f4.restype = C.c_int
     lib.hns_set_phase_profile.argtypes = [C.c_void_p, C.c_void_p]
     lib.hns_set_phase_profile.restype = C.c_int
     lib.hns_hover_step.argtypes = [C.POINTER(HnsCfg), C.POINTER(HnsHoverCfg), C.POINTER(HnsHoverBuffers), C.c_void_p, C.c_void_p]
@@ -266,5 +277,5 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "hns_create", "hns_destroy", "hns_bind", "hns_step", "hns_reset", "hns_reset_tasks", "hns_raycast", "hns_set_v_prey",
     "hns_set_smoothness_coef", "hns_set_reset_epoch", "hns_get_reset_epoch", "hns_enable_timing",
-    "hns_step_kernel_ms", "hns_set_phase_profile", "hns_set_state", "hns_get_state", "hns_refresh_derived_state", "hns_fps", "hns_fps_scratch_bytes", "hns_perturb_tasks", "hns_tp_bind", "hns_tp_refresh", "hns_tp_packed_bytes", "hns_tp_observe", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
+    "hns_step_kernel_ms", "hns_region_begin", "hns_region_end", "hns_region_ms", "hns_copy_f4", "hns_set_phase_profile", "hns_set_state", "hns_get_state", "hns_refresh_derived_state", "hns_fps", "hns_fps_scratch_bytes", "hns_perturb_tasks", "hns_tp_bind", "hns_tp_refresh", "hns_tp_packed_bytes", "hns_tp_observe", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
 ]

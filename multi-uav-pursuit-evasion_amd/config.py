@@ -56,6 +56,14 @@ DEFAULT_TASK = {
     "target_detect_radius": 100.0,
     "collision_radius": 0.07,
     "cylinder": {"size": 0.1, "fixed_num": None, "min_num": 4, "max_num": 5, "obs_max_cylinder": 3},
+    # --- switches of this build (no key of the reference's task files) ---
+    # pid_reset: who clears the body-rate controller's integrator / last body rate.
+    #   "reference": only `reset_pid = tensordict['done']` at the beginning of a step (transforms.py:449-454); `_reset_idx` leaves the controller
+    #                alone, so with a collector that resets done envs the state carries over into the next episode — as in the reference;
+    #   "on_reset":  hns_reset zeroes it for the envs it resets and the step never does (rounds 1-3 of this build).
+    "pid_reset": "reference",
+    # reset_extra_step: 1 = `_reset_idx` ends with one physics step of the whole scene, no rotor forces (hideandseek.py:722-723); 0 = none
+    "reset_extra_step": 1,
 }
 
 DEFAULT_ALGO = {"name": "mappo", "use_TP_net": 0, "train_every": 64}
@@ -257,6 +265,11 @@ def resolve_hns_cfg(cfg, num_envs=None, env_index_offset=0, drone_params=None, w
     if NT not in (1, 2):
         raise ValueError("task.num_targets must be 1 (the reference) or 2 (extension)")
     c.num_targets = NT
+    pid_reset = str(t.get("pid_reset", "reference"))
+    if pid_reset not in ("reference", "on_reset"):
+        raise ValueError("task.pid_reset must be 'reference' or 'on_reset'")
+    c.pid_reset_on_reset = 1 if pid_reset == "on_reset" else 0
+    c.reset_extra_step = 1 if int(t.get("reset_extra_step", 1)) else 0
     c.tp_use_obstacles = 1 if use_obst else 0
     c.max_episode_length = int(cfg.env.max_episode_length)
     c.use_deployment = int(t.use_deployment)

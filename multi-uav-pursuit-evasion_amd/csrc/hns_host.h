@@ -32,10 +32,9 @@ struct hns_env {
     uint32_t epoch = 0;
     int grid = 0, threads = 0;
     size_t lds_step = 0, lds_reset = 0;
-    void (*step_fn)(const hns::Params) = nullptr;
     void (*reset_fn)(const hns::Params) = nullptr;
-    void (*step_args_fn)(const hns::StepArgs) = nullptr;   // step kernel taking the split argument block (else step_fn)
-    void (*step_args_prof_fn)(const hns::StepArgs) = nullptr;   // ... compiled with the per-wave phase stamps (hns_set_phase_profile)
+    void (*step_args_fn)(const hns::StepArgs) = nullptr;        // the step kernel instantiation serving this env (hns_inst.hip)
+    void (*step_args_prof_fn)(const hns::StepArgs) = nullptr;   // ... compiled with the per-wave phase stamps (hns_set_phase_profile); whole tiles, k <= 4 only
     // device copy of the step launch's Params (allocated by hns_create) and what feeds it: a ring of pinned host images, one
     // stream-ordered hipMemcpyAsync per change on `last_stream` (the stream of the latest step / reset / observe call)
     static constexpr int kParamRing = 8;
@@ -44,7 +43,11 @@ struct hns_env {
     hipEvent_t ring_events[kParamRing] = {};                     // recorded behind each slot's copy
     bool ring_pending[kParamRing] = {};
     int ring_next = 0;
-    std::vector<hns::Params *> captured_images;                  // pinned images a stream capture took (they must outlive the graph)
+    // pinned images for changes made INSIDE a stream capture (they must outlive the graph, so they are never reused): a fixed pool made
+    // by hns_create — hipHostMalloc is illegal while a capture is active in the default (global) capture mode
+    static constexpr int kCaptureImages = 16;
+    hns::Params *capture_pool = nullptr;                         // pinned, [kCaptureImages]
+    int capture_used = 0;
     hipStream_t last_stream = nullptr;
     bool params_valid = false;
     unsigned long long *prof = nullptr;
@@ -53,6 +56,8 @@ struct hns_env {
     uint64_t step_count = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // recorded, not yet harvested
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;     // free event pairs
+    hipEvent_t region_ev[2] = {};                            // hns_region_begin / hns_region_end (made by the first hns_region_begin)
+    int region_state = 0;                                    // 0 none, 1 begun, 2 complete
     hns_tp_state tp;
 };
 

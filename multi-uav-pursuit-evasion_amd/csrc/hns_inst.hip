@@ -1,0 +1,38 @@
+// hns_inst.hip — the step and reset kernels instantiated for ONE pursuer count (compiled once per count: -DHNS_INST_A=1 ... 7, side
+// by side; __graft_entry__.build), and the host-side choice among them.
+#include "hns_host.h"
+#include "hns_reset_kernel.h"
+#include "hns_step_kernel.h"
+
+#ifndef HNS_INST_A
+#error "compile with -DHNS_INST_A=<pursuers per env>"
+#endif
+#define HNS_CAT2(a, b) a##b
+#define HNS_CAT(a, b) HNS_CAT2(a, b)
+
+// Which instantiation serves an env: whole 64-env tiles with k <= 4 take the tuned kernel (and, with a phase-profile
+// buffer attached, its stamped twin); ragged batches and wider selections take the generic one.
+void HNS_CAT(hns_select_kernels_, HNS_INST_A)(hns_env *env) {
+    constexpr int A = HNS_INST_A;
+    using namespace hns;
+    const hns_cfg &c = env->cfg;
+    const bool two = c.num_targets == 2, wide = c.obs_max_cylinder > kMaxK, ragged = c.num_envs % kEPB != 0;
+    if (wide) {
+        env->step_args_fn = two ? hns_step_v4_kernel<A, 2, true, kWideK, false> : hns_step_v4_kernel<A, 1, true, kWideK, false>;
+        env->reset_fn = two ? hns_reset_kernel<A, 2, kWideK> : hns_reset_kernel<A, 1, kWideK>;
+    } else {
+        if (ragged) env->step_args_fn = two ? hns_step_v4_kernel<A, 2, true, kMaxK, false> : hns_step_v4_kernel<A, 1, true, kMaxK, false>;
+        else {
+            env->step_args_fn = two ? hns_step_v4_kernel<A, 2, false, kMaxK, false> : hns_step_v4_kernel<A, 1, false, kMaxK, false>;
+            env->step_args_prof_fn = two ? hns_step_v4_kernel<A, 2, false, kMaxK, true> : hns_step_v4_kernel<A, 1, false, kMaxK, true>;
+        }
+        env->reset_fn = two ? hns_reset_kernel<A, 2> : hns_reset_kernel<A, 1>;
+    }
+    env->threads = Geo<A>::T;
+    env->cyl_magic = (uint32_t)(0xFFFFFFFFull / (uint32_t)(3 * c.num_cylinders) + 1ull);
+    env->grid = (c.num_envs + kEPB - 1) / kEPB;
+    const int NT = two ? 2 : 1;
+    env->lds_step = (size_t)lds_layout_v3(A, c.num_cylinders, c.obs_max_cylinder, NT).total * sizeof(float);
+    env->lds_reset = (size_t)lds_layout(A, c.num_cylinders, c.obs_max_cylinder, NT).total * sizeof(float) +
+                     (size_t)kEPB * kGridStride;      // + per-env occupancy grid / free-cell list
+}

@@ -1291,6 +1291,14 @@ int hns_tp_bind(hns_env *env, const hns_tp_buffers *b, int32_t history_step, int
 int hns_tp_refresh(hns_env *env, void *stream) {
     if (!env) { hns_set_error("hns_tp_refresh: null env"); return HNS_ERR_INVALID_ARG; }
     if (!env->tp.bound) { hns_set_error("hns_tp_refresh: hns_tp_bind first"); return HNS_ERR_NOT_BOUND; }
+    {   // as for a step launch: the caller's current device must be the env's (the attribute below is per device, and so is the launch)
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != env->device) {
+            hns_set_error("hns_tp_observe / hns_tp_refresh: the current HIP device is not the one this env was created on");
+            return HNS_ERR_DEVICE;
+        }
+        env->last_stream = static_cast<hipStream_t>(stream);
+    }
     TpParams p;
     tp_fill_params(env, p);
     if (tp_use_ws(tp_nxc(p.I))) hipLaunchKernelGGL(hns::hns_tp_pack_ws_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, p, tp_nxc(p.I));
@@ -1303,6 +1311,14 @@ int hns_tp_refresh(hns_env *env, void *stream) {
 int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
     if (!env) { hns_set_error("hns_tp_observe: null env"); return HNS_ERR_INVALID_ARG; }
     if (!env->tp.bound) { hns_set_error("hns_tp_observe: hns_tp_bind first"); return HNS_ERR_NOT_BOUND; }
+    {   // as for a step launch: the caller's current device must be the env's (the attribute below is per device, and so is the launch)
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != env->device) {
+            hns_set_error("hns_tp_observe / hns_tp_refresh: the current HIP device is not the one this env was created on");
+            return HNS_ERR_DEVICE;
+        }
+        env->last_stream = static_cast<hipStream_t>(stream);
+    }
     if (env->tp.dirty) {
         const int rc = hns_tp_refresh(env, stream);
         if (rc != HNS_OK) return rc;

@@ -132,7 +132,10 @@ class _PlainEnvBase:
         # transform's keys (merged into what the caller's tensordict already holds under `stats` / `info`).  The returned tree and its
         # leaves are persistent (views of the buffers the kernel rewrites in place), so a tensordict that already went through this
         # merge and still holds that tree needs nothing (a collector that reuses its tensordicts, return_same_td: ~5 us of Python per step)
-        if getattr(tensordict, "_hns_merged", None) is out and self._still_merged(tensordict, out):
+        if isinstance(tensordict, dict) and getattr(tensordict, "_hns_merged", None) is out and self._still_merged(tensordict, out):
+            return tensordict
+        if not isinstance(tensordict, dict):      # a tensordict type that is not the dict-based shim (real tensordict without torchrl): plain update
+            tensordict.update(out)
             return tensordict
         for k, v in dict.items(out):
             cur = tensordict.get(k)
@@ -226,6 +229,12 @@ class HideAndSeek(_EnvBase):
             setattr(self._hbuf, name, t.data_ptr() if (t is not None and t.numel()) else None)
         if not write_critic_state:
             self._hbuf.state_drones = None
+        # task.pid_reset = reference: `reset_pid = tensordict['done']` (transforms.py:449-454).  The step reads the byte at its very beginning
+        # and writes `done` at its very end, so the input IS the done buffer: what the previous step (or a reset, which clears it) left there
+        # is what the root `done` of the stepped tensordict holds in the collector's / rollout's loop; a tensordict whose root `done` is
+        # another tensor is copied in first (`_step`)
+        self.pid_reset_reference = int(self.hcfg.pid_reset_on_reset) == 0
+        self._hbuf.reset_pid = self._bufs["done"].data_ptr() if self.pid_reset_reference else None
         self._env = C.c_void_p()
         self._check(self._lib.hns_create(C.byref(self.hcfg), C.byref(self._env)), "hns_create")
         self._check(self._lib.hns_bind(self._env, C.byref(self._hbuf)), "hns_bind")
@@ -265,6 +274,7 @@ class HideAndSeek(_EnvBase):
         self._state_version = 0          # bumped by every step()/reset(): lazily assembled entries refill once per version
         self._state_buf = None
         self._action_shape = torch.Size([self.num_envs, self.num_agents, 4])
+        self._done_ptr = self._bufs["done"].data_ptr()
 
     # ---- registry (isaac_env.py:154-161) ----------------------------------------------------------
     def __init_subclass__(cls, **kw):
@@ -383,6 +393,12 @@ class HideAndSeek(_EnvBase):
             action = action.float().contiguous()
         if action.shape != self._action_shape:
             raise ValueError(f"action shape {tuple(action.shape)} != {tuple(self._action_shape)}")
+        if self.pid_reset_reference:
+            # the incoming root `done` is the controller's reset_pid; the env's own done buffer (what `next.done` of the last step aliases,
+            # cleared by reset for the envs it resets) already is that input unless the caller's tensordict carries another tensor
+            d = tensordict.get("done", None)
+            if d is not None and d.data_ptr() != self._done_ptr:
+                self._bufs["done"].copy_(d.reshape(self.num_envs).to(torch.uint8))
         rc = self._lib.hns_step(self._env, action.data_ptr(), _raw_stream(self._dev_index))
         if rc != 0:
             self._check(rc, "hns_step")
@@ -511,6 +527,34 @@ class HideAndSeek(_EnvBase):
         n = C.c_int(0)
         ms = float(self._lib.hns_step_kernel_ms(self._env, C.byref(n)))
         return ms, n.value
+
+    def region_begin(self):
+        """One start event on the stream the steps are launched on (hns_region_begin); `region_end` records the stop event,
+        `region_ms` waits for it.  Nothing is added to the launches in between."""
+        self._check(self._lib.hns_region_begin(self._env, _raw_stream(self._dev_index)), "hns_region_begin")
+
+    def region_end(self):
+        self._check(self._lib.hns_region_end(self._env, _raw_stream(self._dev_index)), "hns_region_end")
+
+    def region_ms(self):
+        return float(self._lib.hns_region_ms(self._env))
+
+    def device_copy_GBs(self, mbytes=256, reps=20):
+        """The box's achievable HBM rate with the library's float4 copy kernel (hns_copy_f4): read + written bytes per second."""
+        n = mbytes * 1024 * 1024
+        src = torch.empty(n // 4, dtype=torch.float32, device=self.device).normal_()
+        dst = torch.empty_like(src)
+        st = _raw_stream(self._dev_index)
+        for _ in range(3):
+            self._check(self._lib.hns_copy_f4(dst.data_ptr(), src.data_ptr(), n, st), "hns_copy_f4")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            self._lib.hns_copy_f4(dst.data_ptr(), src.data_ptr(), n, st)
+        e1.record()
+        torch.cuda.synchronize(self.device)
+        assert torch.equal(dst, src)
+        return reps * 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
     # ---- helpers for tests / tools --------------------------------------------------------------------------------
     def rand_step_input(self, action=None):

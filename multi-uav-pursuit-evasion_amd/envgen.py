@@ -144,7 +144,9 @@ class GenBuffer:
         """More than four pursuers: the reference's queue flood as written (hideandseek_envgen.py:246-262), because of what its
         `if len(found) == 4: break` does there — the fourth free cell found is never enqueued and the remaining neighbours of the
         cell being expanded are skipped, which changes which cells the fifth and later pursuers get near the arena rim.  (Up to
-        four pursuers the flood ends at that `break` and the rank table above gives the same cells.)"""
+        four pursuers the flood ends at that `break` and the rank table above gives the same cells.)  Where the reference's list ends up
+        with MORE than num_agents cells (it appends every free neighbour it visits) its `np.array(...)` of ragged rows fails; taking the
+        first num_agents in discovery order is this build's choice for that case, as is the error below when the flood ends with fewer."""
         from collections import deque
         n, A, B = self.num_grid, self.num_agents, self.buffer_length
         cells = np.zeros((B, A + 1, 2), dtype=np.float64)
@@ -165,6 +167,9 @@ class GenBuffer:
                             if len(found) == 4:
                                 break
                         queue.append((nx, ny))
+            if len(found) < A:
+                raise ValueError(f"init_easy_cases: the flood from cell ({x}, {y}) reached only {len(found)} free cells for {A} pursuers "
+                                 "(the reference's `if len(found) == 4: break` skips the rest of the cell being expanded; use fewer pursuers or a larger grid)")
             cells[k, :A] = found[:A]
             cells[k, A] = (x, y)
         xy = np.clip((cells - n // 2) * self.grid_size, -self.boundary, self.boundary)

@@ -166,18 +166,25 @@ class GlobalSuccessRate:
 
     def __init__(self):
         self._table = None
+        self._rate = None
+        self._fresh = False
 
     def update(self, table):
-        """Keep the gathered moments; nothing is read back here (a `.item()` per rollout would drain the launch queue every 64 steps —
-        the rate is only needed while the curriculum is active, at episode ends)."""
+        """Keep the gathered moments; nothing is read back here (a `.item()` per rollout would drain the launch queue every 64 steps).
+        The rate is read back ONCE per table, by the first `rate` access after this call — `env._step` asks on every step once the
+        curriculum is active and an episode length has passed, and must not pay a host synchronisation each time."""
         self._table = table
+        self._fresh = False
 
     @property
     def rate(self):
         if self._table is None:
             return None
-        tot = self._table.sum(0)
-        return float(tot[3] / tot[4]) if float(tot[4]) > 0 else None
+        if not self._fresh:
+            tot = self._table.sum(0)[3:5].tolist()                  # one read-back: [sum of success, count]
+            self._rate = tot[0] / tot[1] if tot[1] > 0 else None
+            self._fresh = True
+        return self._rate
 
     def __call__(self, env):
         r = self.rate

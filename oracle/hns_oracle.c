@@ -611,9 +611,14 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
         float thrust[HNS_MAX_AGENTS][4], moment[HNS_MAX_AGENTS][4], thr_diff[HNS_MAX_AGENTS];
         float tw[HNS_MAX_AGENTS][3];
         float sum_ae = 0.0f;
+        /* reset_pid = tensordict['done'] (transforms.py:449-454 -> lee_position_controller.py:497-502): read before anything of this env is
+         * written — it may alias `done` (include/hns.h) */
+        const int reset_pid = b->reset_pid && b->reset_pid[e];
         for (int a = 0; a < A; ++a) {
             size_t ia = (size_t)e * A + a;
             float cmd[4], ctbr[4], trate[3];
+            if (reset_pid)
+                for (int i = 0; i < 3; ++i) { b->pid_integ[ia * 4 + i] = 0.0f; b->pid_last_rate[ia * 4 + i] = 0.0f; }
             o_ctbr_pid(c, action + ia * 4, ds + 13 * a + 3, ds + 13 * a + 10, b->prev_action + ia * 4,
                        b->pid_integ + ia * 4, b->pid_last_rate + ia * 4, cmd, b->action_error + ia, ctbr, trate);
             if (b->ctbr) for (int i = 0; i < 4; ++i) b->ctbr[ia * 4 + i] = ctbr[i];                 /* transforms.py:456 */
@@ -748,13 +753,15 @@ static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *m
     for (int e = 0; e < E; ++e) {
         /* :712 sets first_capture_step for ALL envs on any reset call */
         b->stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * E + e] = (float)c->max_episode_length;
-        if (mask && !mask[e]) continue;
+        const int masked = !(mask && !mask[e]);
+        if (!masked && !c->reset_extra_step) continue;
         o_rng rng = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(e + c->env_index_offset), epoch, 0u, {0, 0, 0, 0}, 0};
         float *ds = b->drone_state + (size_t)e * A * 13;
         const int NT = o_nt(c), SD = o_self_dim(c);
         float *tp = b->target_pos + (size_t)e * 3 * NT;
         float *cyl = b->cylinders + (size_t)e * C * 3;
         const float *task = (tasks && e >= task_first) ? tasks + (size_t)e * (3 * A + 3 * NT + 3 * C) : NULL;
+        if (masked) {
         for (int a = 0; a < A; ++a) {
             float *d = ds + 13 * a;
             if (task) {
@@ -776,8 +783,10 @@ static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *m
             float pa = 0.0f;
             for (int i = 0; i < 4; ++i) {
                 b->throttle[ia * 4 + i] = c->hover_throttle;
-                b->pid_integ[ia * 4 + i] = 0.0f;
-                b->pid_last_rate[ia * 4 + i] = 0.0f;
+                if (c->pid_reset_on_reset) {      /* 0 = the reference: `_reset_idx` never touches the controller (cleared through reset_pid) */
+                    b->pid_integ[ia * 4 + i] = 0.0f;
+                    b->pid_last_rate[ia * 4 + i] = 0.0f;
+                }
                 float thr = c->hover_throttle;
                 float ci = 0.5f * (c->max_thrust_ratio + (2.0f * (thr * thr) - 1.0f));   /* :714-716 */
                 pa = (i == 0) ? ci : pa + ci;
@@ -858,8 +867,17 @@ static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *m
         b->stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * E + e] = (float)c->max_episode_length;
         b->progress[e] = 0.0f;
         b->done[e] = 0;
+        }   /* masked */
+        if (c->reset_extra_step) {
+            /* hideandseek.py:722-723: `_reset_idx` ends with one sim.step() of the WHOLE scene — no rotor force (apply_action runs in
+             * _pre_sim_step only): every drone integrates one dt under gravity and damping, every evader (gravity disabled, :544-565) moves
+             * one dt with the velocity it holds; envs that are not being reset included */
+            const float zero[3] = {0.0f, 0.0f, 0.0f};
+            for (int a = 0; a < A; ++a) o_integrate(c, ds + 13 * a, zero, zero);
+            for (int i = 0; i < 3 * NT; ++i) tp[i] = tp[i] + b->target_vel[(size_t)e * 3 * NT + i] * c->dt;
+        }
         o_obs_side side;
-        o_obs(c, A, C, K, ds, tp, cyl, 0.0f, b->obs_self + (size_t)e * A * SD,
+        o_obs(c, A, C, K, ds, tp, cyl, b->progress[e], b->obs_self + (size_t)e * A * SD,
               b->obs_others + (size_t)e * A * (A - 1) * 3, b->obs_cylinders + (size_t)e * A * K * 5,
               (c->write_critic_state && b->state_drones) ? b->state_drones + (size_t)e * A * SD : NULL, &side);
         for (int a = 0; a < A; ++a) b->pid_last_rate[((size_t)e * A + a) * 4 + 3] = (float)(side.blocked[a] + 2 * side.blocked1[a]);

@@ -69,8 +69,12 @@ def set_threads(n):
 
 
 def step(cfg, arrs, action):
+    """One step.  `reset_pid` (include/hns.h): an explicit `arrs["reset_pid"]` ([E] u8, or None for NULL) is passed on; without the key the
+    wrapper mirrors the Python env — with cfg.pid_reset_on_reset == 0 (task.pid_reset: reference) the input aliases `done`."""
     action = f32(action)
     b = as_struct(arrs)
+    if "reset_pid" not in arrs and not cfg.pid_reset_on_reset:
+        b.reset_pid = arrs["done"].ctypes.data
     rc = lib().hns_oracle_step(C.byref(cfg), C.byref(b), _p(action))
     assert rc == 0, rc
 

@@ -29,6 +29,8 @@ Fixtures written (tests/golden/*.npz):
   g_grid       continuous_to_grid / grid_to_continuous / set_outside_circle_to_one (hideandseek.py:121-181)
   g_episode_*  closed-loop episodes: reference functions for every stage + the build's
                integrator spec (A5, self-golden for that one stage), teacher-forcing states stored.
+  g_episode_resetpid_*  the same loop with the controller's reset_pid = the root `done` of the stepped tensordict
+               (transforms.py:449-454), across resets of the done envs (their deterministic effects restated, see the function)
 """
 import ast
 import importlib.util
@@ -803,6 +805,124 @@ def gen_episode(tag, E, A, C, T, seed, max_len, action_scale=0.5, task=None, n_a
          meta=np.array([E, A, C, T, max_len], dtype=np.int64))
 
 
+def gen_episode_resetpid(tag, E, A, C, T, seed, max_len, reset_at, action_scale=0.5):
+    """A closed-loop episode whose controller sees the REAL root `done` (transforms.py:449-454: reset_pid = tensordict['done']),
+    crossing resets — VERDICT r3 #4.  As gen_episode, every stage of a step is reference code except the integrator; here the stepped
+    tensordict carries `done` = the `done` the previous step returned (what torchrl's step_mdp hands back as the root), so envs whose
+    episode ended keep pulsing reset_pid until they are reset.  At the steps in `reset_at` the done envs are reset as
+    HideAndSeek._reset_idx (hideandseek.py:609-723) + MultirotorBase._reset_idx (multirotor.py:635-650) leave them — restated here,
+    since those methods are Isaac view calls: placement from a task vector (drawn here, as the envgen path hands one to
+    hns_reset_tasks), identity attitude (rpy box collapsed to zero), zero velocity, hover throttle, zeroed stats, first_capture_step
+    set for ALL envs (:712), prev_action[..., 3] (:714-716), progress 0, root done False, the controller NOT touched, then the one
+    extra physics step of the whole scene (:722-723: integrator spec with zero force and torque, the evader moving with the velocity it
+    holds) and the observation pass (isaac_env.py:221)."""
+    g = torch.Generator().manual_seed(seed)
+    env = ShimEnv(E, A, C, None, max_len=max_len)
+    tr = ShimTransform()
+    s = rand_scene(g, E, A, C, spread=0.5)
+    s["vel"] = s["vel"] * 0.1
+    s["pos"][..., 2] = 0.5 + 0.2 * torch.rand(E, A, generator=g)
+    s["tpos"][..., 2] = 0.5 + 0.2 * torch.rand(E, 1, generator=g)
+    d = env.drone
+    hover = math.sqrt(CF["mass"] * 9.81 / (4 * float(d.rotor_module.KF.data[0, 0, 0])))
+    d.rotor_module.throttle.data.fill_(hover)
+    d.set_state(s["pos"], s["rot"], s["vel"])
+    env.target.pos = s["tpos"].clone()
+    env.cylinders.pos = s["cyl"].clone()
+    env.progress_buf = torch.randint(0, 4, (E,), generator=g).float() + (max_len - 6)     # episodes end at steps 2 .. 5
+    env.info["prev_action"][..., 3] = 0.575
+    env._compute_state_and_obs()
+    names = ["action", "root_done", "pos", "rot", "vel", "tpos", "tvel", "throttle", "integ", "last", "prev_action", "progress", "stats", "aerr",
+             "state_self", "state_others", "cylinders", "state_drones", "reward", "done"]
+    rec = {k: [] for k in names}
+    init = dict(pos=d.w_pos.clone(), rot=d.w_rot.clone(), vel=d.w_vel.clone(), tpos=env.target.pos.clone(), throttle=d.throttle.data.clone(),
+                prev_action=env.info["prev_action"].clone(), progress=env.progress_buf.clone(), stats=_stats_arr(env).clone(), cyl=s["cyl"].clone())
+    resets = {k: [] for k in ["step", "mask", "tasks", "pos", "rot", "vel", "tpos", "cyl", "throttle", "prev_action", "progress", "stats", "integ", "last",
+                              "state_self", "state_others", "cylinders", "state_drones"]}
+    root_done = torch.zeros(E, 1, dtype=torch.bool)
+    zero_f = torch.zeros(E, A, 3)
+    for t in range(T):
+        if t in reset_at:
+            ids = root_done[:, 0].nonzero().squeeze(-1)
+            assert 0 < len(ids) < E or t != reset_at[0], "the first reset must find some envs done and some still running"
+            s2 = rand_scene(g, E, A, C, spread=0.5)
+            s2["pos"][..., 2] = 0.5 + 0.2 * torch.rand(E, A, generator=g)
+            s2["tpos"][..., 2] = 0.5 + 0.2 * torch.rand(E, 1, generator=g)
+            tasks = torch.cat([s2["pos"].reshape(E, -1), s2["tpos"].reshape(E, -1), s2["cyl"].reshape(E, -1)], dim=1)
+            pos, rot, vel = d.w_pos.clone(), d.w_rot.clone(), d.w_vel.clone()
+            pos[ids] = s2["pos"][ids]
+            rot[ids] = torch.tensor([1.0, 0.0, 0.0, 0.0])
+            vel[ids] = 0.0
+            env.target.pos[ids] = s2["tpos"][ids]
+            cyl = env.cylinders.pos.clone()
+            cyl[ids] = s2["cyl"][ids]
+            env.cylinders.pos = cyl
+            d.rotor_module.throttle.data[ids] = hover
+            d.throttle_difference[ids] = 0.0
+            for k in ShimEnv.STATS:
+                env.stats[k][ids] = 0.0
+            env.stats["first_capture_step"] = torch.ones_like(env.stats["first_capture_step"]) * max_len
+            cmd_init = 2.0 * d.throttle.data[ids] ** 2 - 1.0
+            env.info["prev_action"][ids, :, 3] = (0.5 * (CF["max_thrust_ratio"] + cmd_init)).mean(dim=-1)
+            env.prev_actions[ids] = env.info["prev_action"][ids]
+            env.progress_buf[ids] = 0.0
+            # the extra sim.step(): the whole scene, no rotor forces
+            pos, rot, vel, tpos = integrate_spec(pos, rot, vel, zero_f.clone(), zero_f.clone(), env.target.pos, env.target.vel[..., :3].clone(), PHYS)
+            d.set_state(pos, rot, vel)
+            env.target.pos = tpos
+            tdo = env._compute_state_and_obs()
+            root_done = root_done.clone()
+            root_done[ids] = False
+            ob = tdo[("agents", "observation")]
+            mask = torch.zeros(E, dtype=torch.uint8)
+            mask[ids] = 1
+            for k, v in dict(step=torch.tensor(t), mask=mask, tasks=tasks, pos=pos, rot=rot, vel=vel, tpos=tpos, cyl=cyl, throttle=d.throttle.data,
+                             prev_action=env.info["prev_action"], progress=env.progress_buf, stats=_stats_arr(env),
+                             integ=tr.controller.integ.reshape(E, A, 3), last=tr.controller.last_body_rate.reshape(E, A, 3),
+                             state_self=ob["state_self"], state_others=ob["state_others"], cylinders=ob["cylinders"],
+                             state_drones=tdo[("agents", "state")]["state_drones"]).items():
+                resets[k].append(v.clone())
+        action = torch.randn(E, A, 4, generator=g) * action_scale
+        action[..., 3] += 0.3
+        td = TensorDict({"agents": {"action": action.clone()},
+                         "info": {"drone_state": env.info["drone_state"].clone(), "prev_action": env.info["prev_action"].clone()},
+                         "stats": {}, "done": root_done.clone()}, [E])
+        td = tr.inv(td)                                   # A1 + A2 with reset_pid = the root done
+        env._pre_sim_step(td)
+        rotor_f = d.rotor_rec.calls[-1]["forces"].reshape(E, A, 4, 3)
+        base = d.base_link.calls[-1]
+        T_i = rotor_f[..., 2]
+        ang = torch.tensor(CF["rotor_configuration"]["rotor_angles"], dtype=torch.float32)
+        l = torch.tensor(CF["rotor_configuration"]["arm_lengths"], dtype=torch.float32)
+        tsum = ((T_i[..., 0] + T_i[..., 1]) + T_i[..., 2]) + T_i[..., 3]
+        tvec = torch.zeros(E, A, 3); tvec[..., 2] = tsum
+        force_w = ref_torch.quat_rotate(d.w_rot, tvec) + base["forces"].reshape(E, A, 3)
+        yaw = ref_torch.quat_rotate_inverse(d.w_rot, base["torques"].reshape(E, A, 3))[..., 2]
+        sx, cx = torch.sin(ang) * l, torch.cos(ang) * l
+        torque_b = torch.stack([
+            ((sx[0] * T_i[..., 0] + sx[1] * T_i[..., 1]) + sx[2] * T_i[..., 2]) + sx[3] * T_i[..., 3],
+            -(((cx[0] * T_i[..., 0] + cx[1] * T_i[..., 1]) + cx[2] * T_i[..., 2]) + cx[3] * T_i[..., 3]),
+            yaw], dim=-1)
+        tvel = env.target.vel[..., :3].clone()
+        pos, rot, vel, tpos = integrate_spec(d.w_pos, d.w_rot, d.w_vel, force_w, torque_b, env.target.pos, tvel, PHYS)
+        d.set_state(pos, rot, vel)
+        env.target.pos = tpos
+        env.progress_buf = env.progress_buf + 1
+        tdo = env._compute_state_and_obs()
+        out = env._compute_reward_and_done()
+        ob = tdo[("agents", "observation")]
+        for k, v in dict(action=action, root_done=root_done, pos=pos, rot=rot, vel=vel, tpos=tpos, tvel=tvel, throttle=d.throttle.data,
+                         integ=tr.controller.integ.reshape(E, A, 3), last=tr.controller.last_body_rate.reshape(E, A, 3),
+                         prev_action=env.info["prev_action"], progress=env.progress_buf, stats=_stats_arr(env), aerr=env.action_error_order1,
+                         state_self=ob["state_self"], state_others=ob["state_others"], cylinders=ob["cylinders"],
+                         state_drones=tdo[("agents", "state")]["state_drones"], reward=out[("agents", "reward")], done=out["done"]).items():
+            rec[k].append(v.clone())
+        root_done = out["done"].clone()                   # step_mdp: next.done becomes the root done of the next stepped tensordict
+    assert torch.stack(rec["root_done"]).any(), "no reset_pid pulse in the sequence"
+    save(f"g_episode_{tag}", **{"init_" + k: v for k, v in init.items()}, **{k: torch.stack(v) for k, v in rec.items()},
+         **{"reset_" + k: torch.stack(v) for k, v in resets.items()}, meta=np.array([E, A, C, T, max_len], dtype=np.int64))
+
+
 if __name__ == "__main__":
     gen_utils()
     gen_rotor()
@@ -820,6 +940,8 @@ if __name__ == "__main__":
     FREE = ("action", "pos", "rot", "vel", "tpos", "tvel", "progress", "reward", "done", "state_self")
     gen_episode("free_a3c8", E=16, A=3, C=8, T=100, seed=20250301, max_len=120, keep=FREE)
     gen_episode("free_a6c16", E=8, A=6, C=16, T=100, seed=20250302, max_len=120, keep=FREE)
+    # the controller's reset_pid fed with the real root `done`, across two resets
+    gen_episode_resetpid("resetpid_a3c5", E=16, A=3, C=5, T=14, seed=20260927, max_len=40, reset_at=(4, 9))
 
 
 # --------------------------------------------------------------------------------------

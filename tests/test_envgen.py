@@ -100,7 +100,7 @@ def test_easy_cases_take_the_cells_a_flood_reaches_first():
 
 def test_oracle_reset_from_task_vectors():
     E, A, Cn = 40, 3, 5
-    cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": Cn, "min_num": 4}, "env": {"num_envs": E}})
+    cfg = config.make_cfg({"num_agents": A, "reset_extra_step": 0, "cylinder": {"max_num": Cn, "min_num": 4}, "env": {"num_envs": E}})   # the placement itself
     c = config.resolve_hns_cfg(cfg)
     gb = GenBuffer(A, Cn, seed=3)
     tasks = _valid_tasks(gb, E, np.random.default_rng(4))
@@ -272,7 +272,7 @@ def test_two_evader_task_vectors():
     check, perturbation and task reset."""
     import hns_oracle as O
     E, A, Cn = 48, 4, 6
-    c = config.resolve_hns_cfg(config.make_cfg({"num_agents": A, "num_targets": 2, "cylinder": {"max_num": Cn, "min_num": 3}, "env": {"num_envs": E}}))
+    c = config.resolve_hns_cfg(config.make_cfg({"num_agents": A, "num_targets": 2, "reset_extra_step": 0, "cylinder": {"max_num": Cn, "min_num": 3}, "env": {"num_envs": E}}))
     gb = GenBuffer(A, Cn, seed=1, num_targets=2, buffer_length=64)
     assert gb.task_dim == 3 * (A + 2 + Cn) and gb.task_bounds().shape == (gb.task_dim, 2)
     tasks = _valid_tasks(gb, E, np.random.default_rng(2))

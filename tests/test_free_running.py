@@ -19,7 +19,8 @@ TAGS = ["free_a3c8", "free_a6c16"]
 
 
 def _cfg(E, A, C, max_len):
-    return config.make_cfg({"num_agents": A, "cylinder": {"max_num": C, "obs_max_cylinder": 3, "min_num": min(4, C)},
+    # (fixtures generated with `done = False` on every stepped tensordict: no reset_pid through the step, see test_oracle_episode._cfg)
+    return config.make_cfg({"num_agents": A, "pid_reset": "on_reset", "cylinder": {"max_num": C, "obs_max_cylinder": 3, "min_num": min(4, C)},
                             "env": {"num_envs": E, "max_episode_length": max_len}})
 
 

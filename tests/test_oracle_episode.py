@@ -11,7 +11,9 @@ from hns_amd import abi, config
 
 def _cfg(E, A, C, max_len, n_active=None):
     cyl = {"max_num": C, "obs_max_cylinder": 3, "min_num": min(4, C)}
-    cfg = config.make_cfg({"num_agents": A, "cylinder": cyl, "env": {"num_envs": E, "max_episode_length": max_len}})
+    # (these episodes were generated with `done = False` on every stepped tensordict — make_golden.py gen_episode — so the controller is
+    #  never reset through the step: task.pid_reset = on_reset binds no reset_pid input; g_episode_resetpid covers the other mode)
+    cfg = config.make_cfg({"num_agents": A, "pid_reset": "on_reset", "cylinder": cyl, "env": {"num_envs": E, "max_episode_length": max_len}})
     return config.resolve_hns_cfg(cfg)
 
 

@@ -61,7 +61,7 @@ def test_step_invariants(seed, A, C, scale):
 @given(seed=st.integers(0, 2**31 - 1))
 def test_done_and_stats_division(seed):
     E, A, L = 16, 3, 9
-    c, arrs = _env(E, A, 5, seed, max_len=L)
+    c, arrs = _env(E, A, 5, seed, max_len=L, reset_extra_step=0)     # (with the extra physics step a reset moves every env: next test)
     rng = np.random.default_rng(seed)
     sidx = abi.STAT_NAMES.index
     for t in range(L):
@@ -84,9 +84,42 @@ def test_done_and_stats_division(seed):
     assert (arrs["progress"][::2] == 0).all() and not arrs["stats"][:, ::2][np.arange(24) != sidx("first_capture_step")].any()
 
 
+@settings(max_examples=5, deadline=None)
+@given(seed=st.integers(0, 2**31 - 1))
+def test_reset_extra_step_moves_the_whole_scene(seed):
+    """hideandseek.py:722-723 (task.reset_extra_step: 1): `_reset_idx` ends with one physics step of every env — no rotor forces, so a
+    drone's new state is the integrator applied with zero force and torque, an evader moves by dt times the velocity it holds; the
+    controller state is not touched (task.pid_reset: reference), the done flag of the reset envs is cleared."""
+    E, A, L = 12, 3, 6
+    c0, arrs0 = _env(E, A, 5, seed, max_len=L, reset_extra_step=0)
+    c1, arrs1 = _env(E, A, 5, seed, max_len=L, reset_extra_step=1)
+    assert c1.reset_extra_step == 1 and c1.pid_reset_on_reset == 0
+    # first reset (all envs): the placement of the plain reset, then one free-fall step
+    ds = O.integrate(c0, arrs0["drone_state"], np.zeros((E * A, 3), np.float32), np.zeros((E * A, 3), np.float32))
+    assert (arrs1["drone_state"].reshape(E * A, 13) == ds).all() and (ds[:, 9] < 0).all()      # falling
+    assert (arrs1["target_pos"] == arrs0["target_pos"]).all()                                    # the evader held no velocity yet
+    rng = np.random.default_rng(seed)
+    for t in range(L):
+        O.step(c1, arrs1, rng.standard_normal((E, A, 4)).astype(np.float32))
+    assert arrs1["done"].all()
+    keep = {k: v.copy() for k, v in arrs1.items()}
+    mask = np.zeros(E, np.uint8)
+    mask[::3] = 1
+    O.reset(c1, arrs1, mask, seed, 1)
+    others = mask == 0
+    n = int(others.sum()) * A
+    ds = O.integrate(c1, keep["drone_state"][others], np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32))
+    assert (arrs1["drone_state"][others].reshape(-1, 13) == ds).all()
+    assert (arrs1["target_pos"][others] == keep["target_pos"][others] + keep["target_vel"][others] * np.float32(c1.dt)).all()
+    assert (arrs1["progress"][others] == L).all() and arrs1["done"][others].all() and not arrs1["done"][mask == 1].any()
+    assert (arrs1["pid_integ"] == keep["pid_integ"]).all() and (arrs1["pid_last_rate"][..., :3] == keep["pid_last_rate"][..., :3]).all()
+    assert (arrs1["obs_self"][others][..., 3:10] == arrs1["drone_state"][others][..., 3:10]).all()       # the observation follows the moved state
+    assert (arrs1["target_pos"][mask == 1] != keep["target_pos"][mask == 1]).any()
+
+
 def test_reset_distribution_matches_reference_ranges():
     """hideandseek.py:283-313,576-607: sampling boxes, 9x9 grid cells, distinct free cells, active counts."""
-    c, arrs = _env(4096, 3, 5, 1234)
+    c, arrs = _env(4096, 3, 5, 1234, reset_extra_step=0)
     r = 0.9 / np.sqrt(2.0)
     p = arrs["drone_state"][..., :3]
     assert (p[..., 0] >= 0.1).all() and (p[..., 0] <= r - 0.1 + 1e-6).all() and (np.abs(p[..., 1]) <= r - 0.1 + 1e-6).all()

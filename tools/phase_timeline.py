@@ -2,7 +2,7 @@
 """Absolute timeline of the step kernel's phases by dispatch round (blockIdx / 256): when do the workgroups that
 share a CU load, compute and store?  Uses the per-wave phase stamps (hns_set_phase_profile): slot 14/15 are the
 chip-wide 100 MHz clock at start/end, the others the shader clock; each wave's stamps are placed on the chip-wide
-axis through its own start.  HNS_LIBRARY / HNS_LAB_STAGGER / HNS_LAB_FLAGS select the build and the experiment."""
+axis through its own start.  HNS_LIBRARY selects the build."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

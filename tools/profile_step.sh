@@ -15,5 +15,6 @@ for d in stats pmc1 pmc2 pmc3; do
   db=$(ls $OUT/$d/*/*.db 2>/dev/null | head -1)
   [ -n "$db" ] && python tools/rocpd_summary.py "$db" hns_ > $OUT/$d.csv && rm -rf $OUT/$d
 done
-grep -h '"metric"' $OUT/stats.log | cut -c1-120
-cat $OUT/*.csv
+# the profile file: tables + a header computed from them (KERNEL / BYTES name the kernel and its algorithmic bytes per launch)
+python tools/make_profile_txt.py $OUT "${KERNEL:-hns_step_v4_kernelILi3ELi1}" "${BYTES:-100466688}" "$TAG - tools/profile_step.sh $TAG $*" > $OUT/profile.txt
+head -12 $OUT/profile.txt
