@@ -73,6 +73,10 @@ def parse_args():
                     help="optional extra leg (e.g. 2): the env batch as shards on separate HIP streams of one GPU, reported as "
                          "`stream_shards`; off by default so that a profile of the default command holds whole-batch launches only")
     ap.add_argument("--group-steps", type=int, default=1000)
+    ap.add_argument("--state-digest", type=int, default=0,
+                    help="check-out for the multi-GPU plumbing (tests/test_bench_contract.py): S > 0 = the job's env batch is stepped with ONE global action stream "
+                         "(every rank takes its slice) and the line carries sha256 digests of the state after the timed region, one per S equal env slices of the "
+                         "GLOBAL batch, so a W-rank run and a 1-rank run of the same global batch can be compared slice by slice")
     ap.add_argument("--tp-steps", type=int, default=300,
                     help="extra leg: steps with the trajectory predictor in the observation (algo.use_TP_net: 1, the reference's "
                          "default config), reported as `tp_mode`; 0 = skip")
@@ -243,7 +247,13 @@ def main():
     lib, henv = env._lib, env._env
     stream = torch.cuda.current_stream(device)
     sptr = Cx.c_void_p(stream.cuda_stream)
-    actions, tds = action_ring(E, A, 1000 + rank)
+    if args.state_digest:
+        # one action stream for the global batch: generated whole on every rank (same seed), sliced by rank
+        gen = torch.Generator(device=device).manual_seed(1000)
+        actions = [torch.randn(world * E, A, 4, generator=gen, device=device)[rank * E:(rank + 1) * E].contiguous() for _ in range(8)]
+        tds = [TensorDict({"agents": {"action": a}}, [E]) for a in actions]
+    else:
+        actions, tds = action_ring(E, A, 1000 + rank)
     aptr = [Cx.c_void_p(a.data_ptr()) for a in actions]
     R = len(actions)
     reward, success = env._bufs["reward"], env.stats["success"]
@@ -314,6 +324,28 @@ def main():
     env.enable_kernel_timing(0)
     region_ms = env.region_ms()
     in_ms, in_n = env.kernel_ms() if in_region_events else (-1.0, 0)
+    state_digest = None
+    if args.state_digest:
+        import hashlib
+        S = args.state_digest
+        assert S % world == 0 and E % (S // world) == 0, "--state-digest: the slices must tile every rank's shard"
+        per, n = S // world, E // (S // world)
+        st = env.export_state()
+        mine = []
+        for i in range(per):
+            h = hashlib.sha256()
+            for k in sorted(st):
+                if k == "nonfinite":
+                    continue
+                v = st[k]
+                h.update(v[:, i * n:(i + 1) * n].tobytes() if k == "stats" else v[i * n:(i + 1) * n].tobytes())
+            mine.append(h.hexdigest())
+        if world > 1:
+            allv = [None] * world
+            dist.all_gather_object(allv, mine)
+            state_digest = [d for r in allv for d in r]
+        else:
+            state_digest = mine
     env.enable_kernel_timing(1)
     for i in range(16):
         env.step(tds[i % R])
@@ -379,13 +411,16 @@ def main():
         roofline["kernel"] = "hns_step_v4_kernel<%d,%d,%s,4,false>" % (A, args.targets, "false" if E % 64 == 0 else "true")
         if kernel_by_rank:
             roofline["kernel_us_by_rank"] = {"min": min(kernel_by_rank), "max": max(kernel_by_rank), "all": kernel_by_rank}
-        # achievable HBM bandwidth on this box ("measure achievable with a device copy kernel and report both"): the library's
-        # float4 copy kernel (hns_copy_f4; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy), 256 MB read + 256 MB written per pass
+        # achievable bandwidth on this box ("measure achievable with a device copy kernel and report both"): the library's float4
+        # copy kernel (hns_copy_f4; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy) at two footprints — 2 x 48 MiB, about what one
+        # step of the headline batch touches (the 256 MiB Infinity Cache holds it between launches, as it holds the step's buffers), and
+        # 2 x 1 GiB (every byte to / from HBM)
         try:
-            copy_gbs = round(env.device_copy_GBs(256, 20), 1)
-            roofline["device_copy_GBs"] = copy_gbs
-            roofline["device_copy_kernel"] = "hns_copy_f4_kernel (float4 per lane, four pieces per thread), 2 x 256 MiB per pass"
-            roofline["frac_of_device_copy"] = round(roofline["achieved"] / copy_gbs, 4)
+            like, hbm = round(env.device_copy_GBs(48, 40), 1), round(env.device_copy_GBs(1024, 10), 1)
+            roofline["device_copy_GBs"] = hbm
+            roofline["device_copy_GBs_at_step_footprint"] = like
+            roofline["device_copy_kernel"] = "hns_copy_f4_kernel (one float4 per thread): 2 x 1 GiB per pass (HBM only) / 2 x 48 MiB per pass (Infinity-Cache resident, like the step's 105 MB)"
+            roofline["frac_of_device_copy"] = round(roofline["achieved"] / (like if E * algorithmic_bytes_per_env(A, C, K, NT=args.targets) < 200e6 else hbm), 4)
         except Exception as ex:  # noqa: BLE001
             roofline["device_copy_error"] = str(ex)[:200]
 
@@ -613,7 +648,7 @@ def main():
                        "episode_length": args.episode, "critic_state_output": args.critic_state,
                        "sharding": f"contiguous env slices x{n_ranks}", "world_size_launched": world, "ranks": n_ranks,
                        "collective": "1 all-gather of 5 fp64 per 64-step rollout" if world > 1 else "none"},
-            "collective_us": collective,
+            "collective_us": collective, "state_digest": state_digest,
             "env_frames_per_s": round(value / A, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "abi_rate": abi_rate, "configs": configs or None,
             "tp_mode": tp_mode, "stream_shards": streams_mode,

@@ -364,7 +364,7 @@ int hns_region_begin(hns_env *env, void *stream);
 int hns_region_end(hns_env *env, void *stream);
 float hns_region_ms(hns_env *env);
 /* Measurement yardstick (SURVEY §8d "achievable with a device copy kernel"): dst[i] = src[i] over `bytes` (a multiple of 16, both 16-byte
- * aligned device pointers) as 16-byte loads / stores, one float4 per thread and pass.  Not part of the environment. */
+ * aligned device pointers) as 16-byte loads / stores, one float4 per thread.  Not part of the environment. */
 int hns_copy_f4(void *dst, const void *src, size_t bytes, void *stream);
 
 /* Diagnostics: attach a device buffer of [num_waves, 16] uint64 (num_waves = ceil(E/64)*(A+1)); lane 0

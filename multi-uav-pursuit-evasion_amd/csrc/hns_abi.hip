@@ -258,16 +258,12 @@ __global__ __launch_bounds__(256) void hns_raycast_kernel(const RayParams p) {
     }
 }
 
-// measurement yardstick (hns_copy_f4): a plain float4 copy, four pieces per thread, all four loads in flight before the first store
+// measurement yardstick (hns_copy_f4): a plain float4 copy, one piece per thread.  Of the shapes tried on this chip (tools/microbench/copy_rate.hip:
+// 4 / 8 pieces per thread, persistent grid-stride grids, non-temporal accesses, hipMemcpyAsync) this simplest one is the fastest or within 5 % of the
+// fastest at every size: 6.6-7.1 TB/s for footprints the Infinity Cache holds, 6.0-6.25 TB/s beyond it (MI355X_MICROARCH.md: 6.29).
 __global__ __launch_bounds__(256) void hns_copy_f4_kernel(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n4) {
-    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
-    float4 v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (base + i * 256 < n4) v[i] = src[base + i * 256];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (base + i * 256 < n4) dst[base + i * 256] = v[i];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) dst[i] = src[i];
 }
 
 }  // namespace hns
@@ -729,9 +725,9 @@ int hns_copy_f4(void *dst, const void *src, size_t bytes, void *stream) {
     }
     const size_t n4 = bytes / 16;
     if (n4 == 0) return HNS_OK;
-    constexpr int kPer = 4, kT = 256;                    // four float4 per thread, a wave's four passes each one contiguous 1 KB
-    const size_t blocks = (n4 + (size_t)kT * kPer - 1) / ((size_t)kT * kPer);
-    hipLaunchKernelGGL(hns::hns_copy_f4_kernel, dim3((unsigned)blocks), dim3(kT), 0, static_cast<hipStream_t>(stream),
+    const size_t blocks = (n4 + 255) / 256;
+    if (blocks > 0x7fffffffull) { set_error("hns_copy_f4: more than 2^31 workgroups"); return HNS_ERR_INVALID_ARG; }
+    hipLaunchKernelGGL(hns::hns_copy_f4_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<float4 *>(dst), static_cast<const float4 *>(src), n4);
     HNS_CHECK_HIP(hipGetLastError());
     return HNS_OK;

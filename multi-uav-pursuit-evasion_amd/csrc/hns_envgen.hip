@@ -37,6 +37,7 @@ struct FpsParams {
     int n, d, k, start, groups;
     int in_lds;            // the workgroup's points are staged in LDS (rows of d+1 floats: conflict-free)
     int xcds;              // hns_fps_xcd_kernel: workgroups with blockIdx % 8 < xcds work (1 or 2 XCDs)
+    int batch;             // hns_fps_xcd_kernel: candidates per exchange (1 .. kFxB; below)
     int32_t *out_idx;      // [k]
     unsigned long long *scratch;   // [0]: error word; [8 ..): granules [2 parity][groups]
 };
@@ -192,17 +193,183 @@ __global__ __launch_bounds__(kFpsThreads) void hns_fps_kernel(const FpsParams p)
 // those with blockIdx % 8 != 0 — by the round-robin dispatch, the ones on the other XCDs — leave at once.
 constexpr int kFxThreads = 1024, kFxGroups = 32, kFxStride = 8, kFxPts = 2, kFxD = 36;
 
+// Several samples per exchange (round 4).  Sequential farthest-point sampling is k strictly dependent rounds, and a round costs its
+// latency (exchange 0.8 us + the dependent fetch of the winner + two workgroup barriers), not its arithmetic.  But the NEXT samples are
+// often already decided: let p1 > p2 > ... be the candidates in key order (min-distance, ties -> lower index) BEFORE p1 is applied.  Applying
+// p1 can only lower keys.  If dist(p2, p1) >= d(p2), p2's key does not move, every other key was below it and stays below it: p2 IS the
+// next sample of the sequential algorithm.  By induction p_m is accepted when dist(p_m, p_j) >= d(p_m) for all accepted j < m; at the
+// first candidate that fails the prefix ends (its key drops, the next sample may be any point).  So an exchange carries the top kFxB
+// candidates of every workgroup, every workgroup derives the same global top kFxB, wave 0 evaluates the kFxB (kFxB - 1) / 2 pair
+// distances with the SAME sequential fma chain the update uses (so ">= d" decides exactly what min(d, dist) would), and the accepted
+// prefix is applied in one round.  The indices are those of sequential sampling, bit for bit (tests/test_hip_envgen.py against the oracle's
+// sequential loop); only the number of exchanges changes: ~k / (mean accepted) instead of k.
+constexpr int kFxB = 4;
+
+// The workgroup's top `nb` keys (uniform result in top[]): nb max-reductions; the thread that owns a winner pops it from its sorted pair.
+template <int THREADS>
+HNS_DEV void fps_top(unsigned long long (&mine)[2], int nb, unsigned long long (*s_red)[THREADS / 64], unsigned long long (&top)[kFxB]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int pass = 0; pass < kFxB; ++pass) {
+        top[pass] = 0ull;
+        if (pass < nb) {
+            unsigned long long best = mine[0];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const unsigned long long o = __shfl_xor(best, off);
+                best = o > best ? o : best;
+            }
+            if (lane == 0) s_red[pass & 1][wave] = best;
+            __syncthreads();                             // (double-buffered by pass parity: one barrier per pass)
+            best = s_red[pass & 1][lane & (THREADS / 64 - 1)];
+#pragma unroll
+            for (int off = THREADS / 128; off >= 1; off >>= 1) {
+                const unsigned long long o = __shfl_xor(best, off);
+                best = o > best ? o : best;
+            }
+            top[pass] = best;
+            if (best != 0ull && mine[0] == best) { mine[0] = mine[1]; mine[1] = 0ull; }
+        }
+    }
+}
+
+// One exchange: publish the workgroup's top `nb` candidates, sweep everybody's, take the global top nb, accept the prefix that sequential
+// sampling would select next (at most max_accept).  Returns the number accepted (their indices in s_acc), or -1 after reporting that a
+// workgroup never showed up.
+template <int THREADS>
+HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, int r, const unsigned long long (&top)[kFxB], int nb, int max_accept,
+                           int *s_acc, int *s_nacc, int *s_fail, float *warm) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = p.d;
+    const unsigned long long tag = (unsigned long long)(r % 4095 + 1) << 52;
+    gu64 *slot = gran + (size_t)(r & 1) * G * kFxB;
+    if (tid < kFxB) {
+        unsigned long long mine = 0ull;
+#pragma unroll
+        for (int i = 0; i < kFxB; ++i) mine = tid == i ? top[i] : mine;
+        if (tid < nb) {
+            __hip_atomic_store(slot + g_self * kFxB + tid, tag | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mine != 0ull) {
+                // pull the candidate's row into the XCD's L2 while the exchange is in flight: if it wins, every workgroup fetches it next
+                const int ci = (int)(0xFFFFFu - (unsigned)(mine & 0xFFFFFu));
+                const float *row = p.points + (size_t)ci * d;
+                float a = row[0];
+                for (int c = 8; c < d; c += 8) a += row[c];
+                *warm += a + row[d - 1];
+            }
+        }
+    }
+    if (wave == 0) {
+        constexpr int U = kFxGroups * 2 * kFxB / 64;          // granules per lane at two XCDs
+        unsigned long long v[U];
+        const int total = G * kFxB;
+        bool fail = false;
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int g = u * 64 + lane;                    // granule (workgroup g / kFxB, candidate g % kFxB): only the first nb of a workgroup are written
+                const bool live = g < total && (g & (kFxB - 1)) < nb;
+                v[u] = live ? __hip_atomic_load(slot + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) ok = ok && ((v[u] >> 52) == (tag >> 52));
+            if (__all(ok)) break;
+            if (++spins > kFpsSpinLimit) { fail = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] &= 0xFFFFFFFFFFFFFull;
+        // the global top nb: nb max-reductions over the wave, the lane holding a winner clears it
+        unsigned long long gtop[kFxB];
+#pragma unroll
+        for (int pass = 0; pass < kFxB; ++pass) {
+            unsigned long long gb = 0ull;
+            if (pass < nb) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) gb = v[u] > gb ? v[u] : gb;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const unsigned long long o = __shfl_xor(gb, off);
+                    gb = o > gb ? o : gb;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = (gb != 0ull && v[u] == gb) ? 0ull : v[u];
+            }
+            gtop[pass] = gb;
+        }
+        int gi[kFxB];
+        float gd[kFxB];
+#pragma unroll
+        for (int m = 0; m < kFxB; ++m) {
+            gi[m] = (int)(0xFFFFFu - (unsigned)(gtop[m] & 0xFFFFFu));
+            const unsigned key = (unsigned)(gtop[m] >> 20);      // min-distance bits + 1; 0 = no candidate (or a point already chosen)
+            gd[m] = key != 0u ? __uint_as_float(key - 1u) : kInf;
+        }
+        // pair (a < b) on lane a + b (b - 1) / 2: the update's own chain, dist(x = candidate b, q = candidate a)
+        int pa = 0, pb = 1;
+#pragma unroll
+        for (int b2 = 1; b2 < kFxB; ++b2)
+#pragma unroll
+            for (int a2 = 0; a2 < b2; ++a2)
+                if (lane == a2 + b2 * (b2 - 1) / 2) { pa = a2; pb = b2; }
+        int ia = gi[0], ib = gi[1];
+#pragma unroll
+        for (int m = 0; m < kFxB; ++m) { ia = pa == m ? gi[m] : ia; ib = pb == m ? gi[m] : ib; }
+        float acc = 0.0f;
+        if (!fail && nb > 1 && lane < kFxB * (kFxB - 1) / 2 && pb < nb && gtop[0] != 0ull) {
+            const bool have = (pb == 1 ? gtop[1] : pb == 2 ? gtop[2] : gtop[3]) != 0ull;
+            if (have) {
+                const float *xa = p.points + (size_t)ia * d, *xb = p.points + (size_t)ib * d;
+                for (int c = 0; c < d; ++c) {
+                    const float df = xb[c] - xa[c];
+                    acc = HNS_FMA(df, df, acc);
+                }
+            }
+        }
+        // accepted prefix: candidate m needs dist(m, j) >= d(m) for every j < m
+        int nacc = gtop[0] != 0ull ? 1 : 0;
+        bool open = nacc == 1;
+#pragma unroll
+        for (int m = 1; m < kFxB; ++m) {
+            bool okm = open && m < nb && gtop[m] != 0ull;
+#pragma unroll
+            for (int j = 0; j < m; ++j) {
+                const float dj = __shfl(acc, j + m * (m - 1) / 2);
+                okm = okm && (dj >= gd[m]);
+            }
+            open = okm;
+            nacc += okm ? 1 : 0;
+        }
+        nacc = nacc < max_accept ? nacc : max_accept;
+        if (lane == 0) {
+            *s_nacc = nacc;
+#pragma unroll
+            for (int m = 0; m < kFxB; ++m) s_acc[m] = gi[m];
+            if (fail || gtop[0] == 0ull) *s_fail = 1;          // (no candidate at all cannot happen while samples are still due: k <= n)
+        }
+    }
+    __syncthreads();
+    if (*s_fail) {
+        if (tid == 0) __hip_atomic_store((gu64 *)p.scratch, 1ull + (unsigned long long)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return -1;
+    }
+    return *s_nacc;
+}
+
 // FULL: exactly 36 coordinates (16-byte row loads, wide scalar loads).  Otherwise rows are zero-padded to 36 in registers: a zero
 // difference leaves the sequential fma chain unchanged, bit for bit (acc + 0 * 0 = acc for acc >= 0).
 template <bool FULL>
 __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams p) {
     if ((int)(blockIdx.x % kFxStride) >= p.xcds) return;
-    __shared__ unsigned long long s_best[kFxThreads / 64];
-    __shared__ int s_cur;
+    __shared__ unsigned long long s_red[2][kFxThreads / 64];
+    __shared__ int s_acc[kFxB];
+    __shared__ int s_nacc;
     __shared__ int s_fail;
     const int G = kFxGroups * p.xcds;
     const int tid = threadIdx.x, g_self = (blockIdx.x / kFxStride) * p.xcds + blockIdx.x % kFxStride;
     const int gtid = g_self * kFxThreads + tid, stride = G * kFxThreads, d = FULL ? kFxD : p.d;
+    const int nb = p.batch < 1 ? 1 : (p.batch > kFxB ? kFxB : p.batch);
     gu64 *gran = (gu64 *)(p.scratch + 8);
     typedef const float __attribute__((address_space(4))) cfloat;      // `points` is immutable while the kernel runs: constant memory
     cfloat *qbase = (cfloat *)p.points;
@@ -226,43 +393,65 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         }
     }
     if (tid == 0) s_fail = 0;
-    int cur = p.start;
+    int cur[kFxB] = {p.start, 0, 0, 0};
+    int ncur = 1, nout = 0;
     float warm = 0.0f;                                  // sum of the rows touched to warm the L2 (kept alive by the store below)
     __syncthreads();
-    for (int r = 0; r < p.k; ++r) {
-        if (g_self == 0 && tid == 0) p.out_idx[r] = cur;
-        if (r == p.k - 1) break;
-        // the newest sample: uniform address -> scalar loads, 12 coordinates at a time, used as scalar operands; every point's
-        // distance stays ONE sequential fmaf chain over the coordinates (= the oracle)
-        cfloat *qrow = qbase + (size_t)__builtin_amdgcn_readfirstlane(cur) * d;
-        float acc[kFxPts];
+    for (int r = 0;; ++r) {                             // r counts exchanges, nout the samples written
+        if (g_self == 0 && tid < ncur) {
+            int mine = cur[0];
 #pragma unroll
-        for (int j = 0; j < kFxPts; ++j) acc[j] = 0.0f;
-#pragma unroll
-        for (int c0 = 0; c0 < kFxD; c0 += 12) {
-            float q[12];
-#pragma unroll
-            for (int c = 0; c < 12; ++c) q[c] = (FULL || c0 + c < d) ? qrow[(FULL || c0 + c < d) ? c0 + c : 0] : 0.0f;
-#pragma unroll
-            for (int j = 0; j < kFxPts; ++j)
-#pragma unroll
-                for (int c = 0; c < 12; ++c) {
-                    const float df = x[j][c0 + c] - q[c];
-                    acc[j] = HNS_FMA(df, df, acc[j]);
-                }
+            for (int m = 1; m < kFxB; ++m) mine = tid == m ? cur[m] : mine;
+            p.out_idx[nout + tid] = mine;
         }
-        unsigned long long best = 0;
+        nout += ncur;
+        if (nout >= p.k) break;
+        // the newest samples: uniform addresses -> scalar loads, 12 coordinates at a time, used as scalar operands; every point's
+        // distance to each of them stays ONE sequential fmaf chain over the coordinates (= the oracle)
+        for (int m = 0; m < ncur; ++m) {
+            const int cm = __builtin_amdgcn_readfirstlane(m == 0 ? cur[0] : m == 1 ? cur[1] : m == 2 ? cur[2] : cur[3]);
+            cfloat *qrow = qbase + (size_t)cm * d;
+            float acc[kFxPts];
+#pragma unroll
+            for (int j = 0; j < kFxPts; ++j) acc[j] = 0.0f;
+#pragma unroll
+            for (int c0 = 0; c0 < kFxD; c0 += 12) {
+                float q[12];
+#pragma unroll
+                for (int c = 0; c < 12; ++c) q[c] = (FULL || c0 + c < d) ? qrow[(FULL || c0 + c < d) ? c0 + c : 0] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < kFxPts; ++j)
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) {
+                        const float df = x[j][c0 + c] - q[c];
+                        acc[j] = HNS_FMA(df, df, acc[j]);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < kFxPts; ++j) {
+                const int i = gtid + j * stride;
+                // a chosen point leaves the pool (-1 never wins), so the k indices are distinct even among duplicates
+                dist[j] = (i == cm) ? -1.0f : (acc[j] < dist[j] ? acc[j] : dist[j]);
+            }
+        }
+        unsigned long long mine[2] = {0ull, 0ull};
 #pragma unroll
         for (int j = 0; j < kFxPts; ++j) {
             const int i = gtid + j * stride;
-            const float m = (i == cur) ? -1.0f : (acc[j] < dist[j] ? acc[j] : dist[j]);
-            dist[j] = m;
+            const float m = dist[j];
             const unsigned long long key = m < 0.0f ? 0ull : (unsigned long long)__float_as_uint(m) + 1ull;
-            const unsigned long long cand = (key << 20) | (unsigned long long)(0xFFFFFu - (unsigned)i);
-            if (i < p.n) best = cand > best ? cand : best;
+            const unsigned long long cand = (i < p.n && key != 0ull) ? ((key << 20) | (unsigned long long)(0xFFFFFu - (unsigned)i)) : 0ull;
+            if (cand > mine[0]) { mine[1] = mine[0]; mine[0] = cand; }
+            else if (cand > mine[1]) mine[1] = cand;
         }
-        cur = fps_exchange<kFxThreads>(p, gran, G, g_self, r, best, s_best, &s_cur, &s_fail, nullptr, &warm);
-        if (cur < 0) return;
+        static_assert(kFxPts == 2, "a thread's candidates are a sorted pair");
+        unsigned long long top[kFxB];
+        fps_top<kFxThreads>(mine, nb, s_red, top);
+        const int left = p.k - nout;
+        ncur = fps_exchange_b<kFxThreads>(p, gran, G, g_self, r, top, nb, left < kFxB ? left : kFxB, s_acc, &s_nacc, &s_fail, &warm);
+        if (ncur < 0) return;
+#pragma unroll
+        for (int m = 0; m < kFxB; ++m) cur[m] = s_acc[m];
     }
     if (warm == -1.0f) p.scratch[1] = 1;               // never true (coordinates are normalised to [0, 1]): the loads above are not dead
 }
@@ -363,7 +552,7 @@ int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start,
     HNS_CHECK_HIP(hipMemsetAsync(scratch, 0, hns_fps_scratch_bytes(), s));
     hns::FpsParams p;
     p.points = points; p.n = n; p.d = d; p.k = k; p.start = start; p.groups = groups;
-    p.out_idx = out_idx; p.scratch = (unsigned long long *)scratch; p.xcds = 0;
+    p.out_idx = out_idx; p.scratch = (unsigned long long *)scratch; p.xcds = 0; p.batch = 1;
     // the generator's own shape: the XCD-local kernel (same results; HNS_FPS_KERNEL=chip keeps the chip-wide one, for A/B measurements)
     static const bool chip_only = [] { const char *e = getenv("HNS_FPS_KERNEL"); return e && e[0] == 'c'; }();
     const int fx_cap = hns::kFxGroups * hns::kFxThreads * hns::kFxPts;        // points one XCD's registers hold
@@ -371,6 +560,9 @@ int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start,
         cus >= hns::kFxGroups * hns::kFxStride && (reinterpret_cast<uintptr_t>(points) & 15) == 0) {
         p.xcds = n <= fx_cap ? 1 : 2;                 // two XCDs: the exchange crosses the fabric once, still a quarter of the chip
         p.groups = hns::kFxGroups * p.xcds; p.in_lds = 0;
+        // samples per exchange (HNS_FPS_BATCH=1 keeps one per exchange, for A/B measurements; the indices are the same either way)
+        static const int batch = [] { const char *e = getenv("HNS_FPS_BATCH"); const int b = e ? atoi(e) : hns::kFxB; return b < 1 ? 1 : (b > hns::kFxB ? hns::kFxB : b); }();
+        p.batch = batch;
         hipLaunchKernelGGL(d == hns::kFxD ? hns::hns_fps_xcd_kernel<true> : hns::hns_fps_xcd_kernel<false>, dim3(hns::kFxGroups * hns::kFxStride),
                            dim3(hns::kFxThreads), 0, s, p);
         HNS_CHECK_HIP(hipGetLastError());

@@ -1084,6 +1084,39 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : NXC == 2 ? WS_OCC2 
 #endif
             WS_STAMP(2)                                    // 2: matrix products of the tile
             // cell update of units 8 r + 4 hb + j (torch.nn.LSTM gate order i, f, g, o = accumulator registers j, 4 + j, 8 + j, 12 + j)
+#ifndef TP_CELL_V1
+            // Round 4: 22 vector instructions per unit, 8 of them transcendental (was 26 / 9).  With e_x = 2^(pre-activation) (the weight
+            // image carries -log2 e, -2 log2 e for the g gate):
+            //   sigmoid(i) tanh(g) = (2 - E_g) / (E_i E_g) = (1 - e_g) / fma(e_i, E_g, E_g)                 one reciprocal for both gates,
+            //   o tanh(c')         = (1 - e_c) / fma(e_o, E_c, E_c)                                         the "1 +" of E_i / E_o folded into the fma,
+            //   the fp16 split of h = P Q straight from the exact product: hi = RN16(P Q) (v_fma_mixlo/hi_f16), lo = RN16(P Q - hi) (the same
+            //   instruction with hi as its f16 addend): two instructions instead of multiply + convert + convert back + subtract + convert, the
+            //   halves land packed, and hi + lo carries P Q to 2^-22 whichever way hi rounded.
+            // Saturated gates: e_i or e_o = inf -> the fma is inf, its reciprocal 0, the term 0 (P and 1 - e_g are finite: e_g is clamped to 2^64,
+            // e_c <= 2^(2.9 T)); e_f = inf -> forget gate 0.
+            unsigned hi_r[2], lo_r[2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ei = __builtin_amdgcn_exp2f(acc[j]), ef = __builtin_amdgcn_exp2f(acc[4 + j]);
+                const float eg = __builtin_amdgcn_exp2f(__builtin_fminf(acc[8 + j], 64.0f)), eo = __builtin_amdgcn_exp2f(acc[12 + j]);
+                const float Eg = 1.0f + eg;
+                const float ig = (1.0f - eg) * __builtin_amdgcn_rcpf(HNS_FMA(ei, Eg, Eg));
+                const float cn = HNS_FMA(__builtin_amdgcn_rcpf(1.0f + ef), c[te][j], ig);
+                c[te][j] = cn;
+                const float ec = __builtin_amdgcn_exp2f(cn * (2.0f * kNegLog2e));
+                const float Ec = 1.0f + ec;
+                const float P = 1.0f - ec, Q = __builtin_amdgcn_rcpf(HNS_FMA(eo, Ec, Ec));
+                if ((j & 1) == 0) {
+                    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi_r[j >> 1]) : "v"(P), "v"(Q));
+                    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo_r[j >> 1]) : "v"(P), "v"(Q), "v"(hi_r[j >> 1]));
+                } else {
+                    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi_r[j >> 1]) : "v"(P), "v"(Q));
+                    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo_r[j >> 1]) : "v"(P), "v"(Q), "v"(hi_r[j >> 1]));
+                }
+            }
+            hnew[te][0] = make_uint2(hi_r[0], hi_r[1]);
+            hnew[te][1] = make_uint2(lo_r[0], lo_r[1]);
+#else
             typedef _Float16 half4 __attribute__((ext_vector_type(4)));
             half4 hi4, lo4;
 #pragma unroll
@@ -1119,6 +1152,7 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : NXC == 2 ? WS_OCC2 
             }
             hnew[te][0] = __builtin_bit_cast(uint2, hi4);
             hnew[te][1] = __builtin_bit_cast(uint2, lo4);
+#endif
             WS_STAMP(3)                                    // 3: cell update of the tile
         };
         tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{});

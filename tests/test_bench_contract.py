@@ -99,3 +99,24 @@ def test_bench_refuses_to_fold_rccl_ranks_onto_one_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "2", "--envs", "4096"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode != 0 and "refuse to fold" in (out.stderr + out.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_loop_with_two_hip_shards_reproduces_the_whole_batch():
+    """The multi-GPU plumbing end to end THROUGH bench.py's own loop (steps, episode-boundary resets, the per-rollout collective), with the
+    shards stepped by the HIP kernels: two ranks (gloo, both on cuda:0) over env slices [0, 4096) and [4096, 8192) leave exactly the state one
+    rank leaves for the whole 8192-env batch — slice by slice, sha256 of every buffer.  What the first real 8-GPU run adds is RCCL, not logic."""
+    common = ["--steps", "96", "--warmup", "8", "--episode", "40", "--no-cpu-baseline", "--tp-steps", "0", "--config-steps", "0", "--abi-steps", "0"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--envs", "8192", "--state-digest", "4", *common],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = dict(os.environ, HNS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs", "4096", "--state-digest", "4", *common],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    d2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][0])
+    assert len(d1["state_digest"]) == 4 and d1["state_digest"] == d2["state_digest"]
+    assert len(set(d1["state_digest"])) == 4                        # four different slices, not four times the same bytes
+    assert d2["config"]["ranks"] == 2 and d2["collective_us"]["rollouts"] == 1

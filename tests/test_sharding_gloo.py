@@ -93,6 +93,96 @@ def test_two_rank_shards_equal_single_process():
     assert abs(outs[0][7] - rate) < 1e-12 and abs(outs[1][7] - rate) < 1e-12
 
 
+# ---- BASELINE config 5's job shape: 8 ranks, 6 pursuers / 2 evaders / 16 cylinders, an env count the ranks do not divide ---------------
+def _job8_worker(rank, world, port, E_total, steps, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import hns_amd  # noqa: F401
+    import hns_oracle as O
+    from hns_amd import abi, config, sharding
+    from hns_amd.envgen import GenBuffer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    offset, count = sharding.env_shard(E_total, world, rank)
+    c = _cfg5(count, offset)
+    arrs = O.alloc_buffers(c)
+    O.reset(c, arrs, None, 7, 0)
+    actions = np.random.default_rng(5).standard_normal((steps, E_total, 6, 4)).astype(np.float32)
+    hook = sharding.GlobalSuccessRate()
+    rews, rates = [], []
+    for t in range(steps):
+        O.step(c, arrs, actions[t, offset:offset + count])
+        rews.append(arrs["reward"].copy())
+        if (t + 1) % 4 == 0:                                   # a "rollout" of 4 steps: the job's one collective
+            succ = torch.from_numpy(arrs["stats"][abi.STAT_NAMES.index("success")].copy())
+            hook.update(sharding.allgather_moments(sharding.local_moments(torch.from_numpy(np.stack(rews[-4:])), succ)))
+            rates.append(hook.rate)
+    # one task history for the whole job: every rank contributes a different number of tasks (rank 3 none)
+    gb = sharding.GlobalGenBuffer(GenBuffer(6, 16, seed=11, buffer_length=40, num_targets=2), num_envs_total=E_total)
+    n = [5, 9, 2, 0, 7, 11, 3, 8][rank]
+    gb.insert_history(np.random.default_rng(200 + rank).random((n, gb.task_dim)).astype(np.float32))
+    q.put((rank, offset, count, arrs["drone_state"], arrs["target_pos"], arrs["stats"], np.stack(rews), rates,
+           np.array(gb.inner._history_buffer, copy=True), gb.buffer_share(count, offset, 0.3)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _cfg5(E, offset):
+    from hns_amd import config
+    cfg = config.make_cfg({"num_agents": 6, "num_targets": 2, "cylinder": {"max_num": 16, "min_num": 16},
+                           "env": {"num_envs": E, "max_episode_length": 9}})
+    return config.resolve_hns_cfg(cfg, env_index_offset=offset)
+
+
+@pytest.mark.timeout(600)
+def test_eight_rank_job_of_config_5_equals_single_process():
+    """BASELINE configs[4] as the driver will launch it — 8 ranks, contiguous env slices (env_shard(524288, 8) at full size; 77 envs here, so the
+    slices are 10 and 9 envs), 6v2 / 16 cylinders — on gloo: the shards are bit-identical slices of the single-process batch, the per-rollout
+    all-gather gives every rank the global success rate, and `GlobalGenBuffer` leaves all eight ranks with the history a single process
+    builds from the concatenated contributions (one of them empty)."""
+    import hns_oracle as O
+    from hns_amd import abi, sharding
+    from hns_amd.envgen import GenBuffer
+    E_total, steps, world = 77, 12, 8
+    spans = [sharding.env_shard(524288, 8, r) for r in range(8)]
+    assert all(c == 65536 for _, c in spans) and [o for o, _ in spans] == [65536 * r for r in range(8)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_job8_worker, args=(r, world, port, E_total, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=500) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [o[2] for o in outs] == [10, 10, 10, 10, 10, 9, 9, 9] and [o[1] for o in outs] == [0, 10, 20, 30, 40, 50, 59, 68]
+    c = _cfg5(E_total, 0)
+    full = O.alloc_buffers(c)
+    O.reset(c, full, None, 7, 0)
+    actions = np.random.default_rng(5).standard_normal((steps, E_total, 6, 4)).astype(np.float32)
+    rews, rates = [], []
+    for t in range(steps):
+        O.step(c, full, actions[t])
+        rews.append(full["reward"].copy())
+        if (t + 1) % 4 == 0:
+            rates.append(float(full["stats"][abi.STAT_NAMES.index("success")].astype(np.float64).mean()))
+    np.testing.assert_array_equal(np.concatenate([o[3] for o in outs]), full["drone_state"])
+    np.testing.assert_array_equal(np.concatenate([o[4] for o in outs]), full["target_pos"])
+    np.testing.assert_array_equal(np.concatenate([o[5] for o in outs], axis=1), full["stats"])
+    np.testing.assert_array_equal(np.concatenate([o[6] for o in outs], axis=1), np.stack(rews))
+    for o in outs:                                            # the global rate, on every rank, at every rollout
+        assert len(o[7]) == 3 and all(abs(a - b) < 1e-12 for a, b in zip(o[7], rates))
+    single = GenBuffer(6, 16, seed=11, buffer_length=40, num_targets=2)
+    single.insert_history(np.concatenate([np.random.default_rng(200 + r).random((n, single.task_dim)).astype(np.float32)
+                                          for r, n in enumerate([5, 9, 2, 0, 7, 11, 3, 8])]))
+    assert len(single._history_buffer) == 40                  # 45 contributed: trimmed once, on rank 0
+    for o in outs:
+        np.testing.assert_array_equal(o[8], single._history_buffer)
+    assert sum(o[9] for o in outs) == min(40, int(E_total * 0.7))
+
+
 # ---- one task history for the whole job (sharding.GlobalGenBuffer; reference semantics, hideandseek_envgen.py:209-233) ----------
 def _genbuf_worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "oracle")):

@@ -190,7 +190,7 @@ def test_two_evaders_with_the_task_generator():
     import ctypes as C
     from hns_amd.envgen import HideAndSeek_envgen
     E, L, A, Cn = 6144, 4, 3, 6
-    cfg = config.make_cfg({"name": "HideAndSeek_envgen", "num_agents": A, "num_targets": 2, "ratio_unif": 0.3, "eval_iter": 1, "R_min": 0.0, "R_max": 1.0,
+    cfg = config.make_cfg({"name": "HideAndSeek_envgen", "reset_extra_step": 0, "num_agents": A, "num_targets": 2, "ratio_unif": 0.3, "eval_iter": 1, "R_min": 0.0, "R_max": 1.0,
                            "use_particle_generator": 1, "expand_cylinders": 1, "cylinder": {"max_num": Cn, "min_num": 3},
                            "env": {"num_envs": E, "max_episode_length": L}})
     env = HideAndSeek_envgen(cfg)
