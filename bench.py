@@ -565,7 +565,10 @@ def main():
                    "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tflops / 2500.0, 4),
                                 "note": "useful FLOP of LSTM + FC per launch of hns_tp_observe / its duration / dense f16 peak; every product is issued as three "
                                         "f16 MFMAs (hi*hi, hi*lo, lo*hi of the split operands) to hold the 1e-5 parity, so the matrix pipe does 3x this"},
-                   "what": "env.step with algo.use_TP_net=1: hns_step + hns_tp_observe (window shift, LSTM(16->64)x10 + FC on the matrix cores, 35-value rows)"}
+                   "halves_on_two_streams": env_tp._halves is not None,
+                   "what": "env.step with algo.use_TP_net=1: hns_step + hns_tp_observe (window shift, LSTM(16->64)x10 + FC on the matrix cores, 35-value rows)"
+                           + ("; the batch as two half batches on two streams (task.tp_overlap): step_kernel_us is ONE half's step kernel, observe_us the "
+                              "predictor over the whole batch on one stream" if env_tp._halves is not None else "")}
         del env_tp
 
     # secondary leg: the same envs as G shards on G HIP streams of this GPU (the multi-GPU sharding applied inside one GPU)

@@ -149,6 +149,9 @@ typedef struct hns_cfg {
     int32_t pid_reset_on_reset;/* 0 = the reference: `_reset_idx` (hideandseek.py:609-723) never touches the body-rate controller; its integrator and
                                   last body rate are cleared only through `reset_pid` at the next step (buffers.reset_pid).  1 = hns_reset also zeroes
                                   pid_integ / pid_last_rate of the envs it resets (a fresh controller per episode; rounds 1-3 of this build) */
+    int32_t stats_stride;      /* floats between consecutive rows of buffers.stats: 0 = num_envs (a [HNS_NUM_STATS, E] array of its own); a larger
+                                  value lets an env over a SLICE of a bigger batch address its columns of that batch's array in place (the Python
+                                  env steps the two halves of its batch on two streams when the predictor is on) */
     int32_t reset_extra_step;  /* 1 = the reference: `_reset_idx` ends with one `sim.step()` of the WHOLE scene (hideandseek.py:722-723) — every drone of
                                   every env (reset or not) integrates one dt with no rotor force (gravity + damping), every evader moves one dt with
                                   the velocity it holds; then the observation of all envs is recomputed (isaac_env.py:221).  0 = no extra step */

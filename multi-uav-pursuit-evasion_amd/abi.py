@@ -55,7 +55,7 @@ class HnsCfg(C.Structure):
         ("target_xy_hi", _f * 2), ("z_lo", _f), ("z_hi", _f), ("rpy_lo", _f * 3), ("rpy_hi", _f * 3),
         ("fixed_drone_pos", (_f * 3) * (HNS_MAX_AGENTS + 1)), ("fixed_target_pos", _f * 3),
         ("fixed_cyl_pos", (_f * 3) * HNS_MAX_CYLINDERS), ("fixed_cyl_active", _i), ("tp_use_obstacles", _i),
-        ("pid_reset_on_reset", _i), ("reset_extra_step", _i),
+        ("pid_reset_on_reset", _i), ("stats_stride", _i), ("reset_extra_step", _i),
     ]
 
     def copy(self):

@@ -270,6 +270,7 @@ def resolve_hns_cfg(cfg, num_envs=None, env_index_offset=0, drone_params=None, w
         raise ValueError("task.pid_reset must be 'reference' or 'on_reset'")
     c.pid_reset_on_reset = 1 if pid_reset == "on_reset" else 0
     c.reset_extra_step = 1 if int(t.get("reset_extra_step", 1)) else 0
+    c.stats_stride = E
     c.tp_use_obstacles = 1 if use_obst else 0
     c.max_episode_length = int(cfg.env.max_episode_length)
     c.use_deployment = int(t.use_deployment)

@@ -320,6 +320,8 @@ int hns_create(const hns_cfg *cfg, hns_env **out) {
     hns_env *env = new (std::nothrow) hns_env();
     if (!env) { set_error("hns_create: out of host memory"); return HNS_ERR_INVALID_ARG; }
     env->cfg = *cfg;
+    if (env->cfg.stats_stride == 0) env->cfg.stats_stride = cfg->num_envs;
+    if (env->cfg.stats_stride < cfg->num_envs) { delete env; set_error("hns_create: stats_stride must be 0 or >= num_envs"); return HNS_ERR_INVALID_ARG; }
     if (hipGetDevice(&env->device) != hipSuccess) env->device = 0;
     std::memset(&env->buf, 0, sizeof(env->buf));
     switch (cfg->num_agents) {
@@ -659,7 +661,7 @@ static int copy_state(hns_env *env, const hns_buffers *host, void *stream, bool 
         {host->drone_state, d.drone_state, E * A * 13 * 4}, {host->throttle, d.throttle, E * A * 16}, {host->pid_integ, d.pid_integ, E * A * 16},
         {host->pid_last_rate, d.pid_last_rate, E * A * 16}, {host->prev_action, d.prev_action, E * A * 16},
         {host->target_pos, d.target_pos, E * NT * 12}, {host->target_vel, d.target_vel, E * NT * 12}, {host->cylinders, d.cylinders, E * C * 12},
-        {host->progress, d.progress, E * 4}, {host->stats, d.stats, (size_t)HNS_NUM_STATS * E * 4}, {host->obs_self, d.obs_self, E * A * SD * 4},
+        {host->progress, d.progress, E * 4}, {host->stats, d.stats, c.stats_stride == c.num_envs ? (size_t)HNS_NUM_STATS * E * 4 : 0 /* a slice's columns are not one block: copy through the owner of the array */}, {host->obs_self, d.obs_self, E * A * SD * 4},
         {host->obs_others, d.obs_others, E * A * (A - 1) * 12}, {host->obs_cylinders, d.obs_cylinders, E * A * K * 20},
         {host->state_drones, d.state_drones, E * A * SD * 4}, {host->reward, d.reward, E * A * 4}, {host->action_error, d.action_error, E * A * 4},
         {host->done, d.done, E}, {host->detect, d.detect, E}, {host->nonfinite, d.nonfinite, 4}, {host->ctbr, d.ctbr, E * A * 16}, {host->target_rate, d.target_rate, E * A * 16}};

@@ -205,30 +205,55 @@ constexpr int kFxThreads = 1024, kFxGroups = 32, kFxStride = 8, kFxPts = 2, kFxD
 // sequential loop); only the number of exchanges changes: ~k / (mean accepted) instead of k.
 constexpr int kFxB = 4;
 
-// The workgroup's top `nb` keys (uniform result in top[]): nb max-reductions; the thread that owns a winner pops it from its sorted pair.
+
+// Maximum of a 32-bit value over the wave, uniform result: the row_shr / row_bcast ladder on the VALU's data-parallel primitives (six
+// v_max_u32_dpp and one v_readlane).  `__shfl_xor` trees go through ds_bpermute — an LDS round trip per step, two per 64-bit key: twelve
+// of those max-reductions per exchange were 4-5 us of a 10 us exchange (measured), this form is ~60 cycles each.
+HNS_DEV unsigned wave_max_u32(unsigned v) {
+#define HNS_DPP_MAX(ctrl, rows) { const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rows, 0xf, false); v = o_ > v ? o_ : v; }
+    HNS_DPP_MAX(0x111, 0xf)      // row_shr:1
+    HNS_DPP_MAX(0x112, 0xf)      // row_shr:2
+    HNS_DPP_MAX(0x114, 0xf)      // row_shr:4
+    HNS_DPP_MAX(0x118, 0xf)      // row_shr:8   -> lane 15 of every row holds its row's maximum
+    HNS_DPP_MAX(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
+    HNS_DPP_MAX(0x143, 0xc)      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's
+#undef HNS_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// ... of a candidate key (min-distance bits + 1 in bits 20..51, 0xFFFFF - index below): the distance part first, then the index part among
+// the lanes that hold that distance (ties -> lower index)
+HNS_DEV unsigned long long wave_max_key(unsigned long long k) {
+    const unsigned hi = (unsigned)(k >> 20), lo = (unsigned)k & 0xFFFFFu;
+    const unsigned mh = wave_max_u32(hi);
+    const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+    return ((unsigned long long)mh << 20) | (unsigned long long)ml;
+}
+
+// The workgroup's top `nb` keys (uniform result in top[]): every wave takes its own top nb (nb wave maxima, the lane that owns a winner pops
+// it from its sorted pair), parks them in LDS, and after ONE workgroup barrier every wave takes the top nb of those (THREADS / 64) x kFxB
+// values — one per lane at 1024 threads.
 template <int THREADS>
-HNS_DEV void fps_top(unsigned long long (&mine)[2], int nb, unsigned long long (*s_red)[THREADS / 64], unsigned long long (&top)[kFxB]) {
+HNS_DEV void fps_top(unsigned long long (&mine)[2], int nb, unsigned long long *s_wtop, unsigned long long (&top)[kFxB]) {
+    static_assert(THREADS / 64 * kFxB <= 64, "one parked candidate per lane");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int pass = 0; pass < kFxB; ++pass) {
+        unsigned long long best = 0ull;
+        if (pass < nb) {
+            best = wave_max_key(mine[0]);
+            if (best != 0ull && mine[0] == best) { mine[0] = mine[1]; mine[1] = 0ull; }
+        }
+        if (lane == 0) s_wtop[wave * kFxB + pass] = best;
+    }
+    __syncthreads();
+    unsigned long long v = lane < THREADS / 64 * kFxB ? s_wtop[lane] : 0ull;
 #pragma unroll
     for (int pass = 0; pass < kFxB; ++pass) {
         top[pass] = 0ull;
         if (pass < nb) {
-            unsigned long long best = mine[0];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const unsigned long long o = __shfl_xor(best, off);
-                best = o > best ? o : best;
-            }
-            if (lane == 0) s_red[pass & 1][wave] = best;
-            __syncthreads();                             // (double-buffered by pass parity: one barrier per pass)
-            best = s_red[pass & 1][lane & (THREADS / 64 - 1)];
-#pragma unroll
-            for (int off = THREADS / 128; off >= 1; off >>= 1) {
-                const unsigned long long o = __shfl_xor(best, off);
-                best = o > best ? o : best;
-            }
+            const unsigned long long best = wave_max_key(v);
+            v = (best != 0ull && v == best) ? 0ull : v;
             top[pass] = best;
-            if (best != 0ull && mine[0] == best) { mine[0] = mine[1]; mine[1] = 0ull; }
         }
     }
 }
@@ -236,9 +261,9 @@ HNS_DEV void fps_top(unsigned long long (&mine)[2], int nb, unsigned long long (
 // One exchange: publish the workgroup's top `nb` candidates, sweep everybody's, take the global top nb, accept the prefix that sequential
 // sampling would select next (at most max_accept).  Returns the number accepted (their indices in s_acc), or -1 after reporting that a
 // workgroup never showed up.
-template <int THREADS>
+template <int THREADS, int XM>
 HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, int r, const unsigned long long (&top)[kFxB], int nb, int max_accept,
-                           int *s_acc, int *s_nacc, int *s_fail, float *warm) {
+                           int *s_acc, int *s_nacc, int *s_fail, float *s_rows, float *warm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = p.d;
     const unsigned long long tag = (unsigned long long)(r % 4095 + 1) << 52;
     gu64 *slot = gran + (size_t)(r & 1) * G * kFxB;
@@ -259,7 +284,7 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
         }
     }
     if (wave == 0) {
-        constexpr int U = kFxGroups * 2 * kFxB / 64;          // granules per lane at two XCDs
+        constexpr int U = kFxGroups * XM * kFxB / 64;         // granules per lane with XM XCDs at work
         unsigned long long v[U];
         const int total = G * kFxB;
         bool fail = false;
@@ -288,11 +313,7 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
             if (pass < nb) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) gb = v[u] > gb ? v[u] : gb;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const unsigned long long o = __shfl_xor(gb, off);
-                    gb = o > gb ? o : gb;
-                }
+                gb = wave_max_key(gb);
 #pragma unroll
                 for (int u = 0; u < U; ++u) v[u] = (gb != 0ull && v[u] == gb) ? 0ull : v[u];
             }
@@ -306,6 +327,20 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
             const unsigned key = (unsigned)(gtop[m] >> 20);      // min-distance bits + 1; 0 = no candidate (or a point already chosen)
             gd[m] = key != 0u ? __uint_as_float(key - 1u) : kInf;
         }
+        // the candidates' coordinates: ONE cooperative fetch into LDS (rows of kFxD floats, zero-padded) — the pair distances below and, behind
+        // the barrier, every thread's update read them there; a scalar load per accepted sample from every wave was a dependent
+        // memory round trip each (measured: 11.8 us per exchange of four)
+        if (!fail) {
+            for (int idx = lane; idx < kFxB * kFxD; idx += 64) {
+                const int m = idx / kFxD, c = idx - m * kFxD;
+                const int gim = m == 0 ? gi[0] : m == 1 ? gi[1] : m == 2 ? gi[2] : gi[3];
+                const unsigned long long gtm = m == 0 ? gtop[0] : m == 1 ? gtop[1] : m == 2 ? gtop[2] : gtop[3];
+                s_rows[idx] = (gtm != 0ull && c < d) ? p.points[(size_t)gim * d + c] : 0.0f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // pair (a < b) on lane a + b (b - 1) / 2: the update's own chain, dist(x = candidate b, q = candidate a)
         int pa = 0, pb = 1;
 #pragma unroll
@@ -313,18 +348,13 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
 #pragma unroll
             for (int a2 = 0; a2 < b2; ++a2)
                 if (lane == a2 + b2 * (b2 - 1) / 2) { pa = a2; pb = b2; }
-        int ia = gi[0], ib = gi[1];
-#pragma unroll
-        for (int m = 0; m < kFxB; ++m) { ia = pa == m ? gi[m] : ia; ib = pb == m ? gi[m] : ib; }
         float acc = 0.0f;
-        if (!fail && nb > 1 && lane < kFxB * (kFxB - 1) / 2 && pb < nb && gtop[0] != 0ull) {
-            const bool have = (pb == 1 ? gtop[1] : pb == 2 ? gtop[2] : gtop[3]) != 0ull;
-            if (have) {
-                const float *xa = p.points + (size_t)ia * d, *xb = p.points + (size_t)ib * d;
-                for (int c = 0; c < d; ++c) {
-                    const float df = xb[c] - xa[c];
-                    acc = HNS_FMA(df, df, acc);
-                }
+        if (!fail && nb > 1 && lane < kFxB * (kFxB - 1) / 2) {
+            const float *xa = s_rows + pa * kFxD, *xb = s_rows + pb * kFxD;
+#pragma unroll 4
+            for (int c = 0; c < kFxD; ++c) {                       // (padding: 0 - 0 leaves the chain unchanged)
+                const float df = xb[c] - xa[c];
+                acc = HNS_FMA(df, df, acc);
             }
         }
         // accepted prefix: candidate m needs dist(m, j) >= d(m) for every j < m
@@ -335,7 +365,7 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
             bool okm = open && m < nb && gtop[m] != 0ull;
 #pragma unroll
             for (int j = 0; j < m; ++j) {
-                const float dj = __shfl(acc, j + m * (m - 1) / 2);
+                const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), j + m * (m - 1) / 2));
                 okm = okm && (dj >= gd[m]);
             }
             open = okm;
@@ -357,42 +387,40 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
     return *s_nacc;
 }
 
-// FULL: exactly 36 coordinates (16-byte row loads, wide scalar loads).  Otherwise rows are zero-padded to 36 in registers: a zero
-// difference leaves the sequential fma chain unchanged, bit for bit (acc + 0 * 0 = acc for acc >= 0).
-template <bool FULL>
+// Rows of fewer than 36 coordinates are zero-padded to 36 in registers: a zero difference leaves the sequential fma chain unchanged, bit for
+// bit (acc + 0 * 0 = acc for acc >= 0).  (Round 3 had a second instantiation for exactly 36 coordinates — 16-byte row loads and wide scalar
+// loads of the newest sample; with the samples' rows in LDS the only difference left was the one-time load of the points, and the
+// specialised form did not fit the 128 registers of a 1024-thread workgroup beside the exchange: 37 spilled registers, 28 ms per trim
+// against 13 ms.)
+// PTS points per thread (2: up to 65 536 points per XCD; 1: half that, and 36 registers fewer), XM = the most XCDs an instantiation serves.
+template <int PTS, int XM>
 __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams p) {
     if ((int)(blockIdx.x % kFxStride) >= p.xcds) return;
-    __shared__ unsigned long long s_red[2][kFxThreads / 64];
+    __shared__ unsigned long long s_wtop[kFxThreads / 64 * kFxB];
+    __shared__ __align__(16) float s_rows[kFxB * kFxD];            // the newest samples' coordinates (written by wave 0 in the exchange)
     __shared__ int s_acc[kFxB];
     __shared__ int s_nacc;
     __shared__ int s_fail;
     const int G = kFxGroups * p.xcds;
     const int tid = threadIdx.x, g_self = (blockIdx.x / kFxStride) * p.xcds + blockIdx.x % kFxStride;
-    const int gtid = g_self * kFxThreads + tid, stride = G * kFxThreads, d = FULL ? kFxD : p.d;
+    const int gtid = g_self * kFxThreads + tid, stride = G * kFxThreads, d = p.d;
     const int nb = p.batch < 1 ? 1 : (p.batch > kFxB ? kFxB : p.batch);
     gu64 *gran = (gu64 *)(p.scratch + 8);
-    typedef const float __attribute__((address_space(4))) cfloat;      // `points` is immutable while the kernel runs: constant memory
-    cfloat *qbase = (cfloat *)p.points;
-    float x[kFxPts][kFxD], dist[kFxPts];
+    float x[PTS][kFxD], dist[PTS];
 #pragma unroll
-    for (int j = 0; j < kFxPts; ++j) {
+    for (int j = 0; j < PTS; ++j) {
         dist[j] = kInf;
         int i = gtid + j * stride;
         i = i < p.n ? i : p.n - 1;                      // beyond the end: a copy of the last point, never a candidate (see below)
-        if constexpr (FULL) {
-            const float4 *row = reinterpret_cast<const float4 *>(p.points + (size_t)i * kFxD);   // rows of 144 B: nine 16-byte loads
+        const float *row = p.points + (size_t)i * d;
 #pragma unroll
-            for (int c = 0; c < kFxD / 4; ++c) {
-                const float4 v = row[c];
-                x[j][4 * c] = v.x; x[j][4 * c + 1] = v.y; x[j][4 * c + 2] = v.z; x[j][4 * c + 3] = v.w;
-            }
-        } else {
-            const float *row = p.points + (size_t)i * d;
-#pragma unroll
-            for (int c = 0; c < kFxD; ++c) x[j][c] = c < d ? row[c < d ? c : 0] : 0.0f;
-        }
+        for (int c = 0; c < kFxD; ++c) x[j][c] = c < d ? row[c < d ? c : 0] : 0.0f;
     }
     if (tid == 0) s_fail = 0;
+    if (tid < kFxD) {                                   // the first sample's row
+        int i0 = p.start;
+        s_rows[tid] = tid < d ? p.points[(size_t)i0 * d + tid] : 0.0f;
+    }
     int cur[kFxB] = {p.start, 0, 0, 0};
     int ncur = 1, nout = 0;
     float warm = 0.0f;                                  // sum of the rows touched to warm the L2 (kept alive by the store below)
@@ -406,29 +434,32 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         }
         nout += ncur;
         if (nout >= p.k) break;
-        // the newest samples: uniform addresses -> scalar loads, 12 coordinates at a time, used as scalar operands; every point's
-        // distance to each of them stays ONE sequential fmaf chain over the coordinates (= the oracle)
+        // the newest samples' coordinates sit in LDS (uniform addresses: broadcast reads, 4 at a time); every point's distance to each of
+        // them stays ONE sequential fmaf chain over the coordinates (= the oracle)
+#pragma unroll 1
         for (int m = 0; m < ncur; ++m) {
-            const int cm = __builtin_amdgcn_readfirstlane(m == 0 ? cur[0] : m == 1 ? cur[1] : m == 2 ? cur[2] : cur[3]);
-            cfloat *qrow = qbase + (size_t)cm * d;
-            float acc[kFxPts];
+            const int cm = m == 0 ? cur[0] : m == 1 ? cur[1] : m == 2 ? cur[2] : cur[3];
+            const float4 *qrow = reinterpret_cast<const float4 *>(s_rows + m * kFxD);
+            float acc[PTS];
 #pragma unroll
-            for (int j = 0; j < kFxPts; ++j) acc[j] = 0.0f;
+            for (int j = 0; j < PTS; ++j) acc[j] = 0.0f;
 #pragma unroll
-            for (int c0 = 0; c0 < kFxD; c0 += 12) {
-                float q[12];
+            for (int c0 = 0; c0 < kFxD; c0 += 4) {
+                // two points per thread: at most two quads of q live (all nine reads hoisted to the top spill 28 registers of x under the 128-register
+                // cap); one point per thread: 36 registers to spare, all nine reads in flight at once
+                if (PTS == 2 && (c0 & 7) == 0) asm volatile("" ::: "memory");
+                const float4 q0 = qrow[c0 / 4];
+                const float q[4] = {q0.x, q0.y, q0.z, q0.w};
 #pragma unroll
-                for (int c = 0; c < 12; ++c) q[c] = (FULL || c0 + c < d) ? qrow[(FULL || c0 + c < d) ? c0 + c : 0] : 0.0f;
+                for (int j = 0; j < PTS; ++j)
 #pragma unroll
-                for (int j = 0; j < kFxPts; ++j)
-#pragma unroll
-                    for (int c = 0; c < 12; ++c) {
+                    for (int c = 0; c < 4; ++c) {
                         const float df = x[j][c0 + c] - q[c];
                         acc[j] = HNS_FMA(df, df, acc[j]);
                     }
             }
 #pragma unroll
-            for (int j = 0; j < kFxPts; ++j) {
+            for (int j = 0; j < PTS; ++j) {
                 const int i = gtid + j * stride;
                 // a chosen point leaves the pool (-1 never wins), so the k indices are distinct even among duplicates
                 dist[j] = (i == cm) ? -1.0f : (acc[j] < dist[j] ? acc[j] : dist[j]);
@@ -436,7 +467,7 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         }
         unsigned long long mine[2] = {0ull, 0ull};
 #pragma unroll
-        for (int j = 0; j < kFxPts; ++j) {
+        for (int j = 0; j < PTS; ++j) {
             const int i = gtid + j * stride;
             const float m = dist[j];
             const unsigned long long key = m < 0.0f ? 0ull : (unsigned long long)__float_as_uint(m) + 1ull;
@@ -444,11 +475,11 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
             if (cand > mine[0]) { mine[1] = mine[0]; mine[0] = cand; }
             else if (cand > mine[1]) mine[1] = cand;
         }
-        static_assert(kFxPts == 2, "a thread's candidates are a sorted pair");
+        static_assert(PTS <= 2, "a thread's candidates are a sorted pair");
         unsigned long long top[kFxB];
-        fps_top<kFxThreads>(mine, nb, s_red, top);
+        fps_top<kFxThreads>(mine, nb, s_wtop, top);
         const int left = p.k - nout;
-        ncur = fps_exchange_b<kFxThreads>(p, gran, G, g_self, r, top, nb, left < kFxB ? left : kFxB, s_acc, &s_nacc, &s_fail, &warm);
+        ncur = fps_exchange_b<kFxThreads, XM>(p, gran, G, g_self, r, top, nb, left < kFxB ? left : kFxB, s_acc, &s_nacc, &s_fail, s_rows, &warm);
         if (ncur < 0) return;
 #pragma unroll
         for (int m = 0; m < kFxB; ++m) cur[m] = s_acc[m];
@@ -532,7 +563,7 @@ __global__ __launch_bounds__(256) void hns_perturb_kernel(const PerturbParams p)
 
 extern "C" {
 
-size_t hns_fps_scratch_bytes(void) { return (size_t)(8 + 2 * 2 * hns::kFpsMaxGroups) * sizeof(unsigned long long); }
+size_t hns_fps_scratch_bytes(void) { return (size_t)(8 + 2 * hns::kFxB * hns::kFpsMaxGroups) * sizeof(unsigned long long); }   // error word + granules [2 parities][<= 256 workgroups][<= 4]
 
 int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start, int32_t *out_idx, void *scratch, void *stream) {
     if (!points || !out_idx || !scratch || n < 1 || d < 1 || k < 1 || k > n || start < 0 || start >= n) {
@@ -556,17 +587,27 @@ int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start,
     // the generator's own shape: the XCD-local kernel (same results; HNS_FPS_KERNEL=chip keeps the chip-wide one, for A/B measurements)
     static const bool chip_only = [] { const char *e = getenv("HNS_FPS_KERNEL"); return e && e[0] == 'c'; }();
     const int fx_cap = hns::kFxGroups * hns::kFxThreads * hns::kFxPts;        // points one XCD's registers hold
-    if (!chip_only && d <= hns::kFxD && d >= 4 && n >= 2048 && n <= 2 * fx_cap &&
-        cus >= hns::kFxGroups * hns::kFxStride && (reinterpret_cast<uintptr_t>(points) & 15) == 0) {
-        p.xcds = n <= fx_cap ? 1 : 2;                 // two XCDs: the exchange crosses the fabric once, still a quarter of the chip
-        p.groups = hns::kFxGroups * p.xcds; p.in_lds = 0;
+    if (!chip_only && d <= hns::kFxD && d >= 4 && n >= 2048 && cus >= hns::kFxGroups * hns::kFxStride && (reinterpret_cast<uintptr_t>(points) & 15) == 0) {
         // samples per exchange (HNS_FPS_BATCH=1 keeps one per exchange, for A/B measurements; the indices are the same either way)
         static const int batch = [] { const char *e = getenv("HNS_FPS_BATCH"); const int b = e ? atoi(e) : hns::kFxB; return b < 1 ? 1 : (b > hns::kFxB ? hns::kFxB : b); }();
-        p.batch = batch;
-        hipLaunchKernelGGL(d == hns::kFxD ? hns::hns_fps_xcd_kernel<true> : hns::hns_fps_xcd_kernel<false>, dim3(hns::kFxGroups * hns::kFxStride),
-                           dim3(hns::kFxThreads), 0, s, p);
-        HNS_CHECK_HIP(hipGetLastError());
-        return HNS_OK;
+        // XCDs at work (measured, 5000 of n samples, four per exchange; tools/lab/r04_batch7-8.sh): an exchange's fixed cost grows with the XCDs
+        // it spans (3.7 / 4.4 / 6.5 / 7.8 us on 1 / 2 / 4 / 8), a sample's distance update shrinks (1.2 us on one XCD with two points per
+        // thread, 0.6 / 0.3 us with one point per thread on two / four).  n <= 65 536: two XCDs (8.7 ms; one: 10.7, four: 10.0);
+        // n <= 131 072: four XCDs, one point per thread (10.4 ms; two XCDs with two points per thread: 11.0).  HNS_FPS_XCDS=1|2|4|8 overrides (A/B).
+        static const int forced = [] { const char *e = getenv("HNS_FPS_XCDS"); return e ? atoi(e) : 0; }();
+        int xcds = forced ? forced : (batch > 1 ? (n <= 2 * hns::kFxGroups * hns::kFxThreads ? 2 : 4) : 1);
+        if (xcds != 1 && xcds != 2 && xcds != 4 && xcds != 8) xcds = 8;
+        // two points per thread on one or two XCDs (110 registers), one per thread on four or eight (the sweep of up to 1024 granules takes the rest)
+        auto capacity = [&](int x) { return (long)x * hns::kFxGroups * hns::kFxThreads * (x <= 2 ? hns::kFxPts : 1); };
+        while (xcds < 8 && capacity(xcds) < n) xcds *= 2;
+        if (capacity(xcds) >= n) {
+            p.xcds = xcds; p.groups = hns::kFxGroups * xcds; p.in_lds = 0; p.batch = batch;
+            const bool one = (long)p.groups * hns::kFxThreads >= n;          // one point per thread suffices
+            auto fn = xcds <= 2 ? (one ? hns::hns_fps_xcd_kernel<1, 2> : hns::hns_fps_xcd_kernel<2, 2>) : hns::hns_fps_xcd_kernel<1, 8>;
+            hipLaunchKernelGGL(fn, dim3(hns::kFxGroups * hns::kFxStride), dim3(hns::kFxThreads), 0, s, p);
+            HNS_CHECK_HIP(hipGetLastError());
+            return HNS_OK;
+        }
     }
     const int per_thread = (n + groups * hns::kFpsThreads - 1) / (groups * hns::kFpsThreads);
     const size_t q_floats = (size_t)((d + 3) & ~3), pts_floats = (size_t)per_thread * hns::kFpsThreads * (d + 1);

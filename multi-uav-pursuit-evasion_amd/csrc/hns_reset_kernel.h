@@ -48,7 +48,7 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
 
     if (env_wave && valid) {
         // hideandseek.py:712 resets first_capture_step for ALL envs on any reset call
-        b.stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * E + e] = (float)c.max_episode_length;
+        b.stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * c.stats_stride + e] = (float)c.max_episode_length;
     }
     if (env_wave && masked) {
         Rng rng = {p.seed_lo, p.seed_hi, (uint32_t)(e + c.env_index_offset), p.epoch, 0u, {0u, 0u, 0u, 0u}, 0};
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
                 cyl[3 * k + 2] = (k >= n_active) ? c.invalid_z : 0.5f * c.cylinder_height;
             }
         }
-        for (int sidx = 0; sidx < HNS_NUM_STATS; ++sidx) b.stats[(size_t)sidx * E + e] = 0.0f;   // :711
-        b.stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * E + e] = (float)c.max_episode_length;
+        for (int sidx = 0; sidx < HNS_NUM_STATS; ++sidx) b.stats[(size_t)sidx * c.stats_stride + e] = 0.0f;   // :711
+        b.stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * c.stats_stride + e] = (float)c.max_episode_length;
         b.progress[e] = 0.0f;
         b.done[e] = 0;
     }

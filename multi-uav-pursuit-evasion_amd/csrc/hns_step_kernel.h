@@ -451,7 +451,7 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         const int e = e0 + (valid ? le : nv - 1);
         if constexpr (PROF) prof_mark(p.prof, 0);
         if constexpr (PROF) prof_mark(p.prof, 14);
-        const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.num_envs;
+        const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.stats_stride;      // (E: the row stride of `stats`, = num_envs unless the env is a slice)
         const LdsV3 L = lds_layout_v3(A, C, K, NT);
         float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red, *sEnvOut = smem + L.envout;
         float *cylw = sCyl + le * L.cyl_stride;

@@ -275,29 +275,13 @@ HNS_DEV void tp_write_row(const TpParams &p, int er, int a, const float *pr, con
 // up with dynamically indexed register arrays in scratch memory for some shapes: 20x slower).
 // The kernel as a whole is bound by the gate nonlinearities (10 transcendental ops per unit and
 // timestep), not by this block.
-#ifndef TP_DEPTH
-#define TP_DEPTH 2
-#endif
-constexpr int kTpDepth = TP_DEPTH;
+constexpr int kTpDepth = 2;
 
-// A unit pair's values.  TP_PK = 1 keeps them as packed fp32 (v_pk_add/mul/fma_f32); the default issues two plain instructions per
+// A unit pair's values.  0 = 1 keeps them as packed fp32 (v_pk_add/mul/fma_f32); the default issues two plain instructions per
 // operation: on gfx950 a packed fp32 instruction occupies a lone wave's issue for 11 cycles (two plain ones: 2 x 5.2-6), saves
 // nothing at 4 waves per SIMD either (0.177 against 2 x 0.19-0.27 instructions per cycle), and beside a running MFMA it waits for
 // the matrix pipe — one packed instruction per MFMA and wave, where plain and transcendental ones still find 2-3 issue slots
 // (tools/microbench/simd_share.hip; round 3).
-#ifndef TP_PK
-#define TP_PK 0
-#endif
-#if TP_PK
-typedef f32x2 tpv2;
-HNS_DEV tpv2 tp_v2(float a, float b) { return (f32x2){a, b}; }
-HNS_DEV tpv2 tp_add_s(tpv2 a, float s) { return a + s; }
-HNS_DEV tpv2 tp_mul_s(tpv2 a, float s) { return a * s; }
-HNS_DEV tpv2 tp_mul_2(tpv2 a, tpv2 b) { return a * b; }
-HNS_DEV tpv2 tp_sub_2(tpv2 a, tpv2 b) { return a - b; }
-HNS_DEV tpv2 tp_fma_2(tpv2 a, tpv2 b, tpv2 c) { return __builtin_elementwise_fma(a, b, c); }
-HNS_DEV tpv2 tp_fma_s(tpv2 a, float b, float c) { return __builtin_elementwise_fma(a, (f32x2)b, (f32x2)c); }
-#else
 struct tpv2 {
     float x, y;
     __device__ __forceinline__ float operator[](int i) const { return i ? y : x; }
@@ -309,7 +293,6 @@ HNS_DEV tpv2 tp_mul_2(tpv2 a, tpv2 b) { return tpv2{a.x * b.x, a.y * b.y}; }
 HNS_DEV tpv2 tp_sub_2(tpv2 a, tpv2 b) { return tpv2{a.x - b.x, a.y - b.y}; }
 HNS_DEV tpv2 tp_fma_2(tpv2 a, tpv2 b, tpv2 c) { return tpv2{HNS_FMA(a.x, b.x, c.x), HNS_FMA(a.y, b.y, c.y)}; }
 HNS_DEV tpv2 tp_fma_s(tpv2 a, float b, float c) { return tpv2{HNS_FMA(a.x, b, c), HNS_FMA(a.y, b, c)}; }
-#endif
 // v_exp_f32 / v_rcp_f32 on both halves of a pair (transcendentals have no packed form)
 HNS_DEV tpv2 tp_exp2_2(tpv2 v) { return tp_v2(__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])); }
 HNS_DEV tpv2 tp_rcp_2(tpv2 v) { return tp_v2(__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])); }
@@ -340,19 +323,6 @@ struct TpCell {
     static __device__ __forceinline__ void slice(TpCellCtx &x) {
         constexpr int S = K % 5, u0 = 2 * (K / 5), u1 = u0 + 1;
         tpv2 *t = x.t;
-#ifdef TP_ABL_NOCELL                           // lab: no nonlinearities (timing of the matrix products + operand traffic alone)
-        if constexpr (S == 4) {
-            const tpv2 h = tp_mul_s(tp_v2(x.z[0][u0], x.z[3][u1]), 1e-3f);
-            if constexpr (TJ == 0) { x.h[u0] = h[0]; x.h[u1] = h[1]; }
-            else {
-                half2v a, b;
-                tp_split_v2(h, a, b);
-                x.hh[2 + (u0 >> 3)][u0 & 7] = a[0]; x.hl[2 + (u0 >> 3)][u0 & 7] = b[0];
-                x.hh[2 + (u1 >> 3)][u1 & 7] = a[1]; x.hl[2 + (u1 >> 3)][u1 & 7] = b[1];
-            }
-        }
-        return;
-#endif
         if constexpr (S == 0) {            // 1 + e_i, 1 + e_f
             t[0] = tp_add_s(tp_exp2_2(tp_v2(x.z[0][u0], x.z[0][u1])), 1.0f);
             t[1] = tp_add_s(tp_exp2_2(tp_v2(x.z[1][u0], x.z[1][u1])), 1.0f);
@@ -437,17 +407,10 @@ struct TpGate {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const float4 bv = b4[v];
-#if TP_PK
-                const f32x2 lo = __builtin_elementwise_fma((f32x2){c.acc[q][4 * v], c.acc[q][4 * v + 1]}, (f32x2)kTpLoInv, (f32x2){bv.x, bv.y});
-                const f32x2 hi = __builtin_elementwise_fma((f32x2){c.acc[q][4 * v + 2], c.acc[q][4 * v + 3]}, (f32x2)kTpLoInv, (f32x2){bv.z, bv.w});
-                c.acc[q][4 * v] = lo[0]; c.acc[q][4 * v + 1] = lo[1];
-                c.acc[q][4 * v + 2] = hi[0]; c.acc[q][4 * v + 3] = hi[1];
-#else
                 c.acc[q][4 * v] = HNS_FMA(c.acc[q][4 * v], kTpLoInv, bv.x);
                 c.acc[q][4 * v + 1] = HNS_FMA(c.acc[q][4 * v + 1], kTpLoInv, bv.y);
                 c.acc[q][4 * v + 2] = HNS_FMA(c.acc[q][4 * v + 2], kTpLoInv, bv.z);
                 c.acc[q][4 * v + 3] = HNS_FMA(c.acc[q][4 * v + 3], kTpLoInv, bv.w);
-#endif
             }
         }
     }
@@ -456,12 +419,7 @@ struct TpGate {
     static __device__ __forceinline__ void step(const Ctx &c) {
         if constexpr (n == NLO) scale_bias(c);
         constexpr int ci = chunk(n), q = tile(n);
-#ifdef TP_ABL_NOMFMA                           // lab: no matrix products (the accumulators take one operand register each instead)
-        c.acc[q][n % 16] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, c.a[n % RING]).x & 0x3f000000u);
-        if constexpr (false) {
-#else
         if constexpr (ci < NXC) {
-#endif
             if constexpr (vlo(n)) c.acc[q] = TP_MFMA(c.a[n % RING], c.xl[ci], c.acc[q]);
             else c.acc[q] = TP_MFMA(c.a[n % RING], c.xh[ci], c.acc[q]);
         } else {
@@ -613,9 +571,6 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
     for (int i = 0; i < 32; ++i) c[i] = 0.0f;
     float hn0[16];                          // h_t of tile pair 0's units, parked while tile pair 1 still reads h_{t-1}
 
-#ifdef TP_PHASES
-    unsigned long long ph[4] = {0, 0, 0, 0}, last = __builtin_readcyclecounter();
-#endif
     // one timestep; t = 0 (h_0 = 0: no recurrent product) is peeled so that the loop body is straight-line code
     auto timestep = [&](int t, auto with_h) {
         constexpr bool WITH_H = decltype(with_h)::value;
@@ -646,14 +601,7 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
         // the MFMAs of the second (not at t = 0: too few MFMAs without the recurrent product)
         f32x16 acc0[4], acc1[4];
         TpCellCtx cell0{acc0, c, hn0, hh, hl, {}}, cell1{acc1, c, hn0, hh, hl, {}};
-#ifdef TP_PHASES
-#define TP_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); if (WITH_H) ph[i] += now_ - last; last = now_; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define TP_STAMP(i)
-#endif
-        TP_STAMP(0)                                  // 0: split / window rows of this timestep
         tp_gate_tiles<NXC, WITH_H>(acc0, aw, 0, hb, sBias, xh, xl, hh, hl);
-        TP_STAMP(1)                                  // 1: gate tiles of units 0..31
         constexpr bool SIDE = WITH_H;
         if constexpr (SIDE) {
             tp_gate_tiles<NXC, WITH_H, true>(acc1, aw, 1, hb, sBias, xh, xl, hh, hl, &cell0);
@@ -662,10 +610,8 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
             __builtin_amdgcn_sched_barrier(0);            // acc0 is dead before acc1 goes live
             tp_gate_tiles<NXC, WITH_H>(acc1, aw, 1, hb, sBias, xh, xl, hh, hl);
         }
-        TP_STAMP(2)                                  // 2: gate tiles of units 32..63 (+ the cell update of units 0..31)
         TpCell<1>::run_all(cell1);
         __builtin_amdgcn_sched_barrier(0);
-        TP_STAMP(3)                                  // 3: cell update of units 32..63
         // h_{t-1} is dead now: h_t -> B operands of the next timestep
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
@@ -677,9 +623,6 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
     };
     timestep(0, std::false_type{});
     for (int t = 1; t < T; ++t) timestep(t, std::true_type{});
-#ifdef TP_PHASES
-    if (prof && lane == 0) { prof[5] = ph[0]; prof[6] = ph[1]; prof[7] = ph[2]; prof[8] = ph[3]; }
-#endif
 
     if (prof && lane == 0) prof[2] = __builtin_amdgcn_s_memrealtime();
     // ---- output layer on h_T: tanh(W_fc h + b), rescaled to arena units (hideandseek.py:834-836) ----
@@ -767,11 +710,7 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
 // no scaling pass, no bias pass.  The one operand whose magnitude would make the weights' low term matter, `progress`
 // (up to max_episode_length), enters as progress/1024 against its weight column x 1024 (both exact).
 constexpr int kWsWaves = 8, kWsThreads = kWsWaves * 64, kWsEnvs = 128, kWsTiles = 4;
-#ifdef WS_NOPROG
-constexpr float kWsProgScale = 1.0f, kWsProgInv = 1.0f;
-#else
 constexpr float kWsProgScale = 1024.0f, kWsProgInv = 1.0f / 1024.0f;
-#endif
 
 struct WsImage { int a, wfc, bias, bfc, slots; };     // offsets in 16-byte slots
 __host__ __device__ constexpr WsImage ws_image(int nxc) {
@@ -858,13 +797,10 @@ __global__ __launch_bounds__(256) void hns_tp_pack_ws_kernel(const TpParams p, i
 // lands in a register an MFMA in flight still reads corrupts the operand (found in round 2 on the A side, and again here on the
 // B side: 1-3 envs in 256 off by 1e-5 while the compiler placed the reads).  BASE rotates the slots from tile to tile so that the
 // first reads of a tile, which may be issued right behind the previous tile's last MFMA, never target that MFMA's slot.
-#ifndef WS_D2
-#define WS_D2 3          // lab: read-ahead distance of the operand ring in the two-chunk instantiation
-#endif
 template <int NXC, bool WITH_H>
 struct WsTile {
     static constexpr int NX2 = 2 * NXC, NCROSS = NX2 + (WITH_H ? 8 : 0), N = NCROSS + NXC + (WITH_H ? 4 : 0);
-    static constexpr int D = NXC == 2 ? WS_D2 : 3, RING = D + 1;
+    static constexpr int D = NXC == 2 ? 3 : 3, RING = D + 1;
     static constexpr bool lead(int k) { return k >= NCROSS; }
     static constexpr bool is_x(int k) { return k < NX2 || (lead(k) && k < NCROSS + NXC); }
     static constexpr int chunk(int k) { return k < NX2 ? k / 2 : k < NCROSS ? (k - NX2) / 2 : k < NCROSS + NXC ? k - NCROSS : k - NCROSS - NXC; }
@@ -889,11 +825,7 @@ struct WsTile {
     }
     template <int BASE, int k>
     static __device__ __forceinline__ void step(const Ctx &c) {
-#ifdef TP_ABL_NOMFMA                           // lab: no matrix products
-        c.acc[k % 16] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, c.b[(k + BASE) % RING]).x & 0x3f000000u);
-#else
         c.acc = TP_MFMA(c.aw[a_term(k)][a_chunk(k)], c.b[(k + BASE) % RING], c.acc);
-#endif
         if constexpr (k + D < N) c.b[(k + D + BASE) % RING] = load<k + D>(c);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -908,24 +840,10 @@ struct WsTile {
     }
 };
 
-#ifndef WS_OCC
-#define WS_OCC 4
-#endif
-#ifndef WS_OCC2
-#define WS_OCC2 2      // lab: waves per SIMD the two-chunk instantiation is compiled for (4 = the 128-register cap: spills)
-#endif
-#ifndef WS_ABL
-#define WS_ABL 0       // lab: 1 = no frame phase inside the loop, 2 = no barriers inside the loop (timing only, results wrong)
-#endif
-#if WS_ABL & 2
-#define WS_SYNC()
-#else
-#define WS_SYNC() __syncthreads()
-#endif
 // frames of two and more chunks hold 48-72 registers of weights per lane (two chunks under the 128-register cap of four waves per SIMD spill into
 // the hot loop: 186 us against 133 us for THREE chunks without the cap) and 66-116 KB of LDS: one workgroup per CU, two waves per SIMD
 template <int NXC>
-__global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : NXC == 2 ? WS_OCC2 : 2) void hns_tp_lstm_ws_kernel(const TpParams p) {
+__global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void hns_tp_lstm_ws_kernel(const TpParams p) {
     constexpr int NC = NXC + 4;
     constexpr WsImage L = ws_image(NXC);
     extern __shared__ __align__(16) uint4 simg[];
@@ -1035,17 +953,8 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : NXC == 2 ? WS_OCC2 
     const float4 *sBias = reinterpret_cast<const float4 *>(sB) + (r * 2 + hb) * 4;
     if (prof && lane == 0) prof[1] = __builtin_amdgcn_s_memrealtime();
 
-#ifdef WS_PHASES                                           // lab: cycles per phase, summed over the timesteps with a recurrent product (tools/tp_phase_profile.py --ws)
-    unsigned long long wph[5] = {0, 0, 0, 0, 0}, wlast = __builtin_readcyclecounter();
-#define WS_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); if (t > 0) wph[i] += now_ - wlast; wlast = now_; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define WS_STAMP(i)
-#endif
     for (int t = 0; t < T; ++t) {
-        WS_STAMP(4)                                        // 4: publishing h + loop overhead
-        WS_SYNC();                                         // x_t and h_{t-1} are in LDS
-        WS_STAMP(0)                                        // 0: barrier waits
-#if !(WS_ABL & 1)
+        __syncthreads();                                         // x_t and h_{t-1} are in LDS
         if (t + 1 < T) {                                   // frame t+1 -> the other x buffer (last read at timestep t-1)
             emit(t + 1, xn);
             if (t + 2 < T) {
@@ -1057,8 +966,6 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : NXC == 2 ? WS_OCC2 
                 } else load_row(t + 3, xn);
             }
         }
-#endif
-        WS_STAMP(1)                                        // 1: next frame
         auto tile = [&](auto te_c) {
             constexpr int te = decltype(te_c)::value;
             f32x16 acc;
@@ -1079,12 +986,7 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : NXC == 2 ? WS_OCC2 
                     W::template run<(W::N * te) % W::RING>(cx);
                 }
             }
-#ifdef WS_NOPS
-            asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
-#endif
-            WS_STAMP(2)                                    // 2: matrix products of the tile
             // cell update of units 8 r + 4 hb + j (torch.nn.LSTM gate order i, f, g, o = accumulator registers j, 4 + j, 8 + j, 12 + j)
-#ifndef TP_CELL_V1
             // Round 4: 22 vector instructions per unit, 8 of them transcendental (was 26 / 9).  With e_x = 2^(pre-activation) (the weight
             // image carries -log2 e, -2 log2 e for the g gate):
             //   sigmoid(i) tanh(g) = (2 - E_g) / (E_i E_g) = (1 - e_g) / fma(e_i, E_g, E_g)                 one reciprocal for both gates,
@@ -1116,49 +1018,10 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : NXC == 2 ? WS_OCC2 
             }
             hnew[te][0] = make_uint2(hi_r[0], hi_r[1]);
             hnew[te][1] = make_uint2(lo_r[0], lo_r[1]);
-#else
-            typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-            half4 hi4, lo4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#ifdef TP_ABL_NOCELL                           // lab: no nonlinearities
-                const float h = (acc[j] + acc[12 + j]) * 1e-3f;
-#else
-                const float Ei = 1.0f + __builtin_amdgcn_exp2f(acc[j]);
-                const float Ef = 1.0f + __builtin_amdgcn_exp2f(acc[4 + j]);
-                const float Eg = 1.0f + __builtin_amdgcn_exp2f(acc[8 + j]);
-                const float Eo = 1.0f + __builtin_amdgcn_exp2f(acc[12 + j]);
-                const float gi = __builtin_amdgcn_rcpf(Ei), gf = __builtin_amdgcn_rcpf(Ef);
-                const float gg = HNS_FMA(__builtin_amdgcn_rcpf(Eg), 2.0f, -1.0f);
-                const float cn = HNS_FMA(gf, c[te][j], gi * gg);
-                c[te][j] = cn;
-                const float Ec = 1.0f + __builtin_amdgcn_exp2f(cn * (2.0f * kNegLog2e));
-                // h = o tanh(c') = (2 - Ec) / (Eo Ec): one reciprocal (Ec <= 1 + 2^(2.9 T) stays finite; Eo = inf gives 0)
-#ifdef WS_H2RCP
-                const float h = __builtin_amdgcn_rcpf(Eo) * HNS_FMA(__builtin_amdgcn_rcpf(Ec), 2.0f, -1.0f);
-#else
-                const float h = (2.0f - Ec) * __builtin_amdgcn_rcpf(Eo * Ec);
-#endif
-#endif
-                _Float16 a, b;
-                ws_split(h, a, b);
-                hi4[j] = a; lo4[j] = b;
-#ifdef WS_DEBUG                                              // lab: one (env, unit)'s pre-activations, cell state and h per timestep
-                if (p.prof && e0 + te * 32 + (lane & 31) == WS_DEBUG_ENV && 8 * r + 4 * hb + j == WS_DEBUG_UNIT) {
-                    float *dbg = reinterpret_cast<float *>(p.prof) + 4096 + t * 8;
-                    dbg[0] = acc[j]; dbg[1] = acc[4 + j]; dbg[2] = acc[8 + j]; dbg[3] = acc[12 + j]; dbg[4] = cn; dbg[5] = h; dbg[6] = (float)a; dbg[7] = (float)b;
-                }
-#endif
-            }
-            hnew[te][0] = __builtin_bit_cast(uint2, hi4);
-            hnew[te][1] = __builtin_bit_cast(uint2, lo4);
-#endif
-            WS_STAMP(3)                                    // 3: cell update of the tile
         };
         tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{});
         tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{});
-        WS_SYNC();                                         // every wave has read h_{t-1}
-        WS_STAMP(0)
+        __syncthreads();                                         // every wave has read h_{t-1}
         // publish this slice of h_t: chunk r >> 1, k-slots 4 (r & 1) .. + 3 of both lane halves
 #pragma unroll
         for (int te = 0; te < kWsTiles; ++te)
@@ -1168,14 +1031,6 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? WS_OCC : NXC == 2 ? WS_OCC2 
     }
     __syncthreads();
     if (prof && lane == 0) prof[2] = __builtin_amdgcn_s_memrealtime();
-#ifdef WS_PHASES
-    if (prof && lane == 0) {
-        unsigned hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        prof[5] = wph[0]; prof[6] = wph[1]; prof[7] = wph[2]; prof[8] = wph[3]; prof[9] = wph[4]; prof[10] = ((unsigned long long)xcc << 32) | hwid;
-    }
-#endif
 
     // ---- output layer on h_T (waves 0..3, one column tile each): tanh(W_fc h + b), rescaled to arena units (hideandseek.py:834-836) ----
     float *sPred = reinterpret_cast<float *>(sX);           // [env 128][16], or [env 128][32] with more than five predicted points (3F > 16): 16 KB,

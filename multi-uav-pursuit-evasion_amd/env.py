@@ -266,6 +266,17 @@ class HideAndSeek(_EnvBase):
             self._tp_weight_ptrs = None
             self._tp_weight_versions = None
             self._tp_filled = False
+        # Step + predictor as two half-batches on two streams (round 4): envs are independent, so the halves [0, E/2) and
+        # [E/2, E) are stepped by two more handles over slices of the SAME buffers (pointers offset, `stats` addressed with the whole
+        # batch's row stride), one on the caller's stream and one on a side stream, forked and joined with events inside `_step`.
+        # OFF by default (task.tp_overlap: 1 turns it on): two free-running streams gain 7 % (118 -> 110 us per 65 536-env step,
+        # tools/tp_overlap_lab.py), but `step()` must join them before it returns — its outputs feed the policy on the caller's stream — and
+        # with a fork and a join per step the pair measures SLOWER than the whole batch on one stream (131.5 against 113.2 us, bench.py
+        # `tp_mode`, round 4): kept for consumers that can take the halves un-joined (asynchronous collectors), bit-identical either way.
+        self._halves = None
+        ov = cfg.task.get("tp_overlap", 0)
+        if self.use_TP_net and E % 128 == 0 and (ov == 1 or ov == "1"):
+            self._make_halves()
         self._set_specs()
         self.success_rate_fn = None      # optional callable(env) -> success rate over the WHOLE (sharded) batch
         self._since_full_reset = 0
@@ -275,6 +286,51 @@ class HideAndSeek(_EnvBase):
         self._state_buf = None
         self._action_shape = torch.Size([self.num_envs, self.num_agents, 4])
         self._done_ptr = self._bufs["done"].data_ptr()
+
+    def _make_halves(self):
+        E, h = self.num_envs, self.num_envs // 2
+        self._side_stream = torch.cuda.Stream(self.device)
+        self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+        halves = []
+        for i in range(2):
+            cfg_i = self.hcfg.copy()
+            cfg_i.num_envs = h
+            cfg_i.env_index_offset = int(self.hcfg.env_index_offset) + i * h
+            cfg_i.stats_stride = E
+            hb = abi.HnsBuffers()
+            for name in abi.BUFFER_FIELDS:
+                if name == "reset_pid":
+                    continue
+                t = self._bufs.get(name)
+                ptr = getattr(self._hbuf, name)
+                if t is None or not ptr:
+                    setattr(hb, name, None)
+                elif name == "stats":
+                    setattr(hb, name, t[:, i * h:].data_ptr())           # columns [i h, (i + 1) h) of every row
+                elif name == "nonfinite":
+                    setattr(hb, name, t.data_ptr())                       # one sticky word for the whole batch
+                else:
+                    setattr(hb, name, t[i * h:].data_ptr())
+            hb.reset_pid = self._bufs["done"][i * h:].data_ptr() if self.pid_reset_reference else None
+            env_i = C.c_void_p()
+            self._check(self._lib.hns_create(C.byref(cfg_i), C.byref(env_i)), "hns_create (half batch)")
+            self._check(self._lib.hns_bind(env_i, C.byref(hb)), "hns_bind (half batch)")
+            halves.append(SimpleNamespace(env=env_i, cfg=cfg_i, hbuf=hb, first=i * h, tp_bound=None))
+        self._halves = halves
+
+    def _bind_tp_halves(self, ws):
+        """hns_tp_bind of the two half-batch handles: the learner's parameter tensors and the shared operand image, the unit-major buffers offset."""
+        NT, h = self.num_targets, self.num_envs // 2
+        for i, hv in enumerate(self._halves):
+            tb = abi.HnsTpBuffers()
+            for f, w in zip(abi.TP_WEIGHT_FIELDS, ws):
+                setattr(tb, f, w.data_ptr())
+            for name, t in self._tp_bufs.items():
+                per_unit = name in ("history", "pred", "groundtruth", "tp_done")
+                setattr(tb, name, t.data_ptr() if name == "packed" else t[i * h * (NT if per_unit else 1):].data_ptr())
+            if not self.write_critic_state:
+                tb.state_drones = None
+            self._check(self._lib.hns_tp_bind(hv.env, C.byref(tb), self.tp_history_step, self.tp_future_step), "hns_tp_bind (half batch)")
 
     # ---- registry (isaac_env.py:154-161) ----------------------------------------------------------
     def __init_subclass__(cls, **kw):
@@ -293,9 +349,12 @@ class HideAndSeek(_EnvBase):
         F = int(t.get("future_predcition_step", 5))
         NT = self.num_targets
         D = abi.self_dim(NT) + (3 * F * NT if self.use_TP_net else 0)               # 20 or 35 (two evaders: 24 or 24 + 6F)
-        obs = {"state_self": unbounded_spec((E, A, 1, D), dev), "cylinders": unbounded_spec((E, A, K, 5), dev)}
+        # key order as the reference declares it (hideandseek.py:338-352: state_self, state_others, cylinders): the attention encoder builds its
+        # token sequence in spec-key order with the first key as the query (learning/modules/networks.py:250-298)
+        obs = {"state_self": unbounded_spec((E, A, 1, D), dev)}
         if A > 1:
             obs["state_others"] = unbounded_spec((E, A, A - 1, 3), dev)
+        obs["cylinders"] = unbounded_spec((E, A, K, 5), dev)
         # (`state.cylinders` is declared (k, 5) although the tensor the reference returns is [E, A, k, 5], :887)
         state = {"state_drones": unbounded_spec((E, A, D), dev), "cylinders": unbounded_spec((E, K, 5), dev)}
         # the TP entry is part of the spec whether or not the predictor is used (:358-374)
@@ -337,6 +396,9 @@ class HideAndSeek(_EnvBase):
         return self
 
     def close(self):
+        for hv in (getattr(self, "_halves", None) or []):
+            self._lib.hns_destroy(hv.env)
+        self._halves = None
         if getattr(self, "_env", None):
             self._lib.hns_destroy(self._env)
             self._env = None
@@ -371,6 +433,8 @@ class HideAndSeek(_EnvBase):
         if self.use_TP_net:
             self._tp_observe()
         td = self._obs_tensordict()
+        if not self.training:
+            td = self._fresh_obs(td)              # eval mode: new tensors, as in `_fresh_step_output`
         td.set("stats", last_stats)
         td.set("truncated", (self.progress_buf > self.max_episode_length).unsqueeze(1))
         return td
@@ -399,9 +463,12 @@ class HideAndSeek(_EnvBase):
             d = tensordict.get("done", None)
             if d is not None and d.data_ptr() != self._done_ptr:
                 self._bufs["done"].copy_(d.reshape(self.num_envs).to(torch.uint8))
-        rc = self._lib.hns_step(self._env, action.data_ptr(), _raw_stream(self._dev_index))
-        if rc != 0:
-            self._check(rc, "hns_step")
+        if self._halves is not None:
+            self._step_halves(action)
+        else:
+            rc = self._lib.hns_step(self._env, action.data_ptr(), _raw_stream(self._dev_index))
+            if rc != 0:
+                self._check(rc, "hns_step")
         self._action_keepalive = action
         self._since_full_reset += 1
         self._state_version += 1
@@ -415,9 +482,12 @@ class HideAndSeek(_EnvBase):
             rate = self.success_rate_fn(self) if self.success_rate_fn is not None else float(self.stats["success"].mean())
             if bool(done.any()) and rate >= 0.98:
                 self.v_prey = min(1.3, self.v_prey + 0.05)
-                self._check(self._lib.hns_set_v_prey(self._env, C.c_float(self.v_prey)), "hns_set_v_prey")
-        if self.use_TP_net:
+                for h in self._handles():
+                    self._check(self._lib.hns_set_v_prey(h, C.c_float(self.v_prey)), "hns_set_v_prey")
+        if self.use_TP_net and self._halves is None:
             self._tp_observe()
+        if not self.training:
+            return self._fresh_step_output()
         if self._next_cache is None:
             # every leaf is a view of a persistent buffer that the kernel just rewrote in place, so
             # the output tree is built once and handed out again (the reference's collector runs
@@ -435,13 +505,59 @@ class HideAndSeek(_EnvBase):
             self._next_cache = TensorDict(out, self.batch_size)
         return self._next_cache
 
+    def _fresh_step_output(self):
+        """`env.eval()` (scripts/train.py:213-214 before `env.rollout(...)`, :225-233): the observation, state, predictor entries, reward and `done`
+        are NEW tensors at every step, as the reference's are (torch.cat / stack results, hideandseek.py:856-917, 1056-1064) — `EnvBase.rollout`
+        keeps the step outputs by reference (`tensordict.clone(False)`) and stacks them afterwards, which needs them to stay what they were.
+        `stats` and `info` stay the persistent tensors they are in the reference as well (`"stats": self.stats`).  In train mode (the collector's
+        path: it copies every step into its own storage) the leaves are zero-copy views of the buffers the next step rewrites."""
+        b = self._bufs
+        nxt = self._fresh_obs(self._obs_tensordict())
+        nxt.set(("agents", "reward"), b["reward"].unsqueeze(-1).clone())
+        nxt.set("done", b["done"].view(torch.bool).unsqueeze(-1).clone())
+        out = {"next": nxt, "stats": {"action_error_order1": b["action_error"]}, "info": {"prev_action": b["prev_action"]}}
+        if self.publish_ctbr:
+            out["ctbr"] = b["ctbr"]
+            out["target_rate"] = b["target_rate"][..., :3]
+        return TensorDict(out, self.batch_size)
+
+    @staticmethod
+    def _fresh_obs(td):
+        agents = td.get("agents")
+        for group in ("observation", "state", "TP"):
+            g = agents.get(group, None)
+            if g is not None:
+                for k in list(g.keys()):
+                    g.set(k, g.get(k).clone())
+        return td
+
+    def _step_halves(self, action):
+        """hns_step + hns_tp_observe of [0, E/2) on the caller's stream and of [E/2, E) on the side stream, between a fork and a join event
+        (legal inside a stream capture: the side stream joins the capture through the fork event)."""
+        self._tp_sync_weights()
+        main = torch.cuda.current_stream(self.device)
+        side = self._side_stream
+        lib, (ha, hb) = self._lib, self._halves
+        fill = 0 if self._tp_filled else 1
+        self._ev_fork.record(main)
+        side.wait_event(self._ev_fork)
+        a0 = action.data_ptr()
+        rc = lib.hns_step(ha.env, a0, C.c_void_p(main.cuda_stream)) or lib.hns_tp_observe(ha.env, fill, C.c_void_p(main.cuda_stream))
+        rc = rc or lib.hns_step(hb.env, a0 + hb.first * self.num_agents * 16, C.c_void_p(side.cuda_stream)) or lib.hns_tp_observe(hb.env, fill, C.c_void_p(side.cuda_stream))
+        if rc != 0:
+            self._check(rc, "hns_step / hns_tp_observe (half batch)")
+        self._ev_join.record(side)
+        main.wait_event(self._ev_join)
+        self._tp_filled = True
+
     def _obs_tensordict(self):
         b = self._bufs
         if self.use_TP_net:
             tb = self._tp_bufs
-            obs = {"state_self": tb["obs_self"].unsqueeze(2), "cylinders": b["obs_cylinders"]}
+            obs = {"state_self": tb["obs_self"].unsqueeze(2)}
             if self.num_agents > 1:
                 obs["state_others"] = b["obs_others"]
+            obs["cylinders"] = b["obs_cylinders"]
             if self.write_critic_state:
                 state = {"state_drones": tb["state_drones"], "cylinders": b["obs_cylinders"]}
             else:
@@ -453,9 +569,10 @@ class HideAndSeek(_EnvBase):
                       "TP_done": tb["tp_done"].view(torch.bool).view(E, 2)[:, :1]}
             return TensorDict({"agents": {"observation": obs, "state": state, "TP": tp}, "stats": self.stats, "info": self.info},
                               self.batch_size)
-        obs = {"state_self": b["obs_self"].unsqueeze(2), "cylinders": b["obs_cylinders"]}
+        obs = {"state_self": b["obs_self"].unsqueeze(2)}
         if self.num_agents > 1:
             obs["state_others"] = b["obs_others"]
+        obs["cylinders"] = b["obs_cylinders"]
         if self.write_critic_state:
             state = {"state_drones": b["state_drones"], "cylinders": b["obs_cylinders"]}
         else:
@@ -481,6 +598,14 @@ class HideAndSeek(_EnvBase):
         append, TP_net forward on the matrix cores, 35-value rows (hns_tp_observe).  `self.TP`'s
         parameters are re-packed into the operand image only when their version counters moved
         (optimiser step / load_state_dict), re-bound only if the learner swapped the tensors."""
+        self._tp_sync_weights()
+        rc = self._lib.hns_tp_observe(self._env, 0 if self._tp_filled else 1, self._stream())
+        if rc != 0:
+            self._check(rc, "hns_tp_observe")
+        self._tp_filled = True                      # the window is never reset per env (hideandseek.py:825-830)
+
+    def _tp_sync_weights(self):
+        """(Re-)bind / re-pack the predictor's parameters when the learner swapped or updated them (see `_tp_observe`)."""
         tp = self.TP            # attribute lookups, not state_dict(): this runs every step
         ws = (tp.lstm.weight_ih_l0, tp.lstm.weight_hh_l0, tp.lstm.bias_ih_l0, tp.lstm.bias_hh_l0, tp.fc.weight, tp.fc.bias)
         ptrs = tuple(w.data_ptr() for w in ws)
@@ -496,20 +621,24 @@ class HideAndSeek(_EnvBase):
             if not self.write_critic_state:
                 tb.state_drones = None
             self._check(self._lib.hns_tp_bind(self._env, C.byref(tb), self.tp_history_step, self.tp_future_step), "hns_tp_bind")
+            if self._halves is not None:
+                self._bind_tp_halves(ws)
             self._tp_weight_ptrs, self._tp_weight_versions = ptrs, versions
+            self._tp_refresh_all()
         elif versions != self._tp_weight_versions:
-            self._check(self._lib.hns_tp_refresh(self._env, self._stream()), "hns_tp_refresh")
+            self._tp_refresh_all()
             self._tp_weight_versions = versions
-        rc = self._lib.hns_tp_observe(self._env, 0 if self._tp_filled else 1, self._stream())
-        if rc != 0:
-            self._check(rc, "hns_tp_observe")
-        self._tp_filled = True                      # the window is never reset per env (hideandseek.py:825-830)
+
+    def _tp_refresh_all(self):
+        """One re-pack of the operand image on the caller's stream (the handles share it); every handle is told its image is current."""
+        for h in [self._env] + [hv.env for hv in (self._halves or [])]:
+            self._check(self._lib.hns_tp_refresh(h, self._stream()), "hns_tp_refresh")
 
     def refresh_tp_weights(self):
         """Re-pack the predictor's parameters now.  `_tp_observe` notices optimiser steps and `load_state_dict` through
         the tensors' version counters; writes through `.data` do not move them — call this after such an update."""
         if self.use_TP_net and self._tp_weight_ptrs is not None:
-            self._check(self._lib.hns_tp_refresh(self._env, self._stream()), "hns_tp_refresh")
+            self._tp_refresh_all()
 
     # ---- schedule hooks -------------------------------------------------------------------------------------------
     def set_update_epoch(self, epoch):
@@ -518,14 +647,21 @@ class HideAndSeek(_EnvBase):
         t = self.cfg.task
         coef = min(float(t.get("max_smoothness_coef", 5.0)),
                    float(t.get("init_smoothness_coef", 0.0)) + float(t.get("smooth_lr", 0.0)) * self.update_epoch)
-        self._check(self._lib.hns_set_smoothness_coef(self._env, C.c_float(coef)), "hns_set_smoothness_coef")
+        for h in self._handles():
+            self._check(self._lib.hns_set_smoothness_coef(h, C.c_float(coef)), "hns_set_smoothness_coef")
+
+    def _handles(self):
+        return [self._env] + [hv.env for hv in (self._halves or [])]
+
+    def _timed_handle(self):
+        return self._halves[0].env if self._halves is not None else self._env      # (halves: the launches of [0, E/2))
 
     def enable_kernel_timing(self, on=True):
-        self._check(self._lib.hns_enable_timing(self._env, int(on)), "hns_enable_timing")
+        self._check(self._lib.hns_enable_timing(self._timed_handle(), int(on)), "hns_enable_timing")
 
     def kernel_ms(self):
         n = C.c_int(0)
-        ms = float(self._lib.hns_step_kernel_ms(self._env, C.byref(n)))
+        ms = float(self._lib.hns_step_kernel_ms(self._timed_handle(), C.byref(n)))
         return ms, n.value
 
     def region_begin(self):
@@ -623,7 +759,8 @@ class HideAndSeek(_EnvBase):
         self.seed, epoch, self._since_full_reset, self.update_epoch = (int(x) for x in z["_meta"])
         self._check(self._lib.hns_set_reset_epoch(self._env, C.c_uint32(epoch)), "hns_set_reset_epoch")
         self.v_prey = float(z["_v_prey"])
-        self._check(self._lib.hns_set_v_prey(self._env, C.c_float(self.v_prey)), "hns_set_v_prey")
+        for h in self._handles():
+            self._check(self._lib.hns_set_v_prey(h, C.c_float(self.v_prey)), "hns_set_v_prey")
         self.set_update_epoch(self.update_epoch)
         if self.use_TP_net and "_tp_history" in z.files:
             self._tp_bufs["history"].copy_(torch.from_numpy(z["_tp_history"]))

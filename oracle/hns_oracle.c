@@ -600,6 +600,7 @@ void hns_oracle_set_threads(int n) { g_step_threads = n < 1 ? 1 : n; }
 
 int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action) {
     const int E = c->num_envs, A = c->num_agents, C = c->num_cylinders, K = c->obs_max_cylinder;
+    const size_t S = c->stats_stride ? (size_t)c->stats_stride : (size_t)E;       /* row stride of `stats` (include/hns.h) */
     if (A < 1 || A > HNS_MAX_AGENTS || C > HNS_MAX_CYLINDERS || K > C) return HNS_ERR_INVALID_ARG;
 #pragma omp parallel for schedule(static) num_threads(g_step_threads)
     for (int e = 0; e < E; ++e) {
@@ -633,15 +634,15 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
         }
         /* A10  hideandseek.py:731-733 */
         float mae = sum_ae * c->inv_num_agents;
-        stats[(size_t)HNS_ST_ACTION_ERROR_ORDER1_MEAN * E] += mae;
-        if (mae > stats[(size_t)HNS_ST_ACTION_ERROR_ORDER1_MAX * E]) stats[(size_t)HNS_ST_ACTION_ERROR_ORDER1_MAX * E] = mae;
+        stats[(size_t)HNS_ST_ACTION_ERROR_ORDER1_MEAN * S] += mae;
+        if (mae > stats[(size_t)HNS_ST_ACTION_ERROR_ORDER1_MAX * S]) stats[(size_t)HNS_ST_ACTION_ERROR_ORDER1_MAX * S] = mae;
         /* A6 on S_t */
         float dpos[HNS_MAX_AGENTS * 3];
         for (int a = 0; a < A; ++a) for (int i = 0; i < 3; ++i) dpos[3 * a + i] = ds[13 * a + i];
         float force[3], tvel[3];
-        o_prey(c, A, C, dpos, tp, cyl, force, tvel, &stats[(size_t)HNS_ST_OUT_OF_ARENA * E]);
+        o_prey(c, A, C, dpos, tp, cyl, force, tvel, &stats[(size_t)HNS_ST_OUT_OF_ARENA * S]);
         float force1[3], tvel1[3] = {0.0f, 0.0f, 0.0f};
-        if (NT == 2) o_prey(c, A, C, dpos, tp + 3, cyl, force1, tvel1, &stats[(size_t)HNS_ST_OUT_OF_ARENA * E]);
+        if (NT == 2) o_prey(c, A, C, dpos, tp + 3, cyl, force1, tvel1, &stats[(size_t)HNS_ST_OUT_OF_ARENA * S]);
         /* A4 forces/torques on S_t, then A5 */
         float fw[HNS_MAX_AGENTS][3], tb[HNS_MAX_AGENTS][3];
         for (int a = 0; a < A; ++a) {
@@ -685,7 +686,7 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
          * parity tests check the kernel's carried-over flag against an independent evaluation. */
         for (int a = 0; a < A; ++a) b->pid_last_rate[((size_t)e * A + a) * 4 + 3] = (float)(side.blocked[a] + 2 * side.blocked1[a]);
         o_reward(c, A, C, K, ds, tp, cyl, b->progress[e], &side, b->action_error + (size_t)e * A, thr_diff,
-                 stats, (size_t)E, b->reward + (size_t)e * A, b->done + e);
+                 stats, S, b->reward + (size_t)e * A, b->done + e);
         if (b->detect) b->detect[e] = (uint8_t)(side.bdetect | (side.bdetect1 << 1));
         for (int k = 0; k < NT; ++k) {
             float s = (tp[3 * k] + tp[3 * k + 1]) + tp[3 * k + 2];
@@ -749,10 +750,11 @@ int hns_oracle_reset_tasks(const hns_cfg *c, const hns_buffers *b, const uint8_t
 static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *mask, uint64_t seed, uint32_t epoch,
                         const float *tasks, int task_first) {
     const int E = c->num_envs, A = c->num_agents, C = c->num_cylinders, K = c->obs_max_cylinder, G = c->grid_num;
+    const size_t S = c->stats_stride ? (size_t)c->stats_stride : (size_t)E;
     if (G > 16) return HNS_ERR_INVALID_ARG;
     for (int e = 0; e < E; ++e) {
         /* :712 sets first_capture_step for ALL envs on any reset call */
-        b->stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * E + e] = (float)c->max_episode_length;
+        b->stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * S + e] = (float)c->max_episode_length;
         const int masked = !(mask && !mask[e]);
         if (!masked && !c->reset_extra_step) continue;
         o_rng rng = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(e + c->env_index_offset), epoch, 0u, {0, 0, 0, 0}, 0};
@@ -863,8 +865,8 @@ static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *m
                 cyl[3 * k + 2] = (k >= n_active) ? c->invalid_z : 0.5f * c->cylinder_height;
             }
         }
-        for (int s = 0; s < HNS_NUM_STATS; ++s) b->stats[(size_t)s * E + e] = 0.0f;
-        b->stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * E + e] = (float)c->max_episode_length;
+        for (int s = 0; s < HNS_NUM_STATS; ++s) b->stats[(size_t)s * S + e] = 0.0f;
+        b->stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * S + e] = (float)c->max_episode_length;
         b->progress[e] = 0.0f;
         b->done[e] = 0;
         }   /* masked */
@@ -962,7 +964,7 @@ void hns_oracle_obs_reward(const hns_cfg *c, const hns_buffers *b, const float *
         bdetect[e] = (uint8_t)side.bdetect;
         if (do_reward)
             o_reward(c, A, C, K, ds, tp, cyl, b->progress[e], &side, b->action_error + (size_t)e * A,
-                     thr_diff + (size_t)e * A, b->stats + e, (size_t)E, b->reward + (size_t)e * A, b->done + e);
+                     thr_diff + (size_t)e * A, b->stats + e, c->stats_stride ? (size_t)c->stats_stride : (size_t)E, b->reward + (size_t)e * A, b->done + e);
     }
 }
 int hns_oracle_cell(const hns_cfg *c, float x) { return o_cell(c, x); }

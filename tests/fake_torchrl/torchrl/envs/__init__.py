@@ -141,6 +141,34 @@ class EnvBase(nn.Module):
             tensordict = td_reset
         return tensordict
 
+    def rollout(self, max_steps, policy=None, callback=None, auto_reset=True, auto_cast_to_device=False, break_when_any_done=True,
+                return_contiguous=True, tensordict=None):
+        """torchrl 0.1.1 `EnvBase.rollout`: reset (auto_reset), then policy -> step -> keep `tensordict.clone(False)` (the step's tensors BY
+        REFERENCE) -> step_mdp -> callback; no reset inside the loop — with break_when_any_done=False finished envs keep being stepped with
+        their root `done` set; the kept steps are stacked along a new last batch dimension, lazily with return_contiguous=False."""
+        from .utils import step_mdp
+        if auto_reset:
+            if tensordict is not None:
+                raise RuntimeError("tensordict cannot be provided when auto_reset is True")
+            tensordict = self.reset()
+        elif tensordict is None:
+            raise RuntimeError("tensordict must be provided when auto_reset is False")
+        if policy is None:
+            def policy(td):
+                return td.update(self.action_spec.rand())
+        kept = []
+        for i in range(max_steps):
+            tensordict = policy(tensordict)
+            tensordict = self.step(tensordict)
+            kept.append(tensordict.clone(False))
+            if (break_when_any_done and bool(tensordict.get(("next", "done")).any())) or i == max_steps - 1:
+                break
+            tensordict = step_mdp(tensordict, keep_other=True, exclude_action=False, exclude_reward=True)
+            if callback is not None:
+                callback(self, tensordict)
+        out = LazyStackedTensorDict(kept, len(self.batch_size))
+        return out.contiguous() if return_contiguous else out
+
     def set_seed(self, seed=None, static_seed=False):
         if seed is not None:
             torch.manual_seed(seed)
@@ -158,6 +186,42 @@ class EnvBase(nn.Module):
 
     def __repr__(self):
         return f"{self.__class__.__name__}(batch_size={tuple(self.batch_size)}, device={self.device})"
+
+
+class LazyStackedTensorDict:
+    """What `torch.stack(list_of_tensordicts, dim)` gives in tensordict 0.1.2: the tensordicts are kept; an entry is stacked when it is read."""
+
+    def __init__(self, tds, dim):
+        self.tensordicts, self.stack_dim = list(tds), dim
+        b = tuple(tds[0].batch_size)
+        self.batch_size = torch.Size((*b[:dim], len(tds), *b[dim:]))
+
+    def get(self, key, default=None):
+        vals = [td.get(key, None) for td in self.tensordicts]
+        if any(v is None for v in vals):
+            if default is None:
+                raise KeyError(key)
+            return default
+        if isinstance(vals[0], TensorDictBase):
+            return LazyStackedTensorDict(vals, self.stack_dim)
+        return torch.stack(vals, self.stack_dim)
+
+    def __getitem__(self, key):
+        if isinstance(key, (str, tuple)) and (isinstance(key, str) or all(isinstance(k, str) for k in key)):
+            return self.get(key)
+        raise NotImplementedError("only key access")
+
+    def keys(self, *a, **k):
+        return self.tensordicts[0].keys(*a, **k)
+
+    def clone(self, recurse=True):
+        return LazyStackedTensorDict([td.clone(recurse) for td in self.tensordicts], self.stack_dim)
+
+    def contiguous(self):
+        out = TensorDict({}, self.batch_size, self.tensordicts[0].device)
+        for k in self.tensordicts[0].keys(True, True):
+            out.set(k, self.get(k))
+        return out
 
 
 class Transform(nn.Module):

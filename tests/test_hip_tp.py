@@ -294,3 +294,50 @@ def test_tp_random_configuration_matches_oracle(seed):
             td.set("_reset", done.clone())
             env.reset(td)
             O.tp_observe(env.hcfg, env.export_state(), tpa, fill=False)
+
+
+@pytest.mark.parametrize("E,A,NT", [(256, 3, 1), (384, 6, 1), (256, 3, 2)])
+def test_step_and_predictor_as_two_half_batches_on_two_streams(E, A, NT):
+    """task.tp_overlap: the halves [0, E/2) and [E/2, E) stepped by two handles over slices of the same buffers, on two streams
+    between a fork and a join event, leave every buffer — step state, statistics (a [24, E] array addressed with the whole batch's row stride),
+    the predictor's window, predictions and rows — bit-identical to the whole batch on one stream, across a masked reset, a curriculum change of
+    the evader's speed and an in-place parameter update."""
+    def make(overlap):
+        cfg = config.make_cfg({"num_agents": A, "num_targets": NT, "tp_overlap": overlap, "cylinder": {"max_num": 5, "min_num": 3},
+                               "env": {"num_envs": E, "max_episode_length": 9}}, algo={"use_TP_net": 1, "critic_input": "state"})
+        env = HideAndSeek(cfg)
+        env.set_seed(11)
+        torch.manual_seed(5)
+        for p_ in env.TP.parameters():
+            torch.nn.init.uniform_(p_, -0.3, 0.3)
+        env.reset()
+        return env
+    whole, split = make(0), make(1)
+    assert whole._halves is None and split._halves is not None and int(split._halves[1].cfg.stats_stride) == E
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for t in range(14):
+        a = torch.randn(E, A, 4, generator=g).to(whole.device)
+        for env in (whole, split):
+            env.step(env.rand_step_input(a.clone()))
+        if t == 8:                                         # every env done: reset two thirds of them
+            mask = torch.zeros(E, 1, dtype=torch.bool, device=whole.device)
+            mask[::3] = True
+            mask[1::3] = True
+            for env in (whole, split):
+                from hns_amd.tensordict_shim import TensorDict
+                env.reset(TensorDict({"_reset": mask.clone()}, [E]))
+        if t == 4:
+            for env in (whole, split):
+                env.v_prey = 1.1
+                for h in env._handles():
+                    env._check(env._lib.hns_set_v_prey(h, C.c_float(1.1)), "hns_set_v_prey")
+        if t == 10:
+            for env in (whole, split):
+                with torch.no_grad():
+                    env.TP.fc.bias.add_(0.05)                # version counter moves: every handle's image is re-packed
+    a, b = whole.export_state(), split.export_state()
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), f"{k} differs between the whole batch and the two half batches"
+    for k in ("history", "pred", "obs_self", "state_drones", "groundtruth", "tp_done"):
+        assert torch.equal(whole._tp_bufs[k], split._tp_bufs[k]), f"predictor buffer {k} differs"
+    assert whole.check_finite() and split.check_finite()

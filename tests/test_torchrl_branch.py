@@ -59,3 +59,15 @@ def test_env_under_transformed_env_and_collector(use_tp):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert r["rollouts"] == 4 and r["masked_resets"] >= 2 and r["use_tp"] == use_tp
+
+
+@pytest.mark.gpu
+def test_env_under_rollout_evaluate_and_a_learner():
+    """scripts/train.py's other two consumers (VERDICT r3 #9): `evaluate()`'s `env.rollout(..., auto_reset=True, break_when_any_done=False,
+    return_contiguous=False)` in eval mode with a callback, and two PPO-style iterations of an attention policy that reads the observation in
+    spec-key order; every trajectory replayed on the oracle bit for bit, reset_pid pulsing past the end of the episode."""
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    out = subprocess.run([sys.executable, os.path.join(FAKE, "run_rollout.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["evaluate_steps"] == 13 and r["reset_pid_pulses"] == 3 * 192 and r["frames"] == 6 and r["ppo_iterations"] == 2
