@@ -433,7 +433,10 @@ static int upload_step_params(hns_env *env) {
     }
     Params q;
     fill_step_params(env, q);
-    if (env->params_valid && memcmp(&q, env->params_host, sizeof(Params)) == 0) return HNS_OK;
+    // unchanged since the last upload: nothing to do — unless a stream capture once took a change: a replay of that graph rewrites the device
+    // block behind the host's back, so the last image enqueued from here no longer says what the block holds (found by
+    // test_setter_inside_a_capture_in_the_default_mode: the third replay flew the captured speed)
+    if (env->params_valid && env->capture_used == 0 && memcmp(&q, env->params_host, sizeof(Params)) == 0) return HNS_OK;
     memcpy(env->params_host, &q, sizeof(Params));
     if (!env->params_valid) {
         HNS_CHECK_HIP(hipMemcpy(env->params_dev, env->params_host, sizeof(Params), hipMemcpyHostToDevice));

@@ -198,12 +198,12 @@ constexpr int kFxThreads = 1024, kFxGroups = 32, kFxStride = 8, kFxPts = 2, kFxD
 // often already decided: let p1 > p2 > ... be the candidates in key order (min-distance, ties -> lower index) BEFORE p1 is applied.  Applying
 // p1 can only lower keys.  If dist(p2, p1) >= d(p2), p2's key does not move, every other key was below it and stays below it: p2 IS the
 // next sample of the sequential algorithm.  By induction p_m is accepted when dist(p_m, p_j) >= d(p_m) for all accepted j < m; at the
-// first candidate that fails the prefix ends (its key drops, the next sample may be any point).  So an exchange carries the top kFxB
+// first candidate that fails the prefix ends (its key drops, the next sample may be any point).  So an exchange carries the top kFxB (8)
 // candidates of every workgroup, every workgroup derives the same global top kFxB, wave 0 evaluates the kFxB (kFxB - 1) / 2 pair
 // distances with the SAME sequential fma chain the update uses (so ">= d" decides exactly what min(d, dist) would), and the accepted
 // prefix is applied in one round.  The indices are those of sequential sampling, bit for bit (tests/test_hip_envgen.py against the oracle's
 // sequential loop); only the number of exchanges changes: ~k / (mean accepted) instead of k.
-constexpr int kFxB = 4;
+constexpr int kFxB = 8;
 
 
 // Maximum of a 32-bit value over the wave, uniform result: the row_shr / row_bcast ladder on the VALU's data-parallel primitives (six
@@ -229,12 +229,13 @@ HNS_DEV unsigned long long wave_max_key(unsigned long long k) {
     return ((unsigned long long)mh << 20) | (unsigned long long)ml;
 }
 
-// The workgroup's top `nb` keys (uniform result in top[]): every wave takes its own top nb (nb wave maxima, the lane that owns a winner pops
+// The workgroup's top `nb` keys, left in s_top[0 .. kFxB) (LDS: whatever is indexed by a run-time value lives there — a register array indexed
+// by the lane or by a loop counter ends up in scratch memory): every wave takes its own top nb (nb wave maxima, the lane that owns a winner pops
 // it from its sorted pair), parks them in LDS, and after ONE workgroup barrier every wave takes the top nb of those (THREADS / 64) x kFxB
 // values — one per lane at 1024 threads.
 template <int THREADS>
-HNS_DEV void fps_top(unsigned long long (&mine)[2], int nb, unsigned long long *s_wtop, unsigned long long (&top)[kFxB]) {
-    static_assert(THREADS / 64 * kFxB <= 64, "one parked candidate per lane");
+HNS_DEV void fps_top(unsigned long long (&mine)[2], int nb, unsigned long long *s_wtop, unsigned long long *s_top) {
+    static_assert(THREADS / 64 * kFxB <= 128, "at most two parked candidates per lane");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int pass = 0; pass < kFxB; ++pass) {
@@ -246,31 +247,34 @@ HNS_DEV void fps_top(unsigned long long (&mine)[2], int nb, unsigned long long *
         if (lane == 0) s_wtop[wave * kFxB + pass] = best;
     }
     __syncthreads();
-    unsigned long long v = lane < THREADS / 64 * kFxB ? s_wtop[lane] : 0ull;
+    unsigned long long v0 = lane < THREADS / 64 * kFxB ? s_wtop[lane] : 0ull, v1 = lane + 64 < THREADS / 64 * kFxB ? s_wtop[lane + 64] : 0ull;
+    if (wave != 0) return;                                   // (the publishers are threads 0 .. nb - 1)
 #pragma unroll
     for (int pass = 0; pass < kFxB; ++pass) {
-        top[pass] = 0ull;
+        unsigned long long best = 0ull;
         if (pass < nb) {
-            const unsigned long long best = wave_max_key(v);
-            v = (best != 0ull && v == best) ? 0ull : v;
-            top[pass] = best;
+            best = wave_max_key(v0 > v1 ? v0 : v1);
+            v0 = (best != 0ull && v0 == best) ? 0ull : v0;
+            v1 = (best != 0ull && v1 == best) ? 0ull : v1;
         }
+        if (lane == 0) s_top[pass] = best;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // One exchange: publish the workgroup's top `nb` candidates, sweep everybody's, take the global top nb, accept the prefix that sequential
 // sampling would select next (at most max_accept).  Returns the number accepted (their indices in s_acc), or -1 after reporting that a
 // workgroup never showed up.
 template <int THREADS, int XM>
-HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, int r, const unsigned long long (&top)[kFxB], int nb, int max_accept,
+HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, int r, const unsigned long long *s_top, int nb, int max_accept,
                            int *s_acc, int *s_nacc, int *s_fail, float *s_rows, float *warm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = p.d;
     const unsigned long long tag = (unsigned long long)(r % 4095 + 1) << 52;
     gu64 *slot = gran + (size_t)(r & 1) * G * kFxB;
     if (tid < kFxB) {
-        unsigned long long mine = 0ull;
-#pragma unroll
-        for (int i = 0; i < kFxB; ++i) mine = tid == i ? top[i] : mine;
+        const unsigned long long mine = s_top[tid];
         if (tid < nb) {
             __hip_atomic_store(slot + g_self * kFxB + tid, tag | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (mine != 0ull) {
@@ -330,12 +334,18 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
         // the candidates' coordinates: ONE cooperative fetch into LDS (rows of kFxD floats, zero-padded) — the pair distances below and, behind
         // the barrier, every thread's update read them there; a scalar load per accepted sample from every wave was a dependent
         // memory round trip each (measured: 11.8 us per exchange of four)
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < kFxB; ++m) s_acc[m] = gtop[m] != 0ull ? gi[m] : -1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (!fail) {
             for (int idx = lane; idx < kFxB * kFxD; idx += 64) {
                 const int m = idx / kFxD, c = idx - m * kFxD;
-                const int gim = m == 0 ? gi[0] : m == 1 ? gi[1] : m == 2 ? gi[2] : gi[3];
-                const unsigned long long gtm = m == 0 ? gtop[0] : m == 1 ? gtop[1] : m == 2 ? gtop[2] : gtop[3];
-                s_rows[idx] = (gtm != 0ull && c < d) ? p.points[(size_t)gim * d + c] : 0.0f;
+                const int gim = s_acc[m];
+                s_rows[idx] = (gim >= 0 && c < d) ? p.points[(size_t)gim * d + c] : 0.0f;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -374,8 +384,6 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
         nacc = nacc < max_accept ? nacc : max_accept;
         if (lane == 0) {
             *s_nacc = nacc;
-#pragma unroll
-            for (int m = 0; m < kFxB; ++m) s_acc[m] = gi[m];
             if (fail || gtop[0] == 0ull) *s_fail = 1;          // (no candidate at all cannot happen while samples are still due: k <= n)
         }
     }
@@ -392,13 +400,15 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
 // loads of the newest sample; with the samples' rows in LDS the only difference left was the one-time load of the points, and the
 // specialised form did not fit the 128 registers of a 1024-thread workgroup beside the exchange: 37 spilled registers, 28 ms per trim
 // against 13 ms.)
-// PTS points per thread (2: up to 65 536 points per XCD; 1: half that, and 36 registers fewer), XM = the most XCDs an instantiation serves.
+// PTS points per thread (1 in every instantiation that ships: 32 768 points per XCD; with 2 the eight-candidate exchange does not fit the 128
+// registers of a 1024-thread workgroup), XM = the most XCDs an instantiation serves.
 template <int PTS, int XM>
 __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams p) {
     if ((int)(blockIdx.x % kFxStride) >= p.xcds) return;
     __shared__ unsigned long long s_wtop[kFxThreads / 64 * kFxB];
     __shared__ __align__(16) float s_rows[kFxB * kFxD];            // the newest samples' coordinates (written by wave 0 in the exchange)
-    __shared__ int s_acc[kFxB];
+    __shared__ unsigned long long s_top[kFxB];
+    __shared__ int s_acc[kFxB];                                    // the newest samples' indices (the first: `start`)
     __shared__ int s_nacc;
     __shared__ int s_fail;
     const int G = kFxGroups * p.xcds;
@@ -421,16 +431,13 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         int i0 = p.start;
         s_rows[tid] = tid < d ? p.points[(size_t)i0 * d + tid] : 0.0f;
     }
-    int cur[kFxB] = {p.start, 0, 0, 0};
+    if (tid == 0) s_acc[0] = p.start;
     int ncur = 1, nout = 0;
     float warm = 0.0f;                                  // sum of the rows touched to warm the L2 (kept alive by the store below)
     __syncthreads();
     for (int r = 0;; ++r) {                             // r counts exchanges, nout the samples written
         if (g_self == 0 && tid < ncur) {
-            int mine = cur[0];
-#pragma unroll
-            for (int m = 1; m < kFxB; ++m) mine = tid == m ? cur[m] : mine;
-            p.out_idx[nout + tid] = mine;
+            p.out_idx[nout + tid] = s_acc[tid];
         }
         nout += ncur;
         if (nout >= p.k) break;
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         // them stays ONE sequential fmaf chain over the coordinates (= the oracle)
 #pragma unroll 1
         for (int m = 0; m < ncur; ++m) {
-            const int cm = m == 0 ? cur[0] : m == 1 ? cur[1] : m == 2 ? cur[2] : cur[3];
+            const int cm = s_acc[m];
             const float4 *qrow = reinterpret_cast<const float4 *>(s_rows + m * kFxD);
             float acc[PTS];
 #pragma unroll
@@ -476,13 +483,10 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
             else if (cand > mine[1]) mine[1] = cand;
         }
         static_assert(PTS <= 2, "a thread's candidates are a sorted pair");
-        unsigned long long top[kFxB];
-        fps_top<kFxThreads>(mine, nb, s_wtop, top);
+        fps_top<kFxThreads>(mine, nb, s_wtop, s_top);
         const int left = p.k - nout;
-        ncur = fps_exchange_b<kFxThreads, XM>(p, gran, G, g_self, r, top, nb, left < kFxB ? left : kFxB, s_acc, &s_nacc, &s_fail, s_rows, &warm);
+        ncur = fps_exchange_b<kFxThreads, XM>(p, gran, G, g_self, r, s_top, nb, left < kFxB ? left : kFxB, s_acc, &s_nacc, &s_fail, s_rows, &warm);
         if (ncur < 0) return;
-#pragma unroll
-        for (int m = 0; m < kFxB; ++m) cur[m] = s_acc[m];
     }
     if (warm == -1.0f) p.scratch[1] = 1;               // never true (coordinates are normalised to [0, 1]): the loads above are not dead
 }
@@ -586,24 +590,20 @@ int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start,
     p.out_idx = out_idx; p.scratch = (unsigned long long *)scratch; p.xcds = 0; p.batch = 1;
     // the generator's own shape: the XCD-local kernel (same results; HNS_FPS_KERNEL=chip keeps the chip-wide one, for A/B measurements)
     static const bool chip_only = [] { const char *e = getenv("HNS_FPS_KERNEL"); return e && e[0] == 'c'; }();
-    const int fx_cap = hns::kFxGroups * hns::kFxThreads * hns::kFxPts;        // points one XCD's registers hold
-    if (!chip_only && d <= hns::kFxD && d >= 4 && n >= 2048 && cus >= hns::kFxGroups * hns::kFxStride && (reinterpret_cast<uintptr_t>(points) & 15) == 0) {
+    if (!chip_only && d <= hns::kFxD && d >= 4 && n >= 2048 && cus >= hns::kFxGroups * hns::kFxStride) {
         // samples per exchange (HNS_FPS_BATCH=1 keeps one per exchange, for A/B measurements; the indices are the same either way)
         static const int batch = [] { const char *e = getenv("HNS_FPS_BATCH"); const int b = e ? atoi(e) : hns::kFxB; return b < 1 ? 1 : (b > hns::kFxB ? hns::kFxB : b); }();
-        // XCDs at work (measured, 5000 of n samples, four per exchange; tools/lab/r04_batch7-8.sh): an exchange's fixed cost grows with the XCDs
-        // it spans (3.7 / 4.4 / 6.5 / 7.8 us on 1 / 2 / 4 / 8), a sample's distance update shrinks (1.2 us on one XCD with two points per
-        // thread, 0.6 / 0.3 us with one point per thread on two / four).  n <= 65 536: two XCDs (8.7 ms; one: 10.7, four: 10.0);
-        // n <= 131 072: four XCDs, one point per thread (10.4 ms; two XCDs with two points per thread: 11.0).  HNS_FPS_XCDS=1|2|4|8 overrides (A/B).
+        // XCDs at work, one point per thread (measured with four samples per exchange, 5000 of n samples; tools/lab/r04_batch7-8.sh): an exchange's fixed
+        // cost grows with the XCDs it spans (3.7 / 4.4 / 6.5 / 7.8 us on 1 / 2 / 4 / 8), a sample's distance update shrinks (0.6 / 0.3 us on
+        // two / four; 1.2 us on one XCD with two points per thread).  n <= 32 768: one XCD, <= 65 536: two, <= 131 072: four; beyond that the
+        // chip-wide kernel.  HNS_FPS_XCDS=1|2|4 overrides (A/B).
         static const int forced = [] { const char *e = getenv("HNS_FPS_XCDS"); return e ? atoi(e) : 0; }();
-        int xcds = forced ? forced : (batch > 1 ? (n <= 2 * hns::kFxGroups * hns::kFxThreads ? 2 : 4) : 1);
-        if (xcds != 1 && xcds != 2 && xcds != 4 && xcds != 8) xcds = 8;
-        // two points per thread on one or two XCDs (110 registers), one per thread on four or eight (the sweep of up to 1024 granules takes the rest)
-        auto capacity = [&](int x) { return (long)x * hns::kFxGroups * hns::kFxThreads * (x <= 2 ? hns::kFxPts : 1); };
-        while (xcds < 8 && capacity(xcds) < n) xcds *= 2;
+        int xcds = (forced == 1 || forced == 2 || forced == 4) ? forced : 1;
+        auto capacity = [&](int x) { return (long)x * hns::kFxGroups * hns::kFxThreads; };
+        while (xcds < 4 && capacity(xcds) < n) xcds *= 2;
         if (capacity(xcds) >= n) {
             p.xcds = xcds; p.groups = hns::kFxGroups * xcds; p.in_lds = 0; p.batch = batch;
-            const bool one = (long)p.groups * hns::kFxThreads >= n;          // one point per thread suffices
-            auto fn = xcds <= 2 ? (one ? hns::hns_fps_xcd_kernel<1, 2> : hns::hns_fps_xcd_kernel<2, 2>) : hns::hns_fps_xcd_kernel<1, 8>;
+            auto fn = xcds <= 2 ? hns::hns_fps_xcd_kernel<1, 2> : hns::hns_fps_xcd_kernel<1, 4>;
             hipLaunchKernelGGL(fn, dim3(hns::kFxGroups * hns::kFxStride), dim3(hns::kFxThreads), 0, s, p);
             HNS_CHECK_HIP(hipGetLastError());
             return HNS_OK;

@@ -394,6 +394,53 @@ def test_setter_between_graph_replays():
     assert (np.abs(np.abs(host["target_vel"]) - 0.6) < 0.05).mean() > 0.9
 
 
+def test_setter_inside_a_capture_in_the_default_mode():
+    """a configuration setter INSIDE `torch.cuda.graph` in its default (global) capture mode, where hipHostMalloc is refused: the
+    image of a captured change comes from the pool hns_create made, nothing is allocated, the capture stays valid, and every replay applies the
+    captured change again — step at the speed in force, change it to 0.6, step at 0.6.  After 16 captured changes the pool is used up and the
+    setter says so (HNS_ERR_CONFIG) instead of allocating."""
+    import ctypes as C
+    E, A = 128, 3
+    env = make_env(E, A, 6, max_len=50)
+    env.set_seed(9)
+    env.reset()
+    host = O.alloc_buffers(env.hcfg)
+    O.reset(env.hcfg, host, None, env.seed, 0)
+    act = torch.randn(E, A, 4, generator=torch.Generator().manual_seed(29)).to(env.device)
+    a_np = act.cpu().numpy()
+    stream = torch.cuda.Stream(env.device)
+    sp, ap = C.c_void_p(stream.cuda_stream), C.c_void_p(act.data_ptr())
+    lib, h = env._lib, env._env
+    with torch.cuda.stream(stream):
+        assert lib.hns_step(h, ap, sp) == 0, lib.hns_last_error()                                 # warm-up on the capture stream
+        O.step(env.hcfg, host, a_np)
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):                                           # capture_error_mode = "global", the default
+            assert lib.hns_step(h, ap, sp) == 0, lib.hns_last_error()
+            assert lib.hns_set_v_prey(h, C.c_float(0.6)) == 0, lib.hns_last_error()
+            assert lib.hns_step(h, ap, sp) == 0, lib.hns_last_error()
+        speed = float(env.hcfg.v_prey)
+        for rep in range(3):
+            if rep:                                                                             # back to the old speed between replays (ring image, not captured)
+                assert lib.hns_set_v_prey(h, C.c_float(speed)) == 0, lib.hns_last_error()
+            graph.replay()
+            env.hcfg.v_prey = speed
+            O.step(env.hcfg, host, a_np)
+            env.hcfg.v_prey = 0.6
+            O.step(env.hcfg, host, a_np)
+        stream.synchronize()
+        assert_same(host, env.export_state(), "after three replays of a graph that holds a setter")
+        # the pool: 16 captured changes per env
+        g2 = torch.cuda.CUDAGraph()
+        rcs = []
+        with torch.cuda.graph(g2, stream=stream):
+            for i in range(17):
+                rcs.append(lib.hns_set_v_prey(h, C.c_float(0.5 + 0.01 * i)))
+        stream.synchronize()
+    assert rcs[:15] == [0] * 15 and rcs[15] == abi.HNS_ERR_CONFIG and b"pool" in lib.hns_last_error()
+
+
 def test_line_of_sight_flag_is_derived_state():
     """The step kernel does not re-evaluate the evader policy's line of sight (hideandseek.py:1080): it reads the flag the previous
     step / the reset stored in pid_last_rate[..., 3] for the same positions (include/hns.h).  (i) after resets and steps the stored

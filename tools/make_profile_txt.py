@@ -3,7 +3,7 @@
 and above them a header whose every number is COMPUTED HERE from those tables (a hand-written header once quoted another
 run than the table under it).
 
-usage: make_profile_txt.py <dir> <kernel-substring> <algorithmic bytes per launch> [title words ...]   > profiles/rNN_<name>.txt
+usage: make_profile_txt.py <dir> <kernel-substring> <algorithmic bytes per launch | flop:<useful FLOP per launch>> [title words ...]   > profiles/rNN_<name>.txt
 """
 import glob
 import json
@@ -32,7 +32,9 @@ def read_tables(path):
 
 
 def main():
-    d, sub, nbytes = sys.argv[1], sys.argv[2], float(sys.argv[3])
+    d, sub = sys.argv[1], sys.argv[2]
+    flop = float(sys.argv[3][5:]) if sys.argv[3].startswith("flop:") else None
+    nbytes = 0.0 if flop is not None else float(sys.argv[3])
     title = " ".join(sys.argv[4:]) or os.path.basename(d.rstrip("/"))
     files = sorted(glob.glob(os.path.join(d, "*.csv")))
     stats, counters, pmc_ns = None, {}, []
@@ -53,14 +55,19 @@ def main():
            "tools/rocpd_summary.py); every number in this header is computed from the tables below"]
     if stats:
         t = stats["avg_ns"] * 1e-9
-        out.append(f"# kernel `{sub}`: {stats['calls']} launches, avg {stats['avg_ns'] / 1e3:.3f} us (min {stats['min_ns'] / 1e3:.2f}, max {stats['max_ns'] / 1e3:.2f})"
-                   f" -> {nbytes:,.0f} B algorithmic per launch / avg = {nbytes / t / 1e12:.3f} TB/s = {nbytes / t / HBM_PEAK:.4f} of 8 TB/s")
+        head = f"# kernel `{sub}`: {stats['calls']} launches, avg {stats['avg_ns'] / 1e3:.3f} us (min {stats['min_ns'] / 1e3:.2f}, max {stats['max_ns'] / 1e3:.2f})"
+        if flop is not None:
+            out.append(head + f" -> {flop:.4g} useful FLOP per launch / avg = {flop / t / 1e12:.1f} TFLOP/s = {flop / t / 2.5e15:.4f} of the 2.5 PF dense f16 matrix peak")
+        elif nbytes > 0:
+            out.append(head + f" -> {nbytes:,.0f} B algorithmic per launch / avg = {nbytes / t / 1e12:.3f} TB/s = {nbytes / t / HBM_PEAK:.4f} of 8 TB/s")
+        else:
+            out.append(head)
     for name, rec in pmc_ns:
         out.append(f"# (under counter collection, {name}: {rec['calls']} launches, avg {rec['avg_ns'] / 1e3:.3f} us)")
     if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
         tr = counters["FETCH_SIZE"] * 1024 * 2 + counters["WRITE_SIZE"] * 1024
         out.append(f"# traffic per launch: FETCH_SIZE {counters['FETCH_SIZE']:.1f} KiB x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE {counters['WRITE_SIZE']:.1f} KiB"
-                   f" = {tr / 1e6:.2f} MB = {tr / nbytes:.3f} x algorithmic")
+                   f" = {tr / 1e6:.2f} MB" + (f" = {tr / nbytes:.3f} x algorithmic" if nbytes > 0 else ""))
     if "SQ_INSTS_VALU" in counters:
         extra = "".join(f", {k} {counters[k]:.4g}" for k in ("SQ_INSTS_MFMA", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES") if k in counters)
         out.append(f"# instructions per launch: SQ_INSTS_VALU {counters['SQ_INSTS_VALU']:.4g}{extra}")

@@ -15,4 +15,5 @@ for d in stats pmc1 pmc2; do
   db=$(ls $OUT/$d/*/*.db 2>/dev/null | head -1)
   [ -n "$db" ] && python tools/rocpd_summary.py "$db" hns_ > $OUT/$d.csv && rm -rf $OUT/$d
 done
-cat $OUT/*.csv
+python tools/make_profile_txt.py $OUT "${KERNEL:-hns_fps_xcd_kernel}" 0 "$TAG - tools/profile_envgen.sh $TAG" > $OUT/profile.txt
+head -6 $OUT/profile.txt; grep -h "hns_" $OUT/stats.csv | head -8
