@@ -789,44 +789,46 @@ __global__ __launch_bounds__(256) void hns_tp_pack_ws_kernel(const TpParams p, i
     }
 }
 
-// One column tile's matrix products in the weight-stationary kernel: op k = (A operand: split term and k-chunk of this wave's rows,
-// B operand: x or h chunk, hi or lo term, read from LDS).  Cross terms of every chunk first, then the leading terms (they read
-// the hi operands a second time), all into one accumulator that starts at the bias.
-// The B operands go through a ring of four registers, three reads ahead of the matrix pipe.  A ring slot is refilled only after
-// the NEXT op has issued: every op depends on its predecessor's accumulator, so that one has retired by then — a ds_read that
-// lands in a register an MFMA in flight still reads corrupts the operand (found in round 2 on the A side, and again here on the
-// B side: 1-3 envs in 256 off by 1e-5 while the compiler placed the reads).  BASE rotates the slots from tile to tile so that the
-// first reads of a tile, which may be issued right behind the previous tile's last MFMA, never target that MFMA's slot.
+// One column tile's matrix products in the weight-stationary kernel, all into one accumulator that starts at the bias.  Per 16-wide k-chunk
+// (x chunks, then the four h chunks) three ops: w_lo x v_hi, w_hi x v_hi, w_hi x v_lo — the hi operand of the activations is READ ONCE and
+// used by two consecutive ops (round 4; until round 3 the cross terms of every chunk came first and the leading terms read the hi operands
+// a second time: 15 ds_read_b128 per tile, now 10 — a third of the kernel's LDS operand traffic, which is what it waits for).
+// The B operands go through a ring of four registers.  A ring slot is refilled only after the op BEHIND its last user has issued: every op
+// depends on its predecessor's accumulator, so that one has retired by then — a ds_read that lands in a register an MFMA in flight still
+// reads corrupts the operand (found in round 2 on the A side, and in round 3 on the B side: 1-3 envs in 256 off by 1e-5 while the compiler
+// placed the reads).  Load l (chunk l / 2, term l % 2) sits in slot (l + BASE) % 4; loads 0..2 are issued up front, load 3 behind op 0, and then
+// 2 c behind op 3 c - 4 and 2 c + 1 behind op 3 c - 3: three to five ops ahead of their first use.  BASE rotates from tile to tile so that the
+// up-front reads of a tile, which may be issued right behind the previous tile's last MFMA, never target that MFMA's slot.
 template <int NXC, bool WITH_H>
 struct WsTile {
-    static constexpr int NX2 = 2 * NXC, NCROSS = NX2 + (WITH_H ? 8 : 0), N = NCROSS + NXC + (WITH_H ? 4 : 0);
-    static constexpr int D = NXC == 2 ? 3 : 3, RING = D + 1;
-    static constexpr bool lead(int k) { return k >= NCROSS; }
-    static constexpr bool is_x(int k) { return k < NX2 || (lead(k) && k < NCROSS + NXC); }
-    static constexpr int chunk(int k) { return k < NX2 ? k / 2 : k < NCROSS ? (k - NX2) / 2 : k < NCROSS + NXC ? k - NCROSS : k - NCROSS - NXC; }
-    static constexpr int b_term(int k) { return lead(k) ? 0 : (k < NX2 ? k % 2 : (k - NX2) % 2); }       // cross terms: hi operand (with w2), then lo (with w1)
-    static constexpr int a_term(int k) { return lead(k) ? 0 : 1 - b_term(k); }
-    static constexpr int a_chunk(int k) { return is_x(k) ? chunk(k) : NXC + chunk(k); }
+    static constexpr int NCH = NXC + (WITH_H ? 4 : 0), N = 3 * NCH, NL = 2 * NCH, RING = 4;
+    static constexpr int load_of(int k) { return 2 * (k / 3) + (k % 3 == 2 ? 1 : 0); }
+    static constexpr int a_term(int k) { return k % 3 == 0 ? 1 : 0; }
+    static constexpr int refill(int k) { return k % 3 == 2 ? 2 * ((k + 4) / 3) : (k % 3 == 0 ? 2 * ((k + 3) / 3) + 1 : -1); }
+    static constexpr int base(int te) { return (NL * te) % RING; }
     struct Ctx {
         f32x16 &acc;
         half8 (&b)[RING];
         const half8 (&aw)[2][NXC + 4];
         const uint4 *xb, *hp;     // x buffer of this timestep / h buffer, both + tile * 64 + lane
     };
-    template <int k>
+    template <int l>
     static __device__ __forceinline__ half8 load(const Ctx &c) {
-        constexpr int off = ((chunk(k) * 2 + b_term(k)) * 4) * 64;
-        return __builtin_bit_cast(half8, is_x(k) ? c.xb[off] : c.hp[off]);
+        constexpr int ch = l / 2, term = l % 2;
+        constexpr bool is_x = ch < NXC;
+        constexpr int off = (((is_x ? ch : ch - NXC) * 2 + term) * 4) * 64;
+        return __builtin_bit_cast(half8, is_x ? c.xb[off] : c.hp[off]);
     }
-    template <int BASE, int k>
+    template <int BASE, int l>
     static __device__ __forceinline__ void pro(const Ctx &c) {
-        c.b[(k + BASE) % RING] = load<k>(c);
+        c.b[(l + BASE) % RING] = load<l>(c);
         __builtin_amdgcn_sched_barrier(0);
     }
     template <int BASE, int k>
     static __device__ __forceinline__ void step(const Ctx &c) {
-        c.acc = TP_MFMA(c.aw[a_term(k)][a_chunk(k)], c.b[(k + BASE) % RING], c.acc);
-        if constexpr (k + D < N) c.b[(k + D + BASE) % RING] = load<k + D>(c);
+        c.acc = TP_MFMA(c.aw[a_term(k)][k / 3], c.b[(load_of(k) + BASE) % RING], c.acc);
+        constexpr int l = refill(k);
+        if constexpr (l >= 3 && l < NL) c.b[(l + BASE) % RING] = load<l>(c);
         __builtin_amdgcn_sched_barrier(0);
     }
     template <int BASE, int... Ps, int... Ks>
@@ -836,7 +838,7 @@ struct WsTile {
     }
     template <int BASE>
     static __device__ __forceinline__ void run(const Ctx &c) {
-        run_seq<BASE>(c, std::make_integer_sequence<int, (D < N ? D : N)>{}, std::make_integer_sequence<int, N>{});
+        run_seq<BASE>(c, std::make_integer_sequence<int, (NL < 3 ? NL : 3)>{}, std::make_integer_sequence<int, N>{});
     }
 };
 
@@ -979,11 +981,11 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
                 if (t > 0) {
                     using W = WsTile<NXC, true>;
                     const typename W::Ctx cx{acc, bring, aw, xb, hp};
-                    W::template run<(W::N * te) % W::RING>(cx);
+                    W::template run<W::base(te)>(cx);
                 } else {
                     using W = WsTile<NXC, false>;
                     const typename W::Ctx cx{acc, bring, aw, xb, hp};
-                    W::template run<(W::N * te) % W::RING>(cx);
+                    W::template run<W::base(te)>(cx);
                 }
             }
             // cell update of units 8 r + 4 hb + j (torch.nn.LSTM gate order i, f, g, o = accumulator registers j, 4 + j, 8 + j, 12 + j)

@@ -441,6 +441,30 @@ def test_setter_inside_a_capture_in_the_default_mode():
     assert rcs[:15] == [0] * 15 and rcs[15] == abi.HNS_ERR_CONFIG and b"pool" in lib.hns_last_error()
 
 
+@pytest.mark.parametrize("E,A,NT,K", [(64, 3, 1, 3), (70, 3, 1, 3), (128, 6, 2, 3), (130, 2, 2, 3), (96, 3, 1, 6)])
+def test_reset_pid_pulses_past_the_end_of_the_episode(E, A, NT, K):
+    """task.pid_reset = reference (the default): stepping on past `done` without a reset — what `env.rollout(..., break_when_any_done=False)` does —
+    the controller is reset through the incoming `done` at EVERY step.  Through every instantiation of the step kernel (whole tiles, a ragged last
+    tile, two evaders: the byte comes through the parameter block there, wide k) HIP == oracle bit for bit; and the pulses do something: the
+    same actions with task.pid_reset = on_reset end with another integrator."""
+    def run(mode):
+        env = make_env(E, A, 8, max_len=4, K=K, num_targets=NT, pid_reset=mode)
+        env.set_seed(5)
+        env.reset()
+        host = env.export_state()
+        g = torch.Generator().manual_seed(77)
+        for t in range(11):
+            a = torch.randn(E, A, 4, generator=g)
+            env.step(env.rand_step_input(a.to(env.device)))
+            O.step(env.hcfg, host, a.numpy())
+            if t >= 4:
+                assert host["done"].all()
+        assert_same(host, env.export_state(), f"pid_reset = {mode}")
+        return host["pid_integ"]
+    ref, own = run("reference"), run("on_reset")
+    assert np.abs(ref - own).max() > 1e-3
+
+
 def test_line_of_sight_flag_is_derived_state():
     """The step kernel does not re-evaluate the evader policy's line of sight (hideandseek.py:1080): it reads the flag the previous
     step / the reset stored in pid_last_rate[..., 3] for the same positions (include/hns.h).  (i) after resets and steps the stored
