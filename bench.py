@@ -60,9 +60,10 @@ def parse_args():
     ap.add_argument("--episode", type=int, default=800)
     ap.add_argument("--critic-state", action="store_true", help="also write the [E,A,20] centralised-critic state (critic_input: state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traffic-live", action="store_true",
-                    help="measure roofline.traffic in THIS run: two extra rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, separate, kernel-trace only) "
-                         "of a short inner run of the same workload; off by default (adds ~1 min), the default is the look-up of the committed passes")
+    ap.add_argument("--traffic-live", action=argparse.BooleanOptionalAction, default=True,
+                    help="measure roofline.traffic in THIS run (default since round 4, N = 1 only): two extra rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, "
+                         "separate, kernel-trace only) of a short inner run of the same workload, ~20 s each, outside every timed region; --no-traffic-live (or a "
+                         "failing rocprofv3) falls back to the look-up of the committed passes (profiles/traffic.json)")
     ap.add_argument("--cpu-steps", type=int, default=100)
     ap.add_argument("--time-every", type=int, default=32)
     ap.add_argument("--abi-steps", type=int, default=500, help="secondary leg: the same steps through the bare C ABI (0 = skip)")
@@ -114,7 +115,7 @@ def live_traffic(args, kernel_substr):
         return None
     inner = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "60", "--warmup", "10", "--envs", str(args.envs), "--agents", str(args.agents),
              "--cylinders", str(args.cylinders), "--targets", str(args.targets), "--no-cpu-baseline", "--tp-steps", "0", "--config-steps", "0", "--abi-steps", "0",
-             "--stream-groups", "0"] + (["--critic-state"] if args.critic_state else [])
+             "--stream-groups", "0", "--no-traffic-live"] + (["--critic-state"] if args.critic_state else [])
     out = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="hns_pmc_", dir="/tmp")
@@ -122,7 +123,7 @@ def live_traffic(args, kernel_substr):
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
                 env.pop(k, None)
-            r = subprocess.run([prof, "--kernel-trace", "--pmc", counter, "-d", d, "--", *inner], cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            r = subprocess.run([prof, "--kernel-trace", "--pmc", counter, "-d", d, "--", *inner], cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 return None

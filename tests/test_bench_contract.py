@@ -44,7 +44,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     tr = d["tp_mode"]["roofline"]                                                          # the predictor against the matrix-core peak
     assert tr["bound"] == "mfma" and tr["unit"] == "TFLOP/s" and tr["peak"] == 2500.0 and 0 < tr["frac"] < 1 and d["tp_mode"]["observe_us"] > 0
     assert "env.step" in d["config"]["workload"] and d["abi_rate"]["value"] > 0        # headline through the Python class, bare ABI beside it
-    assert "look-up" in r["traffic_source"] or r["traffic"] is None                       # PMC traffic is a static look-up, labelled so
+    # PMC traffic: measured in the run itself (two rocprofv3 passes of a short inner run, the default) or, failing that, the labelled look-up
+    assert r["traffic"] is None or "rocprofv3" in r["traffic_source"] or "look-up" in r["traffic_source"]
+    if "rocprofv3 --kernel-trace --pmc" in r.get("traffic_source", ""):
+        assert 0.9 < r["traffic"] / r["bytes_per_launch"] < 1.3 and r["traffic_detail"]["FETCH_SIZE_dispatches"] >= 60
     cf = d["configs"]                                                                      # every other BASELINE configuration
     assert set(cf) == {"cfg2", "cfg4", "cfg5_shard"}
     assert cf["cfg2"]["roofline"]["bytes_per_env"] == 1497 and cf["cfg5_shard"]["roofline"]["frac"] > 0
@@ -106,7 +109,7 @@ def test_bench_loop_with_two_hip_shards_reproduces_the_whole_batch():
     """The multi-GPU plumbing end to end THROUGH bench.py's own loop (steps, episode-boundary resets, the per-rollout collective), with the
     shards stepped by the HIP kernels: two ranks (gloo, both on cuda:0) over env slices [0, 4096) and [4096, 8192) leave exactly the state one
     rank leaves for the whole 8192-env batch — slice by slice, sha256 of every buffer.  What the first real 8-GPU run adds is RCCL, not logic."""
-    common = ["--steps", "96", "--warmup", "8", "--episode", "40", "--no-cpu-baseline", "--tp-steps", "0", "--config-steps", "0", "--abi-steps", "0"]
+    common = ["--steps", "96", "--warmup", "8", "--episode", "40", "--no-cpu-baseline", "--tp-steps", "0", "--config-steps", "0", "--abi-steps", "0", "--no-traffic-live"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--envs", "8192", "--state-digest", "4", *common],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
