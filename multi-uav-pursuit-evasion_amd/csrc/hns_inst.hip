@@ -25,6 +25,15 @@ void HNS_CAT(hns_select_kernels_, HNS_INST_A)(hns_env *env) {
         else {
             env->step_args_fn = two ? hns_step_v4_kernel<A, 2, false, kMaxK, false> : hns_step_v4_kernel<A, 1, false, kMaxK, false>;
             env->step_args_prof_fn = two ? hns_step_v4_kernel<A, 2, false, kMaxK, true> : hns_step_v4_kernel<A, 1, false, kMaxK, true>;
+            // the reference's / BASELINE's shapes: cylinder count and k = 3 as compile-time constants (the stamped twin stays generic in them)
+            if (c.obs_max_cylinder == 3) {
+                switch (c.num_cylinders) {
+                    case 5: env->step_args_fn = two ? hns_step_v4_kernel<A, 2, false, kMaxK, false, 5> : hns_step_v4_kernel<A, 1, false, kMaxK, false, 5>; break;
+                    case 8: env->step_args_fn = two ? hns_step_v4_kernel<A, 2, false, kMaxK, false, 8> : hns_step_v4_kernel<A, 1, false, kMaxK, false, 8>; break;
+                    case 16: env->step_args_fn = two ? hns_step_v4_kernel<A, 2, false, kMaxK, false, 16> : hns_step_v4_kernel<A, 1, false, kMaxK, false, 16>; break;
+                    default: break;
+                }
+            }
         }
         env->reset_fn = two ? hns_reset_kernel<A, 2> : hns_reset_kernel<A, 1>;
     }

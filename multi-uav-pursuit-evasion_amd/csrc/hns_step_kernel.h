@@ -68,15 +68,19 @@ HNS_DEV void env_store_slice(const float *lds, float *g, int n, int lane, int nv
 //   * everything but the pointers behind the first loads comes from a device-resident block through the scalar cache (StepArgs).
 // Three workgroup barriers.
 //
-// Instantiations (hns_inst.hip): <A, NT, GEN, KM, PROF>.  GEN = false is the kernel described above: whole 64-env tiles, k <= 4, nothing
+// Instantiations (hns_inst.hip): <A, NT, GEN, KM, PROF, CS>.  GEN = false is the kernel described above: whole 64-env tiles, k <= 4, nothing
 // predicated.  GEN = true serves every other shape with the SAME phases, barriers, arithmetic and evaluation order (the buffers are
 // bit-identical where both apply; tests/test_hip_parity.py): a ragged last tile (E % 64 != 0 — lanes beyond the batch load the last
 // env's data again, compute, and store nothing; slices end at the batch through their buffer descriptors) and, with KM = kWideK,
 // selections of up to 16 nearest cylinders (rows stored by their threads, not staged).  It reads the parameter block before its
 // first loads and loads rigid-state rows per thread: correct, not tuned — no configuration of the reference's cfg/ needs it.
-template <int A, int NT, bool GEN, int KM, bool PROF>
+// CS > 0: the cylinder count as a compile-time constant, with k = 3 — the shapes of the reference's task files and of BASELINE's configurations
+// (5, 8, 16 slots; obs_max_cylinder 3).  Same arithmetic, same order; the cylinder loops unroll completely and the k-nearest predicates
+// fold away: 6v2 / 16 cylinders 50.4 -> 48.5 us, 3v1 / 8 cylinders 18.7 -> 18.5 us (A/B/A/B on one box, tools/lab/r04_batch18.sh).
+template <int A, int NT, bool GEN, int KM, bool PROF, int CS = 0>
 __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void hns_step_v4_kernel(const StepArgs ka) {
     static_assert(GEN || KM == kMaxK, "wide k-nearest selections: the generic instantiation");
+    static_assert(CS == 0 || (!GEN && !PROF && CS <= HNS_MAX_CYLINDERS), "fixed shapes: the tuned instantiation only");
     // the block behind `rest` is never written while the kernel runs: read it as constant memory (scalar loads, placed like kernel-argument loads)
     typedef const Params __attribute__((address_space(4))) ParamsC;
     ParamsC &p = *(ParamsC *)ka.rest;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PROF) prof_mark(p.prof, 0);
         if constexpr (PROF) prof_mark(p.prof, 14);
-        const int C = c.num_cylinders, K = c.obs_max_cylinder;
+        const int C = CS ? CS : c.num_cylinders, K = CS ? 3 : c.obs_max_cylinder;
         const bool with_state = c.write_critic_state && b.state_drones != nullptr;
         const LdsV3 L = lds_layout_v3(A, C, K, NT);
         float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red;
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         const int e = e0 + (valid ? le : nv - 1);
         if constexpr (PROF) prof_mark(p.prof, 0);
         if constexpr (PROF) prof_mark(p.prof, 14);
-        const int C = c.num_cylinders, K = c.obs_max_cylinder, E = c.stats_stride;      // (E: the row stride of `stats`, = num_envs unless the env is a slice)
+        const int C = CS ? CS : c.num_cylinders, K = CS ? 3 : c.obs_max_cylinder, E = c.stats_stride;      // (E: the row stride of `stats`, = num_envs unless the env is a slice)
         const LdsV3 L = lds_layout_v3(A, C, K, NT);
         float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red, *sEnvOut = smem + L.envout;
         float *cylw = sCyl + le * L.cyl_stride;
