@@ -409,7 +409,7 @@ def main():
                 roofline["traffic_source"] = "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two separate passes of this run's workload (FETCH_SIZE KiB x 2 on gfx950 + WRITE_SIZE KiB)"
                 roofline["traffic_detail"] = live
         roofline["traffic"] = traffic
-        roofline["kernel"] = "hns_step_v4_kernel<%d,%d,%s,4,false>" % (A, args.targets, "false" if E % 64 == 0 else "true")
+        roofline["kernel"] = "hns_step_v4_kernel<%d,%d,%s,4,false,%d>" % (A, args.targets, "false" if E % 64 == 0 else "true", C if (E % 64 == 0 and C in (5, 8, 16)) else 0)
         if kernel_by_rank:
             roofline["kernel_us_by_rank"] = {"min": min(kernel_by_rank), "max": max(kernel_by_rank), "all": kernel_by_rank}
         # achievable bandwidth on this box ("measure achievable with a device copy kernel and report both"): the library's float4

@@ -243,10 +243,13 @@ HNS_DEV void wave_store_rows(float *__restrict__ slab, float *__restrict__ gslic
 // Fast path: 32-bit keys = squared-distance bits with the cylinder index in the 4 low mantissa
 // bits (non-negative floats order like unsigned ints), kept sorted by a branch-free min/max
 // insertion network.  The 2^-19 truncation is covered by the 2^-16 gap test below.
-template <int NT, bool LOS, int KM = kMaxK, class Cfg>
+// KT = keys tracked: one more than the largest k served (KM + 1), or exactly k + 1 where k is a compile-time constant (the fixed-shape
+// instantiations of the step kernel: k = 3 tracks 4 keys — two instructions fewer per cylinder); only bi[0 .. KT) are written.
+template <int NT, bool LOS, int KM = kMaxK, int KT = KM + 1, class Cfg>
 HNS_DEV void cylinder_pass(const Cfg &c, int C, int K, const V3 &pos, const V3 &tp, const V3 &tpB, const float *cyl,
                            int bi[KM + 1], bool &any_block, bool &any_block1) {
-    constexpr int kTrack = KM + 1;              // one more than k: guards the k-th/(k+1)-th boundary
+    static_assert(KT >= 2 && KT <= KM + 1, "tracked keys");
+    constexpr int kTrack = KT;                  // one more than k: guards the k-th/(k+1)-th boundary
     uint32_t key[kTrack];
 #pragma unroll
     for (int i = 0; i < kTrack; ++i) key[i] = 0x7F80000Fu;             // +inf | 15
@@ -279,17 +282,17 @@ HNS_DEV void cylinder_pass(const Cfg &c, int C, int K, const V3 &pos, const V3 &
     for (int i = 0; i < kTrack; ++i) { bd[i] = __uint_as_float(key[i] & 0xFFFFFFF0u); bi[i] = (int)(key[i] & 15u); }
     bool order_safe = bd[0] > 1e-5f;
 #pragma unroll
-    for (int i = 0; i < KM; ++i)
+    for (int i = 0; i < kTrack - 1; ++i)
         if (i < K) order_safe = order_safe && (bd[i + 1] > bd[i] * 1.0000152587890625f);   // 1 + 2^-16
     if (!order_safe) {                          // rare: exact (distance - size) keys, as the reference sorts
 #pragma unroll
         for (int i = 0; i < kTrack; ++i) { bd[i] = kInf; bi[i] = 0; }
         for (int k = 0; k < C; ++k) {
             float md = d_norm3(pos.x - cyl[3 * k], pos.y - cyl[3 * k + 1], pos.z - cyl[3 * k + 2]) - c.cylinder_size;
-            if (md < bd[KM - 1]) {
-                bd[KM - 1] = md; bi[KM - 1] = k;
+            if (md < bd[kTrack - 2]) {         // (the last tracked slot but one = position KM - 1 in the general instantiation: slots beyond k are not read)
+                bd[kTrack - 2] = md; bi[kTrack - 2] = k;
 #pragma unroll
-                for (int i = KM - 1; i > 0; --i) {
+                for (int i = kTrack - 2; i > 0; --i) {
                     if (bd[i] < bd[i - 1]) {
                         float td = bd[i]; bd[i] = bd[i - 1]; bd[i - 1] = td;
                         int ti = bi[i]; bi[i] = bi[i - 1]; bi[i - 1] = ti;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         float stage_v[kStage], own_c[kOwnCyl][3];
         if constexpr (NT == 2) {
             const uintptr_t cw = reinterpret_cast<uintptr_t>(ka.aux);
-            const int Cq = (int)(cw & 15) + 1;
+            const int Cq = CS ? CS : (int)(cw & 15) + 1;
             const float *cyl0 = reinterpret_cast<const float *>(cw & ~(uintptr_t)15);
             const float *gc = cyl0 + (size_t)e0 * Cq * 3 + lane;
 #pragma unroll
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         int knn_idx[KM + 1];
         bool knn_masked[KM];
         bool blocked, blockedB;
-        cylinder_pass<NT, true, KM>(c, C, K, s.pos, tp, tpB, cyl, knn_idx, blocked, blockedB);
+        cylinder_pass<NT, true, KM, (CS ? 4 : KM + 1)>(c, C, K, s.pos, tp, tpB, cyl, knn_idx, blocked, blockedB);
         const bool det = (d < c.drone_detect_radius) && !blocked;                   // :787-789
         last4.w = (float)((blocked ? 1 : 0) + (NT == 2 && blockedB ? 2 : 0));       // = the next step's line of sight at ITS t
         if (valid) reinterpret_cast<float4 *>(b.pid_last_rate)[ia] = last4;
