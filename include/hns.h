@@ -374,6 +374,11 @@ int hns_copy_f4(void *dst, const void *src, size_t bytes, void *stream);
  * of every wave of the step kernel then stamps the shader clock at up to 16 phase boundaries (NULL detaches). */
 int hns_set_phase_profile(hns_env *env, unsigned long long *device_buf);
 
+/* The per-rollout moments of the data-parallel advantage normalisation (learning/mappo.py:391-396 made data-parallel; sharding.py) in ONE launch:
+ * out[0..4] = [sum v, sum v^2, n, sum s, m] in fp64 over `values` [n] fp32 and `success` [m] fp32 (m may be 0: success NULL) — device
+ * pointers; one workgroup, fixed summation order (the same inputs give the same bits on every run). */
+int hns_moments(const float *values, int64_t n, const float *success, int64_t m, double *out, void *stream);
+
 int hns_abi_version(void);
 size_t hns_cfg_size(void);   /* sizeof(hns_cfg) the library was built with (binding self-check) */
 const char *hns_last_error(void);

@@ -258,6 +258,31 @@ __global__ __launch_bounds__(256) void hns_raycast_kernel(const RayParams p) {
     }
 }
 
+// hns_moments: [sum, sum of squares, count, success sum, env count] in fp64, one workgroup, fixed order (thread t takes elements t, t + 1024, ...;
+// then a tree over the 1024 partial sums)
+__global__ __launch_bounds__(1024) void hns_moments_kernel(const float *__restrict__ v, long long n, const float *__restrict__ s, long long m, double *__restrict__ out) {
+    __shared__ double red[3][1024];
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0, c = 0.0;
+    const long long n4 = ((reinterpret_cast<uintptr_t>(v) & 15) == 0) ? n / 4 : 0;
+    const float4 *v4 = reinterpret_cast<const float4 *>(v);
+    for (long long i = t; i < n4; i += 1024) {
+        const float4 q = v4[i];
+        const double x0 = q.x, x1 = q.y, x2 = q.z, x3 = q.w;
+        a += (x0 + x1) + (x2 + x3);
+        b += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+    }
+    for (long long i = 4 * n4 + t; i < n; i += 1024) { const double x = v[i]; a += x; b += x * x; }
+    for (long long i = t; i < m; i += 1024) c += (double)s[i];
+    red[0][t] = a; red[1][t] = b; red[2][t] = c;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+        if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; red[2][t] += red[2][t + w]; }
+        __syncthreads();
+    }
+    if (t == 0) { out[0] = red[0][0]; out[1] = red[1][0]; out[2] = (double)n; out[3] = red[2][0]; out[4] = (double)m; }
+}
+
 // measurement yardstick (hns_copy_f4): a plain float4 copy, one piece per thread.  Of the shapes tried on this chip (tools/microbench/copy_rate.hip:
 // 4 / 8 pieces per thread, persistent grid-stride grids, non-temporal accesses, hipMemcpyAsync) this simplest one is the fastest or within 5 % of the
 // fastest at every size: 6.6-7.1 TB/s for footprints the Infinity Cache holds, 6.0-6.25 TB/s beyond it (MI355X_MICROARCH.md: 6.29).
@@ -721,6 +746,13 @@ float hns_region_ms(hns_env *env) {
     float ms = -1.0f;
     if (hipEventSynchronize(env->region_ev[1]) != hipSuccess || hipEventElapsedTime(&ms, env->region_ev[0], env->region_ev[1]) != hipSuccess) return -1.0f;
     return ms;
+}
+
+int hns_moments(const float *values, int64_t n, const float *success, int64_t m, double *out, void *stream) {
+    if (!values || !out || n < 0 || m < 0 || (m > 0 && !success)) { set_error("hns_moments: bad argument"); return HNS_ERR_INVALID_ARG; }
+    hipLaunchKernelGGL(hns::hns_moments_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), values, (long long)n, success, (long long)m, out);
+    HNS_CHECK_HIP(hipGetLastError());
+    return HNS_OK;
 }
 
 int hns_copy_f4(void *dst, const void *src, size_t bytes, void *stream) {

@@ -26,7 +26,20 @@ def env_shard(num_envs_total, world_size, rank):
 
 
 def local_moments(values, success=None):
-    """[sum, sum of squares, count, success sum, env count] of this rank, fp64."""
+    """[sum, sum of squares, count, success sum, env count] of this rank, fp64.  Contiguous fp32 device tensors go through ONE launch of the
+    library (hns_moments: one workgroup, fixed summation order) instead of eight small torch kernels in front of the collective."""
+    if values.is_cuda and values.dtype == torch.float32 and values.is_contiguous() and (
+            success is None or (success.is_cuda and success.dtype == torch.float32 and success.is_contiguous())):
+        import ctypes as C
+        from . import abi
+        lib = abi.load_library()
+        out = torch.empty(MOMENT_DIM, dtype=torch.float64, device=values.device)
+        with torch.cuda.device(values.device):
+            rc = lib.hns_moments(values.data_ptr(), values.numel(), success.data_ptr() if success is not None else None,
+                                 success.numel() if success is not None else 0, out.data_ptr(), C.c_void_p(torch.cuda.current_stream(values.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"hns_moments failed ({rc}): {lib.hns_last_error().decode()}")
+        return out
     v = values.reshape(-1).double()
     out = torch.zeros(MOMENT_DIM, dtype=torch.float64, device=values.device)
     out[0], out[1], out[2] = v.sum(), (v * v).sum(), float(v.numel())

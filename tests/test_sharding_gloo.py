@@ -332,3 +332,26 @@ print("rccl ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_moments_in_one_launch_match_torch():
+    """sharding.local_moments on device tensors = ONE launch of hns_moments (one workgroup, fixed order): the values of the torch form in fp64 to
+    rounding, bit-identical from run to run, also for a pointer that is not 16-byte aligned and without a success row."""
+    sys.path.insert(0, ROOT)
+    import hns_amd  # noqa: F401
+    from hns_amd import sharding
+    g = torch.Generator(device="cuda").manual_seed(3)
+    base = torch.randn(65536 * 3 + 5, generator=g, device="cuda") * 40 - 60
+    suc = (torch.rand(65536, generator=g, device="cuda") < 0.02).float()
+    for v, s in ((base[:65536 * 3].view(65536, 3), suc), (base[1:65536 * 3 + 4], suc[:777]), (base[:1000], None)):
+        got = sharding.local_moments(v, s)
+        again = sharding.local_moments(v, s)
+        assert torch.equal(got, again)
+        d = v.reshape(-1).double()
+        ref = torch.tensor([float(d.sum()), float((d * d).sum()), float(d.numel()), float(s.double().sum()) if s is not None else 0.0,
+                            float(s.numel()) if s is not None else 0.0], dtype=torch.float64)
+        assert torch.allclose(got.cpu(), ref, rtol=1e-12, atol=1e-9), (got, ref)
+    # the non-contiguous / non-fp32 forms still take the torch path
+    got = sharding.local_moments(base[:2000:2], None)
+    assert abs(float(got[0]) - float(base[:2000:2].double().sum())) < 1e-9
