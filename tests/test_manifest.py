@@ -124,7 +124,9 @@ def test_task_yaml_for_the_unedited_train_script():
         import yaml
         ref, ours = yaml.safe_load(open(ref_yaml)), yaml.safe_load(open(os.path.join(root, "cfg", "task", "HideAndSeek_hip.yaml")))
         assert ours["defaults"][0] == "HideAndSeek"            # hydra: inherits the reference's own task file
-        assert set(ours) - {"defaults"} == {"name", "action_transform", "env", "publish_ctbr"} and "action_transform" in ref
+        # (besides the three overrides: the switches of this build, spelled out at their defaults — none of them a key of the reference's file)
+        assert set(ours) - {"defaults"} == {"name", "action_transform", "env", "publish_ctbr", "pid_reset", "reset_extra_step"} and "action_transform" in ref
+        assert not ({"publish_ctbr", "pid_reset", "reset_extra_step"} & set(ref)) and ours["pid_reset"] == "reference" and ours["reset_extra_step"] == 1
         # ... and what the file leaves out resolves, without hydra, to the reference file's values (the built-in defaults are those)
         full = config.load_cfg(ref_yaml, name="HideAndSeek_hip", action_transform="none", env={"num_envs": 65536, "max_episode_length": ref["env"]["max_episode_length"]})
         c = config.resolve_hns_cfg(full)
