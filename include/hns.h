@@ -323,7 +323,8 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream);
 /* Farthest-point sampling (replaces dgl.geometry.farthest_point_sampler, :291-304): out_idx[0] = start,
  * out_idx[r] = arg-max over all points of the minimum squared distance to out_idx[0..r-1] (ties -> lower
  * index).  points [n,d] fp32, out_idx [k] int32, scratch [hns_fps_scratch_bytes()] — device pointers.
- * One persistent launch (<= one workgroup per CU).  If a workgroup never shows up the kernel gives up
+ * One persistent launch (<= one workgroup per CU).  The XCD-local kernel (up to 36 coordinates, 131 072 points) accepts up to eight samples per
+ * exchange — exactly those sequential sampling would select next, so out_idx does not depend on it.  If a workgroup never shows up the kernel gives up
  * instead of hanging: the first 8 bytes of scratch are then non-zero (check after synchronising). */
 size_t hns_fps_scratch_bytes(void);
 int hns_fps(const float *points, int32_t n, int32_t d, int32_t k, int32_t start, int32_t *out_idx, void *scratch, void *stream);
