@@ -349,6 +349,7 @@ int hns_create(const hns_cfg *cfg, hns_env **out) {
     if (env->cfg.stats_stride < cfg->num_envs) { delete env; set_error("hns_create: stats_stride must be 0 or >= num_envs"); return HNS_ERR_INVALID_ARG; }
     if (hipGetDevice(&env->device) != hipSuccess) env->device = 0;
     std::memset(&env->buf, 0, sizeof(env->buf));
+    if (hipDeviceGetAttribute(&env->cus, hipDeviceAttributeMultiprocessorCount, env->device) != hipSuccess || env->cus < 1) env->cus = 256;
     switch (cfg->num_agents) {
         case 1: hns_select_kernels_1(env); break;
         case 2: hns_select_kernels_2(env); break;
@@ -521,12 +522,12 @@ static int launch_step(hns_env *env, const float *action, hipStream_t stream) {
         }
         // the events ride on the dispatch itself (start / stop of THIS kernel, the timestamps a profiler reads),
         // not on separate marker packets before and after it
-        hipExtLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads), (uint32_t)env->lds_step, stream, ev.first, ev.second, 0, ka);
+        hipExtLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads_step), (uint32_t)env->lds_step, stream, ev.first, ev.second, 0, ka);
         HNS_CHECK_HIP(hipGetLastError());
         env->events.push_back(ev);
         return HNS_OK;
     }
-    hipLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads), env->lds_step, stream, ka);
+    hipLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads_step), env->lds_step, stream, ka);
     HNS_CHECK_HIP(hipGetLastError());
     return HNS_OK;
 }

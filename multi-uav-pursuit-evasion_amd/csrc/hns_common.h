@@ -60,6 +60,19 @@ struct StepArgs {               // 64 B
 };
 static_assert(sizeof(StepArgs) == 64, "the argument block of the step kernel is sized for the fast launch path");
 
+// The parameter block is read through the scalar cache, which every launch starts with cold: a wave that meets a field of a line nobody
+// has touched yet waits for an L2 round trip, and a phase that needs six lines one after the other pays six of them (the controller phase of a
+// pursuer wave does; at small batches, where nothing else runs on the SIMD meanwhile, that is a third of the phase).  A wave with nothing
+// better to do at its start (env wave, helpers) touches one word of every 64-byte line at once: one round trip, then everybody hits.
+HNS_DEV void warm_params(const Params *rest) {
+    typedef const uint32_t __attribute__((address_space(4))) WordC;
+    WordC *w = (WordC *)rest;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < (int)((sizeof(Params) + 63) / 64); ++i) acc |= w[i * 16];
+    asm volatile("" : : "s"(acc));
+}
+
 constexpr int kProfSlots = 16;
 // lane 0 of every wave stamps s_memtime at a phase boundary (only when a buffer is attached)
 HNS_DEV void prof_mark(unsigned long long *prof, int slot) {

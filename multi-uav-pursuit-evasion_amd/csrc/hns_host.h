@@ -30,7 +30,10 @@ struct hns_env {
     bool bound = false;
     int device = 0;          // the HIP device that was current at hns_create; bound buffers must live there
     uint32_t epoch = 0;
-    int grid = 0, threads = 0;
+    int grid = 0, threads = 0;   // threads: the reset kernel's workgroup
+    int threads_step = 0;        // the step kernel's workgroup (the tile mapping: as the reset kernel's; the small-batch mapping: 2 A + 1 waves)
+    int cus = 0;                 // compute units of `device`
+    int small_mapping = 0;       // 1: hns_step_small_kernel serves this env (hns_inst.hip)
     size_t lds_step = 0, lds_reset = 0;
     void (*reset_fn)(const hns::Params) = nullptr;
     void (*step_args_fn)(const hns::StepArgs) = nullptr;        // the step kernel instantiation serving this env (hns_inst.hip)

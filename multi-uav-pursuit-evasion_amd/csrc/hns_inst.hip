@@ -3,6 +3,10 @@
 #include "hns_host.h"
 #include "hns_reset_kernel.h"
 #include "hns_step_kernel.h"
+#include "hns_step_small_kernel.h"
+
+#include <cstdlib>
+#include <cstring>
 
 #ifndef HNS_INST_A
 #error "compile with -DHNS_INST_A=<pursuers per env>"
@@ -38,10 +42,33 @@ void HNS_CAT(hns_select_kernels_, HNS_INST_A)(hns_env *env) {
         env->reset_fn = two ? hns_reset_kernel<A, 2> : hns_reset_kernel<A, 1>;
     }
     env->threads = Geo<A>::T;
+    env->threads_step = Geo<A>::T;
     env->cyl_magic = (uint32_t)(0xFFFFFFFFull / (uint32_t)(3 * c.num_cylinders) + 1ull);
     env->grid = (c.num_envs + kEPB - 1) / kEPB;
     const int NT = two ? 2 : 1;
     env->lds_step = (size_t)lds_layout_v3(A, c.num_cylinders, c.obs_max_cylinder, NT).total * sizeof(float);
     env->lds_reset = (size_t)lds_layout(A, c.num_cylinders, c.obs_max_cylinder, NT).total * sizeof(float) +
                      (size_t)kEPB * kGridStride;      // + per-env occupancy grid / free-cell list
+    // Batches that leave most SIMDs idle take the second mapping (hns_step_small_kernel.h: a helper wave per pursuer wave): one evader, whole
+    // tiles, k <= 4, fewer than kSmallWgPerCu workgroups per CU.  HNS_STEP_MAPPING=tile|small overrides the choice where the shape allows both
+    // (A/B runs, tests/test_hip_parity.py).
+    const char *mp = std::getenv("HNS_STEP_MAPPING");
+    const bool eligible = !two && !wide && !ragged;
+    bool small = eligible && env->grid < kSmallWgPerCu * env->cus;
+    if (mp && !std::strcmp(mp, "tile")) small = false;
+    if (mp && !std::strcmp(mp, "small")) small = eligible;
+    if (small) {
+        env->small_mapping = 1;
+        env->step_args_fn = hns_step_small_kernel<A, false>;
+        env->step_args_prof_fn = hns_step_small_kernel<A, true>;
+        if (c.obs_max_cylinder == 3) {
+            switch (c.num_cylinders) {
+                case 5: env->step_args_fn = hns_step_small_kernel<A, false, 5>; break;
+                case 8: env->step_args_fn = hns_step_small_kernel<A, false, 8>; break;
+                default: break;
+            }
+        }
+        env->threads_step = GeoSmall<A>::T;
+        env->lds_step = (size_t)lds_small_total(A, c.num_cylinders, c.obs_max_cylinder) * sizeof(float);
+    }
 }

@@ -453,6 +453,9 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         const int le = lane;
         const bool valid = !GEN || le < nv;                  // (generic) this env exists; lanes beyond the batch work on the last env's data
         const int e = e0 + (valid ? le : nv - 1);
+#ifndef HNS_NO_WARM
+        warm_params(ka.rest);
+#endif
         if constexpr (PROF) prof_mark(p.prof, 0);
         if constexpr (PROF) prof_mark(p.prof, 14);
         const int C = CS ? CS : c.num_cylinders, K = CS ? 3 : c.obs_max_cylinder, E = c.stats_stride;      // (E: the row stride of `stats`, = num_envs unless the env is a slice)
