@@ -371,9 +371,15 @@ float hns_region_ms(hns_env *env);
  * aligned device pointers) as 16-byte loads / stores, one float4 per thread.  Not part of the environment. */
 int hns_copy_f4(void *dst, const void *src, size_t bytes, void *stream);
 
-/* Diagnostics: attach a device buffer of [num_waves, 16] uint64 (num_waves = ceil(E/64)*(A+1)); lane 0
- * of every wave of the step kernel then stamps the shader clock at up to 16 phase boundaries (NULL detaches). */
+/* Diagnostics: attach a device buffer of [num_waves, 16] uint64 (num_waves = ceil(E/64)*(A+1); ceil(E/64)*(2A+1) when hns_step_mapping() is 1);
+ * lane 0 of every wave of the step kernel then stamps the shader clock at up to 16 phase boundaries (NULL detaches). */
 int hns_set_phase_profile(hns_env *env, unsigned long long *device_buf);
+
+/* Which mapping of the step kernel serves this env: 0 = 64-env tiles of A + 1 waves (batches that fill the chip), 1 = the small-batch mapping
+ * (2 A + 1 waves per tile: a helper wave per pursuer wave; one evader, E % 64 == 0, obs_max_cylinder <= 4, at most two tiles per compute
+ * unit).  Same buffers, bit for bit, either way; chosen by hns_create (the environment variable HNS_STEP_MAPPING=tile|small overrides it
+ * where the shape allows both — A/B measurements and tests). */
+int hns_step_mapping(const hns_env *env);
 
 /* The per-rollout moments of the data-parallel advantage normalisation (learning/mappo.py:391-396 made data-parallel; sharding.py) in ONE launch:
  * out[0..4] = [sum v, sum v^2, n, sum s, m] in fp64 over `values` [n] fp32 and `success` [m] fp32 (m may be 0: success NULL) — device

@@ -235,6 +235,8 @@ def load_library():
     lib.hns_copy_f4.restype = C.c_int
     lib.hns_set_phase_profile.argtypes = [C.c_void_p, C.c_void_p]
     lib.hns_set_phase_profile.restype = C.c_int
+    lib.hns_step_mapping.argtypes = [C.c_void_p]
+    lib.hns_step_mapping.restype = C.c_int
     lib.hns_hover_step.argtypes = [C.POINTER(HnsCfg), C.POINTER(HnsHoverCfg), C.POINTER(HnsHoverBuffers), C.c_void_p, C.c_void_p]
     lib.hns_hover_step.restype = C.c_int
     lib.hns_hover_reset.argtypes = [C.POINTER(HnsCfg), C.POINTER(HnsHoverCfg), C.POINTER(HnsHoverBuffers), C.c_void_p,
@@ -279,5 +281,5 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "hns_create", "hns_destroy", "hns_bind", "hns_step", "hns_reset", "hns_reset_tasks", "hns_raycast", "hns_set_v_prey",
     "hns_set_smoothness_coef", "hns_set_reset_epoch", "hns_get_reset_epoch", "hns_enable_timing",
-    "hns_step_kernel_ms", "hns_region_begin", "hns_region_end", "hns_region_ms", "hns_copy_f4", "hns_moments", "hns_set_phase_profile", "hns_set_state", "hns_get_state", "hns_refresh_derived_state", "hns_fps", "hns_fps_scratch_bytes", "hns_perturb_tasks", "hns_tp_bind", "hns_tp_refresh", "hns_tp_packed_bytes", "hns_tp_observe", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
+    "hns_step_kernel_ms", "hns_region_begin", "hns_region_end", "hns_region_ms", "hns_copy_f4", "hns_moments", "hns_set_phase_profile", "hns_step_mapping", "hns_set_state", "hns_get_state", "hns_refresh_derived_state", "hns_fps", "hns_fps_scratch_bytes", "hns_perturb_tasks", "hns_tp_bind", "hns_tp_refresh", "hns_tp_packed_bytes", "hns_tp_observe", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
 ]

@@ -511,7 +511,6 @@ static int launch_step(hns_env *env, const float *action, hipStream_t stream) {
     const void *aux = env->cfg.num_targets == 2
                           ? reinterpret_cast<const void *>(reinterpret_cast<uintptr_t>(b.cylinders) | (uintptr_t)((env->cfg.num_cylinders - 1) & 15))
                           : static_cast<const void *>(b.reset_pid);
-    const hns::StepArgs ka{action, b.prev_action, b.drone_state, b.pid_integ, b.pid_last_rate, b.throttle, aux, env->params_dev};
     auto fn = (env->prof && env->step_args_prof_fn) ? env->step_args_prof_fn : env->step_args_fn;
     if (env->timing > 0 && (env->step_count++ % (uint64_t)env->timing) == 0) {
         std::pair<hipEvent_t, hipEvent_t> ev{};
@@ -522,12 +521,14 @@ static int launch_step(hns_env *env, const float *action, hipStream_t stream) {
         }
         // the events ride on the dispatch itself (start / stop of THIS kernel, the timestamps a profiler reads),
         // not on separate marker packets before and after it
-        hipExtLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads_step), (uint32_t)env->lds_step, stream, ev.first, ev.second, 0, ka);
+        hipExtLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads_step), (uint32_t)env->lds_step, stream, ev.first, ev.second, 0, static_cast<const hns::Params *>(env->params_dev),
+                              action, b.prev_action, b.drone_state, aux, b.pid_integ, b.pid_last_rate, b.throttle);
         HNS_CHECK_HIP(hipGetLastError());
         env->events.push_back(ev);
         return HNS_OK;
     }
-    hipLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads_step), env->lds_step, stream, ka);
+    hipLaunchKernelGGL(fn, dim3(env->grid), dim3(env->threads_step), env->lds_step, stream, static_cast<const hns::Params *>(env->params_dev), action, b.prev_action,
+                       b.drone_state, aux, b.pid_integ, b.pid_last_rate, b.throttle);
     HNS_CHECK_HIP(hipGetLastError());
     return HNS_OK;
 }
@@ -710,6 +711,8 @@ int hns_set_phase_profile(hns_env *env, unsigned long long *device_buf) {
     env->prof = device_buf;
     return upload_step_params(env);
 }
+
+int hns_step_mapping(const hns_env *env) { return env ? env->small_mapping : HNS_ERR_INVALID_ARG; }
 
 int hns_enable_timing(hns_env *env, int on) {
     if (!env) return HNS_ERR_INVALID_ARG;

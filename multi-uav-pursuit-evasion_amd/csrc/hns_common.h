@@ -25,6 +25,7 @@ enum { R_AERR = 0, R_TD, R_DIST, R_SPEED, R_CC, R_CD, R_CW, R_COLL,
        R_F1X = 8 };
 enum { F_CAP = 1, F_BLOCKED = 2, F_DET = 4, F_DET1 = 8 };
 constexpr int kGridStride = 516;   // bytes of reset scratch per env: 2 x 256 + 4 (an odd dword stride: lanes = envs hit different LDS banks)
+constexpr int kSmallWgPerCu = 2;   // the small-batch mapping (hns_step_small_kernel.h) serves grids of up to this many workgroups per CU (hns_inst.hip)
 constexpr int kMaxT = 2;   // evaders per env (1 = the reference; 2 = BASELINE config 5's extension)
 
 template <int A>
@@ -59,6 +60,14 @@ struct StepArgs {               // 64 B
     const Params *rest;         // device copy of the launch's Params (action = null), kept by the env handle
 };
 static_assert(sizeof(StepArgs) == 64, "the argument block of the step kernel is sized for the fast launch path");
+// The step kernels take the eight words as SEPARATE parameters: pointer parameters can be preloaded into SGPRs by the dispatcher
+// (-mllvm -amdgpu-kernarg-preload-count=16; __graft_entry__.py sets it for the small-batch mapping's translation units), so a wave issues its
+// first loads without a round trip to the kernel-argument segment; an aggregate passed by value is not eligible.  The body packs them back into a StepArgs.
+// (14 dwords are preloaded: the parameter block — the env wave's first need — leads, `throttle`, the last of a pursuer wave's first loads, trails)
+#define HNS_STEP_PARAMS                                                                                                                    \
+    const Params *ka_rest, const float *ka_action, float *ka_prev_action, float *ka_drone_state, const void *ka_aux, float *ka_pid_integ, \
+        float *ka_pid_last_rate, float *ka_throttle
+#define HNS_STEP_ARGS_PACK const StepArgs ka{ka_action, ka_prev_action, ka_drone_state, ka_pid_integ, ka_pid_last_rate, ka_throttle, ka_aux, ka_rest}
 
 // The parameter block is read through the scalar cache, which every launch starts with cold: a wave that meets a field of a line nobody
 // has touched yet waits for an L2 round trip, and a phase that needs six lines one after the other pays six of them (the controller phase of a

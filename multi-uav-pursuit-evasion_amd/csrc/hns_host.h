@@ -11,8 +11,9 @@
 
 namespace hns {
 struct Params;
-struct StepArgs;
 }
+// the step kernels' signature (hns_common.h: HNS_STEP_PARAMS)
+typedef void (*hns_step_fn)(const hns::Params *, const float *, float *, float *, const void *, float *, float *, float *);
 
 void hns_set_error(const std::string &m);
 
@@ -36,8 +37,8 @@ struct hns_env {
     int small_mapping = 0;       // 1: hns_step_small_kernel serves this env (hns_inst.hip)
     size_t lds_step = 0, lds_reset = 0;
     void (*reset_fn)(const hns::Params) = nullptr;
-    void (*step_args_fn)(const hns::StepArgs) = nullptr;        // the step kernel instantiation serving this env (hns_inst.hip)
-    void (*step_args_prof_fn)(const hns::StepArgs) = nullptr;   // ... compiled with the per-wave phase stamps (hns_set_phase_profile); whole tiles, k <= 4 only
+    hns_step_fn step_args_fn = nullptr;        // the step kernel instantiation serving this env (hns_inst.hip)
+    hns_step_fn step_args_prof_fn = nullptr;   // ... compiled with the per-wave phase stamps (hns_set_phase_profile); whole tiles, k <= 4 only
     // device copy of the step launch's Params (allocated by hns_create) and what feeds it: a ring of pinned host images, one
     // stream-ordered hipMemcpyAsync per change on `last_stream` (the stream of the latest step / reset / observe call)
     static constexpr int kParamRing = 8;

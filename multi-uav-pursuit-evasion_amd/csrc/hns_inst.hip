@@ -1,9 +1,9 @@
 // hns_inst.hip — the step and reset kernels instantiated for ONE pursuer count (compiled once per count: -DHNS_INST_A=1 ... 7, side
-// by side; __graft_entry__.build), and the host-side choice among them.
+// by side; __graft_entry__.build), and the host-side choice among them.  Two translation units per count: the tile mapping + reset
+// kernels, and (-DHNS_INST_SMALL=1) the small-batch mapping, which is compiled with its pointer parameters preloaded into SGPRs
+// (-mllvm -amdgpu-kernarg-preload-count=16: -0.15 ... -0.4 us per step below 32 768 envs; the tile mapping at 65 536 envs measured
+// 0.15 us SLOWER with it — 4 096 waves whose launch each waits for the preload — so it stays without; tools/lab/r04_batch32.sh).
 #include "hns_host.h"
-#include "hns_reset_kernel.h"
-#include "hns_step_kernel.h"
-#include "hns_step_small_kernel.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -13,6 +13,34 @@
 #endif
 #define HNS_CAT2(a, b) a##b
 #define HNS_CAT(a, b) HNS_CAT2(a, b)
+
+#ifdef HNS_INST_SMALL
+#include "hns_step_small_kernel.h"
+
+// hns_step_small_kernel for an env the caller found eligible (one evader, whole tiles, k <= 4)
+void HNS_CAT(hns_select_small_, HNS_INST_A)(hns_env *env) {
+    constexpr int A = HNS_INST_A;
+    using namespace hns;
+    const hns_cfg &c = env->cfg;
+    env->small_mapping = 1;
+    env->step_args_fn = hns_step_small_kernel<A, false>;
+    env->step_args_prof_fn = hns_step_small_kernel<A, true>;
+    if (c.obs_max_cylinder == 3) {
+        switch (c.num_cylinders) {
+            case 5: env->step_args_fn = hns_step_small_kernel<A, false, 5>; break;
+            case 8: env->step_args_fn = hns_step_small_kernel<A, false, 8>; break;
+            default: break;
+        }
+    }
+    env->threads_step = GeoSmall<A>::T;
+    env->lds_step = (size_t)lds_layout_small(A, c.num_cylinders, c.obs_max_cylinder).total * sizeof(float);
+}
+
+#else
+#include "hns_reset_kernel.h"
+#include "hns_step_kernel.h"
+
+void HNS_CAT(hns_select_small_, HNS_INST_A)(hns_env *env);
 
 // Which instantiation serves an env: whole 64-env tiles with k <= 4 take the tuned kernel (and, with a phase-profile
 // buffer attached, its stamped twin); ragged batches and wider selections take the generic one.
@@ -50,25 +78,13 @@ void HNS_CAT(hns_select_kernels_, HNS_INST_A)(hns_env *env) {
     env->lds_reset = (size_t)lds_layout(A, c.num_cylinders, c.obs_max_cylinder, NT).total * sizeof(float) +
                      (size_t)kEPB * kGridStride;      // + per-env occupancy grid / free-cell list
     // Batches that leave most SIMDs idle take the second mapping (hns_step_small_kernel.h: a helper wave per pursuer wave): one evader, whole
-    // tiles, k <= 4, fewer than kSmallWgPerCu workgroups per CU.  HNS_STEP_MAPPING=tile|small overrides the choice where the shape allows both
+    // tiles, k <= 4, at most kSmallWgPerCu workgroups per CU.  HNS_STEP_MAPPING=tile|small overrides the choice where the shape allows both
     // (A/B runs, tests/test_hip_parity.py).
     const char *mp = std::getenv("HNS_STEP_MAPPING");
     const bool eligible = !two && !wide && !ragged;
-    bool small = eligible && env->grid < kSmallWgPerCu * env->cus;
+    bool small = eligible && env->grid <= kSmallWgPerCu * env->cus;
     if (mp && !std::strcmp(mp, "tile")) small = false;
     if (mp && !std::strcmp(mp, "small")) small = eligible;
-    if (small) {
-        env->small_mapping = 1;
-        env->step_args_fn = hns_step_small_kernel<A, false>;
-        env->step_args_prof_fn = hns_step_small_kernel<A, true>;
-        if (c.obs_max_cylinder == 3) {
-            switch (c.num_cylinders) {
-                case 5: env->step_args_fn = hns_step_small_kernel<A, false, 5>; break;
-                case 8: env->step_args_fn = hns_step_small_kernel<A, false, 8>; break;
-                default: break;
-            }
-        }
-        env->threads_step = GeoSmall<A>::T;
-        env->lds_step = (size_t)lds_small_total(A, c.num_cylinders, c.obs_max_cylinder) * sizeof(float);
-    }
+    if (small) HNS_CAT(hns_select_small_, HNS_INST_A)(env);
 }
+#endif

@@ -78,7 +78,8 @@ HNS_DEV void env_store_slice(const float *lds, float *g, int n, int lane, int nv
 // (5, 8, 16 slots; obs_max_cylinder 3).  Same arithmetic, same order; the cylinder loops unroll completely and the k-nearest predicates
 // fold away: 6v2 / 16 cylinders 50.4 -> 48.5 us, 3v1 / 8 cylinders 18.7 -> 18.5 us (A/B/A/B on one box, tools/lab/r04_batch18.sh).
 template <int A, int NT, bool GEN, int KM, bool PROF, int CS = 0>
-__global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void hns_step_v4_kernel(const StepArgs ka) {
+__global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void hns_step_v4_kernel(HNS_STEP_PARAMS) {
+    HNS_STEP_ARGS_PACK;
     static_assert(GEN || KM == kMaxK, "wide k-nearest selections: the generic instantiation");
     static_assert(CS == 0 || (!GEN && !PROF && CS <= HNS_MAX_CYLINDERS), "fixed shapes: the tuned instantiation only");
     // the block behind `rest` is never written while the kernel runs: read it as constant memory (scalar loads, placed like kernel-argument loads)
@@ -564,6 +565,13 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         if constexpr (PROF) prof_mark(p.prof, 2);
         __syncthreads();                                                            // barrier 1: positions at t, line-of-sight flags, action errors
         if constexpr (PROF) prof_mark(p.prof, 12);
+#ifndef HNS_NO_PIN
+        // Most of the statistics rows fetched above are first used behind barrier 3, behind this wave's stores of the evader and the rewards.  Left
+        // alone, the compiler waits for them THERE with s_waitcnt vmcnt(n), n = the memory operations issued since — so the wave waits for its own
+        // freshly issued stores to be acknowledged (hns_step_small_kernel.h: 2 500 cycles for 11 stores).  Pin the wait here: only loads are outstanding.
+#pragma unroll
+        for (int i = 0; i < HNS_NUM_STATS; ++i) asm volatile("" : "+v"(st[i]));
+#endif
         // the pursuers' pushes (hideandseek.py:1074-1088), ascending; then arena, then cylinders
         V3 F = {0.f, 0.f, 0.f}, G = {0.f, 0.f, 0.f};
 #pragma unroll

@@ -14,24 +14,43 @@
 //   * behind barrier 2 (positions at t+1 published) a helper selects the k nearest cylinders of its pursuers and counts the cylinder
 //     collisions while the owner computes the distance, speed, drone-collision, wall and smoothness terms, sweeps the cylinders for the
 //     line of sight (detection / capture flags), and stores its controller state, S_{t+1} and its state_others rows;
-//   * behind barrier 3 the owner stores the (masked) state_self rows, the helper its k-nearest rows, the env wave reduces the rewards, and
-//     helper wave 0 (lane <-> env) updates the eight statistics that are plain sums over the pursuers; the env wave keeps eight.
+//   * behind barrier 3 the owner stores the (masked) state_self rows, the helper its k-nearest rows; lane <-> env, helper wave 2 builds the reward
+//     rows and their running sum, helper wave 0 updates the eight statistics that are plain sums over the pursuers, and the env wave keeps
+//     done / progress and the seven statistics decided by the detection and capture flags.
 // 2 A + 1 waves per workgroup, three workgroup barriers, no new exchange beyond the records the tile mapping already publishes (+ one flag).
 #pragma once
 #include "hns_step_kernel.h"
 
 namespace hns {
 
-constexpr int kSmallWgPerCu = 2;   // the small-batch mapping serves grids of fewer workgroups per CU than this (hns_inst.hip)
 template <int A>
 struct GeoSmall {
-    static constexpr int NA = kEPB * A;             // owner threads; helpers: [NA, 2 NA); env wave: [2 NA, 2 NA + 64)
+    static constexpr int NA = kEPB * A;             // owner threads; env wave: [NA, NA + 64); helpers: [NA + 64, 2 NA + 64).  Waves go round the four
+                                                    // SIMDs in this order: with three pursuers the env wave has a SIMD to itself and every owner shares
+                                                    // one with a helper (idle while the owner computes) — with the env wave last, the owner beside it
+                                                    // reached barrier 2 ~900 cycles behind the others (tools/phase_profile.py --waves)
     static constexpr int T = kEPB * (2 * A + 1);
 };
-// LDS: the tile mapping's layout, then one slab per helper wave (k-nearest rows)
-__host__ __device__ inline int lds_small_total(int A, int C, int K) {
-    const LdsV3 L = lds_layout_v3(A, C, K, 1);
-    return L.total + A * L.slab_stride;
+// LDS (float offsets): a staging slab per owner and per helper wave (whole-line stores, as in the tile mapping: rows stored by their lanes were
+// measured too — 27 store instructions of 64 scattered lines each in the last phase keep the CU's one address path busy for most of it, and
+// from 16 384 envs on the step is 2-4 us slower), then the records the tile mapping publishes
+struct LdsSmall { int slab, slab_stride, hslab, hslab_stride, pub, cyl, cyl_stride, tp, red, envout, total; };
+__host__ __device__ inline LdsSmall lds_layout_small(int A, int C, int K) {
+    LdsSmall L;
+    int o = 0;
+    L.slab_stride = slab_floats(A, K, 1);
+    if (L.slab_stride < 64 * 13 + 4) L.slab_stride = r4(64 * 13 + 4);
+    L.slab = o;   o += A * L.slab_stride;
+    L.hslab_stride = r4(slab_rows(A) * K * 5);
+    L.hslab = o;  o += A * L.hslab_stride;
+    L.pub = o;    o += r4(kEPB * A * kPub);
+    L.cyl_stride = (3 * C) | 1;
+    L.cyl = o;    o += r4(kEPB * L.cyl_stride);
+    L.tp = o;     o += r4(kEPB * 4);                         // evader at t+1 [64][3], then the step counter [64]
+    L.red = o;    o += r4(kEPB * A * red_stride(1));
+    L.envout = o; o += r4(kEPB * (A > 3 ? A : 3));           // arena flags, then evader velocity [64,3], then rewards [64,A]
+    L.total = o;
+    return L;
 }
 
 // the statistics helper wave 0 owns: sums of one published reward term over the env's pursuers (hideandseek.py:960-1056)
@@ -46,10 +65,13 @@ HNS_DEV constexpr bool small_early_stat(int i) {
 }
 // ... and what the step never changes (the rows stay as they are: neither loaded nor stored)
 HNS_DEV constexpr bool small_untouched_stat(int i) { return i == HNS_ST_DISTANCE_PREDICTED_REWARD || i == HNS_ST_DISTANCE_THRESHOLD_L; }
-HNS_DEV constexpr bool small_env_stat(int i) { return !small_helper_stat(i) && !small_early_stat(i) && !small_untouched_stat(i); }
+// ... the helper wave that builds the reward rows keeps their sum
+HNS_DEV constexpr bool small_reward_stat(int i) { return i == HNS_ST_RETURN; }
+HNS_DEV constexpr bool small_env_stat(int i) { return !small_helper_stat(i) && !small_early_stat(i) && !small_untouched_stat(i) && !small_reward_stat(i); }
 
 template <int A, bool PROF, int CS = 0>
-__global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(const StepArgs ka) {
+__global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(HNS_STEP_PARAMS) {
+    HNS_STEP_ARGS_PACK;
     typedef const Params __attribute__((address_space(4))) ParamsC;
     ParamsC &p = *(ParamsC *)ka.rest;
     constexpr int NA = GeoSmall<A>::NA, SD = HNS_SELF_DIM, kRedS = red_stride(1), KM = kMaxK;
@@ -86,7 +108,7 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(const
         if constexpr (PROF) prof_mark(p.prof, 14);
         const int C = CS ? CS : c.num_cylinders, K = CS ? 3 : c.obs_max_cylinder;
         const bool with_state = c.write_critic_state && b.state_drones != nullptr;
-        const LdsV3 L = lds_layout_v3(A, C, K, 1);
+        const LdsSmall L = lds_layout_small(A, C, K);
         float *sPub = smem + L.pub, *sTp = smem + L.tp, *sRed = smem + L.red;
         float *slab = smem + L.slab + (tid >> 6) * L.slab_stride;
         const float4 ta = d_action_tanh(act4);
@@ -231,17 +253,16 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(const
             wave_store_rows<SD, slab_rows(A)>(slab, b.obs_self + ((size_t)e0 * A + (tid & ~63)) * SD, row, lane, 64);
         }
         if constexpr (PROF) prof_mark(p.prof, 6);
-    } else if (tid < 2 * NA) {
+    } else if (tid >= NA + kEPB) {
         // ================================= helper waves: cylinders ===================================================
-        const int htid = tid - NA, hw = htid >> 6;
+        const int htid = tid - NA - kEPB, hw = htid >> 6;
         const int le = htid / A;
         if constexpr (WARM) warm_params(ka.rest);
         if constexpr (PROF) prof_mark(p.prof, 0);
         if constexpr (PROF) prof_mark(p.prof, 14);
         const int C = CS ? CS : c.num_cylinders, K = CS ? 3 : c.obs_max_cylinder, E = c.stats_stride;
-        const LdsV3 L = lds_layout_v3(A, C, K, 1);
+        const LdsSmall L = lds_layout_small(A, C, K);
         float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red;
-        float *slab = smem + L.total + hw * L.slab_stride;
         (void)sTp;
         // stage the workgroup's cylinders (one contiguous slice [64][3C]): helper wave w takes the 64-float passes w, w + A, ...;
         // every load issued before the first LDS write
@@ -266,8 +287,9 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(const
             }
         }
         // lane <-> env: helper wave 0 fetches the eight statistics rows it updates behind barrier 3, helper wave 1 the six it updates behind barrier 1
-        constexpr int kEarlyWave = A > 1 ? 1 : 0;
+        constexpr int kEarlyWave = A > 1 ? 1 : 0, kRewardWave = A > 2 ? 2 : A - 1;
         float st[HNS_NUM_STATS];
+        if (hw == kRewardWave) st[HNS_ST_RETURN] = b.stats[(size_t)HNS_ST_RETURN * E + e0 + lane];
         if (hw == 0) {
 #pragma unroll
             for (int i = 0; i < HNS_NUM_STATS; ++i)
@@ -280,6 +302,15 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(const
         }
         if constexpr (PROF) prof_mark(p.prof, 2);
         __syncthreads();                                                            // barrier 1
+        // The statistics rows fetched above are first used behind barrier 3, behind this wave's stores.  Left alone, the compiler waits for them
+        // THERE with s_waitcnt vmcnt(n), n = the memory operations issued since — which makes the wave wait for its own freshly issued stores to be
+        // acknowledged (measured: 2 500 cycles for 11 stores in the env wave's tail).  Pin the wait here, where only loads are outstanding.
+        if (hw == 0) {
+#pragma unroll
+            for (int i = 0; i < HNS_NUM_STATS; ++i)
+                if (small_helper_stat(i)) asm volatile("" : "+v"(st[i]));
+        }
+        if (hw == kRewardWave) asm volatile("" : "+v"(st[HNS_ST_RETURN]));
         if (hw == kEarlyWave) {
             // statistics that only need phase-1 data (hideandseek.py:731-733, :1097-1098, :996-997; :1017-1056 for the division at the episode's end)
             const int e = e0 + lane;
@@ -360,6 +391,7 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(const
                 krow[sidx * 5 + 4] = masked ? mv : cs;
             }
             float *g = b.obs_cylinders + ((size_t)e0 * A + (htid & ~63)) * K * 5;
+            float *slab = smem + L.hslab + hw * L.hslab_stride;
             if (K == 3) {
                 float r[15];
 #pragma unroll
@@ -378,6 +410,34 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(const
                 for (int i = 0; i < 5; ++i) r[i] = krow[i];
                 wave_store_rows<5, slab_rows(A)>(slab, g, r, lane, 64);
             }
+        }
+        if (hw == kRewardWave) {
+            // lane <-> env: the reward rows (hideandseek.py:919-1006) and their running sum
+            float *sEnvOut = smem + L.envout;
+            bool any_cap = false, det_any = false;
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                const int fl = __float_as_int(sRed[(lane * A + j) * kRedS + R_FLAGS]);
+                any_cap |= (fl & F_CAP) != 0;
+                det_any |= (fl & F_DET) != 0;
+            }
+            const float detect_rew = c.detect_reward_coef * (det_any ? 1.0f : 0.0f);
+            const float catch_rew = c.catch_reward_coef * (any_cap ? 1.0f : 0.0f);
+            float sum_rew = 0.f;
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                const float *red = sRed + (lane * A + j) * kRedS;
+                float cr = -c.collision_coef * red[R_CC];
+                cr = cr + -c.collision_coef * red[R_CD];
+                cr = cr + -c.collision_coef * red[R_CW];
+                const float r = ((((red[R_DIST] + detect_rew) + catch_rew) + cr) + red[R_SPEED]) + red[R_SMOOTH];
+                sEnvOut[lane * A + j] = r;
+                sum_rew = (j == 0) ? r : sum_rew + r;
+            }
+            env_store_slice<false>(sEnvOut, b.reward + (size_t)e0 * A, kEPB * A, lane, kEPB * A);
+            flag_nonfinite(b.nonfinite, (sum_rew - sum_rew) != 0.0f, 4u);
+            st[HNS_ST_RETURN] += sum_rew * c.inv_num_agents;
+            st_f1(b.stats + (size_t)HNS_ST_RETURN * E + e0 + lane, st[HNS_ST_RETURN]);
         }
         if (hw == 0) {
             // lane <-> env: the statistics that are sums of one reward term over the env's pursuers (hideandseek.py:960-1056)
@@ -428,9 +488,8 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(const
         if constexpr (PROF) prof_mark(p.prof, 0);
         if constexpr (PROF) prof_mark(p.prof, 14);
         const int C = CS ? CS : c.num_cylinders, K = CS ? 3 : c.obs_max_cylinder, E = c.stats_stride;
-        const LdsV3 L = lds_layout_v3(A, C, K, 1);
-        float *sPub = smem + L.pub, *sCyl = smem + L.cyl, *sTp = smem + L.tp, *sRed = smem + L.red, *sEnvOut = smem + L.envout;
-        const float *cylw = sCyl + le * L.cyl_stride;
+        const LdsSmall L = lds_layout_small(A, C, K);
+        float *sPub = smem + L.pub, *sTp = smem + L.tp, *sRed = smem + L.red, *sEnvOut = smem + L.envout;
         const float *gt = b.target_pos + (size_t)e * 3;
         const V3 tp0 = {gt[0], gt[1], gt[2]};
         float progress = b.progress[e];
@@ -444,9 +503,25 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(const
         bool out_of_arena = false;
         const V3 Fenv = d_prey_arena_term(c, tp0, out_of_arena);                    // hideandseek.py:1090-1112
         sEnvOut[le] = out_of_arena ? 1.0f : 0.0f;                                  // for the helper that keeps the early statistics
+        // cylinder terms (:1114-1136): this lane's env straight from memory (the helpers' staging is only complete at barrier 1, and this wave
+        // has time now — behind the barrier the owners would wait for it)
+        float fcx = 0.f, fcy = 0.f;
+        {
+            const float *cylg = b.cylinders + (size_t)e * C * 3;
+#pragma unroll 4
+            for (int k = 0; k < C; ++k) {
+                float tx, ty;
+                d_prey_cylinder_term(c, tp0, cylg[3 * k], cylg[3 * k + 1], cylg[3 * k + 2], tx, ty);
+                fcx += tx;
+                fcy += ty;
+            }
+        }
         if constexpr (PROF) prof_mark(p.prof, 2);
         __syncthreads();                                                            // barrier 1: positions at t, flags, action errors, staged cylinders
         if constexpr (PROF) prof_mark(p.prof, 12);
+#pragma unroll
+        for (int i = 0; i < HNS_NUM_STATS; ++i)                                     // (the wait for these rows: here, not behind the stores — see the helpers)
+            if (small_env_stat(i)) asm volatile("" : "+v"(st[i]));
         V3 F = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < A; ++j) {                                               // the pursuers' pushes (:1074-1088), ascending
@@ -457,14 +532,6 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(const
             F.x = (j == 0) ? fp.x : F.x + fp.x;
             F.y = (j == 0) ? fp.y : F.y + fp.y;
             F.z = (j == 0) ? fp.z : F.z + fp.z;
-        }
-        float fcx = 0.f, fcy = 0.f;                                                 // cylinder terms (:1114-1136), from the helpers' staging
-#pragma unroll 4
-        for (int k = 0; k < C; ++k) {
-            float tx, ty;
-            d_prey_cylinder_term(c, tp0, cylw[3 * k], cylw[3 * k + 1], cylw[3 * k + 2], tx, ty);
-            fcx += tx;
-            fcy += ty;
         }
         F.x = F.x + Fenv.x; F.y = F.y + Fenv.y; F.z = F.z + Fenv.z;
         F.x = F.x + fcx; F.y = F.y + fcy; F.z = F.z + 0.0f;
@@ -484,7 +551,7 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(const
         if constexpr (PROF) prof_mark(p.prof, 4);
         __syncthreads();                                                            // barrier 3: reward terms and flags
         if constexpr (PROF) prof_mark(p.prof, 5);
-        // ---- phase 3b: flags, reward, done, the env wave's 16 statistics (hideandseek.py:919-1065) ----
+        // ---- phase 3b: flags, done, the env wave's seven statistics (hideandseek.py:919-1065) ----
         const float iA = c.inv_num_agents;
         bool any_cap = false, all_blocked = true, det_any = false;
 #pragma unroll
@@ -497,19 +564,7 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(const
         const float detf = det_any ? 1.0f : 0.0f;
         const float detect_rew = c.detect_reward_coef * detf;
         const float catch_rew = c.catch_reward_coef * (any_cap ? 1.0f : 0.0f);
-        float sum_rew = 0.f;
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-            const float *red = sRed + (le * A + j) * kRedS;
-            float cr = -c.collision_coef * red[R_CC];
-            cr = cr + -c.collision_coef * red[R_CD];
-            cr = cr + -c.collision_coef * red[R_CW];
-            const float r = ((((red[R_DIST] + detect_rew) + catch_rew) + cr) + red[R_SPEED]) + red[R_SMOOTH];
-            sEnvOut[le * A + j] = r;
-            sum_rew = (j == 0) ? r : sum_rew + r;
-        }
-        env_store_slice<false>(sEnvOut, b.reward + (size_t)e0 * A, kEPB * A, lane, kEPB * A);
-        flag_nonfinite(b.nonfinite, (sum_rew - sum_rew) != 0.0f, 4u);
+        if constexpr (PROF) prof_mark(p.prof, 10);
 #define ST(i) st[i]
         ST(HNS_ST_SUM_DETECT_STEP) += 1.0f * detf;
         float sdet = detect_rew, scat = catch_rew;
@@ -528,8 +583,8 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(const
             ST(HNS_ST_DETECT_REWARD) = ST(HNS_ST_DETECT_REWARD) / progress;
             ST(HNS_ST_CATCH_REWARD) = ST(HNS_ST_CATCH_REWARD) / progress;
         }
-        ST(HNS_ST_RETURN) += sum_rew * iA;
 #undef ST
+        if constexpr (PROF) prof_mark(p.prof, 11);
         b.done[e] = (uint8_t)done;
         if (b.detect) b.detect[e] = (uint8_t)(det_any ? 1 : 0);
         b.progress[e] = progress;

@@ -664,6 +664,11 @@ class HideAndSeek(_EnvBase):
         ms = float(self._lib.hns_step_kernel_ms(self._timed_handle(), C.byref(n)))
         return ms, n.value
 
+    @property
+    def step_mapping(self):
+        """'tile' or 'small': which mapping of the step kernel serves this env (hns_step_mapping; csrc/hns_step_small_kernel.h)."""
+        return "small" if self._lib.hns_step_mapping(self._env) == 1 else "tile"
+
     def region_begin(self):
         """One start event on the stream the steps are launched on (hns_region_begin); `region_end` records the stop event,
         `region_ms` waits for it.  Nothing is added to the launches in between."""

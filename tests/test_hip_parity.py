@@ -53,9 +53,47 @@ CASES = [
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"E{c['E']}A{c['A']}C{c['C']}" + (f"K{c['K']}" if c.get("K", 3) > 4 else ""))
 def test_step_and_reset_bit_exact(case):
-    case = dict(case)
+    run_case(dict(case))
+
+
+# Both mappings of the step kernel (csrc/hns_step_kernel.h: 64-env tiles of A + 1 waves; csrc/hns_step_small_kernel.h: a helper wave per pursuer
+# wave, for batches that do not fill the chip) on the same batches: every buffer bit for bit against the oracle, hence against each other.
+MAPPING_CASES = [
+    dict(E=2048, A=3, C=5, cylinder={"fixed_num": 0}),       # the reference's default batch, BASELINE config 2's cylinders
+    dict(E=4096, A=3, C=5, cylinder={"fixed_num": 0}),       # BASELINE config 2
+    dict(E=4096, A=3, C=8, cylinder={"min_num": 8}),
+    dict(E=128, A=1, C=5),                                   # a single pursuer: one helper wave keeps every statistics share
+    dict(E=192, A=2, C=6, K=2),
+    dict(E=64, A=4, C=6, K=4, drone_detect_radius=0.7, target_detect_radius=0.8, use_deployment=1, init_smoothness_coef=2.0),
+    dict(E=128, A=5, C=9, K=1),
+    dict(E=64, A=7, C=16, K=4, cylinder={"min_num": 16}),    # 15 waves per workgroup
+    dict(E=256, A=6, C=16),
+]
+
+
+@pytest.mark.parametrize("mapping", ["tile", "small"])
+@pytest.mark.parametrize("case", MAPPING_CASES, ids=lambda c: f"E{c['E']}A{c['A']}C{c['C']}K{c.get('K', 3)}")
+def test_both_step_mappings_bit_exact(case, mapping, monkeypatch):
+    monkeypatch.setenv("HNS_STEP_MAPPING", mapping)
+    run_case(dict(case), expect_mapping=mapping)
+
+
+def test_step_mapping_is_chosen_by_batch_size(monkeypatch):
+    monkeypatch.delenv("HNS_STEP_MAPPING", raising=False)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert make_env(E=2048, A=3, C=5).step_mapping == "small"
+    assert make_env(E=64 * 2 * cus, A=3, C=5).step_mapping == "small"           # two tiles per compute unit: still the small mapping
+    assert make_env(E=64 * (2 * cus + 1), A=3, C=5).step_mapping == "tile"
+    assert make_env(E=2047, A=3, C=5).step_mapping == "tile"                   # ragged last tile: the generic instantiation
+    assert make_env(E=2048, A=3, C=8, K=5).step_mapping == "tile"              # k > 4
+    assert make_env(E=2048, A=3, C=5, num_targets=2).step_mapping == "tile"    # two evaders
+
+
+def run_case(case, expect_mapping=None):
     O.set_threads(8 if case["E"] > 4096 else 1)
     env = make_env(max_len=12, **case)
+    if expect_mapping is not None:
+        assert env.step_mapping == expect_mapping
     env.set_seed(1234)
     env.reset()
     host = O.alloc_buffers(env.hcfg)

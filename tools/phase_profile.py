@@ -12,10 +12,8 @@ from hns_amd import config
 from hns_amd.env import HideAndSeek
 
 E, A, Cn, NT = 65536, 3, 8, 1
-MAPPING = "tile"                                         # --mapping=small: hns_step_small_kernel (2 A + 1 waves per workgroup: owners, helpers, env wave)
-for a in sys.argv[1:]:
-    if a.startswith("--mapping="): MAPPING = a.split("=")[1]
-os.environ["HNS_STEP_MAPPING"] = MAPPING
+for a in sys.argv[1:]:                                   # --mapping=tile|small: force a mapping of the step kernel (default: the library's choice)
+    if a.startswith("--mapping="): os.environ["HNS_STEP_MAPPING"] = a.split("=")[1]
 for a in sys.argv[1:]:                                   # e.g. --agents=6 --cylinders=16 --targets=2 (BASELINE config 5's shard)
     if a.startswith("--agents="): A = int(a.split("=")[1])
     if a.startswith("--cylinders="): Cn = int(a.split("=")[1])
@@ -24,6 +22,7 @@ for a in sys.argv[1:]:                                   # e.g. --agents=6 --cyl
 cfg = config.make_cfg({"num_agents": A, "num_targets": NT, "cylinder": {"max_num": Cn, "min_num": Cn}, "env": {"num_envs": E}})
 env = HideAndSeek(cfg, write_critic_state="--critic-state" in sys.argv)
 env.reset()
+MAPPING = env.step_mapping                               # small: 2 A + 1 waves per workgroup (owners, env wave, helpers)
 WPB = 2 * A + 1 if MAPPING == "small" else A + 1
 nw = (E // 64) * WPB
 buf = torch.zeros(nw, 16, dtype=torch.int64, device=env.device)
@@ -36,9 +35,8 @@ torch.cuda.synchronize()
 env._lib.hns_set_phase_profile(env._env, None)
 t16 = buf.cpu().numpy().astype(np.int64).reshape(E // 64, WPB, 16)
 # timeline: mean cycles from the workgroup's first stamp to each mark, per role (marks a role does not set are printed as '-')
-ENV = WPB - 1
-roles = [("owner" if MAPPING == "small" else "pursuer", slice(0, A))] + ([("helper", slice(A, 2 * A))] if MAPPING == "small" else []) + [("env", slice(ENV, ENV + 1))]
-marks = [(0, "start"), (1, "loaded"), (2, "at b1"), (12, "past b1"), (3, "at b2"), (8, "past b2"), (10, "sweep in"), (9, "own terms"), (4, "at b3"), (5, "past b3"), (6, "done")]
+roles = [("owner" if MAPPING == "small" else "pursuer", slice(0, A)), ("env", slice(A, A + 1))] + ([("helper", slice(A + 1, 2 * A + 1))] if MAPPING == "small" else [])
+marks = [(0, "start"), (1, "loaded"), (2, "at b1"), (12, "past b1"), (3, "at b2"), (8, "past b2"), (10, "sweep in"), (9, "own terms"), (4, "at b3"), (5, "past b3"), (11, "tail: calc"), (6, "done")]
 blk0 = t16[..., 0].min(axis=1, keepdims=True)
 print("%-10s" % "mark" + "".join("%10s" % r for r, _ in roles))
 for m, name in marks:
