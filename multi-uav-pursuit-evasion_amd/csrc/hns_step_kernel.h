@@ -114,14 +114,18 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
             rr0 = rows4[0]; rr1 = rows4[64]; rr2 = rows4[128];
             if (lane < N4 - 192) rr3 = rows4[192];
         }
-        // reset_pid = the incoming root `done` (transforms.py:449-454): one byte per env; with one evader its pointer rides in the argument block
+        float4 integ4 = reinterpret_cast<const float4 *>(ka.pid_integ)[il];
+        float4 last4 = reinterpret_cast<const float4 *>(ka.pid_last_rate)[il];
+        // reset_pid = the incoming root `done` (transforms.py:449-454): one byte per env; with one evader its pointer rides in the argument block.
+        // Loaded WITHOUT a branch (a null pointer reads a byte of `action` instead and the result is ignored): behind `if (pointer)` the compiler
+        // closed the branch with s_waitcnt vmcnt(0) — every pursuer wave waited for its first loads to land before it issued the remaining ones.
         unsigned rp = 0;
         if constexpr (NT == 1) {
             const uint8_t *rpp = static_cast<const uint8_t *>(ka.aux);
-            if (rpp) rp = rpp[GEN ? (e0 + (le < nv ? le : nv - 1)) : (e0 + le)];
+            const uint8_t *rsafe = rpp ? rpp : reinterpret_cast<const uint8_t *>(ka.action);
+            const unsigned byte = rsafe[GEN ? (e0 + (le < nv ? le : nv - 1)) : (e0 + le)];
+            rp = rpp ? byte : 0u;
         }
-        float4 integ4 = reinterpret_cast<const float4 *>(ka.pid_integ)[il];
-        float4 last4 = reinterpret_cast<const float4 *>(ka.pid_last_rate)[il];
         float4 thr4 = reinterpret_cast<const float4 *>(ka.throttle)[il];
         // (two evaders, see below: this wave's cylinder passes and this pursuer's cylinders — through the kernel argument, issued with the
         //  first loads; the count of cylinders is only known from the parameter block, so the loads cover HNS_MAX_CYLINDERS slots of the
@@ -162,7 +166,11 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         //     cylinder terms of cylinders a, a + A, ... (:1114-1136); the env wave only adds them up, in the reference's order.
         V3 etp0 = {0.f, 0.f, 0.f}, etp1 = {0.f, 0.f, 0.f};
         if constexpr (NT == 2) {
-            if (b.reset_pid) rp = b.reset_pid[e0 + (GEN && le >= nv ? nv - 1 : le)];
+            {   // (two evaders: the pointer comes through the parameter block; branch-free as above)
+                const uint8_t *rsafe = b.reset_pid ? b.reset_pid : reinterpret_cast<const uint8_t *>(ka.action);
+                const unsigned byte = rsafe[e0 + (GEN && le >= nv ? nv - 1 : le)];
+                rp = b.reset_pid ? byte : 0u;
+            }
             const float *gt = b.target_pos + (size_t)(e0 + (GEN && le >= nv ? nv - 1 : le)) * T3;
             etp0 = V3{gt[0], gt[1], gt[2]};
             etp1 = V3{gt[3], gt[4], gt[5]};
@@ -195,6 +203,8 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
             last4.x = r ? 0.0f : last4.x; last4.y = r ? 0.0f : last4.y; last4.z = r ? 0.0f : last4.z;
         }
         d_ctbr_pid_squashed(c, ta, s.q, s.ang, prev4, integ4, last4, cmd, aerr, ctbr4, trate);
+        // (the wait for the last of the first loads HERE, ahead of the two stores below: behind them it would wait for their acknowledgement too)
+        asm volatile("" : "+v"(thr4.x), "+v"(thr4.y), "+v"(thr4.z), "+v"(thr4.w));
         if (b.ctbr && valid) reinterpret_cast<float4 *>(b.ctbr)[ia] = make_float4(ctbr4[0], ctbr4[1], ctbr4[2], ctbr4[3]);           // transforms.py:456
         if (b.target_rate && valid) reinterpret_cast<float4 *>(b.target_rate)[ia] = make_float4(trate[0], trate[1], trate[2], 0.0f);  // :457
         d_rotor(c, cmd, thr4, thrust, moment, thr_diff);

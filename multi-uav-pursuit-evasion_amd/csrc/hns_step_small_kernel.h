@@ -95,13 +95,15 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(HNS_S
         const float4 *rows4 = reinterpret_cast<const float4 *>(ka.drone_state + ((size_t)e0 * A + (tid & ~63)) * 13) + lane;
         float4 rr0 = rows4[0], rr1 = rows4[64], rr2 = rows4[128], rr3 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lane < N4 - 192) rr3 = rows4[192];
-        unsigned rp = 0;
-        {
-            const uint8_t *rpp = static_cast<const uint8_t *>(ka.aux);      // reset_pid = the incoming root `done` (transforms.py:449-454)
-            if (rpp) rp = rpp[e0 + le];
-        }
         float4 integ4 = reinterpret_cast<const float4 *>(ka.pid_integ)[ia];
         float4 last4 = reinterpret_cast<const float4 *>(ka.pid_last_rate)[ia];
+        unsigned rp = 0;
+        {   // reset_pid = the incoming root `done` (transforms.py:449-454); branch-free, as in hns_step_v4_kernel
+            const uint8_t *rpp = static_cast<const uint8_t *>(ka.aux);
+            const uint8_t *rsafe = rpp ? rpp : reinterpret_cast<const uint8_t *>(ka.action);
+            const unsigned byte = rsafe[e0 + le];
+            rp = rpp ? byte : 0u;
+        }
         float4 thr4 = reinterpret_cast<const float4 *>(ka.throttle)[ia];
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PROF) prof_mark(p.prof, 0);
@@ -134,6 +136,8 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(HNS_S
             last4.x = r ? 0.0f : last4.x; last4.y = r ? 0.0f : last4.y; last4.z = r ? 0.0f : last4.z;
         }
         d_ctbr_pid_squashed(c, ta, s.q, s.ang, prev4, integ4, last4, cmd, aerr, ctbr4, trate);
+        // (the wait for the last of the first loads HERE, ahead of the two stores below: behind them it would wait for their acknowledgement too)
+        asm volatile("" : "+v"(thr4.x), "+v"(thr4.y), "+v"(thr4.z), "+v"(thr4.w));
         if (b.ctbr) reinterpret_cast<float4 *>(b.ctbr)[ia] = make_float4(ctbr4[0], ctbr4[1], ctbr4[2], ctbr4[3]);
         if (b.target_rate) reinterpret_cast<float4 *>(b.target_rate)[ia] = make_float4(trate[0], trate[1], trate[2], 0.0f);
         d_rotor(c, cmd, thr4, thrust, moment, thr_diff);
@@ -220,7 +224,8 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(HNS_S
             red[R_FLAGS] = __int_as_float((cap_ok ? F_CAP : 0) | (blocked ? F_BLOCKED : 0) | (det ? F_DET : 0));
         }
         if constexpr (PROF) prof_mark(p.prof, 9);
-        // controller / rotor state, S_{t+1}, state_others: stored here, while the helpers still select their cylinders
+        // controller / rotor state, S_{t+1}, state_others: stored here, while the helpers still select their cylinders (behind barrier 3 — nobody
+        // waits for them — they measured 0.1-0.4 us slower: the launch ends when its last store is acknowledged; tools/lab/r04_batch38.sh)
         last4.w = blocked ? 1.0f : 0.0f;                                            // = the next step's line of sight at ITS t
         reinterpret_cast<float4 *>(b.throttle)[ia] = thr4;
         reinterpret_cast<float4 *>(b.pid_integ)[ia] = integ4;
@@ -351,11 +356,11 @@ __global__ __launch_bounds__(GeoSmall<A>::T, 1) void hns_step_small_kernel(HNS_S
         bool knn_masked[KM];
         bool blocked, blockedB;
         if constexpr (PROF) prof_mark(p.prof, 10);
-        cylinder_pass<1, false, KM, (CS ? 4 : KM + 1)>(c, C, K, pos, pos, pos, cyl, knn_idx, blocked, blockedB);   // (no line of sight here: the owner's sweep)
+        float cc = 0.f;
+        cylinder_pass<1, false, KM, (CS ? 4 : KM + 1)>(c, C, K, pos, pos, pos, cyl, knn_idx, blocked, blockedB);
         if constexpr (PROF) prof_mark(p.prof, 9);
 #pragma unroll
         for (int sidx = 0; sidx < KM; ++sidx) knn_masked[sidx] = (sidx < K) ? cyl[3 * knn_idx[sidx] + 2] < 0.0f : false;   // :759,775-778
-        float cc = 0.f;
         const float rc = c.cylinder_size + c.collision_radius, rc2 = rc * rc;
 #pragma unroll
         for (int sidx = 0; sidx < KM; ++sidx) {
