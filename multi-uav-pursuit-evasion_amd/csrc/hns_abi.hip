@@ -433,6 +433,7 @@ static void fill_step_params(const hns_env *env, Params &p) {
     p.buf = env->buf;
     p.prof = env->prof;
     p.cyl_magic = env->cyl_magic;
+    p.prio_boost = (uint32_t)env->prio_boost;
 }
 
 // Device copy of that block for the step kernel that reads it through `StepArgs::rest`: one allocation in hns_create, refreshed

@@ -48,6 +48,7 @@ struct Params {
     uint32_t cyl_magic;         // ceil(2^32 / (3*C)): index / (3*C) as a multiply-high
     const float *tasks;         // reset: optional [E, 3A+3NT+3C] task vectors (envgen: pursuers | evader(s) | cylinder slots), else null
     int32_t task_first;         // envs >= task_first take their placement from `tasks`
+    uint32_t prio_boost;        // step, tile mapping: pursuer waves run at priority 1 until their integration is done (hns_step_kernel.h; chosen by hns_inst.hip)
 };
 
 struct StepArgs {               // 64 B

@@ -35,6 +35,7 @@ struct hns_env {
     int threads_step = 0;        // the step kernel's workgroup (the tile mapping: as the reset kernel's; the small-batch mapping: 2 A + 1 waves)
     int cus = 0;                 // compute units of `device`
     int small_mapping = 0;       // 1: hns_step_small_kernel serves this env (hns_inst.hip)
+    int prio_boost = 0;          // 1: the tile mapping's pursuer waves start at priority 1 (hns_inst.hip; Params::prio_boost)
     size_t lds_step = 0, lds_reset = 0;
     void (*reset_fn)(const hns::Params) = nullptr;
     hns_step_fn step_args_fn = nullptr;        // the step kernel instantiation serving this env (hns_inst.hip)

@@ -86,5 +86,11 @@ void HNS_CAT(hns_select_kernels_, HNS_INST_A)(hns_env *env) {
     if (mp && !std::strcmp(mp, "tile")) small = false;
     if (mp && !std::strcmp(mp, "small")) small = eligible;
     if (small) HNS_CAT(hns_select_small_, HNS_INST_A)(env);
+    // Tile mapping, one evader, up to three pursuers, one or two full residency rounds (4 workgroups per CU): the pursuer waves run at priority 1
+    // until their integration is done (hns_step_kernel.h).  Measured with alternating blocks in one process (tools/ab_env.py, tools/lab/r04_batch46.sh):
+    // 65 536 envs -3.4 %, 131 072 -4.5 %, 5 cylinder slots -1.5 %, 2 pursuers -0.6 %; 49 152 envs +1 %, 262 144 +1.2 %, 4 pursuers +1.5 %, 6v2 +5 % (off
+    // there).  HNS_STEP_PRIO=0|1 overrides (A/B runs).
+    env->prio_boost = !small && !two && A <= 3 && env->grid > 3 * env->cus && env->grid <= 8 * env->cus;
+    if (const char *pb = std::getenv("HNS_STEP_PRIO")) { if (pb[0] == '0' || pb[0] == '1') env->prio_boost = !small && pb[0] == '1'; }
 }
 #endif

@@ -191,6 +191,14 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
             __builtin_amdgcn_wave_barrier();
         }
         if constexpr (PROF) prof_mark(p.prof, 1);
+        // Issue arbitration among the waves of a SIMD is priority first, then age: left alone, the first two workgroups placed on a CU finish 3 us
+        // before the last two (tools/phase_profile.py --spread: 10.2 / 10.8 / 13.2 / 13.5 us by placement order, all four started within 2 us), and the
+        // launch drains at half occupancy.  With the pursuer waves at priority 1 until their integration is done and at 0 behind it, a workgroup
+        // that lags gets the issue slots of one that leads: 65 536 envs 17.17 -> 16.58 us (alternating blocks in one process, tools/lab/r04_batch46.sh).
+        // Shape dependent — slower with 4+ pursuers, two evaders (+5 %), less than one or more than two residency rounds (+1 %) — so the host
+        // turns it on per env (hns_inst.hip); priorities by phase in finer steps (3-2-1-0, 2-2-1-0, 3-1-1-0) or by placement order measured no better.
+        const bool boost = p.prio_boost != 0;
+        if (boost) __builtin_amdgcn_s_setprio(1);
         // ---- phase 1: controller, rotors, thrust vector (A1-A3) ----
         // line of sight evader -> this pursuer at t (:1080): positions, evader and cylinders are those the previous step (or the reset)
         // evaluated it on for the observation, so that result is carried in the spare fourth column of the controller record
@@ -287,6 +295,7 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         if constexpr (PROF) prof_mark(p.prof, 3);
         __syncthreads();                                                            // barrier 2
         if constexpr (PROF) prof_mark(p.prof, 8);
+        if (boost) __builtin_amdgcn_s_setprio(0);
         // ---- phase 3a: distance and line of sight to the evader, the k nearest cylinders, per-pursuer reward terms on S_{t+1} ----
         const float progress = sTp[kEPB * T3 + le];                                 // progress + 1, published by the env wave
         const V3 tp = {sTp[le * T3], sTp[le * T3 + 1], sTp[le * T3 + 2]};
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         if constexpr (PROF) prof_mark(p.prof, 6);
     } else {
         // ================================= env wave: lane <-> env ========================================
-        __builtin_amdgcn_s_setprio(2);   // one wave in four, but every barrier of its workgroup waits for it
+        __builtin_amdgcn_s_setprio(2);   // one wave in four, but every barrier of its workgroup waits for it (the pursuer waves run at 0 or 1, below)
         const int le = lane;
         const bool valid = !GEN || le < nv;                  // (generic) this env exists; lanes beyond the batch work on the last env's data
         const int e = e0 + (valid ? le : nv - 1);

@@ -55,3 +55,19 @@ rt0, rt1 = t16[..., 14].astype(np.float64) * 10.0, t16[..., 15].astype(np.float6
 z = rt0.min()
 print("global clock (ns): first start 0, last start %.0f, first end %.0f, last end %.0f" % (rt0.max() - z, rt1.min() - z, rt1.max() - z))
 print("per-workgroup duration (ns): median %.0f p10 %.0f p90 %.0f" % tuple(np.percentile((rt1.max(1) - rt0.min(1)), [50, 10, 90])))
+if "--spread" in sys.argv:                                # where the slow workgroups are: by start time, by XCD (workgroup index % 8), by residency slot
+    st, en = rt0.min(1) - z, rt1.max(1) - z
+    dur = en - st
+    q = np.argsort(st)
+    n = len(q) // 4
+    print("duration (ns) by start-time quartile: " + "  ".join("%.0f (starts %.0f-%.0f)" % (dur[q[i * n:(i + 1) * n]].mean(), st[q[i * n]], st[q[(i + 1) * n - 1]]) for i in range(4)))
+    wg = np.arange(len(st))
+    print("by XCD (index %% 8): duration " + " ".join("%.0f" % dur[wg % 8 == x].mean() for x in range(8)) + " | end " + " ".join("%.0f" % en[wg % 8 == x].max() for x in range(8)))
+    per = max(1, len(st) // 4)
+    print("by quarter of the grid (index // %d): start " % per + " ".join("%.0f" % st[wg // per == x].mean() for x in range(4)) + " | duration " + " ".join("%.0f" % dur[wg // per == x].mean() for x in range(4)))
+    print("corr(start, duration) = %.2f; last 5%% to end: durations %.0f, starts %.0f (all: %.0f, %.0f)" % (
+        np.corrcoef(st, dur)[0, 1], dur[np.argsort(en)[-len(en) // 20:]].mean(), st[np.argsort(en)[-len(en) // 20:]].mean(), dur.mean(), st.mean()))
+    seg = [(0, 1, "loads"), (1, 2, "phase 1"), (2, 12, "b1"), (12, 3, "phase 2"), (3, 8, "b2"), (8, 4, "phase 3a"), (4, 5, "b3"), (5, 6, "tail")]
+    slow = np.argsort(dur)[-len(dur) // 10:]; fast = np.argsort(dur)[:len(dur) // 10]
+    print("pursuer-wave segments (cycles), slowest 10%% of workgroups vs fastest 10%%: " + "  ".join(
+        "%s %.0f/%.0f" % (nm, (t16[slow, :A, b] - t16[slow, :A, a]).mean(), (t16[fast, :A, b] - t16[fast, :A, a]).mean()) for a, b, nm in seg))
