@@ -1,8 +1,8 @@
 // hns_inst.hip — the step and reset kernels instantiated for ONE pursuer count (compiled once per count: -DHNS_INST_A=1 ... 7, side
 // by side; __graft_entry__.build), and the host-side choice among them.  Two translation units per count: the tile mapping + reset
 // kernels, and (-DHNS_INST_SMALL=1) the small-batch mapping, which is compiled with its pointer parameters preloaded into SGPRs
-// (-mllvm -amdgpu-kernarg-preload-count=16: -0.15 ... -0.4 us per step below 32 768 envs; the tile mapping at 65 536 envs measured
-// 0.15 us SLOWER with it — 4 096 waves whose launch each waits for the preload — so it stays without; tools/lab/r04_batch32.sh).
+// (-mllvm -amdgpu-kernarg-preload-count=16: -0.15 ... -0.4 us per step below 32 768 envs; for the tile mapping at 65 536 envs and the
+// 6v2 shard no difference beyond the noise of alternating blocks, so it stays without; tools/lab/r04_batch32.sh, _47).
 #include "hns_host.h"
 
 #include <cstdlib>

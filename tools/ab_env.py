@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 import hns_amd
-from hns_amd import config
+from hns_amd import abi, config
 from hns_amd.env import HideAndSeek
 from hns_amd.tensordict_shim import TensorDict
 
@@ -27,6 +27,7 @@ for E in sizes:
     for sset in settings:
         k, v = sset.split("=", 1)
         os.environ[k] = v
+        abi._LIB = None                                      # (HNS_LIBRARY=<another build>: every env loads the library its setting names)
         cfg = config.make_cfg({"num_agents": A, "num_targets": NT, "cylinder": {"max_num": CYL, "min_num": CYL}, "env": {"num_envs": E, "max_episode_length": 1000000}})
         e = HideAndSeek(cfg)
         e.reset()
