@@ -281,12 +281,15 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
             float *pub = sPub + tid * kPub;
             pub[6] = s.pos.x; pub[7] = s.pos.y; pub[8] = s.pos.z;
         }
-        // controller / rotor state: plain stores (they are early: write-through here stalls the wave, measured +0.45 us)
+        // controller / rotor state: write-through as well.  (Round 2 measured +0.45 us for that in the kernel of the time and left them to the end-of-kernel
+        // write-back; on the round-4 kernel, alternating blocks in one process: 65 536 envs 17.20 -> 16.46 us, 131 072 envs -4.5 %, the 6v2 shard
+        // 48.3 -> 46.7 us, 262 144 and 1 048 576 envs unchanged.  The early `ctbr` / `target_rate` and the `pid_last_rate` stores stay plain: write-through
+        // there measured +1 % at 65 536 envs.  tools/lab/r04_batch53.sh, _54, _56.)
         if (valid) {
-            reinterpret_cast<float4 *>(b.throttle)[ia] = thr4;
-            reinterpret_cast<float4 *>(b.pid_integ)[ia] = integ4;
-            reinterpret_cast<float4 *>(b.prev_action)[ia] = prev4;
-            b.action_error[ia] = aerr;
+            st_f4(reinterpret_cast<float4 *>(b.throttle) + ia, thr4);
+            st_f4(reinterpret_cast<float4 *>(b.pid_integ) + ia, integ4);
+            st_f4(reinterpret_cast<float4 *>(b.prev_action) + ia, prev4);
+            st_f1(b.action_error + ia, aerr);
         }
         {   // S_{t+1}: the wave's 64 rows back through the slab, one contiguous slice
             const float row[13] = {s.pos.x, s.pos.y, s.pos.z, s.q.w, s.q.x, s.q.y, s.q.z, s.lin.x, s.lin.y, s.lin.z, s.ang.x, s.ang.y, s.ang.z};

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of two library settings inside ONE process, alternating timed blocks (the pool's boxes drift by a few percent from process to process
 and with the clock state, which is the size of the effects under test):
-  ab_env.py VAR=a VAR=b [envs] [--agents= --targets= --cylinders= --steps= --blocks=]      e.g.  ab_env.py HNS_STEP_PRIO=0 HNS_STEP_PRIO=1 65536
+  ab_env.py VAR=a VAR=b [envs] [--agents= --targets= --cylinders= --steps= --blocks=]      e.g.  ab_env.py HNS_STEP_PRIO=0 HNS_STEP_PRIO=1 65536   (--tp: with the predictor)
 Each setting gets its own env (the variable is read by hns_create); prints the median / min of the per-block step times."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +16,7 @@ from hns_amd.tensordict_shim import TensorDict
 settings = [a for a in sys.argv[1:] if "=" in a and not a.startswith("--")]
 sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [65536]
 steps, blocks, A, NT, CYL = 3000, 7, 3, 1, 8
+TP = "--tp" in sys.argv                                   # with the trajectory predictor in the observation (algo.use_TP_net: 1)
 for a in sys.argv[1:]:
     if a.startswith("--steps="): steps = int(a.split("=")[1])
     if a.startswith("--blocks="): blocks = int(a.split("=")[1])
@@ -28,7 +29,8 @@ for E in sizes:
         k, v = sset.split("=", 1)
         os.environ[k] = v
         abi._LIB = None                                      # (HNS_LIBRARY=<another build>: every env loads the library its setting names)
-        cfg = config.make_cfg({"num_agents": A, "num_targets": NT, "cylinder": {"max_num": CYL, "min_num": CYL}, "env": {"num_envs": E, "max_episode_length": 1000000}})
+        cfg = config.make_cfg({"num_agents": A, "num_targets": NT, "cylinder": {"max_num": CYL, "min_num": CYL},
+                               "env": {"num_envs": E, "max_episode_length": 50000 if TP else 1000000}}, algo={"use_TP_net": 1 if TP else 0})
         e = HideAndSeek(cfg)
         e.reset()
         envs.append(e)
