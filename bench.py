@@ -78,7 +78,7 @@ def parse_args():
                     help="check-out for the multi-GPU plumbing (tests/test_bench_contract.py): S > 0 = the job's env batch is stepped with ONE global action stream "
                          "(every rank takes its slice) and the line carries sha256 digests of the state after the timed region, one per S equal env slices of the "
                          "GLOBAL batch, so a W-rank run and a 1-rank run of the same global batch can be compared slice by slice")
-    ap.add_argument("--tp-steps", type=int, default=300,
+    ap.add_argument("--tp-steps", type=int, default=2000,
                     help="extra leg: steps with the trajectory predictor in the observation (algo.use_TP_net: 1, the reference's "
                          "default config), reported as `tp_mode`; 0 = skip")
     return ap.parse_args()
@@ -232,7 +232,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(n):
             env.step(tds[i % len(tds)])
-            if reset_every and (i + 1) % reset_every == 0:
+            if reset_every and (warm + i + 1) % reset_every == 0:      # (the warm-up steps count towards the episode)
                 done_td.set("_reset", env._bufs["done"])
                 env.reset(done_td)
         env.region_end()
@@ -544,7 +544,9 @@ def main():
     if args.tp_steps > 0 and single and args.targets == 1:
         env_tp = make_env(E, A, C, algo={"use_TP_net": 1})
         n = args.tp_steps
-        dt_tp, _ = timed_steps(env_tp, tds, n, 20)
+        # (a region of 200-300 steps measured 110-114 us per step where 1 000 steps give 102 and 3 000 give 100: the first ~100 steps after the
+        #  set-up run slower — device clocks, first launches — and a short region is mostly those)
+        dt_tp, _ = timed_steps(env_tp, tds, n, 100, reset_every=args.episode)      # (lock-step episodes, reset at the boundary, as the headline region)
         timed_steps(env_tp, tds, 64, 4, timing=4)                 # the step kernel's own duration in this mode (events on its dispatch)
         tp_step_us = env_tp.kernel_ms()[0] * 1e3
         T, F, I = env_tp.tp_history_step, env_tp.tp_future_step, env_tp.tp_frame_dim

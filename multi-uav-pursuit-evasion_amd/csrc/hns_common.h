@@ -25,7 +25,7 @@ enum { R_AERR = 0, R_TD, R_DIST, R_SPEED, R_CC, R_CD, R_CW, R_COLL,
        R_F1X = 8 };
 enum { F_CAP = 1, F_BLOCKED = 2, F_DET = 4, F_DET1 = 8 };
 constexpr int kGridStride = 516;   // bytes of reset scratch per env: 2 x 256 + 4 (an odd dword stride: lanes = envs hit different LDS banks)
-constexpr int kSmallWgPerCu = 2;   // the small-batch mapping (hns_step_small_kernel.h) serves grids of up to this many workgroups per CU (hns_inst.hip)
+constexpr int kSmallWgPerCu = 2;   // the small-batch mapping (hns_step_small_kernel.h) serves grids of up to this many workgroups per CU (one with four and more pursuers; hns_inst.hip)
 constexpr int kMaxT = 2;   // evaders per env (1 = the reference; 2 = BASELINE config 5's extension)
 
 template <int A>

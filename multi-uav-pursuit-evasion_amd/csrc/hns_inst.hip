@@ -82,7 +82,9 @@ void HNS_CAT(hns_select_kernels_, HNS_INST_A)(hns_env *env) {
     // (A/B runs, tests/test_hip_parity.py).
     const char *mp = std::getenv("HNS_STEP_MAPPING");
     const bool eligible = !two && !wide && !ragged;
-    bool small = eligible && env->grid <= kSmallWgPerCu * env->cus;
+    // (2 A + 1 waves per workgroup: with four and more pursuers two of them no longer share a CU — 32 768 envs measured 13.4 / 19.5 / 22.2 us
+    //  with the tile mapping against 17.3 / 22.9 / 25.9 us for 4 / 6 / 7 pursuers, while one tile per CU is faster in the small mapping for every count)
+    bool small = eligible && env->grid <= (A <= 3 ? kSmallWgPerCu : 1) * env->cus;
     if (mp && !std::strcmp(mp, "tile")) small = false;
     if (mp && !std::strcmp(mp, "small")) small = eligible;
     if (small) HNS_CAT(hns_select_small_, HNS_INST_A)(env);

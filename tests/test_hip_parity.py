@@ -84,6 +84,8 @@ def test_step_mapping_is_chosen_by_batch_size(monkeypatch):
     assert make_env(E=2048, A=3, C=5).step_mapping == "small"
     assert make_env(E=64 * 2 * cus, A=3, C=5).step_mapping == "small"           # two tiles per compute unit: still the small mapping
     assert make_env(E=64 * (2 * cus + 1), A=3, C=5).step_mapping == "tile"
+    assert make_env(E=64 * cus, A=6, C=8).step_mapping == "small"                # four and more pursuers: one tile per compute unit
+    assert make_env(E=64 * (cus + 1), A=6, C=8).step_mapping == "tile"
     assert make_env(E=2047, A=3, C=5).step_mapping == "tile"                   # ragged last tile: the generic instantiation
     assert make_env(E=2048, A=3, C=8, K=5).step_mapping == "tile"              # k > 4
     assert make_env(E=2048, A=3, C=5, num_targets=2).step_mapping == "tile"    # two evaders

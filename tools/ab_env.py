@@ -29,8 +29,11 @@ for E in sizes:
         k, v = sset.split("=", 1)
         os.environ[k] = v
         abi._LIB = None                                      # (HNS_LIBRARY=<another build>: every env loads the library its setting names)
-        cfg = config.make_cfg({"num_agents": A, "num_targets": NT, "cylinder": {"max_num": CYL, "min_num": CYL},
-                               "env": {"num_envs": E, "max_episode_length": 50000 if TP else 1000000}}, algo={"use_TP_net": 1 if TP else 0})
+        task = {"num_agents": A, "num_targets": NT, "cylinder": {"max_num": CYL, "min_num": CYL},
+                "env": {"num_envs": E, "max_episode_length": 50000 if TP else 1000000}}
+        if k.startswith("task."):                            # a task option instead of an environment variable: task.tp_overlap=1
+            task[k[5:]] = int(v)
+        cfg = config.make_cfg(task, algo={"use_TP_net": 1 if TP else 0})
         e = HideAndSeek(cfg)
         e.reset()
         envs.append(e)
