@@ -378,7 +378,8 @@ int hns_set_phase_profile(hns_env *env, unsigned long long *device_buf);
 /* Which mapping of the step kernel serves this env: 0 = 64-env tiles of A + 1 waves (batches that fill the chip), 1 = the small-batch mapping
  * (2 A + 1 waves per tile: a helper wave per pursuer wave; one evader, E % 64 == 0, obs_max_cylinder <= 4, at most two tiles per compute
  * unit — one with four and more pursuers).  Same buffers, bit for bit, either way; chosen by hns_create (the environment variable HNS_STEP_MAPPING=tile|small overrides it
- * where the shape allows both — A/B measurements and tests). */
+ * where the shape allows both — A/B measurements and tests; HNS_STEP_PRIO=0|1 likewise overrides whether the tile mapping's pursuer waves
+ * start at a raised issue priority, which hns_create decides from the shape and has no effect on any result). */
 int hns_step_mapping(const hns_env *env);
 
 /* The per-rollout moments of the data-parallel advantage normalisation (learning/mappo.py:391-396 made data-parallel; sharding.py) in ONE launch:
