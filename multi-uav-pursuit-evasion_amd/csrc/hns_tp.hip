@@ -956,6 +956,13 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
     if (prof && lane == 0) prof[1] = __builtin_amdgcn_s_memrealtime();
 
     for (int t = 0; t < T; ++t) {
+        {   // Two workgroups share a CU and the SIMDs issue oldest-first: left alone the older one runs ahead (its recurrence ends at 65-77 us, the
+            // younger one's at ~110 in a stamped launch, tools/tp_phases.py) and the second half of the launch has two waves per SIMD instead of four.
+            // Priority by recurrence step — the workgroup that is behind goes first — keeps them together: step + predictor 100.1 -> 95.3 us
+            // (alternating blocks in one process, tools/lab/r04_batch65.sh, _66; two levels or other thresholds measured no better).
+            const int q = (4 * t) / T;
+            if (q == 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2); else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
         __syncthreads();                                         // x_t and h_{t-1} are in LDS
         if (t + 1 < T) {                                   // frame t+1 -> the other x buffer (last read at timestep t-1)
             emit(t + 1, xn);
