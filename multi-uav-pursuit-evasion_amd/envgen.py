@@ -444,6 +444,9 @@ class HideAndSeek_envgen(HideAndSeek):
         td.set("truncated", (self.progress_buf > self.max_episode_length).unsqueeze(1))
         return td
 
+    def _episode_mirror_needed(self):
+        return bool(self.use_particle_generator) or super()._episode_mirror_needed()
+
     # ---- curriculum at episode end, hideandseek_envgen.py:1241-1246, 1302-1333 ----------------------------
     def _step(self, tensordict):
         out = super()._step(tensordict)
