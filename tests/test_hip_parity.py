@@ -481,6 +481,36 @@ def test_setter_inside_a_capture_in_the_default_mode():
     assert rcs[:15] == [0] * 15 and rcs[15] == abi.HNS_ERR_CONFIG and b"pool" in lib.hns_last_error()
 
 
+def test_masked_reset_reads_progress_back_only_while_something_needs_it():
+    """`_since_full_reset` keeps the per-step host checks (evader-speed curriculum, task generator) off until an episode can have ended.  At a masked
+    reset it is refreshed from max(progress) — a host sync that stalls the step queue at every episode boundary — only while the curriculum is
+    below its cap; at the cap the counter keeps running (an over-estimate, which can only make the checks start early)."""
+    env = make_env(E=128, A=3, C=5, max_len=6)
+    env.reset()
+    act = torch.zeros(128, 3, 4, device=env.device)
+    for _ in range(6):
+        td = env.step(env.rand_step_input(act))
+    assert bool(td[("next", "done")].all()) and env._since_full_reset == 6
+    mask = torch.ones(128, dtype=torch.bool, device=env.device)
+    rtd = env.rand_step_input()
+    rtd.set("_reset", mask)
+    assert env.v_prey >= 1.3 - 1e-6
+    env.reset(rtd)
+    assert env._since_full_reset == 6                        # at the cap: no read-back, the counter runs on
+    for _ in range(6):
+        env.step(env.rand_step_input(act))
+    env.v_prey = 1.0                                         # the curriculum is active: the mirror is consulted, so it is refreshed
+    rtd = env.rand_step_input()
+    mask[:64] = False                                        # half of the envs keep their progress (6 + 1 steps after this reset's ...)
+    rtd.set("_reset", mask)
+    env.reset(rtd)
+    assert env._since_full_reset == 6                        # max(progress) of the envs that were not reset
+    rtd = env.rand_step_input()
+    rtd.set("_reset", torch.ones(128, dtype=torch.bool, device=env.device))
+    env.reset(rtd)
+    assert env._since_full_reset == 0
+
+
 @pytest.mark.parametrize("E,A,NT,K", [(64, 3, 1, 3), (70, 3, 1, 3), (128, 6, 2, 3), (130, 2, 2, 3), (96, 3, 1, 6)])
 def test_reset_pid_pulses_past_the_end_of_the_episode(E, A, NT, K):
     """task.pid_reset = reference (the default): stepping on past `done` without a reset — what `env.rollout(..., break_when_any_done=False)` does —
