@@ -208,7 +208,7 @@ class HideAndSeek(_EnvBase):
         self.num_cylinders = self.hcfg.num_cylinders
         self.obs_max_cylinder = self.hcfg.obs_max_cylinder
         self.v_prey = float(self.hcfg.v_prey)
-        self.update_epoch = 0
+        self._update_epoch = 0                                   # `update_epoch` is a property: assigning it moves the smoothness schedule
         self.seed = 0
         self._render = not headless
         # transforms.py:456-457: `ctbr` and `target_rate` on the input tensordict — extra outputs, written only when asked for
@@ -384,11 +384,52 @@ class HideAndSeek(_EnvBase):
         return int(self._lib.hns_get_reset_epoch(self._env))
 
     def enable_render(self, enable=True):
-        self._render = bool(enable)
-        return self._render
+        if not isinstance(enable, bool) and not callable(enable):                   # isaac_env.py:321-327: a bool or a callable(substep)
+            raise TypeError("enable_render must be a bool or callable.")
+        self._render = enable
+        return bool(enable)
 
     def render(self, mode="human"):
-        return None                                              # rendering is out of scope (SURVEY §2 #17,#19)
+        """`mode="rgb_array"`: an `[H, W, 3]` uint8 top-down frame of ONE env (`task.render_env`, default 0; `task.render_size`, default 128
+        pixels) drawn from the bound buffers — arena disc, active cylinders, pursuers (brighter with height), evader(s) — which is what
+        `evaluate()` stacks and transposes (scripts/train.py:220-223,251-254).  The reference's frame is the Isaac viewport (isaac_env.py:261-280);
+        a viewport is out of scope (SURVEY §2 #17,#19), the frame's type and layout are not.  `mode="human"` (a window) returns None.
+        Off the hot path: one read-back of that env's ~(3 A + 3 NT + 3 C) floats per call."""
+        if mode != "rgb_array":
+            if mode == "human":
+                return None
+            raise NotImplementedError(f"render mode {mode!r} (the reference knows 'human' and 'rgb_array', isaac_env.py:261-280)")
+        if self._render is False:
+            raise RuntimeError(f"Cannot render '{mode}' while rendering is disabled: call enable_render(True) first (isaac_env.py:333-338).")
+        import numpy as np
+        t = self.cfg.task
+        e = min(max(int(t.get("render_env", 0)), 0), self.num_envs - 1)
+        n = int(t.get("render_size", 128))
+        b = self._bufs
+        # one device gather -> one copy to the host: [A + NT + C, 3]
+        pts = torch.cat([b["drone_state"][e, :, 0:3], b["target_pos"][e].reshape(-1, 3), b["cylinders"][e].reshape(-1, 3)], dim=0).cpu().numpy()
+        A, NT = self.num_agents, self.num_targets
+        R, H = float(self.hcfg.arena_size), float(self.hcfg.max_height)
+        half = 1.15 * R                                          # metres from the frame's centre to its edge
+        ax = (np.arange(n, dtype=np.float32) + 0.5) / n * 2.0 * half - half
+        X, Y = np.meshgrid(ax, -ax)                              # row 0 = +y (image convention: y up)
+        img = np.empty((n, n, 3), np.uint8)
+        img[:] = (24, 24, 28)
+        img[X * X + Y * Y <= R * R] = (58, 60, 66)               # the arena disc (hideandseek.py:1094-1103: radius arena_size)
+
+        def disc(p, radius, colour):
+            img[(X - p[0]) ** 2 + (Y - p[1]) ** 2 <= radius * radius] = colour
+
+        for c in pts[A + NT:]:
+            if c[2] > 0.0:                                       # active slots only (inactive ones sit at z = -20, :686-689)
+                disc(c, float(self.hcfg.cylinder_size), (150, 150, 150))
+        px = 2.0 * half / n
+        for k in range(NT):
+            disc(pts[A + k], max(0.05, 1.5 * px), (230, 60, 50))                 # evader: the reference's sphere has r = 0.05 (:544-565)
+        for i in range(A):
+            shade = int(120 + 135 * min(max(float(pts[i, 2]) / max(H, 1e-6), 0.0), 1.0))
+            disc(pts[i], max(0.04, 1.5 * px), (40, shade, 255))
+        return img
 
     def to(self, device):
         if torch.device(device) != self.device:                  # isaac_env.py:300-305
@@ -648,14 +689,27 @@ class HideAndSeek(_EnvBase):
             self._tp_refresh_all()
 
     # ---- schedule hooks -------------------------------------------------------------------------------------------
-    def set_update_epoch(self, epoch):
-        """smoothness schedule, hideandseek.py:988-991 (train_deploy.py:270 sets update_epoch)."""
-        self.update_epoch = int(epoch)
+    @property
+    def update_epoch(self):
+        return self._update_epoch
+
+    @update_epoch.setter
+    def update_epoch(self, epoch):
+        """`base_env.update_epoch = i` (scripts/train_deploy.py:270) is read at every step by the reference's reward (hideandseek.py:988-989:
+        smoothness_coef = min(max, init + smooth_lr * update_epoch)); here the assignment itself pushes the coefficient to the kernel's
+        configuration — one stream-ordered 4-byte copy, and only when the coefficient actually moved."""
+        self._update_epoch = int(epoch)
         t = self.cfg.task
-        coef = min(float(t.get("max_smoothness_coef", 5.0)),
-                   float(t.get("init_smoothness_coef", 0.0)) + float(t.get("smooth_lr", 0.0)) * self.update_epoch)
-        for h in self._handles():
-            self._check(self._lib.hns_set_smoothness_coef(h, C.c_float(coef)), "hns_set_smoothness_coef")
+        init_s = float(t.get("init_smoothness_coef", t.get("smoothness_coef", 0.0)))            # (the envgen YAML names it smoothness_coef)
+        coef = min(float(t.get("max_smoothness_coef", 5.0)), init_s + float(t.get("smooth_lr", 0.0)) * self._update_epoch)
+        if getattr(self, "_env", None) and coef != getattr(self, "_smoothness_coef_pushed", None):
+            for h in self._handles():
+                self._check(self._lib.hns_set_smoothness_coef(h, C.c_float(coef)), "hns_set_smoothness_coef")
+            self._smoothness_coef_pushed = coef
+
+    def set_update_epoch(self, epoch):
+        """Method form of the assignment above (kept for callers of rounds 1-4)."""
+        self.update_epoch = epoch
 
     def _handles(self):
         return [self._env] + [hv.env for hv in (self._halves or [])]

@@ -89,7 +89,6 @@ STEPS = L + 3                                                      # three steps
 with torch.no_grad():
     trajs = env.rollout(max_steps=STEPS, policy=lambda x: policy(x, deterministic=True), callback=Every(lambda *a, **k: frames.append(base_env.render(mode="rgb_array")), 2),
                         auto_reset=True, break_when_any_done=False, return_contiguous=False).clone()
-base_env.enable_render(False)
 done = trajs.get(("next", "done"))
 assert tuple(done.shape) == (E, STEPS, 1) and done.dtype == torch.bool
 first_done = torch.argmax(done.long(), dim=1).cpu()
@@ -113,6 +112,26 @@ assert pulsed == 3 * E
 devs = base_env.export_state()
 for k in ("drone_state", "pid_integ", "pid_last_rate", "stats", "progress"):
     assert np.array_equal(host[k], devs[k], equal_nan=True), f"{k} differs from the oracle after the evaluate rollout"
+# scripts/train.py:236-254 in meaning: re-enable / reset, first_done, take_first_episode over ("next", "stats"), the video array
+base_env.enable_render(not True)                                    # (cfg.headless = True)
+env.reset()
+
+
+def take_first_episode(tensor):
+    indices = first_done.reshape(first_done.shape + (1,) * (tensor.ndim - 2))
+    return torch.take_along_dim(tensor, indices, dim=1).reshape(-1)
+
+
+traj_stats = {k: take_first_episode(v) for k, v in trajs[("next", "stats")].cpu().items()}
+info = {"eval/stats." + k: torch.nanmean(v.float()).item() for k, v in traj_stats.items()}
+assert len(info) == 24 and all(v.shape == (E,) for v in traj_stats.values())
+assert np.isfinite(list(info.values())).all()
+assert all(isinstance(f, np.ndarray) and f.dtype == np.uint8 and f.ndim == 3 and f.shape[2] == 3 for f in frames)
+video_array = np.stack(frames).transpose(0, 3, 1, 2)                # [N, 3, H, W]: what wandb.Video(video_array, fps=..., format="mp4") takes
+assert video_array.shape == (len(frames), 3) + frames[0].shape[:2] and video_array.dtype == np.uint8
+assert len({f.tobytes() for f in frames}) == len(frames)            # the drones moved between frames: no two frames are the same picture
+n_frames = len(frames)
+frames.clear()
 
 # ---- 2. two PPO-style iterations through the collector -----------------------------------------------------------------------------------
 base_env.train()
@@ -145,4 +164,5 @@ for it, data in enumerate(collector):
             O.reset(base_env.hcfg, host, host["done"].copy(), base_env.seed, epoch)
             epoch += 1
 assert all(np.isfinite(losses)) and len(losses) == 2
-print(json.dumps({"evaluate_steps": STEPS, "reset_pid_pulses": pulsed, "frames": len(frames), "ppo_iterations": len(losses)}))
+print(json.dumps({"evaluate_steps": STEPS, "reset_pid_pulses": pulsed, "frames": n_frames, "video_shape": list(video_array.shape),
+                  "eval_stats": len(info), "ppo_iterations": len(losses)}))

@@ -214,6 +214,15 @@ class LazyStackedTensorDict:
     def keys(self, *a, **k):
         return self.tensordicts[0].keys(*a, **k)
 
+    def items(self, *a, **k):
+        return [(key, self.get(key)) for key in self.keys(*a, **k)]
+
+    def to(self, device):
+        return LazyStackedTensorDict([td.to(device) for td in self.tensordicts], self.stack_dim)
+
+    def cpu(self):
+        return self.to("cpu")
+
     def clone(self, recurse=True):
         return LazyStackedTensorDict([td.clone(recurse) for td in self.tensordicts], self.stack_dim)
 
