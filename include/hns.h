@@ -268,8 +268,11 @@ int hns_reset(hns_env *env, const uint8_t *reset_mask, uint64_t seed, void *stre
  * task_first take their placement from `tasks` (device pointer, [E, 3A+3+3C] rows = drone positions,
  * evader position, cylinder positions — the reference's task vector; [E, 3A+6+3C] with both evaders'
  * positions in the two-evader extension) instead of sampling it;
- * orientations are still drawn from the Philox stream.  Envs < task_first reset as in hns_reset. */
-int hns_reset_tasks(hns_env *env, const uint8_t *reset_mask, const float *tasks, int32_t task_first, uint64_t seed,
+ * orientations are still drawn from the Philox stream.  Masked envs < task_first reset as in hns_reset and
+ * their rows of `tasks` are WRITTEN: the placement as sampled, before the extra physics step of
+ * cfg.reset_extra_step (the reference archives `tasks_unif` as sampled, :883-895, and steps the scene
+ * afterwards, :1013).  Rows of envs that are not masked are left alone. */
+int hns_reset_tasks(hns_env *env, const uint8_t *reset_mask, float *tasks, int32_t task_first, uint64_t seed,
                     void *stream);
 
 /* Extension, not in the reference: planar ray-fan range sensor on the bound state.
@@ -347,7 +350,9 @@ uint32_t hns_get_reset_epoch(const hns_env *env);
 /* Fixture injection / read-back for parity tests and checkpoints (the reference's counterpart is the
  * PhysX tensor view API, omni_drones/views/rigid_prim_view.py:61-118): `host` holds HOST pointers with the
  * shapes of hns_buffers; null fields are skipped; copies are asynchronous on `stream` (synchronise before
- * reading what hns_get_state wrote).  Equivalent to the caller copying into / out of its own bound buffers. */
+ * reading what hns_get_state wrote).  Equivalent to the caller copying into / out of its own bound buffers.
+ * `host->stats` is always this handle's dense [HNS_NUM_STATS, num_envs]; for a handle over a slice of a larger batch
+ * (cfg.stats_stride > num_envs) its columns of every device row are copied (one pitched copy). */
 int hns_set_state(hns_env *env, const hns_buffers *host, void *stream);
 int hns_get_state(hns_env *env, const hns_buffers *host, void *stream);
 /* Recomputes the derived part of the state (the line-of-sight column of pid_last_rate, see hns_buffers) from drone_state, target_pos and

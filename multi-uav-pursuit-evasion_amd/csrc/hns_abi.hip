@@ -567,7 +567,7 @@ int hns_reset(hns_env *env, const uint8_t *reset_mask, uint64_t seed, void *stre
     return launch_reset(env, p, static_cast<hipStream_t>(stream));
 }
 
-int hns_reset_tasks(hns_env *env, const uint8_t *reset_mask, const float *tasks, int32_t task_first, uint64_t seed, void *stream) {
+int hns_reset_tasks(hns_env *env, const uint8_t *reset_mask, float *tasks, int32_t task_first, uint64_t seed, void *stream) {
     if (!env || !tasks) { set_error("hns_reset_tasks: null argument"); return HNS_ERR_INVALID_ARG; }
     if (!env->bound) { set_error("hns_reset_tasks: buffers not bound"); return HNS_ERR_NOT_BOUND; }
     if (task_first < 0 || task_first > env->cfg.num_envs) { set_error("hns_reset_tasks: task_first out of range"); return HNS_ERR_INVALID_ARG; }
@@ -692,7 +692,7 @@ static int copy_state(hns_env *env, const hns_buffers *host, void *stream, bool 
         {host->drone_state, d.drone_state, E * A * 13 * 4}, {host->throttle, d.throttle, E * A * 16}, {host->pid_integ, d.pid_integ, E * A * 16},
         {host->pid_last_rate, d.pid_last_rate, E * A * 16}, {host->prev_action, d.prev_action, E * A * 16},
         {host->target_pos, d.target_pos, E * NT * 12}, {host->target_vel, d.target_vel, E * NT * 12}, {host->cylinders, d.cylinders, E * C * 12},
-        {host->progress, d.progress, E * 4}, {host->stats, d.stats, c.stats_stride == c.num_envs ? (size_t)HNS_NUM_STATS * E * 4 : 0 /* a slice's columns are not one block: copy through the owner of the array */}, {host->obs_self, d.obs_self, E * A * SD * 4},
+        {host->progress, d.progress, E * 4}, {host->stats, d.stats, c.stats_stride == c.num_envs ? (size_t)HNS_NUM_STATS * E * 4 : 0 /* a slice's columns: the pitched copy below */}, {host->obs_self, d.obs_self, E * A * SD * 4},
         {host->obs_others, d.obs_others, E * A * (A - 1) * 12}, {host->obs_cylinders, d.obs_cylinders, E * A * K * 20},
         {host->state_drones, d.state_drones, E * A * SD * 4}, {host->reward, d.reward, E * A * 4}, {host->action_error, d.action_error, E * A * 4},
         {host->done, d.done, E}, {host->detect, d.detect, E}, {host->nonfinite, d.nonfinite, 4}, {host->ctbr, d.ctbr, E * A * 16}, {host->target_rate, d.target_rate, E * A * 16}};
@@ -700,6 +700,13 @@ static int copy_state(hns_env *env, const hns_buffers *host, void *stream, bool 
         if (!x.host || !x.dev || x.bytes == 0) continue;
         if (to_device) HNS_CHECK_HIP(hipMemcpyAsync(x.dev, x.host, x.bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
         else HNS_CHECK_HIP(hipMemcpyAsync(const_cast<void *>(x.host), x.dev, x.bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    }
+    if (host->stats && d.stats && c.stats_stride != c.num_envs) {
+        // a handle over a slice of a larger batch (stats rows strided by the owner's env count): the HOST array is this handle's dense
+        // [HNS_NUM_STATS, num_envs], the device side its columns of every row
+        const size_t hp = E * 4, dp = (size_t)c.stats_stride * 4;
+        if (to_device) HNS_CHECK_HIP(hipMemcpy2DAsync(d.stats, dp, host->stats, hp, hp, HNS_NUM_STATS, hipMemcpyHostToDevice, (hipStream_t)stream));
+        else HNS_CHECK_HIP(hipMemcpy2DAsync(const_cast<float *>(host->stats), hp, d.stats, dp, hp, HNS_NUM_STATS, hipMemcpyDeviceToHost, (hipStream_t)stream));
     }
     if (to_device) return hns_refresh_derived_state(env, stream);   // the line-of-sight column belongs to the positions just uploaded
     return HNS_OK;

@@ -46,7 +46,7 @@ struct Params {
     uint32_t seed_lo, seed_hi, epoch;
     unsigned long long *prof;   // optional per-wave phase timestamps (diagnostics), else null
     uint32_t cyl_magic;         // ceil(2^32 / (3*C)): index / (3*C) as a multiply-high
-    const float *tasks;         // reset: optional [E, 3A+3NT+3C] task vectors (envgen: pursuers | evader(s) | cylinder slots), else null
+    float *tasks;               // reset: optional [E, 3A+3NT+3C] task vectors (envgen: pursuers | evader(s) | cylinder slots; rows < task_first are written), else null
     int32_t task_first;         // envs >= task_first take their placement from `tasks`
     uint32_t prio_boost;        // step, tile mapping: pursuer waves run at priority 1 until their integration is done (hns_step_kernel.h; chosen by hns_inst.hip)
 };

@@ -155,6 +155,14 @@ __global__ __launch_bounds__(Geo<A>::T) void hns_reset_kernel(const Params p) {
                 cyl[3 * k + 2] = (k >= n_active) ? c.invalid_z : 0.5f * c.cylinder_height;
             }
         }
+        if (p.tasks && !task) {
+            // envgen: a uniformly sampled task is archived as SAMPLED (hideandseek_envgen.py:883-895 inserts `tasks_unif` before the sim.step of
+            // :1013) — the placement goes back into the caller's task row here, before the extra step below moves the bodies
+            float *row = p.tasks + (size_t)e * (3 * A + 3 * NT + 3 * C);
+            for (int j = 0; j < A; ++j) { row[3 * j] = ds[13 * j]; row[3 * j + 1] = ds[13 * j + 1]; row[3 * j + 2] = ds[13 * j + 2]; }
+            for (int i = 0; i < 3 * NT; ++i) row[3 * A + i] = tp[i];
+            for (int k = 0; k < 3 * C; ++k) row[3 * A + 3 * NT + k] = cyl[k];
+        }
         for (int sidx = 0; sidx < HNS_NUM_STATS; ++sidx) b.stats[(size_t)sidx * c.stats_stride + e] = 0.0f;   // :711
         b.stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * c.stats_stride + e] = (float)c.max_episode_length;
         b.progress[e] = 0.0f;

@@ -77,6 +77,7 @@ class GenBuffer:
         ii, jj = np.meshgrid(np.arange(self.num_grid), np.arange(self.num_grid), indexing="ij")
         self.grid_map = (np.sqrt((ii - half) ** 2 + (jj - half) ** 2) >= half).astype(np.int64)   # :168-181
         self.rng = np.random.default_rng(seed)
+        self.fps_start = None             # start index of the next farthest-point trim; None = drawn at random (DGL draws it at random too)
 
     # -- grid helpers (:121-164) ------------------------------------------------------------------
     def to_grid(self, xy):
@@ -120,15 +121,21 @@ class GenBuffer:
             count += len(ring)
         return rank
 
-    def init_easy_cases(self):
-        """Easy starting tasks (hideandseek_envgen.py:235-277): the evader on a random free cell, the pursuers on the free cells
-        the flood from that cell reaches first.  All samples at once: rank every free cell by the flood table, keep the
-        num_agents smallest per sample."""
+    def init_easy_cases(self, start=None):
+        """Easy starting tasks (hideandseek_envgen.py:235-277): the evader on a random free cell (`start`: given cells [B, 2] instead of
+        drawn ones), the pursuers on the free cells the flood from that cell reaches first.  All samples at once: rank every free cell by the
+        flood table, keep the num_agents smallest per sample.  (As written the reference's method runs for num_agents == 4 only — with fewer
+        pursuers its `found` list holds up to four cells and `np.array` of the ragged rows / the concat with the z column fails,
+        tests/golden/make_golden.py::gen_genbuffer; taking the first num_agents cells in discovery order is this build's reading of the intent.)"""
         if self.num_targets != 1:
             raise NotImplementedError("use_init_easy places one evader (the reference's flood, hideandseek_envgen.py:235-277)")
         n, A, B = self.num_grid, self.num_agents, self.buffer_length
         free = np.argwhere(self.grid_map == 0)                                     # [F, 2]
-        start = free[np.array([self.rng.integers(len(free)) for _ in range(B)])]   # one draw per sample, in sample order
+        if start is None:
+            start = free[np.array([self.rng.integers(len(free)) for _ in range(B)])]   # one draw per sample, in sample order
+        else:
+            start = np.asarray(start, dtype=np.int64).reshape(-1, 2)
+            B = start.shape[0]
         if A > 4:
             return self._easy_cases_literal(start)
         off = free[None, :, :] - start[:, None, :]                                 # [B, F, 2]
@@ -148,7 +155,7 @@ class GenBuffer:
         with MORE than num_agents cells (it appends every free neighbour it visits) its `np.array(...)` of ragged rows fails; taking the
         first num_agents in discovery order is this build's choice for that case, as is the error below when the flood ends with fewer."""
         from collections import deque
-        n, A, B = self.num_grid, self.num_agents, self.buffer_length
+        n, A, B = self.num_grid, self.num_agents, start.shape[0]
         cells = np.zeros((B, A + 1, 2), dtype=np.float64)
         for k in range(B):
             x, y = int(start[k, 0]), int(start[k, 1])
@@ -197,7 +204,8 @@ class GenBuffer:
         elif all_states.shape[0] > self.buffer_length:
             lo, hi = all_states.min(0), all_states.max(0)
             normed = torch.as_tensor((all_states - lo) / (hi - lo + self.eps), device=self.device)
-            idx = farthest_point_sampling(normed, self.buffer_length, start=int(self.rng.integers(all_states.shape[0])))
+            start = int(self.rng.integers(all_states.shape[0])) if self.fps_start is None else int(self.fps_start)
+            idx = farthest_point_sampling(normed, self.buffer_length, start=start)
             self._history_buffer = all_states[idx.cpu().numpy()]
         else:
             self._history_buffer = all_states
@@ -262,6 +270,7 @@ class DeviceGenBuffer:
         self._fps_scratch = torch.zeros(int(self.lib.hns_fps_scratch_bytes()), dtype=torch.uint8, device=self.device)
         self._fps_idx = torch.zeros(buffer_length, dtype=torch.int32, device=self.device)
         self.rng = np.random.default_rng(seed)
+        self.fps_start = None             # as GenBuffer.fps_start
         self._draws = 0
 
     # numpy views for callers that want the reference's attributes (statistics, save_task, tests)
@@ -296,7 +305,8 @@ class DeviceGenBuffer:
         elif n > self.buffer_length:
             lo, hi = all_states.min(0).values, all_states.max(0).values
             normed = ((all_states - lo) / (hi - lo + self.eps)).contiguous()
-            rc = self.lib.hns_fps(normed.data_ptr(), n, self.task_dim, self.buffer_length, int(self.rng.integers(n)),
+            start = int(self.rng.integers(n)) if self.fps_start is None else int(self.fps_start)
+            rc = self.lib.hns_fps(normed.data_ptr(), n, self.task_dim, self.buffer_length, start,
                                   self._fps_idx.data_ptr(), self._fps_scratch.data_ptr(), self.env._stream())
             self.env._check(rc, "hns_fps")
             self._history = all_states.index_select(0, self._fps_idx.long())
@@ -325,6 +335,24 @@ class DeviceGenBuffer:
 
     def save_task(self, model_dir, episode):
         np.save("{}/history_{}.npy".format(model_dir, episode), self._history_buffer)
+
+
+def curriculum_update(gen_buffer, active_cylinders, num_cylinders, R_min, R_max):
+    """The generator's update at the end of every `eval_iter`-th episode (hideandseek_envgen.py:1311-1333): `gen_buffer.update()` (the mean success
+    weight of every task over the episodes it was replayed), the per-cylinder-count statistics, the tasks whose weight lies in [R_min, R_max]
+    inserted into the history (trimmed by farthest-point sampling).  `gen_buffer` is a DeviceGenBuffer (tensors on the env's GPU) or the host
+    GenBuffer (numpy); returns (count of tasks per number of active cylinders [C+1], sum of their weights [C+1], number of tasks kept) — numpy fp64."""
+    gen_buffer.update()
+    w = torch.as_tensor(gen_buffer._weight_buffer).reshape(-1)
+    act = torch.as_tensor(active_cylinders).reshape(-1).long().to(w.device)
+    counts = torch.bincount(act, minlength=num_cylinders + 1).double()
+    sums = torch.bincount(act, weights=w.double(), minlength=num_cylinders + 1)
+    both = torch.stack([counts, sums]).cpu().numpy()                  # one read-back for the 2(C+1) statistics
+    keep = (w <= R_max) & (w >= R_min)
+    states = gen_buffer._state_buffer
+    kept = states[keep] if isinstance(states, torch.Tensor) else states[keep.cpu().numpy()]
+    gen_buffer.insert_history(kept)                                   # (global mode: every rank takes part, also with nothing to add)
+    return both[0], both[1], int(kept.shape[0])
 
 
 class HideAndSeek_envgen(HideAndSeek):
@@ -423,10 +451,8 @@ class HideAndSeek_envgen(HideAndSeek):
                 self.gen_buffer.samplenearby_into(self._tasks_dev[self.num_unif:], self.expand_cylinders, self.expand_step)
             self._check(self._lib.hns_reset_tasks(self._env, mptr, C.c_void_p(self._tasks_dev.data_ptr()),
                                                   C.c_int32(self.num_unif), C.c_uint64(self.seed), self._stream()), "hns_reset_tasks")
-            # the uniform tasks were sampled on the device: read the placement back as task vectors
-            b = self._bufs
-            placed = torch.cat([b["drone_state"][..., :3].reshape(E, -1), b["target_pos"].reshape(E, -1), b["cylinders"].reshape(E, -1)], dim=1)
-            self._tasks_dev[:self.num_unif].copy_(placed[:self.num_unif])
+            # the uniform tasks were sampled by the reset kernel, which wrote them into the rows below num_unif as SAMPLED — before the extra
+            # physics step of task.reset_extra_step moves the bodies (the reference archives `tasks_unif`, :883-895, and steps afterwards, :1013)
             self.gen_buffer.insert(self._tasks_dev)
         else:
             self._check(self._lib.hns_reset_tasks(self._env, mptr, C.c_void_p(self._tasks_dev.data_ptr()),
@@ -440,6 +466,8 @@ class HideAndSeek_envgen(HideAndSeek):
         if self.use_TP_net:
             self._tp_observe()
         td = self._obs_tensordict()
+        if not self.training:
+            td = self._fresh_obs(td)              # eval mode: new tensors, as in the base class's `_reset`
         td.set("stats", last_stats)
         td.set("truncated", (self.progress_buf > self.max_episode_length).unsqueeze(1))
         return td
@@ -479,19 +507,11 @@ class HideAndSeek_envgen(HideAndSeek):
         self.update_iter += 1
         if self.update_iter >= self.eval_iter:
             self.update_iter = 0
-            self.gen_buffer.update()
-            w = self.gen_buffer._weight_buffer
-            act = self.active_cylinders.reshape(-1).long()
-            counts = torch.bincount(act, minlength=Cn + 1).double()
-            sums = torch.bincount(act, weights=w.double(), minlength=Cn + 1)
-            both = torch.stack([counts, sums]).cpu().numpy()                  # one read-back for the 2(C+1) statistics
+            counts, sums, n_kept = curriculum_update(self.gen_buffer, self.active_cylinders, Cn, self.R_min, self.R_max)
             for i in range(Cn + 1):
-                ex[f"ratio_cylinders_{i}"].fill_(float(both[0, i] / E))
-                ex[f"success_cylinders_{i}"].fill_(float(both[1, i] / both[0, i]) if both[0, i] > 0 else 0.0)
-            keep = (w <= self.R_max) & (w >= self.R_min)
-            kept = self.gen_buffer._state_buffer[keep]
-            self.gen_buffer.insert_history(kept)              # (global mode: every rank takes part, also with nothing to add)
-            ex["add_history"].fill_(float(kept.shape[0]))
+                ex[f"ratio_cylinders_{i}"].fill_(float(counts[i] / E))
+                ex[f"success_cylinders_{i}"].fill_(float(sums[i] / counts[i]) if counts[i] > 0 else 0.0)
+            ex["add_history"].fill_(float(n_kept))
         ex["history_buffer"].fill_(float(len(self.gen_buffer)))
         ex["ratio_unif"].fill_(self.ratio_unif)
         self.generator_seconds += time.perf_counter() - t0

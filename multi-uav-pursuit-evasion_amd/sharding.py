@@ -15,6 +15,7 @@ import torch
 import torch.distributed as dist
 
 MOMENT_DIM = 5
+HNS_MOMENTS_MAX = 1 << 18          # elements one workgroup of hns_moments reads in ~10 us (1 MB); larger tensors go to torch's reductions
 
 
 def env_shard(num_envs_total, world_size, rank):
@@ -26,10 +27,12 @@ def env_shard(num_envs_total, world_size, rank):
 
 
 def local_moments(values, success=None):
-    """[sum, sum of squares, count, success sum, env count] of this rank, fp64.  Contiguous fp32 device tensors go through ONE launch of the
-    library (hns_moments: one workgroup, fixed summation order) instead of eight small torch kernels in front of the collective."""
-    if values.is_cuda and values.dtype == torch.float32 and values.is_contiguous() and (
-            success is None or (success.is_cuda and success.dtype == torch.float32 and success.is_contiguous())):
+    """[sum, sum of squares, count, success sum, env count] of this rank, fp64.  Small contiguous fp32 device tensors go through ONE launch of
+    the library (hns_moments: one workgroup, fixed summation order) instead of eight small torch kernels in front of the collective; above
+    HNS_MOMENTS_MAX elements (a whole rollout's advantages: 65 536 x 64 x 3 = 12.6 M values) one workgroup would read ~50 MB from one compute
+    unit, so torch's chip-wide reductions take over."""
+    if values.is_cuda and values.dtype == torch.float32 and values.is_contiguous() and values.numel() <= HNS_MOMENTS_MAX and (
+            success is None or (success.is_cuda and success.dtype == torch.float32 and success.is_contiguous() and success.numel() <= HNS_MOMENTS_MAX)):
         import ctypes as C
         from . import abi
         lib = abi.load_library()

@@ -738,17 +738,17 @@ static int o_cell(const hns_cfg *c, float x) {
 }
 
 static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *mask, uint64_t seed, uint32_t epoch,
-                        const float *tasks, int task_first);
+                        float *tasks, int task_first);
 int hns_oracle_reset(const hns_cfg *c, const hns_buffers *b, const uint8_t *mask, uint64_t seed, uint32_t epoch) {
     return o_reset_impl(c, b, mask, seed, epoch, NULL, 0);
 }
 /* envgen: placement of envs >= task_first from task vectors (hideandseek_envgen.py:896-898) */
 int hns_oracle_reset_tasks(const hns_cfg *c, const hns_buffers *b, const uint8_t *mask, uint64_t seed, uint32_t epoch,
-                           const float *tasks, int task_first) {
+                           float *tasks, int task_first) {
     return o_reset_impl(c, b, mask, seed, epoch, tasks, task_first);
 }
 static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *mask, uint64_t seed, uint32_t epoch,
-                        const float *tasks, int task_first) {
+                        float *tasks, int task_first) {
     const int E = c->num_envs, A = c->num_agents, C = c->num_cylinders, K = c->obs_max_cylinder, G = c->grid_num;
     const size_t S = c->stats_stride ? (size_t)c->stats_stride : (size_t)E;
     if (G > 16) return HNS_ERR_INVALID_ARG;
@@ -864,6 +864,14 @@ static int o_reset_impl(const hns_cfg *c, const hns_buffers *b, const uint8_t *m
                 cyl[3 * k + 1] = o_clamp(y, -c->boundary, c->boundary);
                 cyl[3 * k + 2] = (k >= n_active) ? c->invalid_z : 0.5f * c->cylinder_height;
             }
+        }
+        if (tasks && !task) {
+            /* a uniformly sampled task is archived as sampled: hideandseek_envgen.py:883-895 inserts `tasks_unif` (the sampled placement)
+             * into the generator, the scene's sim.step comes after (:1013) */
+            float *row = tasks + (size_t)e * (3 * A + 3 * NT + 3 * C);
+            for (int a = 0; a < A; ++a) for (int i = 0; i < 3; ++i) row[3 * a + i] = ds[13 * a + i];
+            for (int i = 0; i < 3 * NT; ++i) row[3 * A + i] = tp[i];
+            for (int k = 0; k < 3 * C; ++k) row[3 * A + 3 * NT + k] = cyl[k];
         }
         for (int s = 0; s < HNS_NUM_STATS; ++s) b->stats[(size_t)s * S + e] = 0.0f;
         b->stats[(size_t)HNS_ST_FIRST_CAPTURE_STEP * S + e] = (float)c->max_episode_length;

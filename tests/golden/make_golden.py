@@ -29,6 +29,9 @@ Fixtures written (tests/golden/*.npz):
   g_grid       continuous_to_grid / grid_to_continuous / set_outside_circle_to_one (hideandseek.py:121-181)
   g_episode_*  closed-loop episodes: reference functions for every stage + the build's
                integrator spec (A5, self-golden for that one stage), teacher-forcing states stored.
+  g_genbuffer  the reference's GenBuffer class and the curriculum statements of `_compute_reward_and_done`, executed as written
+               (hideandseek_envgen.py:209-377, :1241-1246, :1302-1336): init_easy_cases, the bounds samplenearby clips to, samplenearby outputs,
+               two task batches through insert / insert_weights / update / statistics / R_min..R_max filter / insert_history (exact FPS, named start)
   g_episode_resetpid_*  the same loop with the controller's reset_pid = the root `done` of the stepped tensordict
                (transforms.py:449-454), across resets of the done envs (their deterministic effects restated, see the function)
 """
@@ -1276,3 +1279,184 @@ def gen_manifest(E=6, A=3, C=5):
 
 if __name__ == "__main__":
     gen_manifest()
+
+
+# ---- A12: the generator's buffer and the curriculum block, executed as the reference wrote them ----------------------------------
+# `GenBuffer` (hideandseek_envgen.py:209-377) is extracted as a whole class; the curriculum statements of `_compute_reward_and_done`
+# (:1241-1246 success_buffer / success_unif, :1302-1333 `if torch.any(done): ...`, :1335-1336) are extracted as AST statements and exec'd against a
+# namespace `self`.  DGL is not installed (and unpinned in the reference): `farthest_point_sampler` is an exact FPS whose start index the
+# generator names (DGL draws it at random) — ties to the lower index; the fixture's point sets are checked to give the same selection in fp32 and fp64.
+def _stmt_sources(relpath, classname, method, wanted):
+    """Source text of the top-level statements of `classname.method` for which `wanted(src_of_statement)` is true, in order."""
+    src = open(os.path.join(REF, relpath)).read()
+    tree = ast.parse(src)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == classname][0]
+    fn = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == method][0]
+    import textwrap
+    out = []
+    for node in fn.body:
+        seg = ast.get_source_segment(src, node)
+        if wanted(seg):
+            out.append(textwrap.dedent(" " * node.col_offset + seg))
+    return out
+
+
+def _exact_fps(points, k, start):
+    n = points.shape[0]
+    idx = np.empty(k, dtype=np.int64)
+    dist = np.full(n, np.inf, dtype=points.dtype)
+    cur = int(start)
+    for i in range(k):
+        idx[i] = cur
+        d = ((points - points[cur]) ** 2).sum(-1)
+        dist = np.minimum(dist, d)
+        dist[cur] = -1.0
+        cur = int(np.argmax(dist))
+    return idx
+
+
+def gen_genbuffer():
+    import collections
+    import copy
+    ENVGEN = "omni_drones/envs/hide_and_seek/hideandseek_envgen.py"
+    src = open(os.path.join(REF, ENVGEN)).read()
+    tree = ast.parse(src)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "GenBuffer"][0]
+    fps_log = {}
+
+    def farthest_point_sampler(pos, npoints, start_idx=None):
+        pts = pos[0].numpy()
+        a = _exact_fps(pts, npoints, fps_log["start"])
+        b = _exact_fps(pts.astype(np.float64), npoints, fps_log["start"])
+        assert np.array_equal(a, b), "fixture point set has a near-tie: fp32 and fp64 FPS disagree; change the seed"
+        fps_log["normed"] = pts.copy()
+        fps_log["idx"] = a
+        return torch.from_numpy(a)[None]
+
+    ns = dict(torch=torch, np=np, math=math, copy=copy, deque=collections.deque, farthest_point_sampler=farthest_point_sampler)
+    exec_functions(extract_source(ENVGEN, ["select_unoccupied_positions", "grid_to_continuous", "continuous_to_grid",
+                                           "set_outside_circle_to_one", "sanity_check"]), ns)
+    # `init_easy_cases` hands its numpy grid map to `select_unoccupied_positions`, whose `torch.nonzero(...)` takes tensors only (:112): as written the
+    # reference's `use_init_easy: 1` raises a TypeError.  The one adaptation made here: the map is converted on the way in; everything else is as written.
+    # Likewise it hands numpy `center_pos` / `center_grid` to `grid_to_continuous`, which adds them to a tensor and clamps with torch (:136-141): converted too.
+    # (`use_init_easy` is 0 in the reference's task file; the method is pinned here as far as it can be made to run.)
+    _select, _g2c = ns["select_unoccupied_positions"], ns["grid_to_continuous"]
+    ns["select_unoccupied_positions"] = lambda occ, n: _select(torch.as_tensor(occ), n)
+    ns["grid_to_continuous"] = lambda g, b, gs, cp, cg: _g2c(g, b, gs, torch.as_tensor(cp), torch.as_tensor(cg))
+    exec(compile(ast.get_source_segment(src, cls), "<ref:GenBuffer>", "exec"), ns)
+    GenBuffer = ns["GenBuffer"]
+    out = {}
+
+    # (1) init_easy_cases: the start cell the reference drew and the cells its flood gave the pursuers
+    # The flood appends EVERY free neighbour of the cell it expands and stops only at `len(found) == 4`, so with fewer than four pursuers `found` holds
+    # up to four cells (ragged rows / a shape mismatch with the z column): as written the method runs for num_agents == 4 only.  `easy_runs` records that.
+    runs = []
+    for A in (1, 2, 3, 4, 5):
+        torch.manual_seed(20241100 + A)
+        gb = GenBuffer(A, 5, "cpu")
+        gb.buffer_length = 160
+        try:
+            easy = gb.init_easy_cases().numpy()                   # [160, A + 1, 3]: pursuers..., evader
+        except (ValueError, RuntimeError, TypeError):
+            runs.append(0)
+            continue
+        runs.append(1)
+        out[f"easy_a{A}"] = easy.astype(np.float64)
+        assert easy.shape == (160, A + 1, 3)
+    out["easy_runs"] = np.array(runs, dtype=np.int64)             # for A = 1..5
+    assert runs[3] == 1
+    out["easy_disc"] = gb.grid_map[0].copy()
+
+    # (2) the bounds `samplenearby` clips to (:320-333), by executing its own statements up to `boundary_task = np.array(boundary_task)`
+    fn = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "samplenearby"][0]
+    for A, Cn in ((3, 5), (4, 5)):
+        gb = GenBuffer(A, Cn, "cpu")
+        env_ns = dict(ns, self=gb)
+        import textwrap
+        for node in fn.body:
+            seg = ast.get_source_segment(src, node)
+            if isinstance(node, ast.Assign) and ("boundary" in seg) or (isinstance(node, ast.AugAssign) and "boundary_task" in seg):
+                exec(textwrap.dedent(" " * node.col_offset + seg), env_ns)
+        out[f"bounds_a{A}c{Cn}"] = np.asarray(env_ns["boundary_task"], dtype=np.float64)
+
+    # (3) samplenearby itself: outputs of the reference on a seeded history (RNG stream unpinned: the test checks properties of THESE outputs)
+    A, Cn = 3, 5
+    gb = GenBuffer(A, Cn, "cpu")
+    rng = np.random.default_rng(20241101)
+
+    def valid_tasks(n):
+        tasks = []
+        free = np.argwhere(gb.grid_map[0] == 0)
+        while len(tasks) < n:
+            cells = free[rng.permutation(len(free))[:A + 1 + Cn]]
+            xy = (cells - gb.num_grid // 2) * gb.grid_size + rng.uniform(-0.04, 0.04, size=(A + 1 + Cn, 2))
+            z = np.concatenate([rng.uniform(1.1, 1.3, size=A + 1), np.where(rng.random(Cn) < 0.7, 0.6, -20.0)])
+            tasks.append(np.concatenate([xy, z[:, None]], axis=1).reshape(-1))
+        return np.asarray(tasks, dtype=np.float32)
+
+    hist = valid_tasks(64)
+    gb._history_buffer = hist.copy()
+    np.random.seed(20241102)
+    for expand in (0, 1):
+        near = gb.samplenearby(200, expand, 0.1)
+        assert near.shape == (200, gb.task_dim)
+        out[f"near_expand{expand}"] = near.astype(np.float64)
+    out["near_history"] = hist
+
+    # (4) two task batches through insert -> insert_weights x eval_iter -> the curriculum block (update, statistics, R_min..R_max filter, insert_history)
+    E, eval_iter, R_min, R_max = 96, 3, 0.3, 0.7
+    blocks = _stmt_sources(ENVGEN, "HideAndSeek_envgen", "_compute_reward_and_done",
+                           lambda s: s.startswith("if self.num_unif < self.num_envs") or s.startswith("if torch.any(done)")
+                           or s.startswith('self.stats["history_buffer"]') or s.startswith('self.stats["ratio_unif"]'))
+    assert len(blocks) == 4, [b[:40] for b in blocks]
+    gb = GenBuffer(A, Cn, "cpu")
+    gb.buffer_length = 80                                         # so that the second batch's insert_history trims by FPS
+    names = ["success", "success_buffer", "success_unif", "history_buffer", "add_history", "ratio_unif"]
+    names += [f"ratio_cylinders_{i}" for i in range(Cn + 1)] + [f"success_cylinders_{i}" for i in range(Cn + 1)]
+    self = types.SimpleNamespace(gen_buffer=gb, stats={k: torch.zeros(E, 1) for k in names}, num_envs=E, num_unif=E, num_cylinders=Cn,
+                                 ratio_unif=0.3, success_threshold=1.0, update_iter=0, eval_iter=eval_iter, R_min=R_min, R_max=R_max,
+                                 device="cpu", active_cylinders=None)
+    env_ns = dict(ns, self=self, done=torch.ones(E, 1, dtype=torch.bool))
+    for batch in range(2):
+        tasks = valid_tasks(E)
+        self.num_unif = E if batch == 0 else 40
+        self.active_cylinders = torch.from_numpy((tasks.reshape(E, -1, 3)[:, A + 1:, 2] > 0.0).sum(-1, keepdims=True).astype(np.float32))
+        gb.insert(tasks)                                           # :895
+        out[f"b{batch}_tasks"] = tasks
+        out[f"b{batch}_num_unif"] = np.int64(self.num_unif)
+        out[f"b{batch}_active"] = self.active_cylinders.numpy().copy()
+        p_env = rng.uniform(0.05, 0.95, size=E)                    # every env's own success probability: weights spread over [0, 1]
+        fps_log["start"] = 17 + batch
+        for ep in range(eval_iter):
+            self.stats["success"] = torch.from_numpy((rng.random(E) < p_env).astype(np.float32)).unsqueeze(1)
+            out[f"b{batch}_success{ep}"] = self.stats["success"].numpy().copy()
+            fps_log.pop("idx", None)
+            for code in blocks:
+                exec(code, env_ns)
+            for k in names[1:]:
+                v = self.stats[k].numpy().astype(np.float64)
+                assert v.shape == (E, 1)
+                out[f"b{batch}_ep{ep}_{k}"] = v[0, 0].copy() if (v == v[0, 0]).all() else v.copy()   # [E, 1] filled with one value -> that value
+            out[f"b{batch}_ep{ep}_update_iter"] = np.int64(self.update_iter)
+        out[f"b{batch}_weight_buffer"] = np.asarray(gb._weight_buffer, dtype=np.float64).copy()
+        out[f"b{batch}_state_buffer"] = np.asarray(gb._state_buffer).copy()
+        out[f"b{batch}_history"] = np.asarray(gb._history_buffer).copy()
+        out[f"b{batch}_fps_start"] = np.int64(fps_log["start"] if "idx" in fps_log else -1)
+        if "idx" in fps_log:
+            out[f"b{batch}_fps_idx"] = fps_log["idx"].copy()
+            out[f"b{batch}_fps_normed"] = fps_log["normed"].copy()
+    assert "b1_fps_idx" in out and out["b0_fps_start"] == -1 and 0 < out["b0_ep2_add_history"] < E
+    out["meta"] = np.array([A, Cn, E, eval_iter, 80], dtype=np.int64)
+    out["r_bounds"] = np.array([R_min, R_max])
+    # (5) success above success_threshold switches the generator to uniform tasks only (:1303-1304)
+    self.success_threshold = 0.5
+    self.stats["success"] = torch.ones(E, 1)
+    gb.insert(valid_tasks(E))
+    for code in blocks:
+        exec(code, env_ns)
+    out["ratio_unif_after_threshold"] = np.float64(self.ratio_unif)
+    save("g_genbuffer", **out)
+
+
+if __name__ == "__main__":
+    gen_genbuffer()

@@ -119,6 +119,38 @@ def test_oracle_reset_from_task_vectors():
     assert np.isfinite(arrs["obs_self"]).all() and not arrs["progress"].any()
 
 
+def test_oracle_task_reset_archives_the_placement_as_sampled():
+    """with the default task.reset_extra_step = 1 the rows of the uniformly sampled envs (below task_first) are written
+    with the placement AS SAMPLED — what the reference inserts into the generator (`tasks_unif`, hideandseek_envgen.py:883-895; the scene's
+    sim.step comes afterwards, :1013) — not with the state after that step: drones would sit g dt^2 lower, the evader displaced by v dt."""
+    E, A, Cn, first = 48, 3, 5, 20
+    gb = GenBuffer(A, Cn, seed=3)
+    base = _valid_tasks(gb, E, np.random.default_rng(4))
+    out = {}
+    for extra in (0, 1):
+        c = config.resolve_hns_cfg(config.make_cfg({"num_agents": A, "reset_extra_step": extra, "cylinder": {"max_num": Cn, "min_num": 4}, "env": {"num_envs": E}}))
+        arrs = O.alloc_buffers(c)
+        arrs["target_vel"][:] = np.random.default_rng(5).uniform(-1.3, 1.3, arrs["target_vel"].shape)   # a held evader velocity: the extra step moves the evader
+        tasks = base.copy()
+        mask = np.ones(E, np.uint8)
+        mask[[3, 30]] = 0                                             # two envs are not reset: their rows stay what they were
+        O.reset_tasks(c, arrs, mask, 5, 0, tasks, first)
+        out[extra] = (tasks, arrs)
+    t0, a0 = out[0]
+    t1, a1 = out[1]
+    np.testing.assert_array_equal(t1, t0)                             # the archive does not depend on the extra step
+    np.testing.assert_array_equal(t1[first:], base[first:])           # given tasks: untouched
+    np.testing.assert_array_equal(t1[3], base[3])                     # not masked: untouched
+    placed0 = np.concatenate([a0["drone_state"][..., :3].reshape(E, -1), a0["target_pos"].reshape(E, -1), a0["cylinders"].reshape(E, -1)], axis=1)
+    keep = np.ones(E, bool)
+    keep[[3, 30]] = False
+    np.testing.assert_array_equal(t1[keep], placed0[keep])            # = where the bodies sit when nothing has been stepped
+    placed1 = a1["drone_state"][..., :3].reshape(E, -1)
+    dz = (t1[:first, 2:3 * A:3] - placed1[:first, 2::3])[keep[:first]]
+    assert (dz > 5e-4).all() and (dz < 2e-3).all()                    # ... while the stepped drones are ~g dt^2 = 0.98 mm lower
+    assert np.abs(a1["target_pos"] - t1[:, 3 * A:3 * A + 3])[keep].max() > 1e-3
+
+
 # (The tests that check "every env sits ON its task vector after a reset" run with task.reset_extra_step = 0: the placement itself, without the one
 #  physics step the reference appends to `_reset_idx`, hideandseek_envgen.py:1012-1013; that step is pinned by tests/test_reset_pid.py and
 #  test_oracle_properties.py, and the other generator tests here run with it, as the default has it.)
@@ -225,6 +257,50 @@ def test_envgen_whole_env_at_65536_envs():
         assert env.num_unif == E - 5000                                   # min(len(history), int(E 0.7)) perturbed tasks
         assert GenBuffer(3, 8).sanity_ok(env.all_tasks[env.num_unif:]).mean() > 0.95
     assert env.check_finite(deep=True) and float(env.stats["history_buffer"][0]) == 5000
+
+
+@pytest.mark.gpu
+def test_envgen_archives_sampled_tasks_with_the_extra_step_on_gpu():
+    """The default path (task.reset_extra_step: 1) on the device: the generator's task batch holds the uniform tasks as sampled — equal to the
+    batch of a twin env that runs without the extra step, and to the oracle's rows — while the bodies have moved one dt."""
+    from hns_amd.envgen import HideAndSeek_envgen
+    E, L = 320, 5
+    envs = {}
+    for extra in (0, 1):
+        cfg = config.make_cfg({"name": "HideAndSeek_envgen", "reset_extra_step": extra, "num_agents": 3, "ratio_unif": 0.3, "eval_iter": 1, "R_min": 0.0, "R_max": 1.0,
+                               "use_particle_generator": 1, "cylinder": {"max_num": 6, "min_num": 3}, "env": {"num_envs": E, "max_episode_length": L}})
+        env = HideAndSeek_envgen(cfg)
+        env.set_seed(11)
+        env.reset()
+        envs[extra] = env
+    assert envs[1].hcfg.reset_extra_step == 1 and envs[1].num_unif == E
+    np.testing.assert_array_equal(envs[1].all_tasks, envs[0].all_tasks)
+    st0, st1 = envs[0].export_state(), envs[1].export_state()
+    placed0 = np.concatenate([st0["drone_state"][..., :3].reshape(E, -1), st0["target_pos"], st0["cylinders"].reshape(E, -1)], axis=1)
+    np.testing.assert_array_equal(envs[1].all_tasks, placed0)
+    dz = envs[1].all_tasks[:, 2:9:3] - st1["drone_state"][..., 2]
+    assert (dz > 5e-4).all() and (dz < 2e-3).all()
+    host = O.alloc_buffers(envs[1].hcfg)
+    tasks = np.zeros_like(envs[1].all_tasks)
+    O.reset_tasks(envs[1].hcfg, host, None, envs[1].seed, 0, tasks, E)
+    np.testing.assert_array_equal(tasks, envs[1].all_tasks)
+    for k in ("drone_state", "target_pos", "cylinders", "obs_self"):
+        np.testing.assert_array_equal(host[k], st1[k], err_msg=k)
+    # second batch: history present -> [uniform | perturbed]; the uniform rows are again the sampled placement, the perturbed rows untouched
+    env = envs[1]
+    for t in range(L):
+        td = env.step(env.rand_step_input())
+    rtd = env.rand_step_input()
+    rtd.set("_reset", td[("next", "done")].squeeze(-1))
+    env.reset(rtd)
+    assert 0 < env.num_unif < E
+    st = env.export_state()
+    placed = np.concatenate([st["drone_state"][..., :3].reshape(E, -1), st["target_pos"], st["cylinders"].reshape(E, -1)], axis=1)
+    dz = env.all_tasks[:, 2:9:3] - st["drone_state"][..., 2]
+    assert (dz > 5e-4).all() and (dz < 2e-3).all()                    # every row (sampled or perturbed) is where the drones were PLACED
+    np.testing.assert_array_equal(env.all_tasks[:, 12:], placed[:, 12:])    # cylinders do not move
+    moved = np.abs(env.all_tasks[:, 9:12] - placed[:, 9:12]).max(axis=1)    # the evader flew one dt with the velocity it held at the episode's end
+    assert (moved > 1e-3).mean() > 0.9 and moved.max() < 1.3 * 0.01 * 1.01
 
 
 @pytest.mark.gpu
@@ -395,3 +471,143 @@ def test_envgen_random_configurations_on_gpu(seed):
             assert bool(ok), k
         assert float(env.stats["history_buffer"][0]) == len(env.gen_buffer)
     assert env.check_finite()                                  # the state buffers (the logging statistic above is not one of them)
+
+
+# ---- A12 against the reference's own GenBuffer and curriculum statements (tests/golden/g_genbuffer.npz, make_golden.py::gen_genbuffer) --------------
+def _scalar(g, key):
+    v = np.asarray(g[key], dtype=np.float64)
+    assert v.ndim == 0, key
+    return float(v)
+
+
+def _replay_batches(g, make_buffer, to_dev=lambda x: x):
+    """Both task batches of the fixture through insert -> insert_weights x eval_iter -> curriculum_update on `make_buffer()`; yields what to compare."""
+    from hns_amd.envgen import curriculum_update
+    A, Cn, E, eval_iter, B = (int(x) for x in g["meta"])
+    R_min, R_max = (float(x) for x in g["r_bounds"])
+    gb = make_buffer(A, Cn, B)
+    for batch in range(2):
+        gb.insert(to_dev(g[f"b{batch}_tasks"]))
+        for ep in range(eval_iter):
+            gb.insert_weights(to_dev(g[f"b{batch}_success{ep}"]))
+        gb.fps_start = int(g[f"b{batch}_fps_start"]) if int(g[f"b{batch}_fps_start"]) >= 0 else None
+        counts, sums, n_kept = curriculum_update(gb, to_dev(g[f"b{batch}_active"]), Cn, R_min, R_max)
+        yield batch, gb, counts, sums, n_kept, E, Cn, eval_iter
+
+
+def _check_batch(g, batch, gb, counts, sums, n_kept, E, Cn, eval_iter):
+    last = eval_iter - 1
+    np.testing.assert_allclose(np.asarray(torch.as_tensor(gb._weight_buffer).cpu()).reshape(-1), g[f"b{batch}_weight_buffer"].reshape(-1), rtol=0, atol=1e-7)
+    np.testing.assert_array_equal(np.asarray(torch.as_tensor(gb._state_buffer).cpu()), g[f"b{batch}_state_buffer"])
+    assert n_kept == _scalar(g, f"b{batch}_ep{last}_add_history")
+    for i in range(Cn + 1):
+        assert abs(counts[i] / E - _scalar(g, f"b{batch}_ep{last}_ratio_cylinders_{i}")) < 1e-6
+        assert abs((sums[i] / counts[i] if counts[i] > 0 else 0.0) - _scalar(g, f"b{batch}_ep{last}_success_cylinders_{i}")) < 1e-6
+    hist = gb._history_buffer
+    assert len(hist) == _scalar(g, f"b{batch}_ep{last}_history_buffer")
+    np.testing.assert_array_equal(hist, g[f"b{batch}_history"])           # the same tasks in the same order: FPS picked the same indices
+
+
+def test_genbuffer_and_curriculum_match_the_reference(golden):
+    """`GenBuffer.insert / insert_weights / update`, the per-cylinder-count statistics, the R_min..R_max filter and `insert_history`
+    incl. the normalisation (x - min) / (max - min + eps) and the farthest-point trim — against the reference's own class and its own curriculum
+    statements (hideandseek_envgen.py:209-377, :1302-1333), executed by make_golden.py with an exact FPS whose start index the fixture names."""
+    g = golden("g_genbuffer")
+    seen = 0
+    for batch, gb, counts, sums, n_kept, E, Cn, eval_iter in _replay_batches(g, lambda A, Cn, B: GenBuffer(A, Cn, seed=0, buffer_length=B)):
+        _check_batch(g, batch, gb, counts, sums, n_kept, E, Cn, eval_iter)
+        seen += 1
+    assert seen == 2 and int(g["b1_fps_start"]) >= 0 and len(g["b1_fps_idx"]) == int(g["meta"][4])
+    # the normalised cloud the reference handed to its sampler, and the selection, from this build's own pieces
+    allst = np.concatenate([g["b0_history"], g["b1_state_buffer"][((g["b1_weight_buffer"] <= g["r_bounds"][1]) & (g["b1_weight_buffer"] >= g["r_bounds"][0])).reshape(-1)]])
+    lo, hi = allst.min(0), allst.max(0)
+    np.testing.assert_array_equal(((allst - lo) / (hi - lo + 1e-5)).astype(np.float32), g["b1_fps_normed"])
+    idx = farthest_point_sampling(torch.from_numpy(g["b1_fps_normed"]), int(g["meta"][4]), start=int(g["b1_fps_start"]))
+    np.testing.assert_array_equal(idx.numpy(), g["b1_fps_idx"])
+
+
+def test_task_bounds_and_samplenearby_against_the_reference(golden):
+    """`task_bounds` = the array the reference's `samplenearby` clips to (:320-333, its own statements executed); the reference's perturbed tasks
+    (its RNG stream is unpinned, so the OUTPUTS are the fixture) pass this build's sanity check, stay inside this build's bounds and within
+    expand_step (one grid cell for an expanded cylinder) of a history entry — the properties this build's own `samplenearby` is held to."""
+    g = golden("g_genbuffer")
+    for A, Cn in ((3, 5), (4, 5)):
+        np.testing.assert_allclose(GenBuffer(A, Cn).task_bounds(), g[f"bounds_a{A}c{Cn}"], rtol=0, atol=1e-12)
+    gb = GenBuffer(3, 5)
+    b = gb.task_bounds()
+    hist = g["near_history"].astype(np.float64)
+    for expand in (0, 1):
+        near = g[f"near_expand{expand}"]
+        assert gb.sanity_ok(near).all()
+        assert (near >= b[:, 0] - 1e-9).all() and (near <= b[:, 1] + 1e-9).all()
+        lim = np.concatenate([np.full(12, 0.1), np.tile([0.2 * expand, 0.2 * expand, 0.0], 5)]) + 1e-6
+        clipped = np.clip(hist, b[:, 0], b[:, 1])                          # (the history's z = 1.1..1.3 already lies in the window)
+        near_some = (np.abs(near[:, None, :] - clipped[None]) <= lim).all(-1).any(-1)
+        assert near_some.all()
+        ours = GenBuffer(3, 5, seed=expand)
+        ours.init_history(g["near_history"])
+        mine = ours.samplenearby(200, expand, 0.1).astype(np.float64)
+        assert ((np.abs(mine[:, None, :] - clipped[None]) <= lim).all(-1).any(-1)).all() and gb.sanity_ok(mine).all()
+        if expand:                                                            # cylinders move by whole cells in both
+            for arr in (near, mine):
+                cyl = arr[:, 12:].reshape(-1, 5, 3)[..., :2] / 0.2
+                assert np.abs(cyl - np.rint(cyl)).max() < 0.21                # = the history's own +-0.04 jitter, kept
+
+
+def test_easy_cases_match_the_reference_flood(golden):
+    """`init_easy_cases` with the reference's own start cells: the pursuers' cells of the reference's flood (hideandseek_envgen.py:246-262; as written it
+    runs for num_agents == 4 only, which the fixture records), z inside the reference's window."""
+    g = golden("g_genbuffer")
+    assert g["easy_runs"].tolist() == [0, 0, 0, 1, 0]                         # A = 1..5: what the reference's method survives
+    ref = g["easy_a4"]                                                        # [160, 5, 3]: pursuers, evader
+    gb = GenBuffer(4, 5, seed=0)
+    assert np.array_equal(gb.grid_map, g["easy_disc"])
+    start = gb.to_grid(ref[:, 4, :2])
+    easy = gb.init_easy_cases(start=start)
+    assert easy.shape == ref.shape
+    np.testing.assert_allclose(easy[..., :2], ref[..., :2], rtol=0, atol=1e-6)
+    assert (np.abs(ref[..., 2] - 0.6) <= 0.1).all() and (np.abs(easy[..., 2] - 0.6) <= 0.1).all()
+
+
+@pytest.mark.gpu
+def test_device_genbuffer_and_episode_end_match_the_reference(golden):
+    """The same fixture through the DEVICE path: `DeviceGenBuffer` (history, weights and the FPS trim `hns_fps` on the GPU) inside
+    `HideAndSeek_envgen._episode_end` — the env's own success / active-cylinder / num_unif state is set to the fixture's, the statistics the
+    reference's block writes (`success_buffer`, `success_unif`, `ratio_cylinders_i`, `success_cylinders_i`, `add_history`, `history_buffer`,
+    `ratio_unif`) and the history are compared after every episode."""
+    from hns_amd import abi
+    from hns_amd.envgen import DeviceGenBuffer, HideAndSeek_envgen
+    g = golden("g_genbuffer")
+    A, Cn, E, eval_iter, B = (int(x) for x in g["meta"])
+    R_min, R_max = (float(x) for x in g["r_bounds"])
+    cfg = config.make_cfg({"name": "HideAndSeek_envgen", "num_agents": A, "ratio_unif": 0.3, "eval_iter": eval_iter, "R_min": R_min, "R_max": R_max,
+                           "use_particle_generator": 1, "cylinder": {"max_num": Cn, "min_num": 2}, "env": {"num_envs": E, "max_episode_length": 5}})
+    env = HideAndSeek_envgen(cfg)
+    env.set_seed(0)
+    env.reset()
+    env.gen_buffer = DeviceGenBuffer(env, buffer_length=B, seed=0)
+    dev = env.device
+    srow = abi.STAT_NAMES.index("success")
+    for batch in range(2):
+        env._tasks_dev.copy_(torch.from_numpy(g[f"b{batch}_tasks"]))
+        env.num_unif = int(g[f"b{batch}_num_unif"])
+        env.active_cylinders = torch.from_numpy(g[f"b{batch}_active"]).to(dev)
+        env.gen_buffer.insert(env._tasks_dev)
+        env.gen_buffer.fps_start = int(g[f"b{batch}_fps_start"]) if int(g[f"b{batch}_fps_start"]) >= 0 else None
+        env.update_iter = 0
+        for ep in range(eval_iter):
+            env._bufs["stats"][srow].copy_(torch.from_numpy(g[f"b{batch}_success{ep}"]).reshape(-1))
+            env._episode_end()
+            assert env.update_iter == int(g[f"b{batch}_ep{ep}_update_iter"])
+            for k in ["success_buffer", "success_unif", "history_buffer", "add_history", "ratio_unif"] + [f"{n}_cylinders_{i}" for n in ("ratio", "success") for i in range(Cn + 1)]:
+                want = np.asarray(g[f"b{batch}_ep{ep}_{k}"], dtype=np.float64)
+                got = env.stats[k].cpu().numpy().astype(np.float64)
+                np.testing.assert_allclose(got, np.broadcast_to(want, got.shape), rtol=0, atol=1e-6, err_msg=f"batch {batch} episode {ep}: stats.{k}")
+        np.testing.assert_array_equal(env.gen_buffer._history_buffer, g[f"b{batch}_history"])
+        np.testing.assert_allclose(env.gen_buffer._weight_buffer.cpu().numpy(), g[f"b{batch}_weight_buffer"].reshape(-1), rtol=0, atol=1e-7)
+    # success above the threshold: uniform tasks only from then on (:1303-1304)
+    env.success_threshold = 0.5
+    env._bufs["stats"][srow].fill_(1.0)
+    env.gen_buffer.insert(env._tasks_dev)
+    env._episode_end()
+    assert env.ratio_unif == float(g["ratio_unif_after_threshold"]) == 1.0

@@ -341,3 +341,33 @@ def test_step_and_predictor_as_two_half_batches_on_two_streams(E, A, NT):
     for k in ("history", "pred", "obs_self", "state_drones", "groundtruth", "tp_done"):
         assert torch.equal(whole._tp_bufs[k], split._tp_bufs[k]), f"predictor buffer {k} differs"
     assert whole.check_finite() and split.check_finite()
+
+
+def test_get_set_state_of_a_half_batch_handle_copies_its_stats_columns():
+    """hns_get_state / hns_set_state on a handle over a SLICE of a larger batch (stats rows strided by the owner's env count) used to
+    skip `stats` silently; now the handle's columns of every row travel as one pitched copy, the other half's columns stay untouched."""
+    E, A = 256, 3
+    cfg = config.make_cfg({"num_agents": A, "tp_overlap": 1, "cylinder": {"max_num": 5, "min_num": 3}, "env": {"num_envs": E, "max_episode_length": 9}},
+                          algo={"use_TP_net": 1})
+    env = HideAndSeek(cfg)
+    env.set_seed(2)
+    env.reset()
+    for _ in range(3):
+        env.step(env.rand_step_input())
+    torch.cuda.synchronize()
+    whole = env._bufs["stats"].cpu().numpy().copy()                       # [24, E]
+    h = E // 2
+    for i, hv in enumerate(env._halves):
+        got = np.full((whole.shape[0], h), np.nan, np.float32)
+        hb = abi.HnsBuffers()
+        hb.stats = got.ctypes.data
+        assert env._lib.hns_get_state(hv.env, C.byref(hb), env._stream()) == 0, env._lib.hns_last_error()
+        torch.cuda.synchronize()
+        assert np.array_equal(got, whole[:, i * h:(i + 1) * h])
+    new = np.random.default_rng(0).random((whole.shape[0], h), dtype=np.float32)
+    hb = abi.HnsBuffers()
+    hb.stats = new.ctypes.data
+    assert env._lib.hns_set_state(env._halves[1].env, C.byref(hb), env._stream()) == 0, env._lib.hns_last_error()
+    torch.cuda.synchronize()
+    after = env._bufs["stats"].cpu().numpy()
+    assert np.array_equal(after[:, h:], new) and np.array_equal(after[:, :h], whole[:, :h])
