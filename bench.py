@@ -10,11 +10,12 @@ north_star).  `python bench.py --gpus N` launches its own N ranks when it was no
 
 Prints ONE JSON line (rank 0):
   * `value` / `ms_per_step`: the timed `env.step` loop; `abi_rate`: the same steps through the bare C ABI;
-  * `roofline`: the step kernel, measured live over the timed region itself — ONE hipEvent pair around it on the step stream
-    (hns_region_begin / hns_region_end), `kernel_us` = max(that device time, the region's wall time) / steps, so `achieved` never
-    exceeds bytes / ms_per_step; dispatch-bound events of sampled launches (`kernel_us_dispatch_events`, long regions only) and of 16
-    launches AFTER the region (`kernel_us_post_region`) are separate fields; per-rank values in `kernel_us_by_rank`; `traffic` is a
-    LOOK-UP of the committed PMC profile; `device_copy_GBs` is the library's float4 copy kernel on the same box;
+  * `roofline`: the step kernel, measured live.  `frac` = `frac_kernel` = algorithmic bytes per launch / `kernel_us`, the kernel ALONE (start / stop events
+    bound to sampled dispatches, hns_enable_timing — what rocprofv3 times; a `profiles/r05_*.txt` header reproduces it); `frac_step_rate` = the same
+    bytes / `step_us`, the timed region per step (ONE hipEvent pair around it on the step stream, never less than its wall time).  Launches overlap head
+    to tail (profiles/r05_launch_overlap.txt), so the step rate can exceed what an isolated kernel sustains; the two are never mixed.  Per-rank kernel
+    times in `kernel_us_by_rank`; `traffic` from two live rocprofv3 PMC passes (N = 1), else a look-up of the committed ones; `device_copy_GBs` is the
+    library's float4 copy kernel on the same box;
   * `configs`: the other BASELINE configurations (cfg2 4 096 envs / no cylinders, cfg4 envgen with the generator's cost
     per episode, cfg5_shard 6v2 / 16 cylinders — one GPU's shard), each with its own ms_per_step and roofline fraction, and
     `beyond_l3`: the headline shape at 262 144 and 1 048 576 envs (0.4 / 1.6 GB touched per step: past the 256 MiB Infinity Cache);
@@ -157,7 +158,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # HNS_BENCH_FORCE_DIST=1: take the distributed branch at world size 1 too (tests/test_bench_contract.py: the RCCL path on a 1-GPU box)
+    force_dist = os.environ.get("HNS_BENCH_FORCE_DIST") == "1" and "WORLD_SIZE" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm; HNS_DIST_BACKEND=gloo only for smoke-testing the N>1 path on a 1-GPU box
@@ -181,7 +184,7 @@ def main():
         if rank == 0:
             import __graft_entry__
             __graft_entry__.build()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
     from hns_amd.env import HideAndSeek
     from hns_amd.tensordict_shim import TensorDict
@@ -189,7 +192,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -210,17 +213,26 @@ def main():
         acts = [torch.randn(E, A, 4, generator=gen, device=device) for _ in range(R)]
         return acts, [TensorDict({"agents": {"action": a}}, [E]) for a in acts]
 
-    def roofline_obj(kernel_ms, E, A, C, NT=1, K=3, source="region"):
-        """Roofline object of the step kernel: algorithmic bytes per launch / its duration."""
+    def roofline_obj(kernel_ms, E, A, C, NT=1, K=3, step_ms=None, samples=None):
+        """Roofline object of the step kernel.  TWO durations, never mixed:
+          * `kernel_us` = the kernel alone: start / stop events bound to sampled dispatches (hns_enable_timing — the timestamps rocprofv3 reads);
+            `frac` = `frac_kernel` = algorithmic bytes per launch / that, the figure a `profiles/*.txt` header reproduces;
+          * `step_us` = the timed region per step (device time between one event pair around it, never less than its wall time);
+            `frac_step_rate` = bytes / that = what the step RATE sustains.  Successive launches overlap head to tail (the next kernel's first
+            workgroups start while the last ones of its predecessor drain: profiles/r05_launch_overlap.txt), so step_us may be below kernel_us."""
         if kernel_ms is None or kernel_ms <= 0:
             return None
         b_env = algorithmic_bytes_per_env(A, C, K, NT=NT)
         achieved = b_env * E / (kernel_ms * 1e-3) / 1e9
-        src = {"region": "one hipEvent pair around the timed region on the step stream (hns_region_begin / hns_region_end) / steps: the step kernel "
-                         "including the gap to its successor (and whatever else the region launches: the episode-boundary resets)",
-               "dispatch": "start / stop events bound to sampled dispatches (hns_enable_timing): the kernel alone"}[source]
-        return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "kernel_us": round(kernel_ms * 1e3, 2), "kernel_us_source": src, "bytes_per_launch": b_env * E, "bytes_per_env": b_env}
+        out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+               "frac_kernel": round(achieved / HBM_PEAK_GBS, 4), "kernel_us": round(kernel_ms * 1e3, 2),
+               "kernel_us_source": "start / stop events bound to sampled dispatches of the step kernel (hns_enable_timing): the kernel alone, as rocprofv3 times it",
+               "kernel_samples": samples, "bytes_per_launch": b_env * E, "bytes_per_env": b_env}
+        if step_ms is not None and step_ms > 0:
+            out["step_us"] = round(step_ms * 1e3, 2)
+            out["frac_step_rate"] = round(b_env * E / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            out["step_us_source"] = "max(device time between ONE hipEvent pair around the timed region on the step stream, wall time of that region) / steps"
+        return out
 
     def timed_steps(env, tds, n, warm, reset_every=None, timing=0):
         """n `env.step` calls (with the episode-boundary reset when given); returns (wall seconds, device ms between one event pair around them)."""
@@ -244,12 +256,23 @@ def main():
             env.enable_kernel_timing(0)
         return dt, env.region_ms()
 
+    def leg_roofline(env, tds, n, dt, rms, E_, A_, C_, NT=1):
+        """Roofline of a configuration leg: the region of `n` steps just timed gives the step rate; the kernel alone comes from 32 event-bracketed
+        dispatches right after it (same env, same state stream, outside the timed region)."""
+        env.enable_kernel_timing(1)
+        for i in range(32):
+            env.step(tds[i % len(tds)])
+        torch.cuda.synchronize(device)
+        env.enable_kernel_timing(0)
+        kms, kn = env.kernel_ms()
+        return roofline_obj(kms if kn > 0 else None, E_, A_, C_, NT=NT, step_ms=max(rms, dt * 1e3) / n, samples=kn)
+
     def cfg2_leg(n):
         # cfg2: 4 096 envs, the default 5 cylinder slots all inactive (BASELINE configs[1]; bytes per env 1 497)
         e2 = make_env(4096, 3, 5, task={"cylinder": {"fixed_num": 0, "min_num": 0}})
         _, td2 = action_ring(4096, 3, 7)
         dt, rms = timed_steps(e2, td2, n, 100)
-        r2 = roofline_obj(rms / n, 4096, 3, 5)
+        r2 = leg_roofline(e2, td2, n, dt, rms, 4096, 3, 5)
         out = {"workload": "HideAndSeek 3v1, 5 cylinder slots all inactive, 4 096 envs", "value": round(4096 * 3 * n / dt, 1), "unit": "agent-steps/s",
                "ms_per_step": round(dt / n * 1e3, 5), "steps": n, "roofline": r2,
                "note": "64 workgroups on 256 CUs: one launch is a single workgroup's latency, not a bandwidth figure"}
@@ -288,7 +311,7 @@ def main():
             if (i + 1) % args.episode == 0:          # lock-step episodes: every env is done now
                 reset_td.set("_reset", env._bufs["done"])
                 env.reset(reset_td)
-            if world > 1 and (i + 1) % rollout == 0:
+            if dist is not None and (i + 1) % rollout == 0:
                 # per-rollout moments for advantage normalisation (learning/mappo.py:391-396 made data-parallel) + the success
                 # rate of the curriculum (hideandseek.py:1012-1015): ONE all-gather of 5 fp64 values per rank over RCCL/xGMI.
                 # Its cost is timed where it is paid: device time between two events on the step stream for RCCL (the collective
@@ -296,12 +319,12 @@ def main():
                 loc = sharding.local_moments(reward, success)
                 if coll_dev == "cpu":
                     c0 = time.perf_counter()
-                    table = sharding.allgather_moments(loc)
+                    table = sharding._allgather(loc)          # (the collective itself, also with one rank)
                     coll_host_us.append((time.perf_counter() - c0) * 1e6)
                 else:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record()
-                    table = sharding.allgather_moments(loc)
+                    table = sharding._allgather(loc)
                     ev[1].record()
                     coll_events.append(ev)
                 rate_hook.update(table)
@@ -355,7 +378,7 @@ def main():
                 v = st[k]
                 h.update(v[:, i * n:(i + 1) * n].tobytes() if k == "stats" else v[i * n:(i + 1) * n].tobytes())
             mine.append(h.hexdigest())
-        if world > 1:
+        if dist is not None:
             allv = [None] * world
             dist.all_gather_object(allv, mine)
             state_digest = [d for r in allv for d in r]
@@ -367,20 +390,22 @@ def main():
     torch.cuda.synchronize(device)
     env.enable_kernel_timing(0)
     post_ms, post_n = env.kernel_ms()
-    # The duration the roofline is priced on: the device time of the region per step, but never less than the wall clock of the same
-    # region per step — the kernel runs once per step, so bytes / ms_per_step bounds what it can have sustained (successive launches
-    # overlap by ~0.5 us: the next kernel's first waves start while the last ones of its predecessor drain, which is why an ISOLATED
-    # dispatch, as rocprofv3 and the dispatch-bound events time it, reads a little longer than either)
-    kernel_ms = max(region_ms, elapsed * 1e3) / args.steps if region_ms > 0 else -1.0
-    roofline = roofline_obj(kernel_ms, E, A, C, NT=args.targets, K=K)
+    # Two durations, reported under their own names: the kernel alone — dispatch-bound events, sampled inside the region when it is
+    # long enough to hold eight of them, otherwise the 16 launches right after it — prices `frac` (= `frac_kernel`); the region per step (device
+    # time of one event pair around it, never less than its wall time) prices `frac_step_rate`.
+    step_ms = max(region_ms, elapsed * 1e3) / args.steps if region_ms > 0 else elapsed * 1e3 / args.steps
+    use_in = in_n >= 8
+    k_ms, k_n = (in_ms, in_n) if use_in else (post_ms, post_n)
+    roofline = roofline_obj(k_ms if k_n > 0 else None, E, A, C, NT=args.targets, K=K, step_ms=step_ms, samples=k_n)
     if roofline is not None:
-        roofline["kernel_us_source"] = "max(device time between ONE hipEvent pair around the timed region on the step stream, wall time of that region) / steps"
+        roofline["kernel_us_source"] += (f"; every {time_every}th launch inside the timed region" if use_in else "; the 16 launches right after the timed region")
         roofline["region_ms"] = round(region_ms, 4)
         roofline["region_wall_ms"] = round(elapsed * 1e3, 4)
         roofline["kernel_us_dispatch_events"] = round(in_ms * 1e3, 2) if in_n > 0 else None
         roofline["dispatch_event_samples_in_region"] = in_n
         roofline["kernel_us_post_region"] = round(post_ms * 1e3, 2) if post_n > 0 else None
         roofline["post_region_samples"] = post_n
+    kernel_ms = k_ms if k_n > 0 else step_ms
 
     coll_us = coll_host_us[-(args.steps // rollout):] if coll_host_us else [a.elapsed_time(b) * 1e3 for a, b in coll_events[-(args.steps // rollout):]]
     collective = None
@@ -390,7 +415,7 @@ def main():
                       ("host time of the call (gloo, host tensors)" if coll_host_us else "device time between two events on the step stream (RCCL)")}
     # ranks that actually took part (an all-reduce of ones), slowest rank's wall time, per-rank kernel time
     n_ranks, n_devices, kernel_by_rank = 1, 1, None
-    if world > 1:
+    if dist is not None:
         ones = torch.ones(1, device=coll_dev, dtype=torch.float64)
         dist.all_reduce(ones)
         n_ranks = int(round(float(ones.item())))
@@ -436,6 +461,7 @@ def main():
             roofline["device_copy_GBs_at_step_footprint"] = like
             roofline["device_copy_kernel"] = "hns_copy_f4_kernel (one float4 per thread): 2 x 1 GiB per pass (HBM only) / 2 x 48 MiB per pass (Infinity-Cache resident, like the step's 105 MB)"
             roofline["frac_of_device_copy"] = round(roofline["achieved"] / (like if E * algorithmic_bytes_per_env(A, C, K, NT=args.targets) < 200e6 else hbm), 4)
+            roofline["frac_of_device_copy_what"] = "achieved (kernel alone) / the copy kernel's rate at the same footprint"
         except Exception as ex:  # noqa: BLE001
             roofline["device_copy_error"] = str(ex)[:200]
 
@@ -463,7 +489,7 @@ def main():
         e5 = make_env(E, 6, 16, NT=2)
         _, td5 = action_ring(E, 6, 9)
         dt, rms = timed_steps(e5, td5, n, 100)
-        r5 = roofline_obj(rms / n, E, 6, 16, NT=2)
+        r5 = leg_roofline(e5, td5, n, dt, rms, E, 6, 16, NT=2)
         assert e5.check_finite()
         if r5 is not None:
             try:
@@ -483,7 +509,7 @@ def main():
             ebv = make_env(eb, A, C)
             _, tdb = action_ring(eb, A, 13, R=2)
             dtb, rmsb = timed_steps(ebv, tdb, nb, 20)
-            rb = roofline_obj(rmsb / nb, eb, A, C)
+            rb = leg_roofline(ebv, tdb, nb, dtb, rmsb, eb, A, C)
             assert ebv.check_finite()
             beyond[str(eb)] = {"workload": f"HideAndSeek {A}v1, {C} cylinders, {eb} envs ({algorithmic_bytes_per_env(A, C, K) * eb / 1e6:.0f} MB algorithmic per step)",
                                "value": round(eb * A * nb / dtb, 1), "unit": "agent-steps/s", "ms_per_step": round(dtb / nb * 1e3, 5), "steps": nb, "roofline": rb}
@@ -523,7 +549,8 @@ def main():
                 ep_ms.append((time.perf_counter() - ts) * 1e3)
             total = time.perf_counter() - t_all
             e4.enable_kernel_timing(0)
-            r4 = roofline_obj(e4.kernel_ms()[0], E, 3, 8, source="dispatch")
+            k4_ms, k4_n = e4.kernel_ms()
+            r4 = roofline_obj(k4_ms if k4_n > 0 else None, E, 3, 8, step_ms=step_s / (L * EP) * 1e3, samples=k4_n)
             steady = sorted(gen_ms[1:])
             # steady state = the last three episodes (one task batch: history full, everything warm); an episode of the reference's
             # 800 steps costs 800 x the measured step time + that episode's measured non-step time
@@ -660,14 +687,15 @@ def main():
                        "num_envs_per_gpu": E, "num_agents": A, "num_targets": args.targets, "num_cylinders": C, "obs_max_cylinder": K,
                        "episode_length": args.episode, "critic_state_output": args.critic_state,
                        "sharding": f"contiguous env slices x{n_ranks}", "world_size_launched": world, "ranks": n_ranks,
-                       "collective": "1 all-gather of 5 fp64 per 64-step rollout" if world > 1 else "none"},
+                       "dist_backend": backend,
+                       "collective": "1 all-gather of 5 fp64 per 64-step rollout" if dist is not None else "none"},
             "collective_us": collective, "state_digest": state_digest,
             "env_frames_per_s": round(value / A, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "abi_rate": abi_rate, "configs": configs or None,
             "tp_mode": tp_mode, "stream_shards": streams_mode,
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

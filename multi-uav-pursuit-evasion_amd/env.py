@@ -487,7 +487,7 @@ class HideAndSeek(_EnvBase):
         nothing consults the mirror (the evader-speed curriculum at its cap, no task generator): the counter then simply keeps
         running, an over-estimate that could only make those checks start early.  The read-back is a host sync: at an episode
         boundary it drains the queue of steps the host had run ahead by and leaves the device idle until the host has caught
-        up — 0.2-0.3 ms per boundary at 65 536 envs (tools/lab/r04_batch73.sh)."""
+        up — 0.2-0.3 ms per boundary at 65 536 envs (tools/lab/r04_batches_1_76.txt, batch 73)."""
         if mask_t is None:
             self._since_full_reset = 0
         elif self._episode_mirror_needed():
