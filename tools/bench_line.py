@@ -3,8 +3,8 @@
 import json, sys
 d = json.loads([l for l in sys.stdin.read().splitlines() if l.startswith("{")][-1])
 r = d.get("roofline") or {}
-print("headline  value %.3e agent-steps/s  ms/step %.5f  kernel_us %s (samples %s)  frac %s  frac of device copy %s  traffic %s" % (
-    d["value"], d["ms_per_step"], r.get("kernel_us"), r.get("samples"), r.get("frac"), r.get("frac_of_device_copy"), r.get("traffic")))
+print("headline  value %.3e agent-steps/s  ms/step %.5f  kernel_us %s (samples %s)  frac_kernel %s  step_us %s  frac_step_rate %s  frac of device copy %s  traffic %s" % (
+    d["value"], d["ms_per_step"], r.get("kernel_us"), r.get("kernel_samples"), r.get("frac"), r.get("step_us"), r.get("frac_step_rate"), r.get("frac_of_device_copy"), r.get("traffic")))
 for k, c in (d.get("configs") or {}).items():
     if k == "beyond_l3":
         for e, cc in c.items():
@@ -12,7 +12,7 @@ for k, c in (d.get("configs") or {}).items():
             print("beyond_l3 %8s envs  value %.3e  ms/step %.5f  kernel_us %s  frac %s" % (e, cc["value"], cc["ms_per_step"], rr.get("kernel_us"), rr.get("frac")))
         continue
     rr = c.get("roofline") or {}
-    line = "%-16s value %.3e  ms/step %.5f  kernel_us %s  frac %s" % (k, c["value"], c["ms_per_step"], rr.get("kernel_us"), rr.get("frac"))
+    line = "%-16s value %.3e  ms/step %.5f  kernel_us %s  frac_kernel %s  frac_step_rate %s" % (k, c["value"], c["ms_per_step"], rr.get("kernel_us"), rr.get("frac"), rr.get("frac_step_rate"))
     if "generator_ms_per_episode" in c:
         line += "\n                 generator ms per episode %s; steady batch %s ms; incl. generator at 800-step episodes %.3e (steady %.3e = %.2f of stepping)" % (
             c["generator_ms_per_episode"], c["generator_ms_task_batch_steady"], c["value_incl_generator_at_800_step_episodes"],
