@@ -10,12 +10,12 @@ north_star).  `python bench.py --gpus N` launches its own N ranks when it was no
 
 Prints ONE JSON line (rank 0):
   * `value` / `ms_per_step`: the timed `env.step` loop; `abi_rate`: the same steps through the bare C ABI;
-  * `roofline`: the step kernel, measured live.  `frac` = `frac_kernel` = algorithmic bytes per launch / `kernel_us`, the kernel ALONE (start / stop events
-    bound to sampled dispatches, hns_enable_timing — what rocprofv3 times; a `profiles/r05_*.txt` header reproduces it); `frac_step_rate` = the same
-    bytes / `step_us`, the timed region per step (ONE hipEvent pair around it on the step stream, never less than its wall time).  Launches overlap head
-    to tail (profiles/r05_launch_overlap.txt), so the step rate can exceed what an isolated kernel sustains; the two are never mixed.  Per-rank kernel
-    times in `kernel_us_by_rank`; `traffic` from two live rocprofv3 PMC passes (N = 1), else a look-up of the committed ones; `device_copy_GBs` is the
-    library's float4 copy kernel on the same box;
+  * `roofline`: the step kernel, measured live.  `frac` = `frac_kernel` = algorithmic bytes per launch / `kernel_us`, the kernel's average launch duration:
+    HIP events around blocks of 64 consecutive plain launches on the step stream, right after the timed region (back to back every dispatch starts
+    the instant its predecessor ends — profiles/r05_launch_overlap.txt — so this is the duration rocprofv3 reports; a `profiles/r05_*.txt` header
+    reproduces it); `frac_step_rate` = the same bytes / `step_us`, the whole timed region per step (ONE hipEvent pair around it, never less than its
+    wall time; resets and host stalls included).  Per-rank kernel times in `kernel_us_by_rank`; `traffic` from two live rocprofv3 PMC passes
+    (N = 1), else a look-up of the committed ones; `device_copy_GBs` is the library's float4 copy kernel on the same box;
   * `configs`: the other BASELINE configurations (cfg2 4 096 envs / no cylinders, cfg4 envgen with the generator's cost
     per episode, cfg5_shard 6v2 / 16 cylinders — one GPU's shard), each with its own ms_per_step and roofline fraction, and
     `beyond_l3`: the headline shape at 262 144 and 1 048 576 envs (0.4 / 1.6 GB touched per step: past the 256 MiB Infinity Cache);
@@ -66,7 +66,8 @@ def parse_args():
                          "separate, kernel-trace only) of a short inner run of the same workload, ~20 s each, outside every timed region; --no-traffic-live (or a "
                          "failing rocprofv3) falls back to the look-up of the committed passes (profiles/traffic.json)")
     ap.add_argument("--cpu-steps", type=int, default=100)
-    ap.add_argument("--time-every", type=int, default=32)
+    ap.add_argument("--time-every", type=int, default=0, help="N > 0: every Nth launch of the timed region is an event-bracketed dispatch (off by default: each one "
+                    "costs the region ~11 us of device idle time)")
     ap.add_argument("--abi-steps", type=int, default=500, help="secondary leg: the same steps through the bare C ABI (0 = skip)")
     ap.add_argument("--config-steps", type=int, default=2000,
                     help="steps of each extra BASELINE configuration leg (0 = skip the legs); regions of a few hundred steps read 3-4 %% slower than the "
@@ -215,18 +216,19 @@ def main():
 
     def roofline_obj(kernel_ms, E, A, C, NT=1, K=3, step_ms=None, samples=None):
         """Roofline object of the step kernel.  TWO durations, never mixed:
-          * `kernel_us` = the kernel alone: start / stop events bound to sampled dispatches (hns_enable_timing — the timestamps rocprofv3 reads);
-            `frac` = `frac_kernel` = algorithmic bytes per launch / that, the figure a `profiles/*.txt` header reproduces;
-          * `step_us` = the timed region per step (device time between one event pair around it, never less than its wall time);
-            `frac_step_rate` = bytes / that = what the step RATE sustains.  Successive launches overlap head to tail (the next kernel's first
-            workgroups start while the last ones of its predecessor drain: profiles/r05_launch_overlap.txt), so step_us may be below kernel_us."""
+          * `kernel_us` = the kernel's average launch duration: HIP events around BLOCKS of consecutive plain launches on the step stream (no reset, no
+            event-bracketed dispatch, no host sync inside a block), device time / launches.  profiles/r05_launch_overlap.txt shows why that is the
+            kernel's duration as rocprofv3 reports it: in a back-to-back stream every dispatch starts the instant its predecessor ends (gap 0 for the
+            median pair, no overlap), so period = duration.  `frac` = `frac_kernel` = algorithmic bytes per launch / that;
+          * `step_us` = the whole timed region per step (one event pair around it, never less than its wall time: resets, host stalls included);
+            `frac_step_rate` = bytes / that."""
         if kernel_ms is None or kernel_ms <= 0:
             return None
         b_env = algorithmic_bytes_per_env(A, C, K, NT=NT)
         achieved = b_env * E / (kernel_ms * 1e-3) / 1e9
         out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                "frac_kernel": round(achieved / HBM_PEAK_GBS, 4), "kernel_us": round(kernel_ms * 1e3, 2),
-               "kernel_us_source": "start / stop events bound to sampled dispatches of the step kernel (hns_enable_timing): the kernel alone, as rocprofv3 times it",
+               "kernel_us_source": "HIP events around blocks of consecutive plain launches of the step kernel on the step stream (device time / launches)",
                "kernel_samples": samples, "bytes_per_launch": b_env * E, "bytes_per_env": b_env}
         if step_ms is not None and step_ms > 0:
             out["step_us"] = round(step_ms * 1e3, 2)
@@ -256,16 +258,34 @@ def main():
             env.enable_kernel_timing(0)
         return dt, env.region_ms()
 
-    def leg_roofline(env, tds, n, dt, rms, E_, A_, C_, NT=1):
-        """Roofline of a configuration leg: the region of `n` steps just timed gives the step rate; the kernel alone comes from 32 event-bracketed
-        dispatches right after it (same env, same state stream, outside the timed region)."""
-        env.enable_kernel_timing(1)
-        for i in range(32):
-            env.step(tds[i % len(tds)])
+    def kernel_blocks(env, tds, blocks=8, per=64, lead=16):
+        """Average launch duration of the step kernel (ms) from `blocks` blocks of `per` consecutive `env.step` launches, each between one event pair
+        on the step stream; `lead` untimed launches before every block keep the queue full (the host issues a launch in a fraction of a kernel's
+        duration at the bench's batch sizes), nothing is synchronised until all blocks are queued.  Returns (mean ms per launch, launches timed,
+        [ms per launch of every block])."""
+        evs = []
         torch.cuda.synchronize(device)
-        env.enable_kernel_timing(0)
-        kms, kn = env.kernel_ms()
-        return roofline_obj(kms if kn > 0 else None, E_, A_, C_, NT=NT, step_ms=max(rms, dt * 1e3) / n, samples=kn)
+        k = 0
+        for _ in range(blocks):
+            for _ in range(lead):
+                env.step(tds[k % len(tds)])
+                k += 1
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(per):
+                env.step(tds[k % len(tds)])
+                k += 1
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize(device)
+        per_block = [a.elapsed_time(b) / per for a, b in evs]
+        return sum(per_block) / len(per_block), blocks * per, per_block
+
+    def leg_roofline(env, tds, n, dt, rms, E_, A_, C_, NT=1):
+        """Roofline of a configuration leg: the region of `n` steps just timed gives the step rate, blocks of consecutive launches right after it (same
+        env, same state stream) the kernel's own duration."""
+        kms, kn, _ = kernel_blocks(env, tds, blocks=4, per=64)
+        return roofline_obj(kms, E_, A_, C_, NT=NT, step_ms=max(rms, dt * 1e3) / n, samples=kn)
 
     def cfg2_leg(n):
         # cfg2: 4 096 envs, the default 5 cylinder slots all inactive (BASELINE configs[1]; bytes per env 1 497)
@@ -343,14 +363,11 @@ def main():
     env.kernel_ms()
     run(args.warmup - min(1, args.warmup))
     sync()
-    # The roofline's kernel time is ONE hipEvent pair around the whole timed region, recorded on the stream the steps are launched on
-    # (hns_region_begin / hns_region_end): device time / steps = the step kernel including the gap to its successor, with no host cost
-    # per launch.  It can never be shorter than bytes / ms_per_step allows.  Dispatch-bound events (the kernel alone, what rocprofv3
-    # reports) ride on every `time_every`-th launch only in regions long enough to hold eight of them — an event-bracketed dispatch
-    # costs the host ~6 us — and are reported beside it (`kernel_us_dispatch_events`); 16 more are taken right AFTER the region
-    # (`kernel_us_post_region`: same env, same state stream, outside every timed quantity).
-    time_every = max(1, args.time_every)
-    in_region_events = args.steps >= 8 * time_every
+    # The timed region: ONE hipEvent pair around it on the stream the steps are launched on (hns_region_begin / hns_region_end) beside the wall clock.
+    # Nothing rides on the launches inside it by default (an event-bracketed dispatch — `--time-every N`, off at 0 — leaves the device idle for
+    # ~11 us around itself, profiles/r05_launch_overlap.txt).  The kernel's own duration is measured right AFTER the region (`kernel_blocks`).
+    time_every = max(0, args.time_every)
+    in_region_events = time_every > 0 and args.steps >= 8 * time_every
     if in_region_events:
         env.enable_kernel_timing(time_every)
     env.region_begin()
@@ -384,28 +401,28 @@ def main():
             state_digest = [d for r in allv for d in r]
         else:
             state_digest = mine
+    # the kernel alone: blocks of consecutive launches right after the region (same env, same state stream, outside every timed quantity) ...
+    blk_ms, blk_n, blk_each = kernel_blocks(env, tds, blocks=8, per=64)
+    # ... and, as a separately named field, 16 ISOLATED dispatches with start / stop events bound to each (hns_enable_timing): such a dispatch sits between
+    # two idle gaps and its events take in more than the kernel (rocprofv3 reads 15.8 us for the dispatches these events read 18-20 us for)
     env.enable_kernel_timing(1)
     for i in range(16):
         env.step(tds[i % R])
     torch.cuda.synchronize(device)
     env.enable_kernel_timing(0)
     post_ms, post_n = env.kernel_ms()
-    # Two durations, reported under their own names: the kernel alone — dispatch-bound events, sampled inside the region when it is
-    # long enough to hold eight of them, otherwise the 16 launches right after it — prices `frac` (= `frac_kernel`); the region per step (device
-    # time of one event pair around it, never less than its wall time) prices `frac_step_rate`.
     step_ms = max(region_ms, elapsed * 1e3) / args.steps if region_ms > 0 else elapsed * 1e3 / args.steps
-    use_in = in_n >= 8
-    k_ms, k_n = (in_ms, in_n) if use_in else (post_ms, post_n)
-    roofline = roofline_obj(k_ms if k_n > 0 else None, E, A, C, NT=args.targets, K=K, step_ms=step_ms, samples=k_n)
+    roofline = roofline_obj(blk_ms, E, A, C, NT=args.targets, K=K, step_ms=step_ms, samples=blk_n)
     if roofline is not None:
-        roofline["kernel_us_source"] += (f"; every {time_every}th launch inside the timed region" if use_in else "; the 16 launches right after the timed region")
+        roofline["kernel_us_blocks"] = [round(x * 1e3, 2) for x in blk_each]
         roofline["region_ms"] = round(region_ms, 4)
         roofline["region_wall_ms"] = round(elapsed * 1e3, 4)
-        roofline["kernel_us_dispatch_events"] = round(in_ms * 1e3, 2) if in_n > 0 else None
-        roofline["dispatch_event_samples_in_region"] = in_n
-        roofline["kernel_us_post_region"] = round(post_ms * 1e3, 2) if post_n > 0 else None
-        roofline["post_region_samples"] = post_n
-    kernel_ms = k_ms if k_n > 0 else step_ms
+        roofline["kernel_us_isolated_dispatch_events"] = round(post_ms * 1e3, 2) if post_n > 0 else None
+        roofline["isolated_dispatch_samples"] = post_n
+        if in_n > 0:
+            roofline["kernel_us_dispatch_events_in_region"] = round(in_ms * 1e3, 2)
+            roofline["dispatch_event_samples_in_region"] = in_n
+    kernel_ms = blk_ms
 
     coll_us = coll_host_us[-(args.steps // rollout):] if coll_host_us else [a.elapsed_time(b) * 1e3 for a, b in coll_events[-(args.steps // rollout):]]
     collective = None
@@ -533,7 +550,6 @@ def main():
             _, td4 = action_ring(E, 3, 11)
             gen_ms, ep_ms, step_s = [], [], 0.0
             rtd = TensorDict({}, [E])
-            e4.enable_kernel_timing(8)
             t_all = time.perf_counter()
             for ep in range(EP):
                 g0 = e4.generator_seconds
@@ -548,9 +564,8 @@ def main():
                 gen_ms.append((e4.generator_seconds - g0) * 1e3)
                 ep_ms.append((time.perf_counter() - ts) * 1e3)
             total = time.perf_counter() - t_all
-            e4.enable_kernel_timing(0)
-            k4_ms, k4_n = e4.kernel_ms()
-            r4 = roofline_obj(k4_ms if k4_n > 0 else None, E, 3, 8, step_ms=step_s / (L * EP) * 1e3, samples=k4_n)
+            k4_ms, k4_n, _ = kernel_blocks(e4, td4, blocks=4, per=64)
+            r4 = roofline_obj(k4_ms, E, 3, 8, step_ms=step_s / (L * EP) * 1e3, samples=k4_n)
             steady = sorted(gen_ms[1:])
             # steady state = the last three episodes (one task batch: history full, everything warm); an episode of the reference's
             # 800 steps costs 800 x the measured step time + that episode's measured non-step time

@@ -29,17 +29,17 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(d["value"] - 4096 * 3 * 64 / (d["ms_per_step"] * 1e-3 * 64)) / d["value"] < 1e-3
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    # two durations under their own names: `frac` = `frac_kernel` prices the kernel ALONE (dispatch-bound events: at this
-    # region length the 16 launches after it), `frac_step_rate` the timed region per step, which can never claim more than the wall clock of
-    # the same region allows
-    assert r["frac"] == r["frac_kernel"] and r["kernel_us"] > 0 and "events bound to sampled dispatches" in r["kernel_us_source"]
-    assert r["kernel_us"] == r["kernel_us_post_region"] and r["kernel_samples"] == 16
+    # two durations under their own names: `frac` = `frac_kernel` prices the kernel's average launch duration (events around blocks of
+    # consecutive launches after the region), `frac_step_rate` the timed region per step, which can never claim more than the wall clock of the same
+    # region allows; isolated event-bracketed dispatches are a third, separately named field
+    assert r["frac"] == r["frac_kernel"] and r["kernel_us"] > 0 and "blocks of consecutive plain launches" in r["kernel_us_source"]
+    assert r["kernel_samples"] == 512 and len(r["kernel_us_blocks"]) == 8 and abs(sum(r["kernel_us_blocks"]) / 8 - r["kernel_us"]) < 0.02
     assert "hipEvent pair" in r["step_us_source"] and r["region_ms"] <= r["region_wall_ms"] * 1.001
     assert abs(r["step_us"] - max(r["region_ms"], r["region_wall_ms"]) * 1e3 / d["steps"]) < 0.02
     assert abs(r["frac_step_rate"] - r["bytes_per_launch"] / (r["step_us"] * 1e-6) / 1e9 / 8000.0) < 2e-4
     wall_rate = r["bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9
     assert wall_rate / 1.03 <= r["frac_step_rate"] * 8000.0 <= wall_rate * 1.001                   # bounded by the wall clock of the same region, both ways
-    assert r["post_region_samples"] == 16 and r["kernel_us_post_region"] > 0 and r["dispatch_event_samples_in_region"] == 0
+    assert r["isolated_dispatch_samples"] == 16 and r["kernel_us_isolated_dispatch_events"] > 0 and "dispatch_event_samples_in_region" not in r
     assert r["device_copy_GBs"] > 0 and "hns_copy_f4" in r["device_copy_kernel"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "agent-steps/s" and "sample" in c
@@ -56,7 +56,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert cf["cfg2"]["roofline"]["bytes_per_env"] == 1497 and cf["cfg5_shard"]["roofline"]["frac"] > 0
     for leg in ("cfg2", "cfg5_shard"):                                                     # the legs carry both figures too
         rl = cf[leg]["roofline"]
-        assert rl["frac"] == rl["frac_kernel"] and rl["frac_step_rate"] > 0 and rl["kernel_samples"] == 32 and rl["step_us"] > 0
+        assert rl["frac"] == rl["frac_kernel"] and rl["frac_step_rate"] > 0 and rl["kernel_samples"] == 256 and rl["step_us"] > 0
     assert len(cf["cfg4"]["generator_ms_per_episode"]) == 4 and cf["cfg4"]["value_incl_generator"] > 0
 
 

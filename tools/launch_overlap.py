@@ -46,6 +46,17 @@ def main():
     print(f"# gap start[i+1] - end[i]: mean {sum(gap) / len(gap) / 1e3:+.3f} us; {len(over)} of {len(gap)} pairs overlap (successor started before this dispatch ended)"
           + (f", mean overlap of those {sum(over) / len(over) / 1e3:.3f} us (max {max(over) / 1e3:.2f})" if over else ""))
     print(f"# mean duration - mean period = {(sum(dur) / n - sum(period) / len(period)) / 1e3:+.3f} us per step")
+    # the whole run of consecutive dispatches in blocks of 64: warm-up (clocks, first launches) against steady state
+    print(f"# whole run of {len(best)} consecutive dispatches, blocks of 64: mean duration / mean period (us)")
+    for b0 in range(0, len(best) - 1, 64):
+        blk = best[b0:b0 + 65]
+        if len(blk) < 2:
+            break
+        d_ = [en - st for st, en in blk[:-1]]
+        p_ = [blk[i + 1][0] - blk[i][0] for i in range(len(blk) - 1)]
+        print(f"#   launches {b0:5d}-{b0 + len(blk) - 2:5d}: duration {sum(d_) / len(d_) / 1e3:7.3f}   period {sum(p_) / len(p_) / 1e3:7.3f}")
+    import statistics
+    print(f"# median gap {statistics.median(gap) / 1e3:+.3f} us, median duration {statistics.median(dur) / 1e3:.3f} us, median period {statistics.median(period) / 1e3:.3f} us (the table's rows)")
     print("i,start_ns,end_ns,duration_ns,gap_to_next_ns")
     for i, (st, en) in enumerate(run):
         print(f"{i},{st - t0},{en - t0},{en - st},{gap[i] if i < len(gap) else ''}")

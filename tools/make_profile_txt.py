@@ -84,7 +84,7 @@ def main():
                     continue
                 r = j.get("roofline") or {}
                 out.append(f"# bench line of the profiled run ({os.path.basename(lg)}; under the profiler): ms_per_step {j.get('ms_per_step')}, roofline.kernel_us "
-                           f"{r.get('kernel_us')}, frac {r.get('frac')}, kernel_us_post_region {r.get('kernel_us_post_region')}")
+                           f"{r.get('kernel_us')} (blocks of consecutive launches), frac {r.get('frac')}, step_us {r.get('step_us')}, frac_step_rate {r.get('frac_step_rate')}")
     print("\n".join(out))
     for f in files:
         print(f"\n## {os.path.splitext(os.path.basename(f))[0]}")
