@@ -541,10 +541,10 @@ def main():
         from hns_amd.envgen import HideAndSeek_envgen
         L, EP = args.envgen_episode_length, args.envgen_episodes
 
-        def envgen_leg():
+        def envgen_leg(R_min=0.0, R_max=1.0):
             t0c = time.perf_counter()
             e4 = make_env(E, 3, 8, cls=HideAndSeek_envgen, episode=L,
-                          task={"name": "HideAndSeek_envgen", "use_particle_generator": 1, "ratio_unif": 0.3, "eval_iter": 3, "R_min": 0.0, "R_max": 1.0})
+                          task={"name": "HideAndSeek_envgen", "use_particle_generator": 1, "ratio_unif": 0.3, "eval_iter": 3, "R_min": R_min, "R_max": R_max})
             torch.cuda.synchronize(device)
             first_reset_ms = (time.perf_counter() - t0c) * 1e3
             _, td4 = action_ring(E, 3, 11)
@@ -570,9 +570,11 @@ def main():
             # steady state = the last three episodes (one task batch: history full, everything warm); an episode of the reference's
             # 800 steps costs 800 x the measured step time + that episode's measured non-step time
             nonstep_last3 = sum(ep_ms[-3:]) * 1e-3 - 3 * L * (step_s / (L * EP))
-            out = {"workload": f"HideAndSeek_envgen, 3v1, 8 cylinders, {E} envs, episodes of {L} steps (the reference: 800), new task batch every 3 episodes, "
-                               "R_min 0.0 / R_max 1.0 (the reference's 0.5 / 0.9 would admit no task under this bench's random policy: every task "
-                               "enters the history here, so the trim runs at its full 5000 + E size - the generator's worst case)",
+            what = ("R_min 0.0 / R_max 1.0 (the reference's 0.5 / 0.9 admits no task under this bench's random policy: every task enters the history here, so the "
+                    "trim runs at its full 5000 + E size - the generator's worst case)" if (R_min, R_max) == (0.0, 1.0) else
+                    f"R_min {R_min} / R_max {R_max} (BASELINE's values; under this bench's random policy almost no task's success rate falls inside, "
+                    "so the history stays small and the trim is short - the generator's cost is the task reset)")
+            out = {"workload": f"HideAndSeek_envgen, 3v1, 8 cylinders, {E} envs, episodes of {L} steps (the reference: 800), new task batch every 3 episodes, " + what,
                    "value": round(E * 3 * L * EP / step_s, 1), "unit": "agent-steps/s (stepping only)", "ms_per_step": round(step_s / (L * EP) * 1e3, 5),
                    "roofline": r4, "episodes": EP, "generator_ms_per_episode": [round(x, 2) for x in gen_ms],
                    "episode_wall_ms": [round(x, 2) for x in ep_ms],
@@ -587,6 +589,7 @@ def main():
             return out
         if args.envgen_episodes > 0:
             configs["cfg4"] = envgen_leg()
+            configs["cfg4_baseline_R"] = envgen_leg(0.5, 0.9)       # BASELINE's R_min / R_max beside the worst case
 
     # secondary leg ("use_TP_net=1 reported separately"): step + hns_tp_observe
     tp_mode = None
@@ -686,7 +689,24 @@ def main():
             O.step(env.hcfg, host, act)
         mdt = time.perf_counter() - m0
         O.set_threads(1)
+        # SURVEY §8(d) also names E = 4 096 (BASELINE configs[1]: 5 cylinder slots, all inactive): the same oracle, one thread and the best thread count
+        c2 = config.resolve_hns_cfg(config.make_cfg({"num_agents": 3, "cylinder": {"max_num": 5, "min_num": 0, "fixed_num": 0}, "env": {"num_envs": 4096, "max_episode_length": args.episode}}))
+        h2 = O.alloc_buffers(c2)
+        O.reset(c2, h2, None, 0, 0)
+        a2 = np.random.default_rng(1).standard_normal((4096, 3, 4)).astype(np.float32)
+        cfg2_cpu = {}
+        for threads in (1, best_n):
+            O.set_threads(threads)
+            O.step(c2, h2, a2)
+            n2 = 200 if threads == 1 else 1000
+            q0 = time.perf_counter()
+            for _ in range(n2):
+                O.step(c2, h2, a2)
+            cfg2_cpu[threads] = 4096 * 3 * n2 / (time.perf_counter() - q0)
+        O.set_threads(1)
         cpu_baseline = {"value": round(E * A * args.cpu_steps / mdt, 1), "unit": "agent-steps/s", "cores": best_n,
+                        "cfg2": {"value": round(max(cfg2_cpu.values()), 1), "unit": "agent-steps/s", "cores": max(cfg2_cpu, key=cfg2_cpu.get),
+                                 "one_core_value": round(cfg2_cpu[1], 1), "sample": "200 / 1000 steps of HideAndSeek 3v1, 5 inactive cylinder slots, 4 096 envs with the C oracle"},
                         "kind": "port", "one_core_value": round(one_core, 1),
                         "sample": f"{args.cpu_steps} steps of the same {E}-env workload with the C oracle "
                                   f"(oracle/hns_oracle.c): {best_n} threads (best of a probe up to {avail}) {mdt:.1f} s, 1 thread {cdt:.1f} s"}

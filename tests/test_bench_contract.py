@@ -43,6 +43,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert r["device_copy_GBs"] > 0 and "hns_copy_f4" in r["device_copy_kernel"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "agent-steps/s" and "sample" in c
+    assert c["cfg2"]["value"] >= c["cfg2"]["one_core_value"] > 0 and "4 096 envs" in c["cfg2"]["sample"]
     assert d["tp_mode"]["value"] > 0 and d["stream_shards"]["groups"] == 2
     tr = d["tp_mode"]["roofline"]                                                          # the predictor against the matrix-core peak
     assert tr["bound"] == "mfma" and tr["unit"] == "TFLOP/s" and tr["peak"] == 2500.0 and 0 < tr["frac"] < 1 and d["tp_mode"]["observe_us"] > 0
@@ -52,7 +53,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     if "rocprofv3 --kernel-trace --pmc" in r.get("traffic_source", ""):
         assert 0.9 < r["traffic"] / r["bytes_per_launch"] < 1.3 and r["traffic_detail"]["FETCH_SIZE_dispatches"] >= 60
     cf = d["configs"]                                                                      # every other BASELINE configuration
-    assert set(cf) == {"cfg2", "cfg4", "cfg5_shard"}
+    assert set(cf) == {"cfg2", "cfg4", "cfg4_baseline_R", "cfg5_shard"} and "R_min 0.5 / R_max 0.9" in cf["cfg4_baseline_R"]["workload"]
     assert cf["cfg2"]["roofline"]["bytes_per_env"] == 1497 and cf["cfg5_shard"]["roofline"]["frac"] > 0
     for leg in ("cfg2", "cfg5_shard"):                                                     # the legs carry both figures too
         rl = cf[leg]["roofline"]

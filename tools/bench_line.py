@@ -24,6 +24,8 @@ if t:
 c = d.get("cpu_baseline")
 if c:
     print("cpu_baseline %.3e agent-steps/s on %d threads (1 thread %.3e)" % (c["value"], c["cores"], c["one_core_value"]))
+    if c.get("cfg2"):
+        print("cpu_baseline cfg2 (4 096 envs) %.3e on %d threads (1 thread %.3e)" % (c["cfg2"]["value"], c["cfg2"]["cores"], c["cfg2"]["one_core_value"]))
 a = d.get("abi_rate")
 if a:
     print("abi_rate  %.3e  ms/step %.5f" % (a["value"], a["ms_per_step"]))
