@@ -460,7 +460,9 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
     extern __shared__ __align__(16) uint4 simg[];
     const TpImage L = tp_image(NXC);
     const int tid = threadIdx.x, I = p.I, T = p.T, R = 3 * p.F;
-    unsigned long long *prof = p.prof ? p.prof + (size_t)(blockIdx.x * kTpWaves + (tid >> 6)) * 16 : nullptr;
+    // (the wave index through readfirstlane: the stamp pointer is wave-uniform and belongs in scalar registers — as a per-lane value it was the
+    //  one thing the two-chunk instantiation spilled across the timestep loop, 3 registers / 16 B of scratch)
+    unsigned long long *prof = p.prof ? p.prof + (size_t)(blockIdx.x * kTpWaves + __builtin_amdgcn_readfirstlane(tid >> 6)) * 16 : nullptr;
     if (prof && (tid & 63) == 0) prof[0] = __builtin_amdgcn_s_memrealtime();
 
     // ---- stage the operand image (88-104 KB, L2-resident, contiguous) ------------------------------
@@ -1111,10 +1113,11 @@ static int tp_nxc(int I) { return (I + 15) / 16; }
 // weight image does not fit beyond three chunks); HNS_TP_KERNEL=tile / ws forces one of them where both exist (A/B measurements)
 static bool tp_use_ws(int nxc) {
     static const int mode = [] { const char *m = getenv("HNS_TP_KERNEL"); return !m ? 0 : (m[0] == 't' ? 1 : (m[0] == 'w' ? 2 : 0)); }();
-    if (nxc > 3) return true;
+    if (nxc > 2) return true;        // three chunks: 137 us against the tile kernel's 245 (tools/tp_widths.py, round 5) — and that instantiation of the tile kernel spilled
+                                     // 23 registers at its 256-register cap: it is no longer built
     if (mode == 1) return false;
     if (mode == 2) return true;
-    return nxc != 2;                 // three chunks: 133 us against the tile kernel's 242 (tools/lab/lab_batch84.sh); two: the tile kernel's 122-127 us
+    return nxc != 2;                 // two chunks: the tile kernel's 135 us against 146 (one register, 8 B, parked in scratch once per launch: the wave's LDS offset)
 }
 static int tp_frame_dim(const hns_cfg &c) { return 7 + 3 * c.num_agents + (c.tp_use_obstacles ? 3 * c.num_cylinders : 0); }
 
@@ -1239,12 +1242,12 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
         HNS_CHECK_HIP(hipGetLastError());
         return HNS_OK;
     }
-    void (*fn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_kernel<1> : nxc == 2 ? hns::hns_tp_lstm_kernel<2> : hns::hns_tp_lstm_kernel<3>;
+    void (*fn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_kernel<1> : hns::hns_tp_lstm_kernel<2>;          // (nxc <= 2 here: tp_use_ws)
     const int waves = hns::tp_waves(nxc);
     const size_t lds = (size_t)hns::tp_image(nxc).bytes + (size_t)waves * 8 * nxc * 64 * sizeof(float)    // image + parked new frame
                        + ((nxc == 1 && 3 * p.F > 16) ? (size_t)waves * 1024 * sizeof(float) : 0);              // + the predictions of more than five points
     // the attribute is per device: remembered per (frame width, device), so envs on two GPUs driven from one thread both get it
-    static thread_local unsigned long long attr_devs[3] = {0ull, 0ull, 0ull};
+    static thread_local unsigned long long attr_devs[2] = {0ull, 0ull};
     const unsigned long long dev_bit = 1ull << (env->device & 63);
     if (!(attr_devs[nxc - 1] & dev_bit)) {
         const size_t lds_cap = (size_t)hns::tp_image(nxc).bytes + (size_t)waves * (8 * nxc * 64 + (nxc == 1 ? 1024 : 0)) * sizeof(float);   // the largest this kernel asks for
