@@ -222,10 +222,16 @@ HNS_DEV unsigned wave_max_u32(unsigned v) {
 }
 // ... of a candidate key (min-distance bits + 1 in bits 20..51, 0xFFFFF - index below): the distance part first, then the index part among
 // the lanes that hold that distance (ties -> lower index)
+// (round 5: the index part takes the second ladder only when several lanes hold the winning distance — equal minimum distances, or no candidate at
+//  all; otherwise it is one ballot and one v_readlane.  These maxima run 24 times per exchange on a wave that issues alone, one dependent
+//  instruction per ~6 cycles: the exchange's serial path, not the distance updates, is what a trim costs — 10 000 points take as long as 70 000.)
 HNS_DEV unsigned long long wave_max_key(unsigned long long k) {
     const unsigned hi = (unsigned)(k >> 20), lo = (unsigned)k & 0xFFFFFu;
     const unsigned mh = wave_max_u32(hi);
-    const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+    const unsigned long long eq = __ballot(hi == mh);
+    unsigned ml;
+    if (__popcll(eq) == 1) ml = (unsigned)__builtin_amdgcn_readlane((int)lo, (int)__builtin_ctzll(eq));
+    else ml = wave_max_u32(hi == mh ? lo : 0u);
     return ((unsigned long long)mh << 20) | (unsigned long long)ml;
 }
 
@@ -234,17 +240,21 @@ HNS_DEV unsigned long long wave_max_key(unsigned long long k) {
 // it from its sorted pair), parks them in LDS, and after ONE workgroup barrier every wave takes the top nb of those (THREADS / 64) x kFxB
 // values — one per lane at 1024 threads.
 template <int THREADS>
-HNS_DEV void fps_top(unsigned long long (&mine)[2], int nb, unsigned long long *s_wtop, unsigned long long *s_top) {
+HNS_DEV void fps_top(unsigned long long (&mine)[2], int nb, unsigned long long *s_wtop, unsigned long long *s_top, bool wave_active) {
     static_assert(THREADS / 64 * kFxB <= 128, "at most two parked candidates per lane");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave_active) {
 #pragma unroll
-    for (int pass = 0; pass < kFxB; ++pass) {
-        unsigned long long best = 0ull;
-        if (pass < nb) {
-            best = wave_max_key(mine[0]);
-            if (best != 0ull && mine[0] == best) { mine[0] = mine[1]; mine[1] = 0ull; }
+        for (int pass = 0; pass < kFxB; ++pass) {
+            unsigned long long best = 0ull;
+            if (pass < nb) {
+                best = wave_max_key(mine[0]);
+                if (best != 0ull && mine[0] == best) { mine[0] = mine[1]; mine[1] = 0ull; }
+            }
+            if (lane == 0) s_wtop[wave * kFxB + pass] = best;
         }
-        if (lane == 0) s_wtop[wave * kFxB + pass] = best;
+    } else if (lane < kFxB) {
+        s_wtop[wave * kFxB + lane] = 0ull;                   // a wave that holds no point has no candidate (and spends no issue slots on finding one)
     }
     __syncthreads();
     unsigned long long v0 = lane < THREADS / 64 * kFxB ? s_wtop[lane] : 0ull, v1 = lane + 64 < THREADS / 64 * kFxB ? s_wtop[lane + 64] : 0ull;
@@ -269,7 +279,7 @@ HNS_DEV void fps_top(unsigned long long (&mine)[2], int nb, unsigned long long *
 // workgroup never showed up.
 template <int THREADS, int XM>
 HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, int r, const unsigned long long *s_top, int nb, int max_accept,
-                           int *s_acc, int *s_nacc, int *s_fail, float *s_rows, float *warm) {
+                           int *s_acc, unsigned *s_key, int *s_nacc, int *s_fail, float *s_rows, float *warm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = p.d;
     const unsigned long long tag = (unsigned long long)(r % 4095 + 1) << 52;
     gu64 *slot = gran + (size_t)(r & 1) * G * kFxB;
@@ -309,8 +319,10 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) v[u] &= 0xFFFFFFFFFFFFFull;
-        // the global top nb: nb max-reductions over the wave, the lane holding a winner clears it
-        unsigned long long gtop[kFxB];
+        // the global top nb: nb max-reductions over the wave, the lane holding a winner clears it.  A winner's row is requested the moment it is
+        // known (lane c loads coordinate c; the loads of winner m fly while winners m + 1 ... are still being found) and lands in LDS behind the
+        // last pass: the dependent fetch of the rows used to follow the whole selection — a memory round trip on the exchange's serial path.
+        float rowv[kFxB];
 #pragma unroll
         for (int pass = 0; pass < kFxB; ++pass) {
             unsigned long long gb = 0ull;
@@ -321,32 +333,16 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
 #pragma unroll
                 for (int u = 0; u < U; ++u) v[u] = (gb != 0ull && v[u] == gb) ? 0ull : v[u];
             }
-            gtop[pass] = gb;
-        }
-        int gi[kFxB];
-        float gd[kFxB];
-#pragma unroll
-        for (int m = 0; m < kFxB; ++m) {
-            gi[m] = (int)(0xFFFFFu - (unsigned)(gtop[m] & 0xFFFFFu));
-            const unsigned key = (unsigned)(gtop[m] >> 20);      // min-distance bits + 1; 0 = no candidate (or a point already chosen)
-            gd[m] = key != 0u ? __uint_as_float(key - 1u) : kInf;
-        }
-        // the candidates' coordinates: ONE cooperative fetch into LDS (rows of kFxD floats, zero-padded) — the pair distances below and, behind
-        // the barrier, every thread's update read them there; a scalar load per accepted sample from every wave was a dependent
-        // memory round trip each (measured: 11.8 us per exchange of four)
-        if (lane == 0) {
-#pragma unroll
-            for (int m = 0; m < kFxB; ++m) s_acc[m] = gtop[m] != 0ull ? gi[m] : -1;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (!fail) {
-            for (int idx = lane; idx < kFxB * kFxD; idx += 64) {
-                const int m = idx / kFxD, c = idx - m * kFxD;
-                const int gim = s_acc[m];
-                s_rows[idx] = (gim >= 0 && c < d) ? p.points[(size_t)gim * d + c] : 0.0f;
+            const int gim = (gb != 0ull && !fail) ? (int)(0xFFFFFu - (unsigned)(gb & 0xFFFFFu)) : -1;
+            if (lane == 0) {
+                s_acc[pass] = gim;
+                s_key[pass] = (unsigned)(gb >> 20);                // min-distance bits + 1; 0 = no candidate (or a point already chosen)
             }
+            rowv[pass] = (gim >= 0 && lane < d) ? p.points[(size_t)gim * d + lane] : 0.0f;      // (rows of kFxD floats, zero-padded)
+        }
+        if (lane < kFxD) {
+#pragma unroll
+            for (int m = 0; m < kFxB; ++m) s_rows[m * kFxD + lane] = rowv[m];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -368,15 +364,17 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
             }
         }
         // accepted prefix: candidate m needs dist(m, j) >= d(m) for every j < m
-        int nacc = gtop[0] != 0ull ? 1 : 0;
+        int nacc = s_acc[0] >= 0 ? 1 : 0;
         bool open = nacc == 1;
 #pragma unroll
         for (int m = 1; m < kFxB; ++m) {
-            bool okm = open && m < nb && gtop[m] != 0ull;
+            const unsigned key = s_key[m];
+            const float gdm = key != 0u ? __uint_as_float(key - 1u) : kInf;
+            bool okm = open && m < nb && s_acc[m] >= 0;
 #pragma unroll
             for (int j = 0; j < m; ++j) {
                 const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), j + m * (m - 1) / 2));
-                okm = okm && (dj >= gd[m]);
+                okm = okm && (dj >= gdm);
             }
             open = okm;
             nacc += okm ? 1 : 0;
@@ -384,7 +382,7 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
         nacc = nacc < max_accept ? nacc : max_accept;
         if (lane == 0) {
             *s_nacc = nacc;
-            if (fail || gtop[0] == 0ull) *s_fail = 1;          // (no candidate at all cannot happen while samples are still due: k <= n)
+            if (fail || s_acc[0] < 0) *s_fail = 1;             // (no candidate at all cannot happen while samples are still due: k <= n)
         }
     }
     __syncthreads();
@@ -409,18 +407,25 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
     __shared__ __align__(16) float s_rows[kFxB * kFxD];            // the newest samples' coordinates (written by wave 0 in the exchange)
     __shared__ unsigned long long s_top[kFxB];
     __shared__ int s_acc[kFxB];                                    // the newest samples' indices (the first: `start`)
+    __shared__ unsigned s_key[kFxB];                               // ... and their distance keys (exchange)
     __shared__ int s_nacc;
     __shared__ int s_fail;
     const int G = kFxGroups * p.xcds;
     const int tid = threadIdx.x, g_self = (blockIdx.x / kFxStride) * p.xcds + blockIdx.x % kFxStride;
-    const int gtid = g_self * kFxThreads + tid, stride = G * kFxThreads, d = p.d;
+    // Point (slot, workgroup) = index slot * G + workgroup, slot = tid (+ j * 1024): the points are dealt round-robin over the workgroups, so that every
+    // workgroup holds the same number (70 536 points on 128 workgroups: 551-552 each, the first 9 of a workgroup's 16 waves) and the waves behind
+    // a workgroup's last point skip the distance update and the candidate search — they used to run both on copies of the last point.  (Before: blocks
+    // of 1024 consecutive points per workgroup, 59 of 128 workgroups without any, the others full: four busy waves per SIMD where there are now two.)
+    // Which thread holds a point does not enter the result: candidates are ordered by (distance, index).
+    const int d = p.d;
     const int nb = p.batch < 1 ? 1 : (p.batch > kFxB ? kFxB : p.batch);
+    const bool wave_active = (tid & ~63) * G + g_self < p.n;       // the wave's first lane holds a point (slot of lane 0, first pass)
     gu64 *gran = (gu64 *)(p.scratch + 8);
     float x[PTS][kFxD], dist[PTS];
 #pragma unroll
     for (int j = 0; j < PTS; ++j) {
         dist[j] = kInf;
-        int i = gtid + j * stride;
+        int i = (tid + j * kFxThreads) * G + g_self;
         i = i < p.n ? i : p.n - 1;                      // beyond the end: a copy of the last point, never a candidate (see below)
         const float *row = p.points + (size_t)i * d;
 #pragma unroll
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         // the newest samples' coordinates sit in LDS (uniform addresses: broadcast reads, 4 at a time); every point's distance to each of
         // them stays ONE sequential fmaf chain over the coordinates (= the oracle)
 #pragma unroll 1
-        for (int m = 0; m < ncur; ++m) {
+        for (int m = 0; m < (wave_active ? ncur : 0); ++m) {
             const int cm = s_acc[m];
             const float4 *qrow = reinterpret_cast<const float4 *>(s_rows + m * kFxD);
             float acc[PTS];
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
             }
 #pragma unroll
             for (int j = 0; j < PTS; ++j) {
-                const int i = gtid + j * stride;
+                const int i = (tid + j * kFxThreads) * G + g_self;
                 // a chosen point leaves the pool (-1 never wins), so the k indices are distinct even among duplicates
                 dist[j] = (i == cm) ? -1.0f : (acc[j] < dist[j] ? acc[j] : dist[j]);
             }
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         unsigned long long mine[2] = {0ull, 0ull};
 #pragma unroll
         for (int j = 0; j < PTS; ++j) {
-            const int i = gtid + j * stride;
+            const int i = (tid + j * kFxThreads) * G + g_self;
             const float m = dist[j];
             const unsigned long long key = m < 0.0f ? 0ull : (unsigned long long)__float_as_uint(m) + 1ull;
             const unsigned long long cand = (i < p.n && key != 0ull) ? ((key << 20) | (unsigned long long)(0xFFFFFu - (unsigned)i)) : 0ull;
@@ -483,9 +488,9 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
             else if (cand > mine[1]) mine[1] = cand;
         }
         static_assert(PTS <= 2, "a thread's candidates are a sorted pair");
-        fps_top<kFxThreads>(mine, nb, s_wtop, s_top);
+        fps_top<kFxThreads>(mine, nb, s_wtop, s_top, wave_active);
         const int left = p.k - nout;
-        ncur = fps_exchange_b<kFxThreads, XM>(p, gran, G, g_self, r, s_top, nb, left < kFxB ? left : kFxB, s_acc, &s_nacc, &s_fail, s_rows, &warm);
+        ncur = fps_exchange_b<kFxThreads, XM>(p, gran, G, g_self, r, s_top, nb, left < kFxB ? left : kFxB, s_acc, s_key, &s_nacc, &s_fail, s_rows, &warm);
         if (ncur < 0) return;
     }
     if (warm == -1.0f) p.scratch[1] = 1;               // never true (coordinates are normalised to [0, 1]): the loads above are not dead
