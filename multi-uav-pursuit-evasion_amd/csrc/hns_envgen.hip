@@ -204,7 +204,25 @@ constexpr int kFxThreads = 1024, kFxGroups = 32, kFxStride = 8, kFxPts = 2, kFxD
 // prefix is applied in one round.  The indices are those of sequential sampling, bit for bit (tests/test_hip_envgen.py against the oracle's
 // sequential loop); only the number of exchanges changes: ~k / (mean accepted) instead of k.
 constexpr int kFxB = 8;
+// ... of which a WORKGROUP contributes at most kFxT, plus a bound (round 5).  The global top 8 of 70 000 points come from 6-8 different workgroups
+// almost always, yet every wave used to extract its top 8 (eight serial wave maxima), every workgroup its top 8 of those, and wave 0 the global top 8
+// of 8 x workgroups granules — two thirds of an exchange's 12 us went into selections (tools/fps_phases.py).  Now a wave extracts its top kFxT + 1, the
+// workgroup publishes its top kFxT as candidates and its (kFxT + 1)-th key as a BOUND: every point of the workgroup that is not published ranks below it.
+// The global selection runs over the candidates only and stops at the first winner that does not beat the largest bound — below that, an unpublished
+// point could rank higher, so the sequential algorithm's next sample is not decided by what was exchanged.  The first winner always beats every bound
+// (the largest key overall is some workgroup's first candidate), so every exchange yields a sample; the indices stay those of sequential sampling, only
+// (rarely: three of the global top 8 in one workgroup, ~1.4 % of the exchanges with 64 workgroups) an exchange ends a few samples early.
+constexpr int kFxT = 2, kFxP = kFxT + 1;
 
+
+#ifdef FPS_PHASES
+#define FPS_STAMP(i) do { if ((threadIdx.x >> 6) == 0 && blockIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); fps_ph[i] += (unsigned)(t_ - fps_last); fps_last = t_; if ((i) == 6) fps_nx += 1; } } while (0)
+__device__ unsigned fps_ph[8];
+__device__ unsigned fps_nx;
+__device__ unsigned long long fps_last;
+#else
+#define FPS_STAMP(i) do {} while (0)
+#endif
 
 // Maximum of a 32-bit value over the wave, uniform result: the row_shr / row_bcast ladder on the VALU's data-parallel primitives (six
 // v_max_u32_dpp and one v_readlane).  `__shfl_xor` trees go through ds_bpermute — an LDS round trip per step, two per 64-bit key: twelve
@@ -235,43 +253,44 @@ HNS_DEV unsigned long long wave_max_key(unsigned long long k) {
     return ((unsigned long long)mh << 20) | (unsigned long long)ml;
 }
 
-// The workgroup's top `nb` keys, left in s_top[0 .. kFxB) (LDS: whatever is indexed by a run-time value lives there — a register array indexed
+// The workgroup's top `pp` keys (its candidates and, last, its bound), left in s_top[0 .. kFxP) (LDS: whatever is indexed by a run-time value lives there — a register array indexed
 // by the lane or by a loop counter ends up in scratch memory): every wave takes its own top nb (nb wave maxima, the lane that owns a winner pops
 // it from its sorted pair), parks them in LDS, and after ONE workgroup barrier every wave takes the top nb of those (THREADS / 64) x kFxB
 // values — one per lane at 1024 threads.
 template <int THREADS>
-HNS_DEV void fps_top(unsigned long long (&mine)[2], int nb, unsigned long long *s_wtop, unsigned long long *s_top, bool wave_active) {
-    static_assert(THREADS / 64 * kFxB <= 128, "at most two parked candidates per lane");
+HNS_DEV void fps_top(unsigned long long (&mine)[2], int pp, unsigned long long *s_wtop, unsigned long long *s_top, bool wave_active) {
+    static_assert(THREADS / 64 * kFxP <= 64, "one parked key per lane");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave_active) {
 #pragma unroll
-        for (int pass = 0; pass < kFxB; ++pass) {
+        for (int pass = 0; pass < kFxP; ++pass) {
             unsigned long long best = 0ull;
-            if (pass < nb) {
+            if (pass < pp) {
                 best = wave_max_key(mine[0]);
                 if (best != 0ull && mine[0] == best) { mine[0] = mine[1]; mine[1] = 0ull; }
             }
-            if (lane == 0) s_wtop[wave * kFxB + pass] = best;
+            if (lane == 0) s_wtop[wave * kFxP + pass] = best;
         }
-    } else if (lane < kFxB) {
-        s_wtop[wave * kFxB + lane] = 0ull;                   // a wave that holds no point has no candidate (and spends no issue slots on finding one)
+    } else if (lane < kFxP) {
+        s_wtop[wave * kFxP + lane] = 0ull;                   // a wave that holds no point has no candidate (and spends no issue slots on finding one)
     }
     __syncthreads();
-    unsigned long long v0 = lane < THREADS / 64 * kFxB ? s_wtop[lane] : 0ull, v1 = lane + 64 < THREADS / 64 * kFxB ? s_wtop[lane + 64] : 0ull;
-    if (wave != 0) return;                                   // (the publishers are threads 0 .. nb - 1)
+    FPS_STAMP(1);
+    unsigned long long v0 = lane < THREADS / 64 * kFxP ? s_wtop[lane] : 0ull;
+    if (wave != 0) return;                                   // (the publishers are threads 0 .. pp - 1)
 #pragma unroll
-    for (int pass = 0; pass < kFxB; ++pass) {
+    for (int pass = 0; pass < kFxP; ++pass) {
         unsigned long long best = 0ull;
-        if (pass < nb) {
-            best = wave_max_key(v0 > v1 ? v0 : v1);
+        if (pass < pp) {
+            best = wave_max_key(v0);
             v0 = (best != 0ull && v0 == best) ? 0ull : v0;
-            v1 = (best != 0ull && v1 == best) ? 0ull : v1;
         }
         if (lane == 0) s_top[pass] = best;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    FPS_STAMP(2);
 }
 
 // One exchange: publish the workgroup's top `nb` candidates, sweep everybody's, take the global top nb, accept the prefix that sequential
@@ -282,12 +301,13 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
                            int *s_acc, unsigned *s_key, int *s_nacc, int *s_fail, float *s_rows, float *warm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = p.d;
     const unsigned long long tag = (unsigned long long)(r % 4095 + 1) << 52;
-    gu64 *slot = gran + (size_t)(r & 1) * G * kFxB;
-    if (tid < kFxB) {
+    const int tp = nb < kFxT ? nb : kFxT, pp = tp + 1;     // this workgroup's candidates, and its bound behind them
+    gu64 *slot = gran + (size_t)(r & 1) * G * kFxP;
+    if (tid < kFxP) {
         const unsigned long long mine = s_top[tid];
-        if (tid < nb) {
-            __hip_atomic_store(slot + g_self * kFxB + tid, tag | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (mine != 0ull) {
+        if (tid < pp) {
+            __hip_atomic_store(slot + g_self * kFxP + tid, tag | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mine != 0ull && tid < tp) {
                 // pull the candidate's row into the XCD's L2 while the exchange is in flight: if it wins, every workgroup fetches it next
                 const int ci = (int)(0xFFFFFu - (unsigned)(mine & 0xFFFFFu));
                 const float *row = p.points + (size_t)ci * d;
@@ -298,17 +318,18 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
         }
     }
     if (wave == 0) {
-        constexpr int U = kFxGroups * XM * kFxB / 64;         // granules per lane with XM XCDs at work
+        constexpr int U = kFxGroups * XM * kFxP / 64;         // granules per lane with XM XCDs at work
+        static_assert(U * 64 == kFxGroups * XM * kFxP, "whole granules per lane");
         unsigned long long v[U];
-        const int total = G * kFxB;
+        const int total = G * kFxP;
         bool fail = false;
         unsigned spins = 0;
         for (;;) {
             bool ok = true;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int g = u * 64 + lane;                    // granule (workgroup g / kFxB, candidate g % kFxB): only the first nb of a workgroup are written
-                const bool live = g < total && (g & (kFxB - 1)) < nb;
+                const int g = u * 64 + lane;                    // granule (workgroup g / kFxP, key g % kFxP): only the first pp of a workgroup are written
+                const bool live = g < total && (g % kFxP) < pp;
                 v[u] = live ? __hip_atomic_load(slot + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
             }
 #pragma unroll
@@ -317,8 +338,17 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
             if (++spins > kFpsSpinLimit) { fail = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }
+        FPS_STAMP(3);
+        // the largest bound: no unpublished point ranks above it; the bounds themselves are not candidates
+        unsigned long long gbound = 0ull;
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] &= 0xFFFFFFFFFFFFFull;
+        for (int u = 0; u < U; ++u) {
+            v[u] &= 0xFFFFFFFFFFFFFull;
+            const bool is_bound = ((u * 64 + lane) % kFxP) == tp;
+            gbound = (is_bound && v[u] > gbound) ? v[u] : gbound;
+            v[u] = is_bound ? 0ull : v[u];
+        }
+        gbound = wave_max_key(gbound);
         // the global top nb: nb max-reductions over the wave, the lane holding a winner clears it.  A winner's row is requested the moment it is
         // known (lane c loads coordinate c; the loads of winner m fly while winners m + 1 ... are still being found) and lands in LDS behind the
         // last pass: the dependent fetch of the rows used to follow the whole selection — a memory round trip on the exchange's serial path.
@@ -330,6 +360,7 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
 #pragma unroll
                 for (int u = 0; u < U; ++u) gb = v[u] > gb ? v[u] : gb;
                 gb = wave_max_key(gb);
+                gb = gb > gbound ? gb : 0ull;                 // at or below the largest bound an unpublished point could rank higher: the decided prefix ends here
 #pragma unroll
                 for (int u = 0; u < U; ++u) v[u] = (gb != 0ull && v[u] == gb) ? 0ull : v[u];
             }
@@ -340,6 +371,7 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
             }
             rowv[pass] = (gim >= 0 && lane < d) ? p.points[(size_t)gim * d + lane] : 0.0f;      // (rows of kFxD floats, zero-padded)
         }
+        FPS_STAMP(4);
         if (lane < kFxD) {
 #pragma unroll
             for (int m = 0; m < kFxB; ++m) s_rows[m * kFxD + lane] = rowv[m];
@@ -379,6 +411,7 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
             open = okm;
             nacc += okm ? 1 : 0;
         }
+        FPS_STAMP(5);
         nacc = nacc < max_accept ? nacc : max_accept;
         if (lane == 0) {
             *s_nacc = nacc;
@@ -386,6 +419,7 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
         }
     }
     __syncthreads();
+    FPS_STAMP(6);
     if (*s_fail) {
         if (tid == 0) __hip_atomic_store((gu64 *)p.scratch, 1ull + (unsigned long long)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return -1;
@@ -403,9 +437,9 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
 template <int PTS, int XM>
 __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams p) {
     if ((int)(blockIdx.x % kFxStride) >= p.xcds) return;
-    __shared__ unsigned long long s_wtop[kFxThreads / 64 * kFxB];
+    __shared__ unsigned long long s_wtop[kFxThreads / 64 * kFxP];
     __shared__ __align__(16) float s_rows[kFxB * kFxD];            // the newest samples' coordinates (written by wave 0 in the exchange)
-    __shared__ unsigned long long s_top[kFxB];
+    __shared__ unsigned long long s_top[kFxP];
     __shared__ int s_acc[kFxB];                                    // the newest samples' indices (the first: `start`)
     __shared__ unsigned s_key[kFxB];                               // ... and their distance keys (exchange)
     __shared__ int s_nacc;
@@ -446,6 +480,7 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         }
         nout += ncur;
         if (nout >= p.k) break;
+        FPS_STAMP(7);
         // the newest samples' coordinates sit in LDS (uniform addresses: broadcast reads, 4 at a time); every point's distance to each of
         // them stays ONE sequential fmaf chain over the coordinates (= the oracle)
 #pragma unroll 1
@@ -477,6 +512,7 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
                 dist[j] = (i == cm) ? -1.0f : (acc[j] < dist[j] ? acc[j] : dist[j]);
             }
         }
+        FPS_STAMP(0);
         unsigned long long mine[2] = {0ull, 0ull};
 #pragma unroll
         for (int j = 0; j < PTS; ++j) {
@@ -488,11 +524,14 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
             else if (cand > mine[1]) mine[1] = cand;
         }
         static_assert(PTS <= 2, "a thread's candidates are a sorted pair");
-        fps_top<kFxThreads>(mine, nb, s_wtop, s_top, wave_active);
+        fps_top<kFxThreads>(mine, (nb < kFxT ? nb : kFxT) + 1, s_wtop, s_top, wave_active);
         const int left = p.k - nout;
         ncur = fps_exchange_b<kFxThreads, XM>(p, gran, G, g_self, r, s_top, nb, left < kFxB ? left : kFxB, s_acc, s_key, &s_nacc, &s_fail, s_rows, &warm);
         if (ncur < 0) return;
     }
+#ifdef FPS_PHASES
+    if (g_self == 0 && tid < 6) p.scratch[2 + tid] = tid < 4 ? (unsigned long long)fps_ph[2 * tid] | ((unsigned long long)fps_ph[2 * tid + 1] << 32) : (tid == 4 ? (unsigned long long)fps_nx : 0ull);
+#endif
     if (warm == -1.0f) p.scratch[1] = 1;               // never true (coordinates are normalised to [0, 1]): the loads above are not dead
 }
 
