@@ -341,18 +341,21 @@ def curriculum_update(gen_buffer, active_cylinders, num_cylinders, R_min, R_max)
     """The generator's update at the end of every `eval_iter`-th episode (hideandseek_envgen.py:1311-1333): `gen_buffer.update()` (the mean success
     weight of every task over the episodes it was replayed), the per-cylinder-count statistics, the tasks whose weight lies in [R_min, R_max]
     inserted into the history (trimmed by farthest-point sampling).  `gen_buffer` is a DeviceGenBuffer (tensors on the env's GPU) or the host
-    GenBuffer (numpy); returns (count of tasks per number of active cylinders [C+1], sum of their weights [C+1], number of tasks kept) — numpy fp64."""
+    GenBuffer (numpy); returns (count of tasks per number of active cylinders [C+1], sum of their weights [C+1] — fp64 tensors on the buffer's device,
+    nothing is read back for them — and the number of tasks kept)."""
     gen_buffer.update()
     w = torch.as_tensor(gen_buffer._weight_buffer).reshape(-1)
     act = torch.as_tensor(active_cylinders).reshape(-1).long().to(w.device)
-    counts = torch.bincount(act, minlength=num_cylinders + 1).double()
-    sums = torch.bincount(act, weights=w.double(), minlength=num_cylinders + 1)
-    both = torch.stack([counts, sums]).cpu().numpy()                  # one read-back for the 2(C+1) statistics
+    # (a one-hot sum instead of torch.bincount — which reads the largest index back to size its output, a host synchronisation per call — and instead of
+    #  index_add_, whose 65 536 fp64 atomics on nine addresses took 5 ms)
+    onehot = (act.unsqueeze(1) == torch.arange(num_cylinders + 1, device=w.device).unsqueeze(0)).double()        # [n, C + 1]
+    counts = onehot.sum(0)
+    sums = (onehot * w.double().unsqueeze(1)).sum(0)
     keep = (w <= R_max) & (w >= R_min)
     states = gen_buffer._state_buffer
-    kept = states[keep] if isinstance(states, torch.Tensor) else states[keep.cpu().numpy()]
+    kept = states[keep] if isinstance(states, torch.Tensor) else states[keep.cpu().numpy()]      # (the one read-back: how many tasks are kept)
     gen_buffer.insert_history(kept)                                   # (global mode: every rank takes part, also with nothing to add)
-    return both[0], both[1], int(kept.shape[0])
+    return counts, sums, int(kept.shape[0])
 
 
 class HideAndSeek_envgen(HideAndSeek):
@@ -390,7 +393,10 @@ class HideAndSeek_envgen(HideAndSeek):
         self.active_cylinders = torch.zeros(E, 1, device=self.device)
         extra = ["success_buffer", "success_unif", "history_buffer", "add_history", "ratio_unif"]
         extra += [f"ratio_cylinders_{i}" for i in range(Cn + 1)] + [f"success_cylinders_{i}" for i in range(Cn + 1)]
-        self._extra = {k: torch.zeros(E, 1, device=self.device) for k in extra}   # :617-651
+        # :617-651 — rows of ONE [n, E] buffer (a statistic is filled by one row assignment, the whole set cloned by one copy)
+        self._extra_buf = torch.zeros(len(extra), E, device=self.device)
+        self._extra_row = {k: i for i, k in enumerate(extra)}
+        self._extra = {k: self._extra_buf[i].unsqueeze(-1) for i, k in enumerate(extra)}
         for k, v in self._extra.items():
             self.stats.set(k, v)
         self.generator_seconds = 0.0
@@ -414,13 +420,26 @@ class HideAndSeek_envgen(HideAndSeek):
         # ... and the shape of the FIRST real update (empty history + every env's task: another launch shape of the trim), with
         # the statistics of _episode_end, so that no first-use cost is left for the first task batch (it read 39 ms against 15 ms
         # for the later ones in round 3's bench, 112 ms on the driver's box of round 2)
+        # (the real code path — curriculum_update on a stand-in batch, the row assignments of _episode_end — so that every torch kernel it launches has
+        #  been launched once: the first real update read 26 ms against 6.7 ms when only the trim had been warmed)
         g._history = torch.zeros(0, g.task_dim, device=self.device)
-        g.insert_history(torch.rand(self.num_envs, g.task_dim, device=self.device))
-        act = torch.zeros(self.num_envs, dtype=torch.long, device=self.device)
-        w = torch.rand(self.num_envs, device=self.device)
-        torch.stack([torch.bincount(act, minlength=self.num_cylinders + 1).double(),
-                     torch.bincount(act, weights=w.double(), minlength=self.num_cylinders + 1)]).cpu()
-        _ = self._tasks_dev[(w <= 1.0) & (w >= 0.0)]
+        g.insert(torch.rand(self.num_envs, g.task_dim, device=self.device))
+        w = torch.rand(self.num_envs, 1, device=self.device)
+        g.insert_weights(w)
+        counts, sums, _ = curriculum_update(g, torch.zeros(self.num_envs, 1, device=self.device), self.num_cylinders, 0.0, 1.0)
+        buf, row, Cn = self._extra_buf, self._extra_row, self.num_cylinders
+        flat = w.reshape(-1)
+        rates = torch.stack([flat[1:].mean(), flat[:1].mean(), flat.mean()])
+        buf[row["success_buffer"]] = rates[0]
+        buf[row["success_unif"]] = flat
+        float(rates[2])
+        r0 = row["ratio_cylinders_0"]
+        buf[r0:r0 + Cn + 1] = (counts / self.num_envs).float().unsqueeze(1)
+        buf[r0:r0 + Cn + 1] = torch.where(counts > 0, sums / counts.clamp(min=1.0), torch.zeros_like(sums)).float().unsqueeze(1)
+        buf[row["add_history"]] = 1.0
+        buf.zero_()
+        int(self._bufs["done"].sum(dtype=torch.int32))
+        self._clone_stats()
         g._history = keep
         torch.cuda.synchronize(self.device)
 
@@ -437,7 +456,7 @@ class HideAndSeek_envgen(HideAndSeek):
         mask_t = None
         if tensordict is not None and "_reset" in tensordict.keys():
             mask_t = tensordict.get("_reset").reshape(self.num_envs).to(torch.uint8).contiguous()
-        last_stats = self.stats.clone()
+        last_stats = self._clone_stats()
         E = self.num_envs
         t0 = time.perf_counter()
         mptr = C.c_void_p(mask_t.data_ptr()) if mask_t is not None else None
@@ -475,32 +494,49 @@ class HideAndSeek_envgen(HideAndSeek):
     def _episode_mirror_needed(self):
         return bool(self.use_particle_generator) or super()._episode_mirror_needed()
 
+    def _note_reset(self, mask_t):
+        """Episodes run in lock step: when the last step saw EVERY env done and the reset's mask is the env's own `done` buffer (what the step wrote, what
+        the reset kernel reads), every env starts over — known without reading max(progress) back."""
+        if mask_t is not None and getattr(self, "_all_done", False) and mask_t.data_ptr() == self._done_ptr:
+            self._since_full_reset = 0
+            return
+        super()._note_reset(mask_t)
+
     # ---- curriculum at episode end, hideandseek_envgen.py:1241-1246, 1302-1333 ----------------------------
     def _step(self, tensordict):
         out = super()._step(tensordict)
         if self.use_particle_generator and self._since_full_reset >= self.max_episode_length:
-            done = self._bufs["done"]
-            if bool(done.any()):
+            n_done = int(self._bufs["done"].sum(dtype=torch.int32))        # ONE read-back: is any env done, and are they all
+            self._all_done = n_done == self.num_envs
+            if n_done:
                 self._episode_end()
+        else:
+            self._all_done = False
         return out
 
     def _episode_end(self):
+        """hideandseek_envgen.py:1241-1246, :1302-1336 at the end of an episode.  Host synchronisations: ONE read-back of the three success rates
+        (the threshold decision below needs a host value) and, every `eval_iter`-th episode, the number of tasks kept + the end of the trim.  Every
+        statistic is a row of `_extra_buf`, filled by row assignments from device values."""
         import time
         t0 = time.perf_counter()
         E, Cn = self.num_envs, self.num_cylinders
         success = self.stats["success"]
-        ex = self._extra
-        if self.num_unif < E:
-            ex["success_buffer"].fill_(float(success[self.num_unif:].mean()))
-            ex["success_unif"].fill_(float(success[:self.num_unif].mean()))
+        buf, row = self._extra_buf, self._extra_row
+        split = self.num_unif < E
+        flat = success.reshape(-1)
+        rates = torch.stack([flat[self.num_unif:].mean() if split else flat.sum() * 0.0, flat[:self.num_unif].mean(), flat.mean()])
+        if split:
+            buf[row["success_buffer"]] = rates[0]
+            buf[row["success_unif"]] = rates[1]
         else:
-            ex["success_buffer"].zero_()
-            ex["success_unif"].copy_(success)
+            buf[row["success_buffer"]] = 0.0
+            buf[row["success_unif"]] = flat
         if self.global_gen_buffer:
             from . import sharding
             mean_success = sharding.global_mean(success)
         else:
-            mean_success = float(success.mean())
+            mean_success = float(rates[2])
         if mean_success > self.success_threshold:
             self.ratio_unif = 1.0
         self.gen_buffer.insert_weights(success)
@@ -508,13 +544,21 @@ class HideAndSeek_envgen(HideAndSeek):
         if self.update_iter >= self.eval_iter:
             self.update_iter = 0
             counts, sums, n_kept = curriculum_update(self.gen_buffer, self.active_cylinders, Cn, self.R_min, self.R_max)
-            for i in range(Cn + 1):
-                ex[f"ratio_cylinders_{i}"].fill_(float(counts[i] / E))
-                ex[f"success_cylinders_{i}"].fill_(float(sums[i] / counts[i]) if counts[i] > 0 else 0.0)
-            ex["add_history"].fill_(float(n_kept))
-        ex["history_buffer"].fill_(float(len(self.gen_buffer)))
-        ex["ratio_unif"].fill_(self.ratio_unif)
+            r0, r1 = row["ratio_cylinders_0"], row["success_cylinders_0"]
+            buf[r0:r0 + Cn + 1] = (counts / E).float().unsqueeze(1)
+            buf[r1:r1 + Cn + 1] = torch.where(counts > 0, sums / counts.clamp(min=1.0), torch.zeros_like(sums)).float().unsqueeze(1)
+            buf[row["add_history"]] = float(n_kept)
+        buf[row["history_buffer"]] = float(len(self.gen_buffer))
+        buf[row["ratio_unif"]] = self.ratio_unif
         self.generator_seconds += time.perf_counter() - t0
+
+    def _clone_stats(self):
+        """The base class's one-copy clone of the 24 task statistics + one copy of the generator's rows."""
+        td = super()._clone_stats(skip=self._extra_row)
+        extra = self._extra_buf.clone()
+        for k, i in self._extra_row.items():
+            td.set(k, extra[i].unsqueeze(-1))
+        return td
 
 
 HideAndSeek.REGISTRY["HideAndSeek_envgen"] = HideAndSeek_envgen
