@@ -714,6 +714,8 @@ def main():
                                   f"(oracle/hns_oracle.c): {best_n} threads (best of a probe up to {avail}) {mdt:.1f} s, 1 thread {cdt:.1f} s"}
 
     if rank == 0:
+        import hashlib
+        lib_sha16 = hashlib.sha256(open(abi.library_path(), "rb").read()).hexdigest()[:16]     # the same digest heads the profiles/*.txt of this build
         out = {
             "metric": "env agent-steps/sec at 65536 envs, HideAndSeek 3v1; 1/2/4/8 GPU",
             "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": n_devices, "steps": args.steps,
@@ -724,7 +726,7 @@ def main():
                        "num_envs_per_gpu": E, "num_agents": A, "num_targets": args.targets, "num_cylinders": C, "obs_max_cylinder": K,
                        "episode_length": args.episode, "critic_state_output": args.critic_state,
                        "sharding": f"contiguous env slices x{n_ranks}", "world_size_launched": world, "ranks": n_ranks,
-                       "dist_backend": backend,
+                       "dist_backend": backend, "library_sha16": lib_sha16,
                        "collective": "1 all-gather of 5 fp64 per 64-step rollout" if dist is not None else "none"},
             "collective_us": collective, "state_digest": state_digest,
             "env_frames_per_s": round(value / A, 1),

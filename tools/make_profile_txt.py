@@ -37,6 +37,17 @@ def main():
     nbytes = 0.0 if flop is not None else float(sys.argv[3])
     title = " ".join(sys.argv[4:]) or os.path.basename(d.rstrip("/"))
     files = sorted(glob.glob(os.path.join(d, "*.csv")))
+    # the profile must belong to the library it claims to describe: refuse summaries older than the built library (VERDICT r4 #1c: a profile three
+    # commits older than the kernel it was quoted for), and name the library by its digest (bench.py prints the same digest in its line)
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multi-uav-pursuit-evasion_amd", "libhns.so")
+    lib_note = ""
+    if os.path.exists(lib):
+        stale = [f for f in files if os.path.getmtime(f) < os.path.getmtime(lib)]
+        if stale and not os.environ.get("HNS_PROFILE_ALLOW_STALE"):
+            sys.stderr.write(f"make_profile_txt: {stale} older than {lib}: profile again with the current build\n")
+            raise SystemExit(3)
+        lib_note = "libhns.so sha256 " + hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
     stats, counters, pmc_ns = None, {}, []
     for f in files:
         for hdr, rows in read_tables(f):
@@ -52,7 +63,7 @@ def main():
                 elif hdr[1] == "counter":
                     counters[r[1]] = float(r[4])
     out = [f"# {title}", f"# composed by tools/make_profile_txt.py from {d}/*.csv (rocprofv3 --kernel-trace --stats, and separate --kernel-trace --pmc passes; "
-           "tools/rocpd_summary.py); every number in this header is computed from the tables below"]
+           "tools/rocpd_summary.py); every number in this header is computed from the tables below" + (f"; {lib_note}" if lib_note else "")]
     if stats:
         t = stats["avg_ns"] * 1e-9
         head = f"# kernel `{sub}`: {stats['calls']} launches, avg {stats['avg_ns'] / 1e3:.3f} us (min {stats['min_ns'] / 1e3:.2f}, max {stats['max_ns'] / 1e3:.2f})"
@@ -85,6 +96,9 @@ def main():
                 r = j.get("roofline") or {}
                 out.append(f"# bench line of the profiled run ({os.path.basename(lg)}; under the profiler): ms_per_step {j.get('ms_per_step')}, roofline.kernel_us "
                            f"{r.get('kernel_us')} (blocks of consecutive launches), frac {r.get('frac')}, step_us {r.get('step_us')}, frac_step_rate {r.get('frac_step_rate')}")
+                t = j.get("tp_mode")
+                if t:
+                    out.append(f"#   its predictor leg: tp_mode.observe_us {t.get('observe_us')}, roofline.frac {t['roofline'].get('frac')}, ms_per_step {t.get('ms_per_step')}, step_kernel_us {t.get('step_kernel_us')}")
     print("\n".join(out))
     for f in files:
         print(f"\n## {os.path.splitext(os.path.basename(f))[0]}")
