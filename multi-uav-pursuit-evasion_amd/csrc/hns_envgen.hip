@@ -203,7 +203,8 @@ constexpr int kFxThreads = 1024, kFxGroups = 32, kFxStride = 8, kFxPts = 2, kFxD
 // distances with the SAME sequential fma chain the update uses (so ">= d" decides exactly what min(d, dist) would), and the accepted
 // prefix is applied in one round.  The indices are those of sequential sampling, bit for bit (tests/test_hip_envgen.py against the oracle's
 // sequential loop); only the number of exchanges changes: ~k / (mean accepted) instead of k.
-constexpr int kFxB = 8;
+constexpr int kFxB = 16;                   // (8 until round 5: with the selections cheap, the accepted prefix was capped 93 % of the time)
+constexpr int kFxPairs = kFxB * (kFxB - 1) / 2;
 // ... of which a WORKGROUP contributes at most kFxT, plus a bound (round 5).  The global top 8 of 70 000 points come from 6-8 different workgroups
 // almost always, yet every wave used to extract its top 8 (eight serial wave maxima), every workgroup its top 8 of those, and wave 0 the global top 8
 // of 8 x workgroups granules — two thirds of an exchange's 12 us went into selections (tools/fps_phases.py).  Now a wave extracts its top kFxT + 1, the
@@ -293,78 +294,100 @@ HNS_DEV void fps_top(unsigned long long (&mine)[2], int pp, unsigned long long *
     FPS_STAMP(2);
 }
 
-// One exchange: publish the workgroup's top `nb` candidates, sweep everybody's, take the global top nb, accept the prefix that sequential
-// sampling would select next (at most max_accept).  Returns the number accepted (their indices in s_acc), or -1 after reporting that a
-// workgroup never showed up.
+// One exchange: publish the workgroup's candidates and its bound, sweep everybody's, take the global top nb among the candidates that beat the largest
+// bound, accept the prefix that sequential sampling would select next (at most max_accept).  Returns the number accepted (their indices in s_acc), or
+// -1 after reporting that a workgroup never showed up.  Granules of one parity: [candidates: workgroup x kFxT][bounds: workgroup].
+// `pairs`: this lane's two candidate pairs (a < b), packed a0 | b0 << 8 | a1 << 16 | b1 << 24 — pair index lane and lane + 64 (the latter for lanes < 56).
+HNS_DEV bool fps_bits_set(unsigned long long m0, unsigned long long m1, int base, int n) {      // bits [base, base + n) of the 128-bit mask (m1:m0), n <= 16
+    const unsigned long long want = (1ull << n) - 1ull;
+    if (base + n <= 64) return ((m0 >> base) & want) == want;
+    if (base >= 64) return ((m1 >> (base - 64)) & want) == want;
+    const int lown = 64 - base;
+    return (m0 >> base) == ((1ull << lown) - 1ull) && (m1 & ((1ull << (n - lown)) - 1ull)) == ((1ull << (n - lown)) - 1ull);
+}
+
 template <int THREADS, int XM>
 HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, int r, const unsigned long long *s_top, int nb, int max_accept,
-                           int *s_acc, unsigned *s_key, int *s_nacc, int *s_fail, float *s_rows, float *warm) {
+                           int *s_acc, unsigned *s_key, int *s_nacc, int *s_fail, float *s_rows, float *warm, unsigned pairs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = p.d;
     const unsigned long long tag = (unsigned long long)(r % 4095 + 1) << 52;
-    const int tp = nb < kFxT ? nb : kFxT, pp = tp + 1;     // this workgroup's candidates, and its bound behind them
+    const int tp = nb < kFxT ? nb : kFxT;                  // this workgroup's candidates; its bound is key number tp of s_top
     gu64 *slot = gran + (size_t)(r & 1) * G * kFxP;
-    if (tid < kFxP) {
+    if (tid <= tp) {
         const unsigned long long mine = s_top[tid];
-        if (tid < pp) {
-            __hip_atomic_store(slot + g_self * kFxP + tid, tag | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (mine != 0ull && tid < tp) {
-                // pull the candidate's row into the XCD's L2 while the exchange is in flight: if it wins, every workgroup fetches it next
-                const int ci = (int)(0xFFFFFu - (unsigned)(mine & 0xFFFFFu));
-                const float *row = p.points + (size_t)ci * d;
-                float a = row[0];
-                for (int c = 8; c < d; c += 8) a += row[c];
-                *warm += a + row[d - 1];
-            }
+        __hip_atomic_store(tid < tp ? slot + g_self * kFxT + tid : slot + G * kFxT + g_self, tag | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mine != 0ull && tid < tp) {
+            // pull the candidate's row into the XCD's L2 while the exchange is in flight: if it wins, every workgroup fetches it next
+            const int ci = (int)(0xFFFFFu - (unsigned)(mine & 0xFFFFFu));
+            const float *row = p.points + (size_t)ci * d;
+            float a = row[0];
+            for (int c = 8; c < d; c += 8) a += row[c];
+            *warm += a + row[d - 1];
         }
     }
     if (wave == 0) {
-        constexpr int U = kFxGroups * XM * kFxP / 64;         // granules per lane with XM XCDs at work
-        static_assert(U * 64 == kFxGroups * XM * kFxP, "whole granules per lane");
-        unsigned long long v[U];
-        const int total = G * kFxP;
+        constexpr int UC = kFxGroups * XM * kFxT / 64, UB = (kFxGroups * XM + 63) / 64;      // candidate / bound granules per lane with XM XCDs at work
+        static_assert(UC * 64 == kFxGroups * XM * kFxT && (UC == 2 || UC == 4), "two or four candidate granules per lane");
+        unsigned long long v[UC], bv[UB];
+        const int ncand = G * kFxT;
         bool fail = false;
         unsigned spins = 0;
         for (;;) {
             bool ok = true;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int g = u * 64 + lane;                    // granule (workgroup g / kFxP, key g % kFxP): only the first pp of a workgroup are written
-                const bool live = g < total && (g % kFxP) < pp;
+            for (int u = 0; u < UC; ++u) {
+                const int g = u * 64 + lane;                    // candidate (workgroup g / kFxT, number g % kFxT): only the first tp of a workgroup are written
+                const bool live = g < ncand && (g % kFxT) < tp;
                 v[u] = live ? __hip_atomic_load(slot + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) ok = ok && ((v[u] >> 52) == (tag >> 52));
+            for (int u = 0; u < UB; ++u) {
+                const int g = u * 64 + lane;
+                bv[u] = g < G ? __hip_atomic_load(slot + ncand + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+            }
+#pragma unroll
+            for (int u = 0; u < UC; ++u) ok = ok && ((v[u] >> 52) == (tag >> 52));
+#pragma unroll
+            for (int u = 0; u < UB; ++u) ok = ok && ((bv[u] >> 52) == (tag >> 52));
             if (__all(ok)) break;
             if (++spins > kFpsSpinLimit) { fail = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         FPS_STAMP(3);
-        // the largest bound: no unpublished point ranks above it; the bounds themselves are not candidates
+        // the largest bound: no unpublished point ranks above it
         unsigned long long gbound = 0ull;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            v[u] &= 0xFFFFFFFFFFFFFull;
-            const bool is_bound = ((u * 64 + lane) % kFxP) == tp;
-            gbound = (is_bound && v[u] > gbound) ? v[u] : gbound;
-            v[u] = is_bound ? 0ull : v[u];
+        for (int u = 0; u < UB; ++u) {
+            const unsigned long long b52 = bv[u] & 0xFFFFFFFFFFFFFull;
+            gbound = b52 > gbound ? b52 : gbound;
         }
         gbound = wave_max_key(gbound);
-        // the global top nb: nb max-reductions over the wave, the lane holding a winner clears it.  A winner's row is requested the moment it is
-        // known (lane c loads coordinate c; the loads of winner m fly while winners m + 1 ... are still being found) and lands in LDS behind the
-        // last pass: the dependent fetch of the rows used to follow the whole selection — a memory round trip on the exchange's serial path.
+        // this lane's candidates in descending order (one compare-exchange, or the five of the four-element network): a pass then compares heads only,
+        // and the lane whose head wins moves up its next one — per pass two instructions per granule used to go into a max and a clear over all of them
+#pragma unroll
+        for (int u = 0; u < UC; ++u) v[u] &= 0xFFFFFFFFFFFFFull;
+#define FPS_CE(i, j) { const unsigned long long hi_ = v[i] > v[j] ? v[i] : v[j], lo_ = v[i] > v[j] ? v[j] : v[i]; v[i] = hi_; v[j] = lo_; }
+        if constexpr (UC == 2) { FPS_CE(0, 1) }
+        else { FPS_CE(0, 1) FPS_CE(2, 3) FPS_CE(0, 2) FPS_CE(1, 3) FPS_CE(1, 2) }
+#undef FPS_CE
+        // the global top nb.  A winner's row is requested the moment it is known (lane c loads coordinate c; the loads of winner m fly while winners
+        // m + 1 ... are still being found) and lands in LDS behind the last pass.
         float rowv[kFxB];
+        bool more = !fail;
 #pragma unroll
         for (int pass = 0; pass < kFxB; ++pass) {
             unsigned long long gb = 0ull;
-            if (pass < nb) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) gb = v[u] > gb ? v[u] : gb;
-                gb = wave_max_key(gb);
+            if (more && pass < nb) {                            // (uniform)
+                gb = wave_max_key(v[0]);
                 gb = gb > gbound ? gb : 0ull;                 // at or below the largest bound an unpublished point could rank higher: the decided prefix ends here
+                if (gb != 0ull && v[0] == gb) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) v[u] = (gb != 0ull && v[u] == gb) ? 0ull : v[u];
+                    for (int u = 0; u + 1 < UC; ++u) v[u] = v[u + 1];
+                    v[UC - 1] = 0ull;
+                }
+                more = gb != 0ull;                            // keys only fall from here on
             }
-            const int gim = (gb != 0ull && !fail) ? (int)(0xFFFFFu - (unsigned)(gb & 0xFFFFFu)) : -1;
+            const int gim = gb != 0ull ? (int)(0xFFFFFu - (unsigned)(gb & 0xFFFFFu)) : -1;
             if (lane == 0) {
                 s_acc[pass] = gim;
                 s_key[pass] = (unsigned)(gb >> 20);                // min-distance bits + 1; 0 = no candidate (or a point already chosen)
@@ -379,35 +402,29 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // pair (a < b) on lane a + b (b - 1) / 2: the update's own chain, dist(x = candidate b, q = candidate a)
-        int pa = 0, pb = 1;
-#pragma unroll
-        for (int b2 = 1; b2 < kFxB; ++b2)
-#pragma unroll
-            for (int a2 = 0; a2 < b2; ++a2)
-                if (lane == a2 + b2 * (b2 - 1) / 2) { pa = a2; pb = b2; }
-        float acc = 0.0f;
-        if (!fail && nb > 1 && lane < kFxB * (kFxB - 1) / 2) {
-            const float *xa = s_rows + pa * kFxD, *xb = s_rows + pb * kFxD;
+        // the pairs' distances — the update's own chain, dist(x = candidate b, q = candidate a) — two pairs per lane; candidate b keeps its key under
+        // candidate a iff dist >= d(b): one predicate per pair, gathered with two ballots
+        const int a0 = pairs & 255, b0 = (pairs >> 8) & 255, a1 = (pairs >> 16) & 255, b1 = pairs >> 24;
+        float acc0 = 0.0f, acc1 = 0.0f;
+        if (!fail && nb > 1) {
+            const float *xa0 = s_rows + a0 * kFxD, *xb0 = s_rows + b0 * kFxD, *xa1 = s_rows + a1 * kFxD, *xb1 = s_rows + b1 * kFxD;
 #pragma unroll 4
             for (int c = 0; c < kFxD; ++c) {                       // (padding: 0 - 0 leaves the chain unchanged)
-                const float df = xb[c] - xa[c];
-                acc = HNS_FMA(df, df, acc);
+                const float df0 = xb0[c] - xa0[c], df1 = xb1[c] - xa1[c];
+                acc0 = HNS_FMA(df0, df0, acc0);
+                acc1 = HNS_FMA(df1, df1, acc1);
             }
         }
-        // accepted prefix: candidate m needs dist(m, j) >= d(m) for every j < m
-        int nacc = s_acc[0] >= 0 ? 1 : 0;
+        const unsigned kb0 = s_key[b0], kb1 = s_key[b1], kme = s_key[lane < kFxB ? lane : 0];
+        const float gd0 = kb0 != 0u ? __uint_as_float(kb0 - 1u) : kInf, gd1 = kb1 != 0u ? __uint_as_float(kb1 - 1u) : kInf;
+        const unsigned long long m0 = __ballot(acc0 >= gd0), m1 = __ballot(lane < kFxPairs - 64 && acc1 >= gd1);
+        const unsigned long long have = __ballot(lane < kFxB && kme != 0u);
+        // accepted prefix: candidate m needs dist(m, j) >= d(m) for every j < m — bits m (m - 1) / 2 ... + m - 1 of the pair mask
+        int nacc = (int)(have & 1ull);
         bool open = nacc == 1;
 #pragma unroll
         for (int m = 1; m < kFxB; ++m) {
-            const unsigned key = s_key[m];
-            const float gdm = key != 0u ? __uint_as_float(key - 1u) : kInf;
-            bool okm = open && m < nb && s_acc[m] >= 0;
-#pragma unroll
-            for (int j = 0; j < m; ++j) {
-                const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), j + m * (m - 1) / 2));
-                okm = okm && (dj >= gdm);
-            }
+            const bool okm = open && m < nb && ((have >> m) & 1ull) != 0ull && fps_bits_set(m0, m1, m * (m - 1) / 2, m);
             open = okm;
             nacc += okm ? 1 : 0;
         }
@@ -415,7 +432,7 @@ HNS_DEV int fps_exchange_b(const FpsParams &p, gu64 *gran, int G, int g_self, in
         nacc = nacc < max_accept ? nacc : max_accept;
         if (lane == 0) {
             *s_nacc = nacc;
-            if (fail || s_acc[0] < 0) *s_fail = 1;             // (no candidate at all cannot happen while samples are still due: k <= n)
+            if (fail || nacc == 0) *s_fail = 1;                // (no candidate at all cannot happen while samples are still due: k <= n)
         }
     }
     __syncthreads();
@@ -471,6 +488,19 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         s_rows[tid] = tid < d ? p.points[(size_t)i0 * d + tid] : 0.0f;
     }
     if (tid == 0) s_acc[0] = p.start;
+    // this lane's two candidate pairs (a < b) for the exchange: pair index lane and lane + 64
+    unsigned pairs = 0u;
+    {
+        const int lane = tid & 63;
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+            const int idx = lane + 64 * which;
+            int b = 1;
+            while ((b + 1) * b / 2 <= idx) ++b;
+            const int a = idx - b * (b - 1) / 2;
+            if (idx < kFxPairs) pairs |= ((unsigned)a | ((unsigned)b << 8)) << (16 * which);
+        }
+    }
     int ncur = 1, nout = 0;
     float warm = 0.0f;                                  // sum of the rows touched to warm the L2 (kept alive by the store below)
     __syncthreads();
@@ -482,34 +512,50 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         if (nout >= p.k) break;
         FPS_STAMP(7);
         // the newest samples' coordinates sit in LDS (uniform addresses: broadcast reads, 4 at a time); every point's distance to each of
-        // them stays ONE sequential fmaf chain over the coordinates (= the oracle)
+        // them stays ONE sequential fmaf chain over the coordinates (= the oracle).  Two samples side by side (round 5: two independent chains, 0.37 ->
+        // 0.33 us per sample; a row beyond `ncur` — another candidate's, always present in LDS — is computed along and not applied).  What bounds the
+        // update is the LDS: nine 16-byte broadcast reads per wave and sample, 9-16 waves per CU.  Measured and dropped: four samples side by side
+        // (57 spilled registers under the 128 of a 1024-thread workgroup), and a sample's row carried in three registers with the coordinate taken
+        // through the DPP row broadcast (v_sub_f32_dpp ... row_newbcast:c — a twelfth of the LDS traffic, the same 72 instructions, and slower:
+        // 13.8 against 12.8 us per exchange, tools/fps_phases.py).
+        constexpr int kGrp = 2;
+        static_assert(kFxB % kGrp == 0, "the update works through the samples in whole groups");
 #pragma unroll 1
-        for (int m = 0; m < (wave_active ? ncur : 0); ++m) {
-            const int cm = s_acc[m];
-            const float4 *qrow = reinterpret_cast<const float4 *>(s_rows + m * kFxD);
-            float acc[PTS];
+        for (int m0 = 0; m0 < (wave_active ? ncur : 0); m0 += kGrp) {
+            float acc[kGrp][PTS];
 #pragma unroll
-            for (int j = 0; j < PTS; ++j) acc[j] = 0.0f;
+            for (int s2 = 0; s2 < kGrp; ++s2)
+#pragma unroll
+                for (int j = 0; j < PTS; ++j) acc[s2][j] = 0.0f;
+            const float4 *qbase = reinterpret_cast<const float4 *>(s_rows + m0 * kFxD);
 #pragma unroll
             for (int c0 = 0; c0 < kFxD; c0 += 4) {
-                // two points per thread: at most two quads of q live (all nine reads hoisted to the top spill 28 registers of x under the 128-register
-                // cap); one point per thread: 36 registers to spare, all nine reads in flight at once
-                if (PTS == 2 && (c0 & 7) == 0) asm volatile("" ::: "memory");
-                const float4 q0 = qrow[c0 / 4];
-                const float q[4] = {q0.x, q0.y, q0.z, q0.w};
+                float4 q4[kGrp];
 #pragma unroll
-                for (int j = 0; j < PTS; ++j)
+                for (int s2 = 0; s2 < kGrp; ++s2) q4[s2] = qbase[s2 * (kFxD / 4) + c0 / 4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float df = x[j][c0 + c] - q[c];
-                        acc[j] = HNS_FMA(df, df, acc[j]);
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int s2 = 0; s2 < kGrp; ++s2) {
+                        const float qc = c == 0 ? q4[s2].x : c == 1 ? q4[s2].y : c == 2 ? q4[s2].z : q4[s2].w;
+#pragma unroll
+                        for (int j = 0; j < PTS; ++j) {
+                            const float df = x[j][c0 + c] - qc;
+                            acc[s2][j] = HNS_FMA(df, df, acc[s2][j]);
+                        }
                     }
             }
 #pragma unroll
-            for (int j = 0; j < PTS; ++j) {
-                const int i = (tid + j * kFxThreads) * G + g_self;
-                // a chosen point leaves the pool (-1 never wins), so the k indices are distinct even among duplicates
-                dist[j] = (i == cm) ? -1.0f : (acc[j] < dist[j] ? acc[j] : dist[j]);
+            for (int s2 = 0; s2 < kGrp; ++s2) {
+                if (m0 + s2 < ncur) {                             // (uniform)
+                    const int cm = s_acc[m0 + s2];
+#pragma unroll
+                    for (int j = 0; j < PTS; ++j) {
+                        const int i = (tid + j * kFxThreads) * G + g_self;
+                        // a chosen point leaves the pool (-1 never wins), so the k indices are distinct even among duplicates
+                        dist[j] = (i == cm) ? -1.0f : (acc[s2][j] < dist[j] ? acc[s2][j] : dist[j]);
+                    }
+                }
             }
         }
         FPS_STAMP(0);
@@ -526,7 +572,7 @@ __global__ __launch_bounds__(kFxThreads) void hns_fps_xcd_kernel(const FpsParams
         static_assert(PTS <= 2, "a thread's candidates are a sorted pair");
         fps_top<kFxThreads>(mine, (nb < kFxT ? nb : kFxT) + 1, s_wtop, s_top, wave_active);
         const int left = p.k - nout;
-        ncur = fps_exchange_b<kFxThreads, XM>(p, gran, G, g_self, r, s_top, nb, left < kFxB ? left : kFxB, s_acc, s_key, &s_nacc, &s_fail, s_rows, &warm);
+        ncur = fps_exchange_b<kFxThreads, XM>(p, gran, G, g_self, r, s_top, nb, left < kFxB ? left : kFxB, s_acc, s_key, &s_nacc, &s_fail, s_rows, &warm, pairs);
         if (ncur < 0) return;
     }
 #ifdef FPS_PHASES
