@@ -198,8 +198,8 @@ constexpr int kFxThreads = 1024, kFxGroups = 32, kFxStride = 8, kFxPts = 2, kFxD
 // often already decided: let p1 > p2 > ... be the candidates in key order (min-distance, ties -> lower index) BEFORE p1 is applied.  Applying
 // p1 can only lower keys.  If dist(p2, p1) >= d(p2), p2's key does not move, every other key was below it and stays below it: p2 IS the
 // next sample of the sequential algorithm.  By induction p_m is accepted when dist(p_m, p_j) >= d(p_m) for all accepted j < m; at the
-// first candidate that fails the prefix ends (its key drops, the next sample may be any point).  So an exchange carries the top kFxB (8)
-// candidates of every workgroup, every workgroup derives the same global top kFxB, wave 0 evaluates the kFxB (kFxB - 1) / 2 pair
+// first candidate that fails the prefix ends (its key drops, the next sample may be any point).  So an exchange carries every workgroup's best
+// candidates (round 4: its top 8; now see kFxT), every workgroup derives the same global top kFxB, wave 0 evaluates the kFxB (kFxB - 1) / 2 pair
 // distances with the SAME sequential fma chain the update uses (so ">= d" decides exactly what min(d, dist) would), and the accepted
 // prefix is applied in one round.  The indices are those of sequential sampling, bit for bit (tests/test_hip_envgen.py against the oracle's
 // sequential loop); only the number of exchanges changes: ~k / (mean accepted) instead of k.
