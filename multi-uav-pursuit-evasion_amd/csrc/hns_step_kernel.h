@@ -114,7 +114,10 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
             rr0 = rows4[0]; rr1 = rows4[64]; rr2 = rows4[128];
             if (lane < N4 - 192) rr3 = rows4[192];
         }
-        float4 integ4 = reinterpret_cast<const float4 *>(ka.pid_integ)[il];
+        // (two evaders: the integrator's quad is loaded LAST of the first loads, below — right behind this load the compiler recycled the quad's unused fourth
+        //  register for an address computation and had to wait, s_waitcnt vmcnt(0), for all the loads issued so far before issuing the remaining fifteen)
+        float4 integ4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (NT == 1) integ4 = reinterpret_cast<const float4 *>(ka.pid_integ)[il];
         float4 last4 = reinterpret_cast<const float4 *>(ka.pid_last_rate)[il];
         // reset_pid = the incoming root `done` (transforms.py:449-454): one byte per env; with one evader its pointer rides in the argument block.
         // Loaded WITHOUT a branch (a null pointer reads a byte of `action` instead and the result is ignored): behind `if (pointer)` the compiler
@@ -135,20 +138,24 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         if constexpr (NT == 2) {
             const uintptr_t cw = reinterpret_cast<uintptr_t>(ka.aux);
             const int Cq = CS ? CS : (int)(cw & 15) + 1;
-            const float *cyl0 = reinterpret_cast<const float *>(cw & ~(uintptr_t)15);
-            const float *gc = cyl0 + (size_t)e0 * Cq * 3 + lane;
+            // (a pointer rebuilt from an integer is a FLAT pointer to the compiler: its loads count on the LDS counter as well, and the wave's first LDS
+            //  round trip — its rigid-state rows through the slab — then waits for every one of them.  Named as global memory, they are global loads.)
+            typedef const float __attribute__((address_space(1))) gcf;
+            const gcf *cyl0 = reinterpret_cast<const gcf *>(cw & ~(uintptr_t)15);
+            const gcf *gc = cyl0 + (size_t)e0 * Cq * 3 + lane;
 #pragma unroll
             for (int i = 0; i < kStage; ++i) {
                 const int pass = (tid >> 6) + i * A;
                 stage_v[i] = (pass < 3 * Cq && (!GEN || pass * 64 + lane < nv * 3 * Cq)) ? gc[pass * 64] : 0.0f;
             }
-            const float *gcy = cyl0 + (size_t)(e0 + (GEN && le >= nv ? nv - 1 : le)) * Cq * 3;
+            const gcf *gcy = cyl0 + (size_t)(e0 + (GEN && le >= nv ? nv - 1 : le)) * Cq * 3;
 #pragma unroll
             for (int i = 0; i < kOwnCyl; ++i) {
                 const int k = a + i * A;
                 const int kc = k < Cq ? k : 0;
                 own_c[i][0] = gcy[3 * kc]; own_c[i][1] = gcy[3 * kc + 1]; own_c[i][2] = gcy[3 * kc + 2];
             }
+            integ4 = reinterpret_cast<const float4 *>(ka.pid_integ)[il];
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PROF) prof_mark(p.prof, 0);
