@@ -32,7 +32,10 @@ def main():
     if len(best) < 2:
         raise SystemExit(f"no run of consecutive `{sub}` dispatches in {db}")
     name = next(n for _, _, n in rows if sub in n)
-    run = best[-limit:] if len(best) > limit else best           # the END of the run: steady state, clocks settled
+    # the MIDDLE of the run: steady state, away from the process's first launches and from whatever the run ends with (bench.py ends its timed
+    # region with event-bracketed blocks and 16 isolated event-bracketed dispatches, each between two idle gaps)
+    mid = len(best) // 2
+    run = best[max(0, mid - limit // 2):max(0, mid - limit // 2) + limit] if len(best) > limit else best
     t0 = run[0][0]
     dur = [en - st for st, en in run]
     gap = [run[i + 1][0] - run[i][1] for i in range(len(run) - 1)]
@@ -40,7 +43,7 @@ def main():
     over = [-g for g in gap if g < 0]
     n = len(run)
     print(f"# launch overlap of `{name[:90]}`")
-    print(f"# tools/launch_overlap.py on a rocprofv3 --kernel-trace database: the last {n} of {len(best)} CONSECUTIVE dispatches of the kernel (nothing else dispatched in between)")
+    print(f"# tools/launch_overlap.py on a rocprofv3 --kernel-trace database: the middle {n} of {len(best)} CONSECUTIVE dispatches of the kernel (nothing else dispatched in between)")
     print(f"# duration end - start: mean {sum(dur) / n / 1e3:.3f} us (min {min(dur) / 1e3:.2f}, max {max(dur) / 1e3:.2f})")
     print(f"# period start[i+1] - start[i]: mean {sum(period) / len(period) / 1e3:.3f} us  -> a step costs the period, a profiler's per-kernel average is the duration")
     print(f"# gap start[i+1] - end[i]: mean {sum(gap) / len(gap) / 1e3:+.3f} us; {len(over)} of {len(gap)} pairs overlap (successor started before this dispatch ended)"
