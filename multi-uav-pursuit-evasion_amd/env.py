@@ -173,6 +173,36 @@ class _PlainEnvBase:
         return self.train(False)
 
 
+def rasterise_top_down(pts, num_agents, num_targets, arena_size, max_height, cylinder_size, n=128):
+    """`[n, n, 3]` uint8 top-down picture of one env: `pts` = `[A + NT + C, 3]` positions (pursuers, evader(s), cylinder slots).  Row 0 is +y, column 0 is -x;
+    the frame spans 1.15 arena radii each way.  Arena disc (hideandseek.py:1094-1103: radius arena_size), active cylinders (z > 0; inactive slots sit at z = -20,
+    :686-689), evader(s) in red (the reference's sphere has r = 0.05, :544-565), pursuers in blue — brighter the higher they fly."""
+    import numpy as np
+    pts = np.asarray(pts, dtype=np.float32)
+    A, NT = int(num_agents), int(num_targets)
+    R, H = float(arena_size), float(max_height)
+    half = 1.15 * R                                          # metres from the frame's centre to its edge
+    ax = (np.arange(n, dtype=np.float32) + 0.5) / n * 2.0 * half - half
+    X, Y = np.meshgrid(ax, -ax)                              # row 0 = +y (image convention: y up)
+    img = np.empty((n, n, 3), np.uint8)
+    img[:] = (24, 24, 28)
+    img[X * X + Y * Y <= R * R] = (58, 60, 66)
+
+    def disc(p, radius, colour):
+        img[(X - p[0]) ** 2 + (Y - p[1]) ** 2 <= radius * radius] = colour
+
+    for c in pts[A + NT:]:
+        if c[2] > 0.0:
+            disc(c, cylinder_size, (150, 150, 150))
+    px = 2.0 * half / n
+    for k in range(NT):
+        disc(pts[A + k], max(0.05, 1.5 * px), (230, 60, 50))
+    for i in range(A):
+        shade = int(120 + 135 * min(max(float(pts[i, 2]) / max(H, 1e-6), 0.0), 1.0))
+        disc(pts[i], max(0.04, 1.5 * px), (40, shade, 255))
+    return img
+
+
 # With torchrl importable the class IS a torchrl `EnvBase` subclass, constructed the way `IsaacEnv` constructs itself
 # (isaac_env.py:54-57: device, batch_size = [num_envs], run_type_checks = False), so `TransformedEnv(base_env, ...)`,
 # the `SyncDataCollector` and MAPPO (scripts/train.py:165-205) take it as they take the reference's env.
@@ -401,35 +431,13 @@ class HideAndSeek(_EnvBase):
             raise NotImplementedError(f"render mode {mode!r} (the reference knows 'human' and 'rgb_array', isaac_env.py:261-280)")
         if self._render is False:
             raise RuntimeError(f"Cannot render '{mode}' while rendering is disabled: call enable_render(True) first (isaac_env.py:333-338).")
-        import numpy as np
         t = self.cfg.task
         e = min(max(int(t.get("render_env", 0)), 0), self.num_envs - 1)
-        n = int(t.get("render_size", 128))
         b = self._bufs
         # one device gather -> one copy to the host: [A + NT + C, 3]
         pts = torch.cat([b["drone_state"][e, :, 0:3], b["target_pos"][e].reshape(-1, 3), b["cylinders"][e].reshape(-1, 3)], dim=0).cpu().numpy()
-        A, NT = self.num_agents, self.num_targets
-        R, H = float(self.hcfg.arena_size), float(self.hcfg.max_height)
-        half = 1.15 * R                                          # metres from the frame's centre to its edge
-        ax = (np.arange(n, dtype=np.float32) + 0.5) / n * 2.0 * half - half
-        X, Y = np.meshgrid(ax, -ax)                              # row 0 = +y (image convention: y up)
-        img = np.empty((n, n, 3), np.uint8)
-        img[:] = (24, 24, 28)
-        img[X * X + Y * Y <= R * R] = (58, 60, 66)               # the arena disc (hideandseek.py:1094-1103: radius arena_size)
-
-        def disc(p, radius, colour):
-            img[(X - p[0]) ** 2 + (Y - p[1]) ** 2 <= radius * radius] = colour
-
-        for c in pts[A + NT:]:
-            if c[2] > 0.0:                                       # active slots only (inactive ones sit at z = -20, :686-689)
-                disc(c, float(self.hcfg.cylinder_size), (150, 150, 150))
-        px = 2.0 * half / n
-        for k in range(NT):
-            disc(pts[A + k], max(0.05, 1.5 * px), (230, 60, 50))                 # evader: the reference's sphere has r = 0.05 (:544-565)
-        for i in range(A):
-            shade = int(120 + 135 * min(max(float(pts[i, 2]) / max(H, 1e-6), 0.0), 1.0))
-            disc(pts[i], max(0.04, 1.5 * px), (40, shade, 255))
-        return img
+        return rasterise_top_down(pts, self.num_agents, self.num_targets, float(self.hcfg.arena_size), float(self.hcfg.max_height),
+                                  float(self.hcfg.cylinder_size), int(t.get("render_size", 128)))
 
     def to(self, device):
         if torch.device(device) != self.device:                  # isaac_env.py:300-305

@@ -54,3 +54,29 @@ def test_bench_algorithmic_bytes_match_the_survey_figures():
     assert bench.algorithmic_bytes_per_env(3, 5, 3) == 1497
     assert bench.algorithmic_bytes_per_env(6, 16, 3) == 3045
     assert bench.algorithmic_bytes_per_env(6, 16, 3, NT=2) == 3045 + 12 + 24 + 16 * 6
+
+
+def test_top_down_raster_of_one_env():
+    """`render(mode="rgb_array")`'s picture (env.rasterise_top_down; scripts/train.py:220-223,251-254 stacks such frames and transposes them to [N, 3, H, W]):
+    uint8 [n, n, 3]; the arena disc, an active cylinder, the evader and a pursuer where they belong; an inactive slot (z = -20) is not drawn."""
+    import numpy as np
+    from hns_amd.env import rasterise_top_down
+    A, NT, n, R = 2, 1, 128, 0.9
+    pts = np.array([[0.5, 0.0, 0.6], [-0.5, 0.3, 1.2],          # pursuers (the second at the ceiling: brightest)
+                    [0.0, -0.5, 0.6],                            # evader
+                    [0.2, 0.4, 0.6], [-0.4, -0.4, -20.0]], np.float32)   # one active cylinder, one inactive slot
+    img = rasterise_top_down(pts, A, NT, R, 1.2, 0.1, n)
+    assert img.shape == (n, n, 3) and img.dtype == np.uint8
+
+    def px(x, y):                                                # metres -> (row, column); row 0 is +y
+        half = 1.15 * R
+        return int((half - y) / (2 * half) * n), int((x + half) / (2 * half) * n)
+    assert tuple(img[px(0.0, 0.0)]) == (58, 60, 66)              # inside the arena
+    assert tuple(img[0, 0]) == (24, 24, 28)                      # outside
+    assert tuple(img[px(0.2, 0.4)]) == (150, 150, 150)           # the active cylinder
+    assert tuple(img[px(-0.4, -0.4)]) == (58, 60, 66)            # the inactive slot: plain arena
+    assert tuple(img[px(0.0, -0.5)]) == (230, 60, 50)            # the evader
+    p0, p1 = img[px(0.5, 0.0)], img[px(-0.5, 0.3)]
+    assert p0[2] == 255 and p1[2] == 255 and p0[0] == 40 and p1[1] == 255 and p0[1] < p1[1]      # pursuers, brighter with height
+    video = np.stack([img, img]).transpose(0, 3, 1, 2)          # what evaluate() hands to wandb.Video
+    assert video.shape == (2, 3, n, n)
