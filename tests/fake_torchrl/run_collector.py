@@ -48,6 +48,11 @@ collector = SyncDataCollector(env, policy=policy, frames_per_batch=frames_per_ba
 host = O.alloc_buffers(base_env.hcfg)
 O.reset(base_env.hcfg, host, None, base_env.seed, 0)
 epoch, n_resets, first = 1, 0, None
+# scripts/train.py:113-116,193-196: the statistics `EpisodeStats` follows are the leaves of the observation spec under "stats"
+stats_keys = [k for k in base_env.observation_spec.keys(True, True) if isinstance(k, tuple) and k[0] == "stats"]
+assert len(stats_keys) == 24 and ("stats", "success") in stats_keys
+from hns_amd import abi
+episodes_seen, pending = 0, None                                  # pending: (env mask, oracle statistics) of an episode that ended on a rollout's last step
 for i, data in enumerate(collector):
     assert tuple(data.batch_size) == (E, T)
     if first is None:
@@ -59,18 +64,43 @@ for i, data in enumerate(collector):
     assert tuple(data.get(("stats", "action_error_order1")).shape) == (E, T, A) and tuple(data.get(("info", "prev_action")).shape) == (E, T, A, 4)
     assert "_reset" not in data.keys()
     acts = data.get(("agents", "action")).cpu().numpy()
+    # EpisodeStats.__call__ (scripts/train.py:58-72) in meaning: the ROOT statistics one step behind a `done` are the finished episode's — the reset that
+    # followed handed the pre-reset statistics back (isaac_env.py:216,223-224) and step_mdp carried them into the next frame:
+    #     tensordict.select(*in_keys)[:, 1:][done_or_truncated[:, :-1]]
+    truncated = data.get(("next", "truncated"), None)
+    assert truncated is None                                      # (the reference's step does not write it either: `done.clone()` is what EpisodeStats uses)
+    dmask = done.squeeze(-1)                                      # [E, T]
+    picked = {k: data.get(k)[:, 1:][dmask[:, :-1]].clone() for k in stats_keys}
+    episodes_seen += int(dmask.sum())
+    expect = {name: [] for name in abi.STAT_NAMES}                # the oracle's statistics of the envs that finished, in (env-major, time) order of the mask
+    ends = []
     for t in range(T):
         O.step(base_env.hcfg, host, np.ascontiguousarray(acts[:, t]))
         assert np.array_equal(host["reward"], rew[:, t, :, 0].cpu().numpy()), f"rollout {i} step {t}: reward differs from the oracle"
         assert np.array_equal(host["done"].astype(bool), done[:, t, 0].cpu().numpy())
         if host["done"].any():
+            if t < T - 1:
+                ends.append((t, host["done"].astype(bool).copy(), host["stats"].copy()))
             O.reset(base_env.hcfg, host, host["done"].copy(), base_env.seed, epoch)
             epoch += 1
             n_resets += 1
+    # boolean-mask indexing of [E, T-1] walks env-major: rebuild the oracle's picks in that order
+    for j, name in enumerate(abi.STAT_NAMES):
+        want = []
+        for e in range(E):
+            for t, dn, st in ends:
+                if dn[e]:
+                    want.append(st[j, e])
+        got = picked[("stats", name)].reshape(-1).cpu().numpy()
+        assert got.shape[0] == len(want), (name, got.shape, len(want))
+        assert np.array_equal(got, np.asarray(want, dtype=np.float32), equal_nan=True), f"rollout {i}: finished-episode statistic {name} differs from the oracle's"
+    if ends:
+        # `pop()` (train.py:74-77) averages them; e.g. no finished episode reports a first capture beyond its length
+        assert (picked[("stats", "first_capture_step")] <= L).all() and picked[("stats", "success")].shape[0] == sum(int(dn.sum()) for _, dn, _ in ends)
 dev = base_env.export_state()
 for k in ("drone_state", "target_pos", "progress", "stats"):
     assert np.array_equal(host[k], dev[k], equal_nan=True), f"{k} differs from the oracle after the rollouts"
 # reset(td) with a tensordict that carries no `_reset` (tensordict 0.1.x: get() raises on a missing key)
 td = env.reset(TensorDict({}, [E], device=base_env.device))
 assert not td.get("done").any()
-print(json.dumps({"rollouts": i + 1, "frames": (i + 1) * E * T, "masked_resets": n_resets, "use_tp": use_tp}))
+print(json.dumps({"rollouts": i + 1, "frames": (i + 1) * E * T, "masked_resets": n_resets, "use_tp": use_tp, "episodes_seen": episodes_seen, "stats_keys": len(stats_keys)}))

@@ -98,6 +98,7 @@ def test_env_under_transformed_env_and_collector(use_tp):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert r["rollouts"] == 4 and r["masked_resets"] >= 2 and r["use_tp"] == use_tp
+    assert r["stats_keys"] == 24 and r["episodes_seen"] >= 2 * 256            # scripts/train.py:53-80,113-116: EpisodeStats' picks ≡ the oracle's finished-episode statistics
 
 
 @pytest.mark.gpu
