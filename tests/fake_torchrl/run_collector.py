@@ -97,10 +97,35 @@ for i, data in enumerate(collector):
     if ends:
         # `pop()` (train.py:74-77) averages them; e.g. no finished episode reports a first capture beyond its length
         assert (picked[("stats", "first_capture_step")] <= L).all() and picked[("stats", "success")].shape[0] == sum(int(dn.sum()) for _, dn, _ in ends)
+    if use_tp:
+        # learning/mappo.py:407-427 + update_TP (:252-268) in meaning: the learner trains the env's predictor on windows of the collected ground truth.
+        #   windows = TP_groundtruth.unfold(1, F + 1, window_step).transpose(2, 3)[:, :, 1:]; mask = TP_done[:, :n] ...; masked_select(...).view(batch, -1, F, 3)
+        F, ws = base_env.TP.future_predcition_step, base_env.TP.window_step
+        gt = data.get(("next", "agents", "TP", "TP_groundtruth"))                 # [E, T, 3] (hideandseek.py:840-842: scaled to (-1, 1))
+        tin = data.get(("next", "agents", "TP", "TP_input"))                      # [E, T, 10, 16]
+        tdone = data.get(("next", "agents", "TP", "TP_done"))                     # [E, T, 1] bool
+        assert tuple(gt.shape) == (E, T, 3) and tuple(tin.shape) == (E, T, 10, 16) and tuple(tdone.shape) == (E, T, 1) and tdone.dtype == torch.bool
+        windows = gt.unfold(dimension=1, size=F + 1, step=ws).transpose(2, 3)[:, :, 1:]
+        batch, _, future_step, pos_dim = windows.shape
+        assert (future_step, pos_dim) == (F, 3)
+        mask = tdone[:, :windows.shape[1]].squeeze(-1).unsqueeze(-1).unsqueeze(-1).expand_as(windows).bool()
+        selected = torch.masked_select(windows, mask).view(batch, -1, future_step, pos_dim)     # needs the same count in every env: episodes are lock step
+        n_sel = selected.shape[1]
+        if n_sel:
+            x, y = tin[:, :n_sel].reshape(-1, 10, 16), selected.reshape(-1, F * 3)
+            assert bool(torch.isfinite(y).all())     # (xy / (0.5 arena_size): up to +-2 — the reference's "clip to (-1, 1)" comment, :839, is not followed by a clip)
+            opt = torch.optim.Adam(base_env.TP.parameters(), lr=1e-3)
+            loss = torch.nn.functional.mse_loss(base_env.TP(x.clone()), y.clone())
+            opt.zero_grad()
+            loss.backward()
+            opt.step()                                                            # in-place update: the env re-packs the operand image at its next step
+            assert np.isfinite(float(loss))
+            tp_updates = globals().get("tp_updates", 0) + 1
 dev = base_env.export_state()
 for k in ("drone_state", "target_pos", "progress", "stats"):
     assert np.array_equal(host[k], dev[k], equal_nan=True), f"{k} differs from the oracle after the rollouts"
 # reset(td) with a tensordict that carries no `_reset` (tensordict 0.1.x: get() raises on a missing key)
 td = env.reset(TensorDict({}, [E], device=base_env.device))
 assert not td.get("done").any()
-print(json.dumps({"rollouts": i + 1, "frames": (i + 1) * E * T, "masked_resets": n_resets, "use_tp": use_tp, "episodes_seen": episodes_seen, "stats_keys": len(stats_keys)}))
+print(json.dumps({"rollouts": i + 1, "frames": (i + 1) * E * T, "masked_resets": n_resets, "use_tp": use_tp, "episodes_seen": episodes_seen, "stats_keys": len(stats_keys),
+                  "tp_updates": globals().get("tp_updates", 0)}))

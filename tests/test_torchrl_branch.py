@@ -99,6 +99,7 @@ def test_env_under_transformed_env_and_collector(use_tp):
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert r["rollouts"] == 4 and r["masked_resets"] >= 2 and r["use_tp"] == use_tp
     assert r["stats_keys"] == 24 and r["episodes_seen"] >= 2 * 256            # scripts/train.py:53-80,113-116: EpisodeStats' picks ≡ the oracle's finished-episode statistics
+    assert (r["tp_updates"] >= 1) == bool(use_tp)                              # learning/mappo.py:407-427,252-268: the predictor trained on windows of the collected ground truth
 
 
 @pytest.mark.gpu
