@@ -11,7 +11,7 @@ bookkeeping on the host (reference omni_drones/envs/hide_and_seek/hideandseek_en
 
 In the env the buffer lives on the device (`DeviceGenBuffer`): the history, the task batch and the
 success weights never leave HBM; `samplenearby` is `hns_perturb_tasks` (one thread per task) and the
-FPS trim is `hns_fps` (one persistent launch, ~30 ms for 5000 of 50 000 tasks) — csrc/hns_envgen.hip.
+FPS trim is `hns_fps` (one persistent launch, 5 ms for 5000 of 70 000 tasks since round 5) — csrc/hns_envgen.hip.
 `GenBuffer` below is the same logic on the host in numpy (the reference's class surface; used by the
 CPU tests and as the plain restatement of the device path).
 
