@@ -5,7 +5,7 @@ Workload = BASELINE.json configs[2]: HideAndSeek 3 pursuers / 1 evader, 8 cylind
 sensing), 65 536 envs per GPU, synthetic N(0,1) policy outputs resident in HBM.  A "step" is one `env.step(td)` of the
 Python class ("time env.step") = one `hns_step` launch over the whole env batch, plus the `reset` at the
 natural 1/800 episode boundary.  Multi-GPU: one process per GPU, contiguous env-index shards, weak scaling; the only
-collective is one RCCL all-gather of 5 fp64 values per 64-step rollout (the advantage-normalisation moments named by
+collective is one RCCL all-gather of 8 fp64 values per 64-step rollout (the advantage-normalisation moments named by
 north_star).  `python bench.py --gpus N` launches its own N ranks when it was not started by torchrun.
 
 Prints ONE JSON line (rank 0):
@@ -334,10 +334,11 @@ def main():
                 env.reset(reset_td)
             if dist is not None and (i + 1) % rollout == 0:
                 # per-rollout moments for advantage normalisation (learning/mappo.py:391-396 made data-parallel) + the success
-                # rate of the curriculum (hideandseek.py:1012-1015): ONE all-gather of 5 fp64 values per rank over RCCL/xGMI.
+                # rate of the curriculum (hideandseek.py:1012-1015) + ValueNorm1's batch moments (valuenorm.py:83-91): ONE all-gather of sharding.MOMENT_DIM = 8 fp64
+                # values per rank over RCCL/xGMI (the reward buffer stands in for the learner's advantages and returns: same shape, same launch).
                 # Its cost is timed where it is paid: device time between two events on the step stream for RCCL (the collective
                 # runs on RCCL's stream, the step stream waits for it), host time of the call for gloo (host tensors)
-                loc = sharding.local_moments(reward, success)
+                loc = sharding.local_moments(reward, success, reward)
                 if coll_dev == "cpu":
                     c0 = time.perf_counter()
                     table = sharding._allgather(loc)          # (the collective itself, also with one rank)
@@ -434,7 +435,7 @@ def main():
     collective = None
     if coll_us:
         collective = {"per_rollout_us_mean": round(sum(coll_us) / len(coll_us), 1), "per_rollout_us_max": round(max(coll_us), 1), "rollouts": len(coll_us),
-                      "rollout_steps": rollout, "what": "local moments (3 tiny reductions) + ONE all-gather of 5 fp64 per rank; " +
+                      "rollout_steps": rollout, "what": "local moments (ONE launch: hns_rollout_moments) + ONE all-gather of 8 fp64 per rank; " +
                       ("host time of the call (gloo, host tensors)" if coll_host_us else "device time between two events on the step stream (RCCL)")}
     # ranks that actually took part (an all-reduce of ones), slowest rank's wall time, per-rank kernel time
     n_ranks, n_devices, kernel_by_rank = 1, 1, None

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HNS_ABI_VERSION 4
+#define HNS_ABI_VERSION 5
 #define HNS_MAX_AGENTS 7    /* pursuers per env: a workgroup is 64 envs = A pursuer waves + one env wave (<= 512 threads) */
 #define HNS_MAX_CYLINDERS 16
 #define HNS_NUM_STATS 24    /* hideandseek.py:400-425 */
@@ -65,6 +65,17 @@ typedef enum hns_stat {
     HNS_ST_ACTION_ERROR_ORDER1_MEAN, HNS_ST_ACTION_ERROR_ORDER1_MAX, HNS_ST_TARGET_PREDICTED_ERROR,
     HNS_ST_DISTANCE_THRESHOLD_L, HNS_ST_OUT_OF_ARENA, HNS_ST_SMOOTHNESS_COEF
 } hns_stat;
+
+/* What hns_step's `action` is — i.e. on which side of the boundary the reference's action transform runs (scripts/train.py:165-171).
+ *   HNS_ACTION_POLICY: the raw policy output (pre-tanh).  hns_step runs PIDRateController._inv_call (transforms.py:425-459) and the
+ *                      body-rate PID (lee_position_controller.py:476-550) itself; `prev_action`, `action_error`, `pid_*` are its state / outputs.
+ *   HNS_ACTION_MOTOR:  the four rotor commands that transform left in ("agents","action") (transforms.py:455-456: the caller keeps
+ *                      `action_transform: PIDrate` and runs the torch controller in front, as the reference's own task file has it).  hns_step
+ *                      starts at HideAndSeek._pre_sim_step (hideandseek.py:725-744): `action` goes straight to the rotors (A3); `prev_action` and
+ *                      `action_error` are INPUTS — what the transform set under ("info","prev_action") / ("stats","action_error_order1"),
+ *                      copied into the bound buffers by the caller (:729-731) — and are not written; `pid_integ`, `reset_pid`, `ctbr`, `target_rate`
+ *                      are not touched (the caller's controller owns that state); of `pid_last_rate` only the line-of-sight column (w) is. */
+typedef enum hns_action_input { HNS_ACTION_POLICY = 0, HNS_ACTION_MOTOR = 1 } hns_action_input;
 
 /* How reset places bodies (hideandseek.py:613-689). */
 typedef enum hns_init_mode {
@@ -155,6 +166,7 @@ typedef struct hns_cfg {
     int32_t reset_extra_step;  /* 1 = the reference: `_reset_idx` ends with one `sim.step()` of the WHOLE scene (hideandseek.py:722-723) — every drone of
                                   every env (reset or not) integrates one dt with no rotor force (gravity + damping), every evader moves one dt with
                                   the velocity it holds; then the observation of all envs is recomputed (isaac_env.py:221).  0 = no extra step */
+    int32_t action_input;      /* hns_action_input: what `action` of hns_step holds (below) */
 } hns_cfg;
 
 /*
@@ -254,7 +266,8 @@ void hns_destroy(hns_env *env);
  * GPU are refused here (HNS_ERR_INVALID_ARG) rather than faulting in a kernel; alignment is checked too. */
 int hns_bind(hns_env *env, const hns_buffers *buffers);
 
-/* One environment step for all E envs.  `action` = raw policy output [E,A,4] (pre-tanh),
+/* One environment step for all E envs.  `action` = raw policy output [E,A,4] (pre-tanh) — or, with cfg.action_input =
+ * HNS_ACTION_MOTOR, the rotor commands of the caller's own controller transform (hns_action_input above) —
  * device pointer.  `stream` is a hipStream_t (NULL = default stream).  Asynchronous. */
 int hns_step(hns_env *env, const float *action, void *stream);
 
@@ -391,6 +404,9 @@ int hns_step_mapping(const hns_env *env);
  * out[0..4] = [sum v, sum v^2, n, sum s, m] in fp64 over `values` [n] fp32 and `success` [m] fp32 (m may be 0: success NULL) — device
  * pointers; one workgroup, fixed summation order (the same inputs give the same bits on every run). */
 int hns_moments(const float *values, int64_t n, const float *success, int64_t m, double *out, void *stream);
+/* The same launch with ValueNorm1's batch moments riding along (learning/utils/valuenorm.py:83-91: `input_vector.mean()`, `(input_vector**2).mean()` over the
+ * rollout's returns, mappo.py:398-399) — SURVEY §8(e)(3): out[0..7] = [sum adv, sum adv^2, n, sum success, m, sum ret, sum ret^2, n_returns]. */
+int hns_rollout_moments(const float *advantages, int64_t n, const float *success, int64_t m, const float *returns, int64_t n_returns, double *out, void *stream);
 
 int hns_abi_version(void);
 size_t hns_cfg_size(void);   /* sizeof(hns_cfg) the library was built with (binding self-check) */

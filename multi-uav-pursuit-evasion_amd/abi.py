@@ -6,13 +6,14 @@ been built (`python -c "import __graft_entry__ as g; g.build()"`).
 import ctypes as C
 import os
 
-HNS_ABI_VERSION = 4
+HNS_ABI_VERSION = 5
 HNS_MAX_AGENTS = 7
 HNS_MAX_CYLINDERS = 16
 HNS_NUM_STATS = 24
 HNS_SELF_DIM = 20
 
 HNS_INIT_RANDOM, HNS_INIT_EVAL, HNS_INIT_SCENARIO = 0, 1, 2
+HNS_ACTION_POLICY, HNS_ACTION_MOTOR = 0, 1      # hns_action_input
 
 # row order of hns_buffers.stats == stats_spec order (reference hideandseek.py:400-425)
 STAT_NAMES = [
@@ -55,7 +56,7 @@ class HnsCfg(C.Structure):
         ("target_xy_hi", _f * 2), ("z_lo", _f), ("z_hi", _f), ("rpy_lo", _f * 3), ("rpy_hi", _f * 3),
         ("fixed_drone_pos", (_f * 3) * (HNS_MAX_AGENTS + 1)), ("fixed_target_pos", _f * 3),
         ("fixed_cyl_pos", (_f * 3) * HNS_MAX_CYLINDERS), ("fixed_cyl_active", _i), ("tp_use_obstacles", _i),
-        ("pid_reset_on_reset", _i), ("stats_stride", _i), ("reset_extra_step", _i),
+        ("pid_reset_on_reset", _i), ("stats_stride", _i), ("reset_extra_step", _i), ("action_input", _i),
     ]
 
     def copy(self):
@@ -231,6 +232,8 @@ def load_library():
     lib.hns_region_ms.restype = C.c_float
     lib.hns_moments.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.hns_moments.restype = C.c_int
+    lib.hns_rollout_moments.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.hns_rollout_moments.restype = C.c_int
     lib.hns_copy_f4.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.hns_copy_f4.restype = C.c_int
     lib.hns_set_phase_profile.argtypes = [C.c_void_p, C.c_void_p]
@@ -281,5 +284,5 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "hns_create", "hns_destroy", "hns_bind", "hns_step", "hns_reset", "hns_reset_tasks", "hns_raycast", "hns_set_v_prey",
     "hns_set_smoothness_coef", "hns_set_reset_epoch", "hns_get_reset_epoch", "hns_enable_timing",
-    "hns_step_kernel_ms", "hns_region_begin", "hns_region_end", "hns_region_ms", "hns_copy_f4", "hns_moments", "hns_set_phase_profile", "hns_step_mapping", "hns_set_state", "hns_get_state", "hns_refresh_derived_state", "hns_fps", "hns_fps_scratch_bytes", "hns_perturb_tasks", "hns_tp_bind", "hns_tp_refresh", "hns_tp_packed_bytes", "hns_tp_observe", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
+    "hns_step_kernel_ms", "hns_region_begin", "hns_region_end", "hns_region_ms", "hns_copy_f4", "hns_moments", "hns_rollout_moments", "hns_set_phase_profile", "hns_step_mapping", "hns_set_state", "hns_get_state", "hns_refresh_derived_state", "hns_fps", "hns_fps_scratch_bytes", "hns_perturb_tasks", "hns_tp_bind", "hns_tp_refresh", "hns_tp_packed_bytes", "hns_tp_observe", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
 ]

@@ -64,6 +64,7 @@ DEFAULT_TASK = {
     "pid_reset": "reference",
     # reset_extra_step: 1 = `_reset_idx` ends with one physics step of the whole scene, no rotor forces (hideandseek.py:722-723); 0 = none
     "reset_extra_step": 1,
+    # action_input (NOT a default here: see `resolve_action_input`): "policy" | "motor" — what ("agents","action") of a stepped tensordict holds
 }
 
 DEFAULT_ALGO = {"name": "mappo", "use_TP_net": 0, "train_every": 64}
@@ -151,11 +152,38 @@ def _merge(dst, src):
     return dst
 
 
-def make_cfg(task=None, algo=None, headless=True, **task_overrides):
-    """Compose a train-style config {task, algo, env, sim, headless} from partial mappings."""
+def resolve_action_input(task):
+    """What the env will be fed under ("agents","action"), decided from the SAME key the reference's script decides on (scripts/train.py:148-171:
+    `cfg.task.action_transform`), so a task file and the script that reads it cannot disagree:
+
+    * `task.action_input` given ("policy" | "motor"): taken as is.
+    * absent, `action_transform` none / null: "policy" — nothing runs in front (train.py:172-173), the raw policy output arrives and hns_step runs
+      tanh -> CTBR -> body-rate PID itself (cfg/task/HideAndSeek_hip.yaml).
+    * absent, any other `action_transform` (the reference's own task files say `PIDrate`, cfg/task/HideAndSeek.yaml:16): "motor" — train.py puts that
+      controller transform in front of the env, which replaces the action by four rotor commands (utils/torchrl/transforms.py:455-456); hns_step
+      then starts at `_pre_sim_step` (hideandseek.py:725-744), as the reference's env does.
+
+    `make_cfg` (this build's programmatic constructor: tests, tools, bench.py) states "policy" explicitly; `load_cfg` (a YAML written for the
+    reference, or hydra's composed config) leaves the key to this rule."""
+    v = task.get("action_input", None)
+    if v is not None:
+        v = str(v).lower()
+        if v not in ("policy", "motor"):
+            raise ValueError("task.action_input must be 'policy' (raw policy output; the controller is fused into the step) or "
+                             "'motor' (rotor commands of the caller's own controller transform)")
+        return v
+    tr = task.get("action_transform", None)
+    return "policy" if tr is None or str(tr).lower() == "none" else "motor"
+
+
+def make_cfg(task=None, algo=None, headless=True, _from_yaml=False, **task_overrides):
+    """Compose a train-style config {task, algo, env, sim, headless} from partial mappings.  Called directly (not through `load_cfg`) the env
+    takes the raw policy action whatever `action_transform` says (`action_input: policy`, see `resolve_action_input`)."""
     t = copy.deepcopy(DEFAULT_TASK)
     _merge(t, task or {})
     _merge(t, task_overrides)
+    if not _from_yaml:
+        t.setdefault("action_input", "policy")
     a = copy.deepcopy(DEFAULT_ALGO)
     _merge(a, algo or {})
     cfg = {"task": t, "algo": a, "env": t["env"], "sim": t["sim"], "headless": headless,
@@ -178,8 +206,8 @@ def load_cfg(path, **task_overrides):
                 task.setdefault(k, {})
                 _merge(task[k], raw[k])
         return make_cfg(task, raw.get("algo") if isinstance(raw.get("algo"), dict) else None,
-                        raw.get("headless", True), **task_overrides)
-    return make_cfg(raw, None, True, **task_overrides)
+                        raw.get("headless", True), _from_yaml=True, **task_overrides)
+    return make_cfg(raw, None, True, _from_yaml=True, **task_overrides)
 
 
 # Hover task (reference cfg/task/Hover.yaml, omni_drones/envs/single/hover.py:76-146)
@@ -270,6 +298,7 @@ def resolve_hns_cfg(cfg, num_envs=None, env_index_offset=0, drone_params=None, w
         raise ValueError("task.pid_reset must be 'reference' or 'on_reset'")
     c.pid_reset_on_reset = 1 if pid_reset == "on_reset" else 0
     c.reset_extra_step = 1 if int(t.get("reset_extra_step", 1)) else 0
+    c.action_input = abi.HNS_ACTION_MOTOR if resolve_action_input(t) == "motor" else abi.HNS_ACTION_POLICY
     c.stats_stride = E
     c.tp_use_obstacles = 1 if use_obst else 0
     c.max_episode_length = int(cfg.env.max_episode_length)

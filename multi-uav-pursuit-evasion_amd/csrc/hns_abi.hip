@@ -258,12 +258,9 @@ __global__ __launch_bounds__(256) void hns_raycast_kernel(const RayParams p) {
     }
 }
 
-// hns_moments: [sum, sum of squares, count, success sum, env count] in fp64, one workgroup, fixed order (thread t takes elements t, t + 1024, ...;
-// then a tree over the 1024 partial sums)
-__global__ __launch_bounds__(1024) void hns_moments_kernel(const float *__restrict__ v, long long n, const float *__restrict__ s, long long m, double *__restrict__ out) {
-    __shared__ double red[3][1024];
-    const int t = threadIdx.x;
-    double a = 0.0, b = 0.0, c = 0.0;
+// hns_moments / hns_rollout_moments: [sum, sum of squares, count, success sum, env count (, sum, sum of squares, count of a second array)] in fp64, one
+// workgroup, fixed order (thread t takes elements t, t + 1024, ...; then a tree over the 1024 partial sums)
+HNS_DEV void moments_pass(const float *__restrict__ v, long long n, int t, double &a, double &b) {
     const long long n4 = ((reinterpret_cast<uintptr_t>(v) & 15) == 0) ? n / 4 : 0;
     const float4 *v4 = reinterpret_cast<const float4 *>(v);
     for (long long i = t; i < n4; i += 1024) {
@@ -273,14 +270,28 @@ __global__ __launch_bounds__(1024) void hns_moments_kernel(const float *__restri
         b += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
     }
     for (long long i = 4 * n4 + t; i < n; i += 1024) { const double x = v[i]; a += x; b += x * x; }
+}
+__global__ __launch_bounds__(1024) void hns_moments_kernel(const float *__restrict__ v, long long n, const float *__restrict__ s, long long m,
+                                                             const float *__restrict__ v2, long long n2, double *__restrict__ out) {
+    __shared__ double red[5][1024];
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0, c = 0.0, a2 = 0.0, b2 = 0.0;
+    moments_pass(v, n, t, a, b);
+    if (v2) moments_pass(v2, n2, t, a2, b2);
     for (long long i = t; i < m; i += 1024) c += (double)s[i];
-    red[0][t] = a; red[1][t] = b; red[2][t] = c;
+    red[0][t] = a; red[1][t] = b; red[2][t] = c; red[3][t] = a2; red[4][t] = b2;
     __syncthreads();
     for (int w = 512; w >= 1; w >>= 1) {
-        if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; red[2][t] += red[2][t + w]; }
+        if (t < w) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) red[r][t] += red[r][t + w];
+        }
         __syncthreads();
     }
-    if (t == 0) { out[0] = red[0][0]; out[1] = red[1][0]; out[2] = (double)n; out[3] = red[2][0]; out[4] = (double)m; }
+    if (t == 0) {
+        out[0] = red[0][0]; out[1] = red[1][0]; out[2] = (double)n; out[3] = red[2][0]; out[4] = (double)m;
+        if (v2) { out[5] = red[3][0]; out[6] = red[4][0]; out[7] = (double)n2; }
+    }
 }
 
 // measurement yardstick (hns_copy_f4): a plain float4 copy, one piece per thread.  Of the shapes tried on this chip (tools/microbench/copy_rate.hip:
@@ -326,6 +337,7 @@ int hns_create(const hns_cfg *cfg, hns_env **out) {
         return HNS_ERR_INVALID_ARG;
     }
     if (cfg->num_targets < 0 || cfg->num_targets > hns::kMaxT) { set_error("hns_create: num_targets must be 0, 1 or 2"); return HNS_ERR_INVALID_ARG; }
+    if (cfg->action_input != HNS_ACTION_POLICY && cfg->action_input != HNS_ACTION_MOTOR) { set_error("hns_create: action_input must be HNS_ACTION_POLICY or HNS_ACTION_MOTOR"); return HNS_ERR_INVALID_ARG; }
     if (cfg->grid_num < 1 || cfg->grid_num > 16) { set_error("hns_create: grid_num out of range"); return HNS_ERR_INVALID_ARG; }
     if (cfg->init_mode != HNS_INIT_SCENARIO) {
         int half = cfg->grid_num / 2, free_cells = 0;
@@ -762,7 +774,16 @@ float hns_region_ms(hns_env *env) {
 
 int hns_moments(const float *values, int64_t n, const float *success, int64_t m, double *out, void *stream) {
     if (!values || !out || n < 0 || m < 0 || (m > 0 && !success)) { set_error("hns_moments: bad argument"); return HNS_ERR_INVALID_ARG; }
-    hipLaunchKernelGGL(hns::hns_moments_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), values, (long long)n, success, (long long)m, out);
+    hipLaunchKernelGGL(hns::hns_moments_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), values, (long long)n, success, (long long)m,
+                       static_cast<const float *>(nullptr), 0ll, out);
+    HNS_CHECK_HIP(hipGetLastError());
+    return HNS_OK;
+}
+
+int hns_rollout_moments(const float *advantages, int64_t n, const float *success, int64_t m, const float *returns, int64_t n_returns, double *out, void *stream) {
+    if (!advantages || !returns || !out || n < 0 || m < 0 || n_returns < 0 || (m > 0 && !success)) { set_error("hns_rollout_moments: bad argument"); return HNS_ERR_INVALID_ARG; }
+    hipLaunchKernelGGL(hns::hns_moments_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), advantages, (long long)n, success, (long long)m,
+                       returns, (long long)n_returns, out);
     HNS_CHECK_HIP(hipGetLastError());
     return HNS_OK;
 }

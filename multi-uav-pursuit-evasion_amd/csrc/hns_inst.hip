@@ -49,7 +49,12 @@ void HNS_CAT(hns_select_kernels_, HNS_INST_A)(hns_env *env) {
     using namespace hns;
     const hns_cfg &c = env->cfg;
     const bool two = c.num_targets == 2, wide = c.obs_max_cylinder > kMaxK, ragged = c.num_envs % kEPB != 0;
-    if (wide) {
+    const bool motor = c.action_input == HNS_ACTION_MOTOR;      // include/hns.h: the caller's controller transform ran in front
+    if (motor) {
+        if (wide) env->step_args_fn = two ? hns_step_v4_kernel<A, 2, true, kWideK, false, 0, true> : hns_step_v4_kernel<A, 1, true, kWideK, false, 0, true>;
+        else env->step_args_fn = two ? hns_step_v4_kernel<A, 2, true, kMaxK, false, 0, true> : hns_step_v4_kernel<A, 1, true, kMaxK, false, 0, true>;
+        env->reset_fn = wide ? (two ? hns_reset_kernel<A, 2, kWideK> : hns_reset_kernel<A, 1, kWideK>) : (two ? hns_reset_kernel<A, 2> : hns_reset_kernel<A, 1>);
+    } else if (wide) {
         env->step_args_fn = two ? hns_step_v4_kernel<A, 2, true, kWideK, false> : hns_step_v4_kernel<A, 1, true, kWideK, false>;
         env->reset_fn = two ? hns_reset_kernel<A, 2, kWideK> : hns_reset_kernel<A, 1, kWideK>;
     } else {
@@ -81,7 +86,7 @@ void HNS_CAT(hns_select_kernels_, HNS_INST_A)(hns_env *env) {
     // tiles, k <= 4, at most kSmallWgPerCu workgroups per CU.  HNS_STEP_MAPPING=tile|small overrides the choice where the shape allows both
     // (A/B runs, tests/test_hip_parity.py).
     const char *mp = std::getenv("HNS_STEP_MAPPING");
-    const bool eligible = !two && !wide && !ragged;
+    const bool eligible = !two && !wide && !ragged && !motor;
     // (2 A + 1 waves per workgroup: with four and more pursuers two of them no longer share a CU — 32 768 envs measured 13.4 / 19.5 / 22.2 us
     //  with the tile mapping against 17.3 / 22.9 / 25.9 us for 4 / 6 / 7 pursuers, while one tile per CU is faster in the small mapping for every count)
     bool small = eligible && env->grid <= (A <= 3 ? kSmallWgPerCu : 1) * env->cus;

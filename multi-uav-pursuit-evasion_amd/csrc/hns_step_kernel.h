@@ -77,10 +77,15 @@ HNS_DEV void env_store_slice(const float *lds, float *g, int n, int lane, int nv
 // CS > 0: the cylinder count as a compile-time constant, with k = 3 — the shapes of the reference's task files and of BASELINE's configurations
 // (5, 8, 16 slots; obs_max_cylinder 3).  Same arithmetic, same order; the cylinder loops unroll completely and the k-nearest predicates
 // fold away: 6v2 / 16 cylinders 50.4 -> 48.5 us, 3v1 / 8 cylinders 18.7 -> 18.5 us (A/B/A/B on one box, tools/lab/r04_batch18.sh).
-template <int A, int NT, bool GEN, int KM, bool PROF, int CS = 0>
-__global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void hns_step_v4_kernel(HNS_STEP_PARAMS) {
+// MOTOR (cfg.action_input = HNS_ACTION_MOTOR, include/hns.h): `action` holds the rotor commands of the caller's own controller transform
+// (transforms.py:455-456) — the step starts at _pre_sim_step (hideandseek.py:725-744): no tanh / CTBR / PID; the action error is read from the
+// bound buffer (:731), `prev_action`, `pid_integ`, `ctbr`, `target_rate` are left alone.  Served by the generic instantiation only (a
+// compatibility path: the torch controller in front costs twenty times this kernel).
+template <int A, int NT, bool GEN, int KM, bool PROF, int CS = 0, bool MOTOR = false>
+__global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK && !MOTOR) ? 4 : 1) void hns_step_v4_kernel(HNS_STEP_PARAMS) {
     HNS_STEP_ARGS_PACK;
     static_assert(GEN || KM == kMaxK, "wide k-nearest selections: the generic instantiation");
+    static_assert(!MOTOR || GEN, "motor-command input: the generic instantiation");
     static_assert(CS == 0 || (!GEN && !PROF && CS <= HNS_MAX_CYLINDERS), "fixed shapes: the tuned instantiation only");
     // the block behind `rest` is never written while the kernel runs: read it as constant memory (scalar loads, placed like kernel-argument loads)
     typedef const Params __attribute__((address_space(4))) ParamsC;
@@ -105,7 +110,8 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         const unsigned il = GEN ? (unsigned)(e0 + (le < nv ? le : nv - 1)) * A + a : ia;   // the record the loads read
         // loads, first needed first: action, previous action, the wave's 64 rigid-state rows, [reset_pid,] PID state, throttle
         const float4 act4 = reinterpret_cast<const float4 *>(ka.action)[il];
-        float4 prev4 = reinterpret_cast<const float4 *>(ka.prev_action)[il];
+        float4 prev4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (!MOTOR) prev4 = reinterpret_cast<const float4 *>(ka.prev_action)[il];
         constexpr int N4 = 64 * 13 / 4;                   // 208 float4 pieces per wave
         const float4 *rows4 = reinterpret_cast<const float4 *>(ka.drone_state + ((size_t)e0 * A + (tid & ~63)) * 13) + lane;
         static_assert(N4 > 192 && N4 <= 256, "three full passes and a partial one");
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         // (two evaders: the integrator's quad is loaded LAST of the first loads, below — right behind this load the compiler recycled the quad's unused fourth
         //  register for an address computation and had to wait, s_waitcnt vmcnt(0), for all the loads issued so far before issuing the remaining fifteen)
         float4 integ4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (NT == 1) integ4 = reinterpret_cast<const float4 *>(ka.pid_integ)[il];
+        if constexpr (NT == 1 && !MOTOR) integ4 = reinterpret_cast<const float4 *>(ka.pid_integ)[il];
         float4 last4 = reinterpret_cast<const float4 *>(ka.pid_last_rate)[il];
         // reset_pid = the incoming root `done` (transforms.py:449-454): one byte per env; with one evader its pointer rides in the argument block.
         // Loaded WITHOUT a branch (a null pointer reads a byte of `action` instead and the result is ignored): behind `if (pointer)` the compiler
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
                 const int kc = k < Cq ? k : 0;
                 own_c[i][0] = gcy[3 * kc]; own_c[i][1] = gcy[3 * kc + 1]; own_c[i][2] = gcy[3 * kc + 2];
             }
-            integ4 = reinterpret_cast<const float4 *>(ka.pid_integ)[il];
+            if constexpr (!MOTOR) integ4 = reinterpret_cast<const float4 *>(ka.pid_integ)[il];
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PROF) prof_mark(p.prof, 0);
@@ -182,7 +188,8 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
             etp0 = V3{gt[0], gt[1], gt[2]};
             etp1 = V3{gt[3], gt[4], gt[5]};
         }
-        const float4 ta = d_action_tanh(act4);           // needs the action only: evaluated while the rest is in flight
+        float4 ta = act4;
+        if constexpr (!MOTOR) ta = d_action_tanh(act4);  // needs the action only: evaluated while the rest is in flight
         Rigid s;
         if constexpr (GEN) {
             load_rigid(ka.drone_state + (size_t)il * 13, s);     // (generic) the thread's own row, 13 scalar loads
@@ -212,6 +219,12 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         const float los_t = last4.w;
         float cmd[4], thr_diff, aerr, thrust[4], moment[4];
         float ctbr4[4], trate[3];
+        if constexpr (MOTOR) {
+            // the caller's transform ran A1 / A2 (and nan_to_num, transforms.py:455): its commands feed the rotors as they are (hideandseek.py:735),
+            // its action error is the statistic's input (:731)
+            cmd[0] = ta.x; cmd[1] = ta.y; cmd[2] = ta.z; cmd[3] = ta.w;
+            aerr = b.action_error[il];
+        } else {
         {   // reset_pid (lee_position_controller.py:497-502): integrator and last body rate start from zero (selects, no branch)
             const bool r = rp != 0;
             integ4.x = r ? 0.0f : integ4.x; integ4.y = r ? 0.0f : integ4.y; integ4.z = r ? 0.0f : integ4.z;
@@ -222,6 +235,7 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         asm volatile("" : "+v"(thr4.x), "+v"(thr4.y), "+v"(thr4.z), "+v"(thr4.w));
         if (b.ctbr && valid) reinterpret_cast<float4 *>(b.ctbr)[ia] = make_float4(ctbr4[0], ctbr4[1], ctbr4[2], ctbr4[3]);           // transforms.py:456
         if (b.target_rate && valid) reinterpret_cast<float4 *>(b.target_rate)[ia] = make_float4(trate[0], trate[1], trate[2], 0.0f);  // :457
+        }
         d_rotor(c, cmd, thr4, thrust, moment, thr_diff);
         const float ts = ((thrust[0] + thrust[1]) + thrust[2]) + thrust[3];
         const V3 tw = d_quat_rot_z(s.q, ts);                                        // multirotor.py:491
@@ -294,9 +308,11 @@ __global__ __launch_bounds__(Geo<A>::T, (NT == 2 && KM == kMaxK) ? 4 : 1) void h
         // there measured +1 % at 65 536 envs.  tools/lab/r04_batch53.sh, _54, _56.)
         if (valid) {
             st_f4(reinterpret_cast<float4 *>(b.throttle) + ia, thr4);
-            st_f4(reinterpret_cast<float4 *>(b.pid_integ) + ia, integ4);
-            st_f4(reinterpret_cast<float4 *>(b.prev_action) + ia, prev4);
-            st_f1(b.action_error + ia, aerr);
+            if constexpr (!MOTOR) {
+                st_f4(reinterpret_cast<float4 *>(b.pid_integ) + ia, integ4);
+                st_f4(reinterpret_cast<float4 *>(b.prev_action) + ia, prev4);
+                st_f1(b.action_error + ia, aerr);
+            }
         }
         {   // S_{t+1}: the wave's 64 rows back through the slab, one contiguous slice
             const float row[13] = {s.pos.x, s.pos.y, s.pos.z, s.q.w, s.q.x, s.q.y, s.q.z, s.lin.x, s.lin.y, s.lin.z, s.ang.x, s.ang.y, s.ang.z};

@@ -6,10 +6,12 @@ scripts/train.py:110-205): constructor `Env(cfg, headless)`, `REGISTRY`, `reset(
 `set_seed()`, `_reset/_step/_set_seed`, spec trees, `agent_spec["drone"]`, `num_envs`,
 `max_episode_length`, `dt`, `progress_buf`, `stats`, `info`, `drone.params`, `drone.n`.
 
-One deliberate difference: the body-rate PID action transform
-(omni_drones/utils/torchrl/transforms.py:404-459) is fused into the step kernel, so this env
-takes the RAW policy action (what the reference feeds to `TransformedEnv.step`) and needs no
-`PIDRateController` transform around it.
+Where the action transform runs (`config.resolve_action_input`): with `task.action_transform: none`
+(cfg/task/HideAndSeek_hip.yaml) the body-rate PID transform (omni_drones/utils/torchrl/transforms.py:404-459) is fused
+into the step kernel and the env takes the RAW policy action (`action_input: policy`).  With the reference's own task file
+(`action_transform: PIDrate`, cfg/task/HideAndSeek.yaml:16) scripts/train.py:165-171 puts the torch controller in front; the env
+then takes its rotor commands and starts at `_pre_sim_step` (hideandseek.py:725-744), as the reference's env does
+(`action_input: motor`) — the controller never runs twice.
 
 Every tensor returned is a view of a persistent device buffer that the next `step()` overwrites
 in place — the same aliasing contract as the reference (`hideandseek.py:901-902`).
@@ -243,6 +245,12 @@ class HideAndSeek(_EnvBase):
         self._render = not headless
         # transforms.py:456-457: `ctbr` and `target_rate` on the input tensordict — extra outputs, written only when asked for
         self.publish_ctbr = bool(int(cfg.task.get("publish_ctbr", 0)))
+        # "policy": ("agents","action") is the raw policy output, A1/A2 run inside hns_step.  "motor": the caller's controller transform ran in front
+        # (scripts/train.py:165-171) and left rotor commands there (transforms.py:455-456); hns_step starts at _pre_sim_step (include/hns.h: hns_action_input)
+        self.action_input = "motor" if int(self.hcfg.action_input) == abi.HNS_ACTION_MOTOR else "policy"
+        self._motor = self.action_input == "motor"
+        if self._motor:
+            self.publish_ctbr = False            # `ctbr` / `target_rate` are the transform's keys then (transforms.py:456-457)
         E, A, Cn, K = self.num_envs, self.num_agents, self.num_cylinders, self.obs_max_cylinder
 
         torch.cuda.set_device(self.device)
@@ -263,7 +271,7 @@ class HideAndSeek(_EnvBase):
         # and writes `done` at its very end, so the input IS the done buffer: what the previous step (or a reset, which clears it) left there
         # is what the root `done` of the stepped tensordict holds in the collector's / rollout's loop; a tensordict whose root `done` is
         # another tensor is copied in first (`_step`)
-        self.pid_reset_reference = int(self.hcfg.pid_reset_on_reset) == 0
+        self.pid_reset_reference = int(self.hcfg.pid_reset_on_reset) == 0 and not self._motor     # (motor: the caller's controller owns that state)
         self._hbuf.reset_pid = self._bufs["done"].data_ptr() if self.pid_reset_reference else None
         self._env = C.c_void_p()
         self._check(self._lib.hns_create(C.byref(self.hcfg), C.byref(self._env)), "hns_create")
@@ -524,7 +532,9 @@ class HideAndSeek(_EnvBase):
             action = action.float().contiguous()
         if action.shape != self._action_shape:
             raise ValueError(f"action shape {tuple(action.shape)} != {tuple(self._action_shape)}")
-        if self.pid_reset_reference:
+        if self._motor:
+            self._take_transform_keys(tensordict)
+        elif self.pid_reset_reference:
             # the incoming root `done` is the controller's reset_pid; the env's own done buffer (what `next.done` of the last step aliases,
             # cleared by reset for the envs it resets) already is that input unless the caller's tensordict carries another tensor
             d = tensordict.get("done", None)
@@ -565,12 +575,40 @@ class HideAndSeek(_EnvBase):
             # beside `next`: what PIDRateController._inv_call leaves on the stepped tensordict (transforms.py:438-457; hideandseek.py:726-731
             # reads the first two back) — views of the buffers the kernel just updated.  They travel in the RETURNED tree, which the base
             # class merges into the caller's: torchrl locks the input tensordict while `_step` runs, new keys cannot be set on it.
-            out = {"next": nxt, "stats": {"action_error_order1": b["action_error"]}, "info": {"prev_action": b["prev_action"]}}
-            if self.publish_ctbr:
-                out["ctbr"] = b["ctbr"]
-                out["target_rate"] = b["target_rate"][..., :3]
+            out = self._beside_next(nxt)
             self._next_cache = TensorDict(out, self.batch_size)
         return self._next_cache
+
+    def _beside_next(self, nxt):
+        """The tree `_step` returns: `next`, and — when the controller is fused into the step — the keys the reference's transform would have
+        left on the stepped tensordict.  With `action_input: motor` that transform ran in the caller's wrapper and set them itself."""
+        b = self._bufs
+        if self._motor:
+            return {"next": nxt}
+        out = {"next": nxt, "stats": {"action_error_order1": b["action_error"]}, "info": {"prev_action": b["prev_action"]}}
+        if self.publish_ctbr:
+            out["ctbr"] = b["ctbr"]
+            out["target_rate"] = b["target_rate"][..., :3]
+        return out
+
+    def _take_transform_keys(self, tensordict):
+        """`action_input: motor` — hideandseek.py:729-731: `self.info["prev_action"] = tensordict[("info", "prev_action")]`,
+        `self.action_error_order1 = tensordict[("stats", "action_error_order1")]`: what PIDRateController._inv_call left on the stepped tensordict
+        (transforms.py:441-443) goes into the bound buffers (the kernel reads the action error for the statistics and the smoothness reward;
+        `info.prev_action` is handed out with the next observation).  A tensordict without them fails here as it fails in the reference."""
+        b = self._bufs
+        try:
+            prev = tensordict[("info", "prev_action")]
+            aerr = tensordict[("stats", "action_error_order1")]
+        except KeyError as e:
+            raise KeyError(f"{e.args[0] if e.args else e}: with task.action_input = 'motor' (task.action_transform = "
+                           f"{self.cfg.task.get('action_transform', None)!r}) the stepped tensordict must carry ('info', 'prev_action') and ('stats', "
+                           "'action_error_order1') as PIDRateController._inv_call leaves them (omni_drones/utils/torchrl/transforms.py:441-443; read at "
+                           "hideandseek.py:729-731).  To feed raw policy actions instead use cfg/task/HideAndSeek_hip.yaml (action_transform: none)") from None
+        if prev.data_ptr() != b["prev_action"].data_ptr():
+            b["prev_action"].copy_(prev.reshape(b["prev_action"].shape))
+        if aerr.data_ptr() != b["action_error"].data_ptr():
+            b["action_error"].copy_(aerr.reshape(b["action_error"].shape))
 
     def _fresh_step_output(self):
         """`env.eval()` (scripts/train.py:213-214 before `env.rollout(...)`, :225-233): the observation, state, predictor entries, reward and `done`
@@ -582,11 +620,7 @@ class HideAndSeek(_EnvBase):
         nxt = self._fresh_obs(self._obs_tensordict())
         nxt.set(("agents", "reward"), b["reward"].unsqueeze(-1).clone())
         nxt.set("done", b["done"].view(torch.bool).unsqueeze(-1).clone())
-        out = {"next": nxt, "stats": {"action_error_order1": b["action_error"]}, "info": {"prev_action": b["prev_action"]}}
-        if self.publish_ctbr:
-            out["ctbr"] = b["ctbr"]
-            out["target_rate"] = b["target_rate"][..., :3]
-        return TensorDict(out, self.batch_size)
+        return TensorDict(self._beside_next(nxt), self.batch_size)
 
     @staticmethod
     def _fresh_obs(td):

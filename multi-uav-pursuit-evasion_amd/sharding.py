@@ -3,18 +3,20 @@ ONE collective the path needs.
 
 Envs are independent units (every per-step interaction is intra-env), so rank r simply owns
 envs [offset, offset+count) of every array and the step needs no data-path collective.  The
-reference has two cross-env reductions, both outside the step proper:
-  * advantage normalisation over the whole rollout (omni_drones/learning/mappo.py:391-396), and
+reference has three cross-env reductions, all outside the step proper:
+  * advantage normalisation over the whole rollout (omni_drones/learning/mappo.py:391-396),
   * `stats["success"].mean()` driving the evader-speed curriculum
-    (omni_drones/envs/hide_and_seek/hideandseek.py:1012-1015).
-Both are folded into a single all-gather of a tiny moment vector per rollout
-(`[sum, sum_sq, count, success_sum, env_count]`), RCCL over xGMI on the GPUs
-(`torch.distributed` backend "nccl"), gloo in the CPU tests.
+    (omni_drones/envs/hide_and_seek/hideandseek.py:1012-1015), and
+  * ValueNorm1's batch moments of the rollout's returns (learning/utils/valuenorm.py:83-91 via mappo.py:398-399).
+All are folded into a single all-gather of a tiny moment vector per rollout (MOMENT_DIM fp64 values, below), RCCL over xGMI
+on the GPUs (`torch.distributed` backend "nccl"), gloo in the CPU tests.  The consumers reproduce what the reference's learner
+computes on the whole batch (tests/golden/g_learner_moments.npz: those statements executed as written).
 """
 import torch
 import torch.distributed as dist
 
-MOMENT_DIM = 5
+# [sum adv, sum adv^2, n_adv, sum success, n_envs, sum returns, sum returns^2, n_returns] — one row per rank
+MOMENT_DIM = 8
 HNS_MOMENTS_MAX = 1 << 18          # elements one workgroup of hns_moments reads in ~10 us (1 MB); larger tensors go to torch's reductions
 
 
@@ -26,20 +28,27 @@ def env_shard(num_envs_total, world_size, rank):
     return offset, count
 
 
-def local_moments(values, success=None):
-    """[sum, sum of squares, count, success sum, env count] of this rank, fp64.  Small contiguous fp32 device tensors go through ONE launch of
-    the library (hns_moments: one workgroup, fixed summation order) instead of eight small torch kernels in front of the collective; above
-    HNS_MOMENTS_MAX elements (a whole rollout's advantages: 65 536 x 64 x 3 = 12.6 M values) one workgroup would read ~50 MB from one compute
-    unit, so torch's chip-wide reductions take over."""
-    if values.is_cuda and values.dtype == torch.float32 and values.is_contiguous() and values.numel() <= HNS_MOMENTS_MAX and (
-            success is None or (success.is_cuda and success.dtype == torch.float32 and success.is_contiguous() and success.numel() <= HNS_MOMENTS_MAX)):
+def _small_dev_f32(t):
+    return t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() <= HNS_MOMENTS_MAX)
+
+
+def local_moments(values, success=None, returns=None):
+    """This rank's row of the moment table (MOMENT_DIM fp64 values; entries of an absent input are 0).  Small contiguous fp32 device tensors go
+    through ONE launch of the library (hns_moments / hns_rollout_moments: one workgroup, fixed summation order) instead of a dozen small torch kernels in
+    front of the collective; above HNS_MOMENTS_MAX elements (a whole rollout's advantages: 65 536 x 64 x 3 = 12.6 M values) one workgroup would read
+    ~50 MB from one compute unit, so torch's chip-wide reductions take over."""
+    if values.is_cuda and _small_dev_f32(values) and _small_dev_f32(success) and _small_dev_f32(returns):
         import ctypes as C
         from . import abi
         lib = abi.load_library()
-        out = torch.empty(MOMENT_DIM, dtype=torch.float64, device=values.device)
+        out = torch.zeros(MOMENT_DIM, dtype=torch.float64, device=values.device)
+        sp, sn = (success.data_ptr(), success.numel()) if success is not None else (None, 0)
+        st = C.c_void_p(torch.cuda.current_stream(values.device).cuda_stream)
         with torch.cuda.device(values.device):
-            rc = lib.hns_moments(values.data_ptr(), values.numel(), success.data_ptr() if success is not None else None,
-                                 success.numel() if success is not None else 0, out.data_ptr(), C.c_void_p(torch.cuda.current_stream(values.device).cuda_stream))
+            if returns is None:
+                rc = lib.hns_moments(values.data_ptr(), values.numel(), sp, sn, out.data_ptr(), st)
+            else:
+                rc = lib.hns_rollout_moments(values.data_ptr(), values.numel(), sp, sn, returns.data_ptr(), returns.numel(), out.data_ptr(), st)
         if rc != 0:
             raise RuntimeError(f"hns_moments failed ({rc}): {lib.hns_last_error().decode()}")
         return out
@@ -49,6 +58,9 @@ def local_moments(values, success=None):
     if success is not None:
         s = success.reshape(-1).double()
         out[3], out[4] = s.sum(), float(s.numel())
+    if returns is not None:
+        r = returns.reshape(-1).double()
+        out[5], out[6], out[7] = r.sum(), (r * r).sum(), float(r.numel())
     return out
 
 
@@ -76,16 +88,49 @@ def global_mean_std(table):
     return mean, torch.sqrt(torch.clamp(var, min=0.0))
 
 
-def normalise_advantages(adv, success=None, eps=1e-7):
-    """Data-parallel form of `(adv - adv.mean()) / adv.std().clip(1e-7)` (mappo.py:391-396).
+def global_value_moments(table):
+    """ValueNorm1.update's two batch moments over the WHOLE sharded batch (valuenorm.py:86-87: `input_vector.mean(dim)`, `(input_vector**2).mean(dim)`
+    with input_shape (1,), i.e. over every leading dimension) from the gathered table, fp64."""
+    tot = table.sum(0)
+    return tot[5] / tot[7], tot[6] / tot[7]
+
+
+def valuenorm1_update(value_normalizer, table):
+    """`self.value_normalizer.update(tensordict["returns"])` (mappo.py:399) for a shard of a data-parallel run: the reference's ValueNorm1 instance
+    (running_mean, running_mean_sq, debiasing_term, beta; valuenorm.py:45-91) updated with the batch moments of ALL ranks' returns, so every rank holds
+    the normaliser a single process would hold.  Lines :88-91 in meaning, with the two batch means taken from the gathered table."""
+    batch_mean, batch_sq_mean = global_value_moments(table)
+    vn, w = value_normalizer, float(value_normalizer.beta)
+    with torch.no_grad():
+        vn.running_mean.mul_(w).add_(batch_mean.to(vn.running_mean) * (1.0 - w))
+        vn.running_mean_sq.mul_(w).add_(batch_sq_mean.to(vn.running_mean_sq) * (1.0 - w))
+        vn.debiasing_term.mul_(w).add_(1.0 * (1.0 - w))
+
+
+def normalise_advantages(adv, success=None, eps=None, form="mappo", returns=None, value_normalizer=None):
+    """Data-parallel form of the learner's advantage normalisation over the whole rollout, from ONE all-gather of the moment table.
+
+    form="mappo" (default — the learner on this path): `(adv - mean) / (std + 1e-8)` as MAPPOPolicy.train_op has it (learning/mappo.py:391-396;
+    `torch.std` = unbiased).  form="ppo": `(adv - mean) / std.clip(1e-7)`, the single-agent learner's (learning/_ppo.py:176).  `eps` overrides the constant.
+    With `returns` the table also carries ValueNorm1's batch moments; a `value_normalizer` (the reference's ValueNorm1 instance) is
+    then updated in place with the global moments (`valuenorm1_update`), as mappo.py:398-399 does right behind the normalisation.
     Returns (normalised advantages, global success rate or None)."""
-    table = allgather_moments(local_moments(adv, success))
+    if form not in ("mappo", "ppo"):
+        raise ValueError("form must be 'mappo' (learning/mappo.py:391-396) or 'ppo' (learning/_ppo.py:176)")
+    table = allgather_moments(local_moments(adv, success, returns))
     mean, std = global_mean_std(table)
     rate = None
     if success is not None:
         tot = table.sum(0)
         rate = float(tot[3] / tot[4])
-    return (adv - mean.to(adv.dtype)) / std.clamp(min=eps).to(adv.dtype), rate
+    if value_normalizer is not None:
+        if returns is None:
+            raise ValueError("a value_normalizer needs the rollout's returns")
+        valuenorm1_update(value_normalizer, table)
+    mean, std = mean.to(adv.dtype), std.to(adv.dtype)
+    if form == "mappo":
+        return (adv - mean) / (std + (1e-8 if eps is None else eps)), rate
+    return (adv - mean) / std.clamp(min=1e-7 if eps is None else eps), rate
 
 
 def _coll_tensor(t):

@@ -618,6 +618,12 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
         for (int a = 0; a < A; ++a) {
             size_t ia = (size_t)e * A + a;
             float cmd[4], ctbr[4], trate[3];
+            if (c->action_input == HNS_ACTION_MOTOR) {
+                /* include/hns.h: the caller's PIDRateController transform ran in front (scripts/train.py:165-171) — `action` holds its rotor
+                 * commands (transforms.py:455-456), b->action_error / b->prev_action what it left under ("stats","action_error_order1") /
+                 * ("info","prev_action"); the step starts at HideAndSeek._pre_sim_step (hideandseek.py:725-735) */
+                for (int i = 0; i < 4; ++i) cmd[i] = action[ia * 4 + i];
+            } else {
             if (reset_pid)
                 for (int i = 0; i < 3; ++i) { b->pid_integ[ia * 4 + i] = 0.0f; b->pid_last_rate[ia * 4 + i] = 0.0f; }
             o_ctbr_pid(c, action + ia * 4, ds + 13 * a + 3, ds + 13 * a + 10, b->prev_action + ia * 4,
@@ -626,6 +632,7 @@ int hns_oracle_step(const hns_cfg *c, const hns_buffers *b, const float *action)
             if (b->target_rate) {                                                                     /* transforms.py:457 */
                 for (int i = 0; i < 3; ++i) b->target_rate[ia * 4 + i] = trate[i];
                 b->target_rate[ia * 4 + 3] = 0.0f;
+            }
             }
             sum_ae = (a == 0) ? b->action_error[ia] : sum_ae + b->action_error[ia];
             o_rotor(c, cmd, b->throttle + ia * 4, thrust[a], moment[a], &thr_diff[a]);

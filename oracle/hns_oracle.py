@@ -88,9 +88,9 @@ def reset(cfg, arrs, mask, seed, epoch):
 
 
 def reset_tasks(cfg, arrs, mask, seed, epoch, tasks, task_first):
+    """`tasks` rows of the masked envs below `task_first` are OUTPUTS (the placement as sampled, include/hns.h): written in place."""
     b = as_struct(arrs)
     m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-    """`tasks` rows of the masked envs below `task_first` are OUTPUTS (the placement as sampled, include/hns.h): written in place."""
     t = f32(tasks)
     rc = lib().hns_oracle_reset_tasks(C.byref(cfg), C.byref(b), _p(m), C.c_uint64(seed), C.c_uint32(epoch), _p(t), int(task_first))
     if rc != 0:

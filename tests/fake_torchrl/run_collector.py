@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Child process of tests/test_torchrl_branch.py: HideAndSeek as a (stand-in) torchrl EnvBase under TransformedEnv + SyncDataCollector,
-wired as scripts/train.py:165-205 wires the reference's env; the collected rollouts are replayed on the CPU oracle."""
+wired as scripts/train.py:165-205 wires the reference's env; the collected rollouts are replayed on the CPU oracle.
+
+argv: [use_TP_net 0|1] [motor] — `motor`: the reference's task file unchanged (`action_transform: PIDrate`, cfg/task/HideAndSeek.yaml:16): train.py:165-171
+puts the controller transform in front; here a stand-in that does what `PIDRateController._inv_call` does (utils/torchrl/transforms.py:425-459) with the
+oracle's restatement of the controller.  The env derives `action_input: motor` from the same key; the oracle follows with its FUSED controller from the raw
+policy actions, so the replay also proves motor == policy."""
 import json
 import os
 import sys
@@ -16,19 +21,62 @@ from hns_amd import config, tensordict_shim
 assert tensordict_shim.USING_REAL_TORCHRL and tensordict_shim.USING_REAL_TENSORDICT, "the stand-in packages were not picked up"
 from hns_amd.env import HideAndSeek
 from tensordict import TensorDict
-from torchrl.envs import Compose, EnvBase, TransformedEnv
+from torchrl.envs import Compose, EnvBase, Transform, TransformedEnv
 from torchrl.collectors import SyncDataCollector
 import hns_oracle as O
 
 use_tp = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+motor = len(sys.argv) > 2 and sys.argv[2] == "motor"
 E, A, L, T = 256, 3, 12, 8
-cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": 5, "min_num": 3}, "env": {"num_envs": E, "max_episode_length": L}},
-                      algo={"use_TP_net": use_tp, "train_every": T})
-base_env = HideAndSeek(cfg, headless=True)
+if motor:
+    import tempfile
+    # a task file as the reference ships it — `action_transform: PIDrate`, no key of this build — read the way hydra's composed config arrives
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        f.write(f"name: HideAndSeek\naction_transform: PIDrate\nnum_agents: {A}\ncylinder:\n  max_num: 5\n  min_num: 3\n"
+                f"env:\n  num_envs: {E}\n  max_episode_length: {L}\n")
+    cfg = config.load_cfg(f.name)
+    os.unlink(f.name)
+    cfg.algo.use_TP_net, cfg.algo.train_every = use_tp, T
+    assert "action_input" not in cfg.task
+else:
+    cfg = config.make_cfg({"num_agents": A, "cylinder": {"max_num": 5, "min_num": 3}, "env": {"num_envs": E, "max_episode_length": L}},
+                          algo={"use_TP_net": use_tp, "train_every": T})
+from omni_drones.envs.isaac_env import IsaacEnv                   # scripts/train.py:100,110-111: the class comes from the registry, by the task's name
+base_env = IsaacEnv.REGISTRY[cfg.task.name](cfg, headless=True)
+assert isinstance(base_env, HideAndSeek) and base_env.action_input == ("motor" if motor else "policy")
 assert isinstance(base_env, EnvBase) and tuple(base_env.batch_size) == (E,)
 assert tuple(base_env.observation_spec.shape) == (E,) and tuple(base_env.input_spec["_action_spec"].shape) == (E,)
 assert tuple(base_env.observation_spec[("agents", "observation", "state_self")].shape) == (E, A, 1, 35 if use_tp else 20)
-env = TransformedEnv(base_env, Compose()).train()            # action_transform: none (cfg/task/HideAndSeek_hip.yaml)
+
+
+class StandInPIDRate(Transform):
+    """What scripts/train.py:165-171 puts in front with `action_transform: PIDrate`: reads ("info","drone_state"), the action, ("info","prev_action") and
+    the root `done` of the stepped tensordict; leaves rotor commands in ("agents","action") and the keys hideandseek.py:729-731 reads back
+    (transforms.py:425-459).  The arithmetic is the oracle's restatement of `_inv_call` + PIDRateController.forward (pinned by g_pid), on the host."""
+
+    def __init__(self, hcfg, device):
+        super().__init__()
+        self.c, self.dev = hcfg, device
+        self.integ = np.zeros((E * A, 3), np.float32)             # the controller's own state (lee_position_controller.py:468-470)
+        self.last = np.zeros((E * A, 3), np.float32)
+
+    def _inv_call(self, td):
+        ds = td[("info", "drone_state")][..., :13].cpu().numpy().reshape(E * A, 13)
+        act = td[("agents", "action")].cpu().numpy()
+        prev = td[("info", "prev_action")].cpu().numpy()
+        reset_pid = np.repeat(td["done"].reshape(E).cpu().numpy().astype(np.uint8), A)          # .expand(-1, num_drones), transforms.py:453
+        r = O.ctbr_pid(self.c, act, ds[:, 3:7], ds[:, 10:13], reset_pid, prev, self.integ, self.last)
+        self.integ, self.last = r["integ"], r["last"]
+        td.set(("stats", "action_error_order1"), torch.from_numpy(r["aerr"].reshape(E, A)).to(self.dev))
+        td.set(("info", "prev_action"), torch.from_numpy(r["prev_action"].reshape(E, A, 4)).to(self.dev))
+        td.set(("agents", "action"), torch.from_numpy(r["cmd"].reshape(E, A, 4)).to(self.dev))
+        td.set("ctbr", torch.from_numpy(r["ctbr"].reshape(E, A, 4)).to(self.dev))
+        td.set("target_rate", torch.from_numpy(r["target_rate"].reshape(E, A, 3)).to(self.dev))
+        return td
+
+
+transforms = [StandInPIDRate(base_env.hcfg, base_env.device)] if motor else []       # action_transform: none (cfg/task/HideAndSeek_hip.yaml) -> nothing
+env = TransformedEnv(base_env, Compose(*transforms)).train()
 env.set_seed(0)
 agent_spec = env.agent_spec["drone"]                          # reached through the wrapper, as train.py:176 does
 assert agent_spec.n == A
@@ -45,8 +93,10 @@ frames_per_batch = env.num_envs * int(cfg.algo.train_every)
 collector = SyncDataCollector(env, policy=policy, frames_per_batch=frames_per_batch, total_frames=frames_per_batch * 4,
                               device=cfg.sim.device, return_same_td=True)
 # the oracle follows: full reset, then every collected action; masked resets where the collector issued them
-host = O.alloc_buffers(base_env.hcfg)
-O.reset(base_env.hcfg, host, None, base_env.seed, 0)
+ocfg = base_env.hcfg.copy()
+ocfg.action_input = 0                                             # the oracle runs the FUSED controller on the raw policy actions, whichever input the env takes
+host = O.alloc_buffers(ocfg)
+O.reset(ocfg, host, None, base_env.seed, 0)
 epoch, n_resets, first = 1, 0, None
 # scripts/train.py:113-116,193-196: the statistics `EpisodeStats` follows are the leaves of the observation spec under "stats"
 stats_keys = [k for k in base_env.observation_spec.keys(True, True) if isinstance(k, tuple) and k[0] == "stats"]
@@ -61,7 +111,9 @@ for i, data in enumerate(collector):
     rew, done = data.get(("next", "agents", "reward")), data.get(("next", "done"))
     assert tuple(rew.shape) == (E, T, A, 1) and tuple(done.shape) == (E, T, 1) and done.dtype == torch.bool
     assert tuple(data.get(("next", "agents", "observation", "state_self")).shape) == (E, T, A, 1, 35 if use_tp else 20)
-    assert tuple(data.get(("stats", "action_error_order1")).shape) == (E, T, A) and tuple(data.get(("info", "prev_action")).shape) == (E, T, A, 4)
+    if not motor:                                                 # (motor: the transform sets them on TransformedEnv._step's shallow clone, as in the reference)
+        assert tuple(data.get(("stats", "action_error_order1")).shape) == (E, T, A)
+    assert tuple(data.get(("info", "prev_action")).shape) == (E, T, A, 4)
     assert "_reset" not in data.keys()
     acts = data.get(("agents", "action")).cpu().numpy()
     # EpisodeStats.__call__ (scripts/train.py:58-72) in meaning: the ROOT statistics one step behind a `done` are the finished episode's — the reset that
@@ -75,13 +127,13 @@ for i, data in enumerate(collector):
     expect = {name: [] for name in abi.STAT_NAMES}                # the oracle's statistics of the envs that finished, in (env-major, time) order of the mask
     ends = []
     for t in range(T):
-        O.step(base_env.hcfg, host, np.ascontiguousarray(acts[:, t]))
+        O.step(ocfg, host, np.ascontiguousarray(acts[:, t]))
         assert np.array_equal(host["reward"], rew[:, t, :, 0].cpu().numpy()), f"rollout {i} step {t}: reward differs from the oracle"
         assert np.array_equal(host["done"].astype(bool), done[:, t, 0].cpu().numpy())
         if host["done"].any():
             if t < T - 1:
                 ends.append((t, host["done"].astype(bool).copy(), host["stats"].copy()))
-            O.reset(base_env.hcfg, host, host["done"].copy(), base_env.seed, epoch)
+            O.reset(ocfg, host, host["done"].copy(), base_env.seed, epoch)
             epoch += 1
             n_resets += 1
     # boolean-mask indexing of [E, T-1] walks env-major: rebuild the oracle's picks in that order
@@ -127,5 +179,5 @@ for k in ("drone_state", "target_pos", "progress", "stats"):
 # reset(td) with a tensordict that carries no `_reset` (tensordict 0.1.x: get() raises on a missing key)
 td = env.reset(TensorDict({}, [E], device=base_env.device))
 assert not td.get("done").any()
-print(json.dumps({"rollouts": i + 1, "frames": (i + 1) * E * T, "masked_resets": n_resets, "use_tp": use_tp, "episodes_seen": episodes_seen, "stats_keys": len(stats_keys),
+print(json.dumps({"action_input": base_env.action_input, "rollouts": i + 1, "frames": (i + 1) * E * T, "masked_resets": n_resets, "use_tp": use_tp, "episodes_seen": episodes_seen, "stats_keys": len(stats_keys),
                   "tp_updates": globals().get("tp_updates", 0)}))

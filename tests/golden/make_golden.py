@@ -32,6 +32,8 @@ Fixtures written (tests/golden/*.npz):
   g_genbuffer  the reference's GenBuffer class and the curriculum statements of `_compute_reward_and_done`, executed as written
                (hideandseek_envgen.py:209-377, :1241-1246, :1302-1336): init_easy_cases, the bounds samplenearby clips to, samplenearby outputs,
                two task batches through insert / insert_weights / update / statistics / R_min..R_max filter / insert_history (exact FPS, named start)
+  g_learner_moments  MAPPOPolicy.train_op's advantage normalisation + ValueNorm1.update / normalize (mappo.py:391-402, valuenorm.py:83-98)
+               on whole [E,T,A,1] tensors: what the data-parallel form (sharding.py) must reproduce from gathered moments
   g_episode_resetpid_*  the same loop with the controller's reset_pid = the root `done` of the stepped tensordict
                (transforms.py:449-454), across resets of the done envs (their deterministic effects restated, see the function)
 """
@@ -835,7 +837,7 @@ def gen_episode_resetpid(tag, E, A, C, T, seed, max_len, reset_at, action_scale=
     env.progress_buf = torch.randint(0, 4, (E,), generator=g).float() + (max_len - 6)     # episodes end at steps 2 .. 5
     env.info["prev_action"][..., 3] = 0.575
     env._compute_state_and_obs()
-    names = ["action", "root_done", "pos", "rot", "vel", "tpos", "tvel", "throttle", "integ", "last", "prev_action", "progress", "stats", "aerr",
+    names = ["action", "root_done", "cmds", "pos", "rot", "vel", "tpos", "tvel", "throttle", "integ", "last", "prev_action", "progress", "stats", "aerr",
              "state_self", "state_others", "cylinders", "state_drones", "reward", "done"]
     rec = {k: [] for k in names}
     init = dict(pos=d.w_pos.clone(), rot=d.w_rot.clone(), vel=d.w_vel.clone(), tpos=env.target.pos.clone(), throttle=d.throttle.data.clone(),
@@ -891,6 +893,7 @@ def gen_episode_resetpid(tag, E, A, C, T, seed, max_len, reset_at, action_scale=
                          "info": {"drone_state": env.info["drone_state"].clone(), "prev_action": env.info["prev_action"].clone()},
                          "stats": {}, "done": root_done.clone()}, [E])
         td = tr.inv(td)                                   # A1 + A2 with reset_pid = the root done
+        cmds = td[("agents", "action")].clone()          # what the transform hands to the env (transforms.py:455-456): the input of `action_input: motor`
         env._pre_sim_step(td)
         rotor_f = d.rotor_rec.calls[-1]["forces"].reshape(E, A, 4, 3)
         base = d.base_link.calls[-1]
@@ -914,7 +917,7 @@ def gen_episode_resetpid(tag, E, A, C, T, seed, max_len, reset_at, action_scale=
         tdo = env._compute_state_and_obs()
         out = env._compute_reward_and_done()
         ob = tdo[("agents", "observation")]
-        for k, v in dict(action=action, root_done=root_done, pos=pos, rot=rot, vel=vel, tpos=tpos, tvel=tvel, throttle=d.throttle.data,
+        for k, v in dict(action=action, root_done=root_done, cmds=cmds, pos=pos, rot=rot, vel=vel, tpos=tpos, tvel=tvel, throttle=d.throttle.data,
                          integ=tr.controller.integ.reshape(E, A, 3), last=tr.controller.last_body_rate.reshape(E, A, 3),
                          prev_action=env.info["prev_action"], progress=env.progress_buf, stats=_stats_arr(env), aerr=env.action_error_order1,
                          state_self=ob["state_self"], state_others=ob["state_others"], cylinders=ob["cylinders"],
@@ -1458,5 +1461,42 @@ def gen_genbuffer():
     save("g_genbuffer", **out)
 
 
+def gen_learner_moments(E=64, T=8, A=3, rollouts=3, seed=20261001):
+    """The consumer of the path's ONE collective, executed as the reference wrote it: the advantage-normalisation statements of MAPPOPolicy.train_op
+    (learning/mappo.py:391-396: `(adv - mean) / (std + 1e-8)`, torch.std = unbiased) and the ValueNorm1 update / normalize that follow them (:398-402 ->
+    learning/utils/valuenorm.py:83-98, loaded by path; cfg/algo/mappo.yaml:44-49: critic.value_norm = ValueNorm1, beta 0.995, input_shape = reward_spec.shape[-1:] = (1,), mappo.py:215-218).
+    The statements run on whole `[E, T, A, 1]` tensors; tests split the same tensors over 1 / 2 / 8 ranks and must land on these outputs."""
+    MAPPO = "omni_drones/learning/mappo.py"
+    blocks = _stmt_sources(MAPPO, "MAPPOPolicy", "train_op",
+                           lambda s: s.startswith("advantages_mean") or s.startswith("advantages_std") or s.startswith("if self.normalize_advantages")
+                           or (s.startswith("if hasattr(self, \"value_normalizer\")") and "value_normalizer.update" in s))
+    assert len(blocks) == 4, blocks
+    valuenorm = load_by_path("ref_valuenorm", "omni_drones/learning/utils/valuenorm.py")
+    algo = yaml.safe_load(open(os.path.join(REF, "cfg/algo/mappo.yaml")))
+    vcfg = algo["critic"]["value_norm"]                  # (mappo.py:158 hands cfg.critic to the critic's constructor, which reads value_norm at :208-218)
+    assert vcfg["class"] == "ValueNorm1" and algo["normalize_advantages"] is True
+    self = types.SimpleNamespace(normalize_advantages=True, value_normalizer=getattr(valuenorm, vcfg["class"])(input_shape=(1,), **vcfg["kwargs"]))
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for r in range(rollouts):
+        # GAE outputs in shape and scale: advantages a few units wide with an offset, returns around the episode's running reward (tens)
+        adv = torch.randn(E, T, A, 1, generator=g) * (1.5 + r) + 0.3 * (r - 1)
+        ret = torch.randn(E, T, A, 1, generator=g) * 4.0 - 12.0 + 5.0 * r
+        tensordict = {"advantages": adv.clone(), "returns": ret.clone()}
+        ns = {"self": self, "tensordict": tensordict, "torch": torch}
+        for code in blocks:
+            exec(code, ns)
+        vn = self.value_normalizer
+        out[f"r{r}_adv"], out[f"r{r}_ret"] = adv, ret
+        out[f"r{r}_adv_normalised"], out[f"r{r}_ret_normalised"] = tensordict["advantages"], tensordict["returns"]
+        out[f"r{r}_running_mean"], out[f"r{r}_running_mean_sq"] = vn.running_mean.clone(), vn.running_mean_sq.clone()
+        out[f"r{r}_debiasing_term"] = vn.debiasing_term.clone()
+        out[f"r{r}_denormalised_probe"] = vn.denormalize(torch.linspace(-2, 2, 9).unsqueeze(-1))      # mappo.py:378-379 on the next rollout
+    out["meta"] = np.array([E, T, A, rollouts], dtype=np.int64)
+    out["beta"] = np.float64(vcfg["kwargs"]["beta"])
+    save("g_learner_moments", **out)
+
+
 if __name__ == "__main__":
     gen_genbuffer()
+    gen_learner_moments()

@@ -86,7 +86,7 @@ def test_two_rank_shards_equal_single_process():
     np.testing.assert_array_equal(rew, rew_full)
     # the one collective reproduces torch's global mean / unbiased std and the global success rate
     adv = torch.from_numpy(rew_full)
-    ref = (adv - adv.mean()) / adv.std().clip(1e-7)
+    ref = (adv - adv.mean()) / (adv.std() + 1e-8)               # learning/mappo.py:391-396
     got = np.concatenate([o[6] for o in outs], axis=1)
     np.testing.assert_allclose(got, ref.numpy(), rtol=2e-5, atol=2e-6)
     rate = float(full["stats"][abi.STAT_NAMES.index("success")].mean())
@@ -317,9 +317,14 @@ suc = (torch.rand(128, 1, device="cuda:0") > 0.5).float()
 table = sharding._allgather(sharding.local_moments(adv, suc))            # the collective itself, not the world_size == 1 shortcut
 assert table.shape == (1, sharding.MOMENT_DIM) and table.is_cuda
 mean, std = sharding.global_mean_std(table)
-ref = (adv - adv.mean()) / adv.std().clip(1e-7)
-got = (adv - mean.float()) / std.clamp(min=1e-7).float()
+ref = (adv - adv.mean()) / (adv.std() + 1e-8)
+got = (adv - mean.float()) / (std.float() + 1e-8)
 assert torch.allclose(got, ref, atol=1e-5), float((got - ref).abs().max())
+ret = torch.randn(64, 128, 3, 1, device="cuda:0") * 4 - 12
+t2 = sharding._allgather(sharding.local_moments(adv, suc, ret))          # with ValueNorm1's batch moments riding along (SURVEY 8(e)(3))
+assert torch.equal(t2[:, :5], table[:, :5])
+bm, bsq = sharding.global_value_moments(t2)
+assert abs(float(bm) - float(ret.double().mean())) < 1e-9 and abs(float(bsq) - float((ret.double() ** 2).mean())) < 1e-9
 acc = sharding._coll_tensor(torch.stack([suc.double().sum(), torch.tensor(float(suc.numel()), dtype=torch.float64, device="cuda:0")]))
 dist.all_reduce(acc)
 assert abs(float(acc[0] / acc[1]) - float(suc.mean())) < 1e-12
@@ -350,8 +355,130 @@ def test_moments_in_one_launch_match_torch():
         assert torch.equal(got, again)
         d = v.reshape(-1).double()
         ref = torch.tensor([float(d.sum()), float((d * d).sum()), float(d.numel()), float(s.double().sum()) if s is not None else 0.0,
-                            float(s.numel()) if s is not None else 0.0], dtype=torch.float64)
+                            float(s.numel()) if s is not None else 0.0, 0.0, 0.0, 0.0], dtype=torch.float64)
         assert torch.allclose(got.cpu(), ref, rtol=1e-12, atol=1e-9), (got, ref)
+        # the same launch with a second array (the rollout's returns): the first five entries do not move, the last three are its moments
+        r = (v.reshape(-1) * 0.25 + 3.0).contiguous()[: max(1, v.numel() // 2)]
+        both = sharding.local_moments(v, s, r)
+        assert torch.equal(both[:5], got[:5]) and torch.equal(both, sharding.local_moments(v, s, r))
+        rd = r.double()
+        assert torch.allclose(both[5:].cpu(), torch.tensor([float(rd.sum()), float((rd * rd).sum()), float(rd.numel())], dtype=torch.float64), rtol=1e-12, atol=1e-9)
     # the non-contiguous / non-fp32 forms still take the torch path
     got = sharding.local_moments(base[:2000:2], None)
     assert abs(float(got[0]) - float(base[:2000:2].double().sum())) < 1e-9
+
+
+# ---- the collective's consumers against the reference's learner ----------------------------------------------------------------
+class _ValueNorm1:
+    """The state and the two read-outs of the reference's ValueNorm1 (learning/utils/valuenorm.py:45-106) that `valuenorm1_update` works on — the class itself
+    cannot travel to the GPU box; g_learner_moments.npz holds what the reference's instance held after each update."""
+
+    def __init__(self, beta, epsilon=1e-5):
+        self.beta, self.epsilon = beta, epsilon
+        self.running_mean, self.running_mean_sq, self.debiasing_term = torch.zeros(1), torch.zeros(1), torch.tensor(0.0)
+
+    def _mean_var(self):
+        d = self.debiasing_term.clamp(min=self.epsilon)
+        mean, mean_sq = self.running_mean / d, self.running_mean_sq / d
+        return mean, (mean_sq - mean ** 2).clamp(min=1e-2)
+
+    def normalize(self, x):
+        mean, var = self._mean_var()
+        return (x - mean) / torch.sqrt(var)
+
+    def denormalize(self, x):
+        mean, var = self._mean_var()
+        return x * torch.sqrt(var) + mean
+
+
+def _check_learner_golden(g, r, adv_n, ret_n, vn, what):
+    # fp32 statements on [E,T,A,1] in the reference against fp64 moments cast to fp32 here: a few ulp of the mean / std
+    np.testing.assert_allclose(adv_n, g[f"r{r}_adv_normalised"], rtol=3e-6, atol=3e-6, err_msg=what)
+    np.testing.assert_allclose(vn.running_mean.numpy(), g[f"r{r}_running_mean"], rtol=2e-6, atol=1e-7, err_msg=what)
+    np.testing.assert_allclose(vn.running_mean_sq.numpy(), g[f"r{r}_running_mean_sq"], rtol=2e-6, atol=1e-7, err_msg=what)
+    np.testing.assert_allclose(float(vn.debiasing_term), float(g[f"r{r}_debiasing_term"]), rtol=1e-6, err_msg=what)
+    np.testing.assert_allclose(ret_n, g[f"r{r}_ret_normalised"], rtol=2e-5, atol=2e-5, err_msg=what)
+    np.testing.assert_allclose(vn.denormalize(torch.linspace(-2, 2, 9).unsqueeze(-1)).numpy(), g[f"r{r}_denormalised_probe"], rtol=2e-5, atol=2e-5, err_msg=what)
+
+
+def test_learner_moments_single_process_lands_on_the_reference(golden):
+    """world_size 1: `normalise_advantages` + `valuenorm1_update` on the whole tensors = mappo.py:391-402 / valuenorm.py:83-98 executed as written."""
+    from hns_amd import sharding
+    g = golden("g_learner_moments")
+    E, T, A, R = (int(x) for x in g["meta"])
+    vn = _ValueNorm1(float(g["beta"]))
+    for r in range(R):
+        adv, ret = torch.from_numpy(g[f"r{r}_adv"]), torch.from_numpy(g[f"r{r}_ret"])
+        adv_n, _ = sharding.normalise_advantages(adv, returns=ret, value_normalizer=vn)
+        _check_learner_golden(g, r, adv_n.numpy(), vn.normalize(ret).numpy(), vn, f"rollout {r}")
+    # the single-agent learner's form stays available and differs only in the guard (learning/_ppo.py:176)
+    a = torch.from_numpy(g["r0_adv"])
+    np.testing.assert_allclose(sharding.normalise_advantages(a, form="ppo")[0].numpy(), ((a - a.mean()) / a.std().clip(1e-7)).numpy(), rtol=3e-6, atol=3e-6)
+    with pytest.raises(ValueError):
+        sharding.normalise_advantages(a, form="tianshou")
+
+
+def _learner_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import hns_amd  # noqa: F401
+    from hns_amd import sharding
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "g_learner_moments.npz")))
+    E, T, A, R = (int(x) for x in g["meta"])
+    off, cnt = sharding.env_shard(E, world, rank)
+    vn = _ValueNorm1(float(g["beta"]))
+    outs = []
+    for r in range(R):
+        adv, ret = torch.from_numpy(g[f"r{r}_adv"][off:off + cnt]).contiguous(), torch.from_numpy(g[f"r{r}_ret"][off:off + cnt]).contiguous()
+        adv_n, _ = sharding.normalise_advantages(adv, returns=ret, value_normalizer=vn)
+        outs.append((adv_n.numpy(), vn.normalize(ret).numpy(), vn.running_mean.numpy().copy(), vn.running_mean_sq.numpy().copy(), vn.debiasing_term.numpy().copy()))   # numpy: torch tensors travel as shared-memory handles the exiting worker takes with it
+    q.put((rank, off, cnt, outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 8])
+def test_learner_moments_sharded_lands_on_the_reference(world, golden):
+    """The same tensors split over 2 / 8 ranks by contiguous env slices: every rank's normalised advantages are the slice of the reference's, and every
+    rank holds the SAME value normaliser a single process would hold — from the one all-gather."""
+    g = golden("g_learner_moments")
+    E, T, A, R = (int(x) for x in g["meta"])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 17 * world) % 2000
+    procs = [ctx.Process(target=_learner_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=500) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(R):
+        adv_n = np.concatenate([o[3][r][0] for o in outs])
+        ret_n = np.concatenate([o[3][r][1] for o in outs])
+        for o in outs[1:]:                                    # one normaliser: bit-identical on every rank
+            assert all(np.array_equal(x, y) for x, y in zip(o[3][r][2:], outs[0][3][r][2:]))
+        vn = _ValueNorm1(float(g["beta"]))
+        vn.running_mean, vn.running_mean_sq, vn.debiasing_term = (torch.from_numpy(np.asarray(x)) for x in outs[0][3][r][2:])
+        _check_learner_golden(g, r, adv_n, ret_n, vn, f"world {world} rollout {r}")
+
+
+@pytest.mark.gpu
+def test_learner_moments_on_device_land_on_the_reference(golden):
+    """The device path: one launch of hns_rollout_moments per rollout feeds both consumers (through the C ABI), against the same fixture."""
+    from hns_amd import sharding
+    g = golden("g_learner_moments")
+    E, T, A, R = (int(x) for x in g["meta"])
+    vn = _ValueNorm1(float(g["beta"]))
+    vn.running_mean, vn.running_mean_sq, vn.debiasing_term = vn.running_mean.cuda(), vn.running_mean_sq.cuda(), vn.debiasing_term.cuda()
+    for r in range(R):
+        adv, ret = torch.from_numpy(g[f"r{r}_adv"]).cuda(), torch.from_numpy(g[f"r{r}_ret"]).cuda()
+        assert adv.numel() <= sharding.HNS_MOMENTS_MAX
+        adv_n, _ = sharding.normalise_advantages(adv, returns=ret, value_normalizer=vn)
+        host = _ValueNorm1(float(g["beta"]))
+        host.running_mean, host.running_mean_sq, host.debiasing_term = vn.running_mean.cpu(), vn.running_mean_sq.cpu(), vn.debiasing_term.cpu()
+        _check_learner_golden(g, r, adv_n.cpu().numpy(), vn.normalize(ret).cpu().numpy(), host, f"device rollout {r}")
