@@ -451,7 +451,8 @@ struct Rng {
     int have;
     __device__ float uniform() {
         if (have == 0) { d_philox(k0, k1, env, epoch, block++, 0u, buf); have = 4; }
-        uint32_t u = buf[4 - have];
+        // the next word by selects: `buf[4 - have]` with a run-time index put the whole generator (44 bytes) in scratch memory
+        const uint32_t u = have == 4 ? buf[0] : have == 3 ? buf[1] : have == 2 ? buf[2] : buf[3];
         have--;
         return (float)(u >> 8) * 5.9604644775390625e-8f;
     }

@@ -66,7 +66,12 @@ void HNS_CAT(hns_select_kernels_, HNS_INST_A)(hns_env *env) {
             if (c.obs_max_cylinder == 3) {
                 switch (c.num_cylinders) {
                     case 5: env->step_args_fn = two ? hns_step_v4_kernel<A, 2, false, kMaxK, false, 5> : hns_step_v4_kernel<A, 1, false, kMaxK, false, 5>; break;
-                    case 8: env->step_args_fn = two ? hns_step_v4_kernel<A, 2, false, kMaxK, false, 8> : hns_step_v4_kernel<A, 1, false, kMaxK, false, 8>; break;
+                    case 8:
+                        // (seven pursuers / two evaders / 8 slots: that one fixed-shape instantiation needed 4 more registers than two 8-wave workgroups
+                        //  per CU leave and spilled them; its shape-generic twin does not — it serves the shape)
+                        if constexpr (A == 7) env->step_args_fn = two ? env->step_args_fn : hns_step_v4_kernel<A, 1, false, kMaxK, false, 8>;
+                        else env->step_args_fn = two ? hns_step_v4_kernel<A, 2, false, kMaxK, false, 8> : hns_step_v4_kernel<A, 1, false, kMaxK, false, 8>;
+                        break;
                     case 16: env->step_args_fn = two ? hns_step_v4_kernel<A, 2, false, kMaxK, false, 16> : hns_step_v4_kernel<A, 1, false, kMaxK, false, 16>; break;
                     default: break;
                 }

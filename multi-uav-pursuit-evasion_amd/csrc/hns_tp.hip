@@ -819,6 +819,9 @@ struct WsTile {
         constexpr int ch = l / 2, term = l % 2;
         constexpr bool is_x = ch < NXC;
         constexpr int off = (((is_x ? ch : ch - NXC) * 2 + term) * 4) * 64;
+#ifdef TP_WS_HALF_B        // (measurement arm: every second operand read skipped — what halving the LDS operand traffic would buy)
+        if constexpr (l % 2 == 1) { half8 r = c.b[0]; asm volatile("" : "+v"(r)); return r; }
+#endif
         return __builtin_bit_cast(half8, is_x ? c.xb[off] : c.hp[off]);
     }
     template <int BASE, int l>
@@ -828,7 +831,11 @@ struct WsTile {
     }
     template <int BASE, int k>
     static __device__ __forceinline__ void step(const Ctx &c) {
+#ifndef TP_WS_NO_MFMA      // (measurement arms TP_WS_*: tools/lab/r06_tp_arms.sh, profiles/r06_tp_where_the_time_goes.txt; never defined in the shipped build)
         c.acc = TP_MFMA(c.aw[a_term(k)][k / 3], c.b[(load_of(k) + BASE) % RING], c.acc);
+#else
+        asm volatile("" : "+v"(c.acc) : "v"(c.aw[a_term(k)][k / 3]), "v"(c.b[(load_of(k) + BASE) % RING]));
+#endif
         constexpr int l = refill(k);
         if constexpr (l >= 3 && l < NL) c.b[(l + BASE) % RING] = load<l>(c);
         __builtin_amdgcn_sched_barrier(0);
@@ -956,6 +963,23 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
     half8 bring[WsTile<NXC, true>::RING];                  // B-operand ring (WsTile)
     const float4 *sBias = reinterpret_cast<const float4 *>(sB) + (r * 2 + hb) * 4;
     if (prof && lane == 0) prof[1] = __builtin_amdgcn_s_memrealtime();
+#ifndef TP_WS_NO_PIN
+    // The weights were fetched with vector loads at the top of the kernel and are first USED inside the timestep loop, so the compiler put their
+    // `s_waitcnt vmcnt(n)` there — at the first matrix instructions of a timestep's first tile (round 6, from the ISA: vmcnt(3) ... vmcnt(0) down the first
+    // chain).  The counter is in order: inside the loop that wait also covers the window row this timestep has just requested (needed one timestep LATER)
+    // and the row it has just stored.  Claim the registers here, once, where nothing else is in flight.  (Measured: no difference, 81.1 against 82.4 us in
+    // one process each — the rows come from the Infinity Cache long before the chain's fourth instruction; kept because the loop's ISA now says what it means.)
+#pragma unroll
+    for (int term = 0; term < 2; ++term)
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) asm volatile("" : "+v"(aw[term][ch]));
+#endif
+#ifdef TP_WS_LOOP_PROF      // (measurement arm: shader-clock cycles of a timestep's five segments, summed over the timesteps -> prof[5..9], tools/tp_phases.py --loop)
+    unsigned long long lp[5] = {0, 0, 0, 0, 0}, lt = __builtin_readcyclecounter();
+#define TP_LP(i) { const unsigned long long n_ = __builtin_readcyclecounter(); lp[i] += n_ - lt; lt = n_; }
+#else
+#define TP_LP(i)
+#endif
 
     for (int t = 0; t < T; ++t) {
         {   // Two workgroups share a CU and the SIMDs issue oldest-first: left alone the older one runs ahead (its recurrence ends at 65-77 us, the
@@ -965,7 +989,9 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
             const int q = (4 * t) / T;
             if (q == 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2); else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
+        TP_LP(4)
         __syncthreads();                                         // x_t and h_{t-1} are in LDS
+        TP_LP(0)
         if (t + 1 < T) {                                   // frame t+1 -> the other x buffer (last read at timestep t-1)
             emit(t + 1, xn);
             if (t + 2 < T) {
@@ -977,14 +1003,20 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
                 } else load_row(t + 3, xn);
             }
         }
+        TP_LP(1)
         auto tile = [&](auto te_c) {
             constexpr int te = decltype(te_c)::value;
             f32x16 acc;
+#ifdef TP_WS_ZERO_BIAS     // (measurement arm: the four bias reads of a tile replaced by register moves)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { float z = 0.0f; asm volatile("" : "+v"(z)); acc[v] = z; }
+#else
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const float4 b = sBias[v];
                 acc[4 * v] = b.x; acc[4 * v + 1] = b.y; acc[4 * v + 2] = b.z; acc[4 * v + 3] = b.w;
             }
+#endif
             {
                 const uint4 *xb = sX + (t & 1) * (NXC * 2 * 4 * 64) + te * 64 + lane, *hp = sH + te * 64 + lane;
                 if (t > 0) {
@@ -1008,6 +1040,11 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
             // Saturated gates: e_i or e_o = inf -> the fma is inf, its reciprocal 0, the term 0 (P and 1 - e_g are finite: e_g is clamped to 2^64,
             // e_c <= 2^(2.9 T)); e_f = inf -> forget gate 0.
             unsigned hi_r[2], lo_r[2];
+#ifdef TP_WS_NO_CELL
+            hi_r[0] = __float_as_uint(acc[0]) ^ __float_as_uint(acc[5]); hi_r[1] = __float_as_uint(acc[2]) ^ __float_as_uint(acc[7]);
+            lo_r[0] = __float_as_uint(acc[8]) ^ __float_as_uint(acc[13]); lo_r[1] = __float_as_uint(acc[10]) ^ __float_as_uint(acc[15]);
+            hi_r[0] &= 0x03ff03ffu; hi_r[1] &= 0x03ff03ffu; lo_r[0] &= 0x03ff03ffu; lo_r[1] &= 0x03ff03ffu;
+#else
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float ei = __builtin_amdgcn_exp2f(acc[j]), ef = __builtin_amdgcn_exp2f(acc[4 + j]);
@@ -1027,12 +1064,17 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
                     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo_r[j >> 1]) : "v"(P), "v"(Q), "v"(hi_r[j >> 1]));
                 }
             }
+#endif
             hnew[te][0] = make_uint2(hi_r[0], hi_r[1]);
             hnew[te][1] = make_uint2(lo_r[0], lo_r[1]);
         };
         tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{});
         tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{});
+        TP_LP(2)
+#ifndef TP_WS_NO_BAR2
         __syncthreads();                                         // every wave has read h_{t-1}
+#endif
+        TP_LP(3)
         // publish this slice of h_t: chunk r >> 1, k-slots 4 (r & 1) .. + 3 of both lane halves
 #pragma unroll
         for (int te = 0; te < kWsTiles; ++te)
@@ -1042,6 +1084,9 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
     }
     __syncthreads();
     if (prof && lane == 0) prof[2] = __builtin_amdgcn_s_memrealtime();
+#ifdef TP_WS_LOOP_PROF
+    if (prof && lane == 0) { for (int i = 0; i < 5; ++i) prof[5 + i] = lp[i]; }
+#endif
 
     // ---- output layer on h_T (waves 0..3, one column tile each): tanh(W_fc h + b), rescaled to arena units (hideandseek.py:834-836) ----
     float *sPred = reinterpret_cast<float *>(sX);           // [env 128][16], or [env 128][32] with more than five predicted points (3F > 16): 16 KB,
