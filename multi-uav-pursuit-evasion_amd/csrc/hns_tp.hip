@@ -185,6 +185,26 @@ HNS_DEV float tp_frame_val(const TpParams &p, int u, int k, bool det) {
     return comp == 2 ? p.cylinder_size : p.cylinders[((size_t)e * p.C + cy) * 3 + comp];
 }
 
+// The same component as an ADDRESS that is always valid plus what to do with the loaded word: the weight-stationary kernel issues the loads of a thread's
+// four frame values and of the detection byte together and selects afterwards — through tp_frame_val every value sat behind its own branch and its own
+// wait for memory (five round trips in the prologue of every workgroup; round 6).  kind: 0 = the word, 1 = the word if the evader is detected else
+// mask_value, 2 = cylinder_size, 3 = zero (beyond the frame).
+HNS_DEV const float *tp_frame_addr(const TpParams &p, int u, int k, int &kind) {
+    const int e = tp_env(p, u);
+    const float *a = p.progress + e;                       // k = 0, and the stand-in address of the kinds that do not use the word
+    kind = k >= p.I ? 3 : 0;
+    if (k >= 1 && k < 7) { kind = 1; a = (k < 4 ? p.target_pos + (size_t)u * 3 + (k - 1) : p.target_vel + (size_t)u * 3 + (k - 4)); }
+    if (k >= 7 && k < p.I) {
+        const int j = k - 7, ag = j / 3;
+        if (ag < p.A) a = p.drone_state + ((size_t)e * p.A + ag) * 13 + (j - 3 * ag);
+        else {
+            const int jc = j - 3 * p.A, cy = jc / 3, comp = jc - 3 * cy;
+            if (comp == 2) kind = 2; else a = p.cylinders + ((size_t)e * p.C + cy) * 3 + comp;
+        }
+    }
+    return a;
+}
+
 // Two evaders: rows of 24 + 6F values = [the reference's 20 + 3F row for evader 0 | rpos of evader 1 (3) | 0 | drone - predicted evader 1 (3F)];
 // groundtruth / tp_done per unit.  Not tuned (plain stores): the shape is an extension.
 HNS_DEV void tp_write_row2(const TpParams &p, int ev, int a, const float *pr0, const float *pr1) {
@@ -864,7 +884,8 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
     const int I = p.I, T = p.T, R = 3 * p.F;
     const int e0 = blockIdx.x * kWsEnvs;
     const uint4 *img = reinterpret_cast<const uint4 *>(p.tp.packed);
-    unsigned long long *prof = p.prof ? p.prof + (size_t)(blockIdx.x * kWsWaves + r) * 16 : nullptr;
+    // (wave-uniform: through readfirstlane the stamp pointer lives in scalar registers — as a per-lane pair it was the first thing spilled across the loop)
+    unsigned long long *prof = p.prof ? p.prof + (size_t)(blockIdx.x * kWsWaves + __builtin_amdgcn_readfirstlane(r)) * 16 : nullptr;
     if (prof && lane == 0) prof[0] = __builtin_amdgcn_s_memrealtime();
 
     // ---- this wave's rows of the weight matrix: A operands for the whole kernel ----
@@ -887,13 +908,21 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
     float *hist = p.tp.history + (size_t)ec * T * I;
     float nf[NXC][4];                                      // the new frame
     {
-        const bool det = tp_det(p, ec);
+        // every load first (the detection byte and the 4 NXC words: independent, one memory round trip), the selects behind them
+        const unsigned dbyte = p.NT == 2 ? p.detect[ec >> 1] : p.detect[ec];
+        int kind[NXC][4];
+#pragma unroll
+        for (int cx = 0; cx < NXC; ++cx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nf[cx][j] = *tp_frame_addr(p, ec, 16 * cx + 4 * q + j, kind[cx][j]);
+        const bool det = p.NT == 2 ? ((dbyte >> (ec & 1)) & 1) != 0 : dbyte != 0;
 #pragma unroll
         for (int cx = 0; cx < NXC; ++cx)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k = 16 * cx + 4 * q + j;
-                nf[cx][j] = k < I ? tp_frame_val(p, ec, k, det) : 0.0f;
+                const int kd = kind[cx][j];
+                const float v = nf[cx][j];
+                nf[cx][j] = kd == 0 ? v : kd == 1 ? (det ? v : p.mask_value) : kd == 2 ? p.cylinder_size : 0.0f;
             }
     }
     auto load_row = [&](int slot, float (&dst)[NXC][4]) {
@@ -1048,7 +1077,10 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float ei = __builtin_amdgcn_exp2f(acc[j]), ef = __builtin_amdgcn_exp2f(acc[4 + j]);
-                const float eg = __builtin_amdgcn_exp2f(__builtin_fminf(acc[8 + j], 64.0f)), eo = __builtin_amdgcn_exp2f(acc[12 + j]);
+                // (the clamp as ONE v_min_f32: fminf() also canonicalises its operand first — a v_max_f32 x, x per unit that no finite input needs)
+                float zg;
+                asm("v_min_f32 %0, 0x42800000, %1" : "=v"(zg) : "v"(acc[8 + j]));
+                const float eg = __builtin_amdgcn_exp2f(zg), eo = __builtin_amdgcn_exp2f(acc[12 + j]);
                 const float Eg = 1.0f + eg;
                 const float ig = (1.0f - eg) * __builtin_amdgcn_rcpf(HNS_FMA(ei, Eg, Eg));
                 const float cn = HNS_FMA(__builtin_amdgcn_rcpf(1.0f + ef), c[te][j], ig);
@@ -1082,6 +1114,19 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
             for (int term = 0; term < 2; ++term)
                 reinterpret_cast<uint2 *>(sH)[((((r >> 1) * 2 + term) * 4 + te) * 64 + lane) * 2 + (r & 1)] = hnew[te][term];
     }
+    // The output layer's weight operands and bias come from the L2 (the packed image): requested HERE, ahead of the barrier that closes the recurrence — the
+    // weight registers of the loop are dead, and the round trip (about a microsecond with every workgroup of the launch in its epilogue at once) runs beside the
+    // wait for the slowest wave instead of behind it (round 6).
+    half8 f1[4], f2[4];
+    float4 fcb[4];
+    if (r < kWsTiles) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            f1[ch] = __builtin_bit_cast(half8, img[L.wfc + ch * 64 + lane]); f2[ch] = __builtin_bit_cast(half8, img[L.wfc + (4 + ch) * 64 + lane]);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) fcb[v] = (reinterpret_cast<const float4 *>(img + L.bfc) + hb * 4)[v];
+    }
     __syncthreads();
     if (prof && lane == 0) prof[2] = __builtin_amdgcn_s_memrealtime();
 #ifdef TP_WS_LOOP_PROF
@@ -1094,20 +1139,13 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
     if (r < kWsTiles) {
         const int te = r;
         f32x16 o;
-        {
-            const float4 *b4 = reinterpret_cast<const float4 *>(img + L.bfc) + hb * 4;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float4 b = b4[v];
-                o[4 * v] = b.x; o[4 * v + 1] = b.y; o[4 * v + 2] = b.z; o[4 * v + 3] = b.w;
-            }
-        }
-        half8 fh[4], fl[4], f1[4], f2[4];                   // every operand in its own register, all read before the first MFMA
+        for (int v = 0; v < 4; ++v) { o[4 * v] = fcb[v].x; o[4 * v + 1] = fcb[v].y; o[4 * v + 2] = fcb[v].z; o[4 * v + 3] = fcb[v].w; }
+        half8 fh[4], fl[4];                                 // every operand in its own register, all read before the first MFMA
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             const uint4 *bh = sH + ((ch * 2) * 4 + te) * 64 + lane;
             fh[ch] = __builtin_bit_cast(half8, bh[0]); fl[ch] = __builtin_bit_cast(half8, bh[4 * 64]);
-            f1[ch] = __builtin_bit_cast(half8, img[L.wfc + ch * 64 + lane]); f2[ch] = __builtin_bit_cast(half8, img[L.wfc + (4 + ch) * 64 + lane]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1158,11 +1196,12 @@ static int tp_nxc(int I) { return (I + 15) / 16; }
 // weight image does not fit beyond three chunks); HNS_TP_KERNEL=tile / ws forces one of them where both exist (A/B measurements)
 static bool tp_use_ws(int nxc) {
     static const int mode = [] { const char *m = getenv("HNS_TP_KERNEL"); return !m ? 0 : (m[0] == 't' ? 1 : (m[0] == 'w' ? 2 : 0)); }();
-    if (nxc > 2) return true;        // three chunks: 137 us against the tile kernel's 245 (tools/tp_widths.py, round 5) — and that instantiation of the tile kernel spilled
-                                     // 23 registers at its 256-register cap: it is no longer built
-    if (mode == 1) return false;
-    if (mode == 2) return true;
-    return nxc != 2;                 // two chunks: the tile kernel's 135 us against 146 (one register, 8 B, parked in scratch once per launch: the wave's LDS offset)
+    if (nxc > 1) return true;        // three chunks: 137 us against the tile kernel's 245 (tools/tp_widths.py, round 5) — and that instantiation of the tile kernel spilled
+                                     // 23 registers at its 256-register cap.  Two chunks: the tile kernel was 8 % ahead (135 against 146 us) with ONE register parked in
+                                     // scratch across its timestep loop; a shorter operand ring, a scalar wave index and a late re-derivation of that offset each left
+                                     // it at 1-10 spilled registers (round 6), so that instantiation is no longer built either: no shipped kernel touches scratch
+                                     // (tests/test_kernel_resources.py)
+    return mode != 1;                // one chunk: the weight-stationary kernel unless HNS_TP_KERNEL=tile asks for the other (A/B)
 }
 static int tp_frame_dim(const hns_cfg &c) { return 7 + 3 * c.num_agents + (c.tp_use_obstacles ? 3 * c.num_cylinders : 0); }
 
@@ -1287,7 +1326,7 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
         HNS_CHECK_HIP(hipGetLastError());
         return HNS_OK;
     }
-    void (*fn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_kernel<1> : hns::hns_tp_lstm_kernel<2>;          // (nxc <= 2 here: tp_use_ws)
+    void (*fn)(const TpParams) = hns::hns_tp_lstm_kernel<1>;          // (nxc == 1 here: tp_use_ws)
     const int waves = hns::tp_waves(nxc);
     const size_t lds = (size_t)hns::tp_image(nxc).bytes + (size_t)waves * 8 * nxc * 64 * sizeof(float)    // image + parked new frame
                        + ((nxc == 1 && 3 * p.F > 16) ? (size_t)waves * 1024 * sizeof(float) : 0);              // + the predictions of more than five points
