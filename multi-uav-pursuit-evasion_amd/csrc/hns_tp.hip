@@ -1077,10 +1077,10 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float ei = __builtin_amdgcn_exp2f(acc[j]), ef = __builtin_amdgcn_exp2f(acc[4 + j]);
-                // (the clamp as ONE v_min_f32: fminf() also canonicalises its operand first — a v_max_f32 x, x per unit that no finite input needs)
-                float zg;
-                asm("v_min_f32 %0, 0x42800000, %1" : "=v"(zg) : "v"(acc[8 + j]));
-                const float eg = __builtin_amdgcn_exp2f(zg), eo = __builtin_amdgcn_exp2f(acc[12 + j]);
+                // (fminf() canonicalises its operand first: a v_max_f32 x, x per unit beside the v_min.  Writing the clamp as ONE v_min_f32 in inline assembly
+                //  was tried in round 6 and is WRONG here: the compiler's hazard recogniser does not see an inline-asm read of a matrix instruction's result and
+                //  leaves out the wait states in front of it — one prediction in 4 500 off by 1.6e-5, tests/test_hip_tp.py[300-1-0])
+                const float eg = __builtin_amdgcn_exp2f(__builtin_fminf(acc[8 + j], 64.0f)), eo = __builtin_amdgcn_exp2f(acc[12 + j]);
                 const float Eg = 1.0f + eg;
                 const float ig = (1.0f - eg) * __builtin_amdgcn_rcpf(HNS_FMA(ei, Eg, Eg));
                 const float cn = HNS_FMA(__builtin_amdgcn_rcpf(1.0f + ef), c[te][j], ig);
@@ -1117,6 +1117,9 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
     // The output layer's weight operands and bias come from the L2 (the packed image): requested HERE, ahead of the barrier that closes the recurrence — the
     // weight registers of the loop are dead, and the round trip (about a microsecond with every workgroup of the launch in its epilogue at once) runs beside the
     // wait for the slowest wave instead of behind it (round 6).
+    // (behind a scheduling barrier: hoisted into the last timestep these loads could land in the registers of weight operands that matrix instructions still
+    //  in flight are reading — the hazard of WsTile's operand ring, on the A side)
+    __builtin_amdgcn_sched_barrier(0);
     half8 f1[4], f2[4];
     float4 fcb[4];
     if (r < kWsTiles) {
