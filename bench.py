@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--settle-steps", type=int, default=1500,
+                    help="pre-region phase of FIXED length, independent of --warmup (round 6): the env's first-use launches (masked reset, event-bracketed dispatch) and this "
+                         "many plain steps, followed by a full reset, before the W warm-up steps.  A region that starts 0.4 ms into the process's life runs on clocks that "
+                         "are still moving (the line's clock_mhz_*); 1 500 steps = 25 ms, where the committed rocprofv3 summaries start averaging too")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=3)
     ap.add_argument("--cylinders", type=int, default=8)
@@ -357,14 +361,20 @@ def main():
     # masked reset (no env is done yet: the state is untouched) before the warm-up pays that once, outside the timed region.
     reset_td.set("_reset", env._bufs["done"])
     env.reset(reset_td)
-    # likewise the event-bracketed dispatch (hipExtLaunchKernelGGL with start / stop events): the first of the W warm-up steps is launched
-    # that way, so that its first-use cost is not part of the timed region either
+    # likewise the event-bracketed dispatch (hipExtLaunchKernelGGL with start / stop events): launched once here, so that its first-use cost is not part of
+    # the timed region either.  Round 6: these first-use launches and `--settle-steps` plain steps form ONE pre-region phase whose length does not depend on
+    # --warmup; a full reset ends it, so the W warm-up steps and the K timed steps meet the episodes a fresh env would.
     env.enable_kernel_timing(1)
-    run(min(1, args.warmup))
+    env.step(tds[0])
     env.enable_kernel_timing(0)
     env.kernel_ms()
-    run(args.warmup - min(1, args.warmup))
+    for i in range(max(0, args.settle_steps)):
+        env.step(tds[i % R])
+    env.reset()
+    progress["t"] = 0
+    run(args.warmup)
     sync()
+    clock_probe_before = env.clock_probe()        # one wave for 20 us on the step stream, right in front of the region's start event
     # The timed region: ONE hipEvent pair around it on the stream the steps are launched on (hns_region_begin / hns_region_end) beside the wall clock.
     # Nothing rides on the launches inside it by default (an event-bracketed dispatch — `--time-every N`, off at 0 — leaves the device idle for
     # ~11 us around itself, profiles/r05_launch_overlap.txt).  The kernel's own duration is measured right AFTER the region (`kernel_blocks`).
@@ -376,8 +386,10 @@ def main():
     t0 = time.perf_counter()
     run(args.steps)
     env.region_end()
+    clock_probe_after = env.clock_probe()         # behind the region's stop event: not part of any timed quantity
     sync()
     elapsed = time.perf_counter() - t0
+    clock_mhz = {"before_region": env.clock_mhz(clock_probe_before), "after_region": env.clock_mhz(clock_probe_after)}
     env.enable_kernel_timing(0)
     region_ms = env.region_ms()
     in_ms, in_n = env.kernel_ms() if in_region_events else (-1.0, 0)
@@ -407,9 +419,12 @@ def main():
     #     — at steady state: a short timed region (the driver's --steps 20 --warmup 5) ends a few hundred microseconds into the device's life in this
     #     process, where blocks read 16.7-19.4 us on a box whose steady launches take 16.0 (clocks still settling); so the blocks start no earlier than
     #     1 500 launches in, which is also what the committed rocprofv3 summaries (thousands of launches) average over
-    for i in range(max(0, 1500 - args.warmup - args.steps)):
+    for i in range(max(0, 1500 - args.settle_steps - args.warmup - args.steps)):
         env.step(tds[i % R])
     blk_ms, blk_n, blk_each = kernel_blocks(env, tds, blocks=8, per=64)
+    clock_probe_blocks = env.clock_probe()
+    torch.cuda.synchronize(device)
+    clock_mhz["after_kernel_blocks"] = env.clock_mhz(clock_probe_blocks)
     # ... and, as a separately named field, 16 ISOLATED dispatches with start / stop events bound to each (hns_enable_timing): such a dispatch sits between
     # two idle gaps and its events take in more than the kernel (rocprofv3 reads 15.8 us for the dispatches these events read 18-20 us for)
     env.enable_kernel_timing(1)
@@ -733,7 +748,17 @@ def main():
                        "episode_length": args.episode, "critic_state_output": args.critic_state,
                        "sharding": f"contiguous env slices x{n_ranks}", "world_size_launched": world, "ranks": n_ranks,
                        "dist_backend": backend, "library_sha16": lib_sha16,
-                       "collective": "1 all-gather of 5 fp64 per 64-step rollout" if dist is not None else "none"},
+                       "collective": "1 all-gather of 8 fp64 per 64-step rollout" if dist is not None else "none",
+                       "pre_region": {"settle_steps": args.settle_steps, "what": "first-use launches + settle_steps plain steps + one full reset, then the W warm-up steps "
+                                                                                 "(fixed length, independent of --warmup)"}},
+            "clock_mhz_before_region": round(clock_mhz["before_region"], 1) if clock_mhz.get("before_region") else None,
+            "clock_mhz_after_region": round(clock_mhz["after_region"], 1) if clock_mhz.get("after_region") else None,
+            "clock_mhz_after_kernel_blocks": round(clock_mhz["after_kernel_blocks"], 1) if clock_mhz.get("after_kernel_blocks") else None,
+            "clock_mhz_what": "shader clock read by a one-wave probe kernel (s_memtime cycles per s_memrealtime 100 MHz tick, 20 us) on the step stream right before the "
+                              "region's start event / right behind its stop event / behind the kernel-duration blocks: the chip clocks to its power budget, a nearly idle "
+                              "chip reads near the 2.4 GHz maximum",
+            "schema": 6, "schema_note": "r05 on: roofline.frac / achieved / kernel_us describe the step kernel ALONE (blocks of plain launches after the region); the region-bounded "
+                                      "figure that BENCH_r01-r04 called frac is frac_step_rate.  r06 on: a fixed pre-region phase (config.pre_region) and clock_mhz_* fields",
             "collective_us": collective, "state_digest": state_digest,
             "env_frames_per_s": round(value / A, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "abi_rate": abi_rate, "configs": configs or None,

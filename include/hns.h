@@ -389,6 +389,11 @@ float hns_region_ms(hns_env *env);
  * aligned device pointers) as 16-byte loads / stores, one float4 per thread.  Not part of the environment. */
 int hns_copy_f4(void *dst, const void *src, size_t bytes, void *stream);
 
+/* Measurement: the shader clock the chip is running at.  One wave spins for `ticks` periods of the constant 100 MHz clock and writes out[0] = shader-clock
+ * cycles elapsed, out[1] = 100 MHz ticks elapsed (device pointer, 2 x uint64): MHz = 100 * out[0] / out[1].  MI355X clocks to its power budget; bench.py
+ * reports this before and after its timed region.  Not part of the environment. */
+int hns_clock_probe(unsigned long long *out, uint32_t ticks, void *stream);
+
 /* Diagnostics: attach a device buffer of [num_waves, 16] uint64 (num_waves = ceil(E/64)*(A+1); ceil(E/64)*(2A+1) when hns_step_mapping() is 1);
  * lane 0 of every wave of the step kernel then stamps the shader clock at up to 16 phase boundaries (NULL detaches). */
 int hns_set_phase_profile(hns_env *env, unsigned long long *device_buf);

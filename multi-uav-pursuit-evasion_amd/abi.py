@@ -234,6 +234,8 @@ def load_library():
     lib.hns_moments.restype = C.c_int
     lib.hns_rollout_moments.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.hns_rollout_moments.restype = C.c_int
+    lib.hns_clock_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.hns_clock_probe.restype = C.c_int
     lib.hns_copy_f4.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.hns_copy_f4.restype = C.c_int
     lib.hns_set_phase_profile.argtypes = [C.c_void_p, C.c_void_p]
@@ -284,5 +286,5 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "hns_create", "hns_destroy", "hns_bind", "hns_step", "hns_reset", "hns_reset_tasks", "hns_raycast", "hns_set_v_prey",
     "hns_set_smoothness_coef", "hns_set_reset_epoch", "hns_get_reset_epoch", "hns_enable_timing",
-    "hns_step_kernel_ms", "hns_region_begin", "hns_region_end", "hns_region_ms", "hns_copy_f4", "hns_moments", "hns_rollout_moments", "hns_set_phase_profile", "hns_step_mapping", "hns_set_state", "hns_get_state", "hns_refresh_derived_state", "hns_fps", "hns_fps_scratch_bytes", "hns_perturb_tasks", "hns_tp_bind", "hns_tp_refresh", "hns_tp_packed_bytes", "hns_tp_observe", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
+    "hns_step_kernel_ms", "hns_region_begin", "hns_region_end", "hns_region_ms", "hns_copy_f4", "hns_moments", "hns_rollout_moments", "hns_clock_probe", "hns_set_phase_profile", "hns_step_mapping", "hns_set_state", "hns_get_state", "hns_refresh_derived_state", "hns_fps", "hns_fps_scratch_bytes", "hns_perturb_tasks", "hns_tp_bind", "hns_tp_refresh", "hns_tp_packed_bytes", "hns_tp_observe", "hns_hover_step", "hns_hover_reset", "hns_abi_version", "hns_cfg_size", "hns_last_error",
 ]

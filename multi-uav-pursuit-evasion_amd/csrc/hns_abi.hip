@@ -294,6 +294,18 @@ __global__ __launch_bounds__(1024) void hns_moments_kernel(const float *__restri
     }
 }
 
+// hns_clock_probe: one wave spins for `ticks` periods of the chip-wide constant 100 MHz clock (s_memrealtime) and reports how many SHADER-clock cycles
+// (s_memtime) went by: out[0] = shader cycles, out[1] = 100 MHz ticks -> MHz = 100 out[0] / out[1].  The chip clocks to its power budget (DVFS); a launch-bound
+// region a few hundred microseconds into a process's life runs on clocks that are still moving — bench.py prints what this reads before and after its timed region.
+__global__ __launch_bounds__(64) void hns_clock_probe_kernel(unsigned long long *__restrict__ out, unsigned ticks) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) { __builtin_amdgcn_s_sleep(8); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+
 // measurement yardstick (hns_copy_f4): a plain float4 copy, one piece per thread.  Of the shapes tried on this chip (tools/microbench/copy_rate.hip:
 // 4 / 8 pieces per thread, persistent grid-stride grids, non-temporal accesses, hipMemcpyAsync) this simplest one is the fastest or within 5 % of the
 // fastest at every size: 6.6-7.1 TB/s for footprints the Infinity Cache holds, 6.0-6.25 TB/s beyond it (MI355X_MICROARCH.md: 6.29).
@@ -784,6 +796,13 @@ int hns_rollout_moments(const float *advantages, int64_t n, const float *success
     if (!advantages || !returns || !out || n < 0 || m < 0 || n_returns < 0 || (m > 0 && !success)) { set_error("hns_rollout_moments: bad argument"); return HNS_ERR_INVALID_ARG; }
     hipLaunchKernelGGL(hns::hns_moments_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), advantages, (long long)n, success, (long long)m,
                        returns, (long long)n_returns, out);
+    HNS_CHECK_HIP(hipGetLastError());
+    return HNS_OK;
+}
+
+int hns_clock_probe(unsigned long long *out, uint32_t ticks, void *stream) {
+    if (!out || ticks == 0 || ticks > 1000000u) { set_error("hns_clock_probe: out (device, 2 x u64) and 1 <= ticks <= 1e6 (10 ms)"); return HNS_ERR_INVALID_ARG; }
+    hipLaunchKernelGGL(hns::hns_clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), out, ticks);
     HNS_CHECK_HIP(hipGetLastError());
     return HNS_OK;
 }

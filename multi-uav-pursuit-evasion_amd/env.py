@@ -794,6 +794,18 @@ class HideAndSeek(_EnvBase):
     def region_ms(self):
         return float(self._lib.hns_region_ms(self._env))
 
+    def clock_probe(self, ticks=2000):
+        """Enqueue one clock probe (hns_clock_probe: one wave for `ticks` x 10 ns) on the current stream; returns the device tensor [shader cycles, 100 MHz ticks] —
+        read it after a synchronisation with `clock_mhz(t)`.  Nothing is read back here."""
+        out = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self._check(self._lib.hns_clock_probe(out.data_ptr(), int(ticks), _raw_stream(self._dev_index)), "hns_clock_probe")
+        return out
+
+    @staticmethod
+    def clock_mhz(probe):
+        c, r = (int(x) for x in probe.tolist())
+        return 100.0 * c / r if r > 0 else None
+
     def device_copy_GBs(self, mbytes=256, reps=20):
         """The box's achievable HBM rate with the library's float4 copy kernel (hns_copy_f4): read + written bytes per second."""
         n = mbytes * 1024 * 1024
