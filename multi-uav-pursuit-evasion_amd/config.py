@@ -227,6 +227,7 @@ def make_hover_cfg(task=None, **task_overrides):
     t = copy.deepcopy(DEFAULT_HOVER_TASK)
     _merge(t, task or {})
     _merge(t, task_overrides)
+    t.setdefault("action_input", "policy")          # programmatic constructor: the raw policy action (see resolve_action_input)
     return Cfg({"task": t, "algo": copy.deepcopy(DEFAULT_ALGO), "env": t["env"], "sim": t["sim"], "headless": True,
                 "physics": copy.deepcopy(DEFAULT_PHYSICS)})
 
@@ -237,6 +238,12 @@ def resolve_hover_cfg(cfg, env_index_offset=0):
     for k in ("omega", "motor", "add_noise", "latency", "action_noise"):
         if t.get(k, False):
             raise NotImplementedError(f"Hover option task.{k}=true is not built (plumbing configuration only)")
+    if resolve_action_input(t) == "motor":
+        # the reference's Hover.yaml says `action_transform: PIDrate` too: scripts/train.py would put the torch controller in front of an env whose step runs the
+        # controller itself.  HideAndSeek takes the motor commands then (hns_cfg.action_input); the plumbing task refuses instead of flying a double controller.
+        raise NotImplementedError("Hover: task.action_transform = %r means the caller's controller transform feeds rotor commands, and the Hover step (plumbing configuration) "
+                                  "only takes the raw policy action — set `action_transform: none` (or `action_input: policy` if nothing runs in front of the env)"
+                                  % (t.get("action_transform", None),))
     if "randomization" in t:
         raise NotImplementedError("Hover domain randomization is not built")
     base = make_cfg({"num_agents": 1, "env": dict(cfg.env), "sim": dict(cfg.sim)})

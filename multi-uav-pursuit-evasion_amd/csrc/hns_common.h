@@ -284,9 +284,10 @@ HNS_DEV void cylinder_pass(const Cfg &c, int C, int K, const V3 &pos, const V3 &
 #pragma unroll 4
     for (int k = 0; k < C; ++k) {
         const float ccx = cyl[3 * k], ccy = cyl[3 * k + 1], ccz = cyl[3 * k + 2];
-        if constexpr (LOS) any_block = d_los_cylinder_fast(los, ccx, ccy, ccz, los_uncertain) || any_block;
-        if constexpr (LOS && NT == 2) any_block1 = d_los_cylinder_fast(los1, ccx, ccy, ccz, los_uncertain1) || any_block1;
         const float ex = pos.x - ccx, ey = pos.y - ccy, ez = pos.z - ccz;
+        // (the line-of-sight tests take the pursuer-relative offsets the key below needs anyway: los.dpx/dpy ARE pos.x/pos.y — d_los_cylinder_fast_rel)
+        if constexpr (LOS) any_block = d_los_cylinder_fast_rel(los, ccx, ccy, ccz, ex, ey, los_uncertain) || any_block;
+        if constexpr (LOS && NT == 2) any_block1 = d_los_cylinder_fast_rel(los1, ccx, ccy, ccz, ex, ey, los_uncertain1) || any_block1;
         const float d2 = HNS_FMA(ez, ez, HNS_FMA(ey, ey, ex * ex));          // the radicand of d_norm3
         uint32_t nk = (__float_as_uint(d2) & 0xFFFFFFF0u) | (uint32_t)k;
 #pragma unroll

@@ -297,6 +297,20 @@ HNS_DEV bool d_los_cylinder_fast(const LosLine &l, float ccx, float ccy, float c
     uncertain = uncertain || !(lo || hi) || !(tpos || tneg);
     return lo && tpos && (numt <= l.dt1) && (ccz > 0.0f);
 }
+// The same test given the pursuer-relative offsets ex = dp.x - ccx, ey = dp.y - ccy, which the k-nearest key of the same cylinder computes anyway
+// (cylinder_pass): ccx - dp.x = -ex and (ccx - dp.x) dx = -(ex dx) exactly, so numt = fma(-ey, dy, -(ex dx)) is the SAME value bit for bit — two
+// subtractions fewer per cylinder and evader (negations ride on the operands).
+HNS_DEV bool d_los_cylinder_fast_rel(const LosLine &l, float ccx, float ccy, float ccz, float ex, float ey, bool &uncertain) {
+    float d2x = ccx - l.tpx, d2y = ccy - l.tpy;
+    float num = __builtin_fabsf(HNS_FMA(l.diffx, d2y, -(l.diffy * d2x)));
+    float numt = HNS_FMA(-ey, l.dy, -(ex * l.dx));
+    bool lo = num < l.plo, hi = num > l.phi;
+    // (the projection's sign is uncertain only in a sliver around zero — ONE compare on |numt|; the exact path decides there.  A NaN needs no flag: neither
+    //  path calls a NaN test blocked.  Round 6: one compare and two scalar operations fewer per cylinder and evader than `!(numt >= 0 || numt < -1e-30)`.)
+    bool tpos = numt >= 0.0f;
+    uncertain = uncertain || !(lo || hi) || (__builtin_fabsf(numt) < 1e-30f);
+    return lo && tpos && (numt <= l.dt1) && (ccz > 0.0f);
+}
 // Exact form: divide and compare, as the reference does (hideandseek.py:47-103)
 template <class Cfg>
 HNS_DEV bool d_los_cylinder(const Cfg &c, const LosLine &l, float d1, float ccx, float ccy, float ccz) {

@@ -1,8 +1,9 @@
 // hns_inst.hip — the step and reset kernels instantiated for ONE pursuer count (compiled once per count: -DHNS_INST_A=1 ... 7, side
 // by side; __graft_entry__.build), and the host-side choice among them.  Two translation units per count: the tile mapping + reset
-// kernels, and (-DHNS_INST_SMALL=1) the small-batch mapping, which is compiled with its pointer parameters preloaded into SGPRs
-// (-mllvm -amdgpu-kernarg-preload-count=16: -0.15 ... -0.4 us per step below 32 768 envs; for the tile mapping at 65 536 envs and the
-// 6v2 shard no difference beyond the noise of alternating blocks, so it stays without; tools/lab/r04_batch32.sh, _47).
+// kernels, and (-DHNS_INST_SMALL=1) the small-batch mapping.  Both are compiled with their pointer parameters preloaded into SGPRs
+// (-mllvm -amdgpu-kernarg-preload-count=16, __graft_entry__.PRELOAD_FLAGS: -0.15 ... -0.4 us per step below 32 768 envs in the small-batch mapping, round 4;
+// the tile mapping since round 5, 16.28 -> 16.11 us at 65 536 envs, nothing either way for the 6v2 shard — profiles/r05_kernarg_preload_ab.txt; the flag also
+// covers hns_reset_kernel's by-value Params, which simply do not fit the 16 preloaded dwords).
 #include "hns_host.h"
 
 #include <cstdlib>

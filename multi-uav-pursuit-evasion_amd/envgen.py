@@ -414,7 +414,10 @@ class HideAndSeek_envgen(HideAndSeek):
                     "hns_perturb_tasks")
         torch.cat([toy, toy]).index_select(0, idx.long()).min(0)          # the torch ops of the trim (allocator, kernels)
         # and one trim at the size of a real update (history + every env's task), so the allocator holds those blocks
+        # (everything the stand-in batches below touch is put back at the end: after construction the generator holds what it held before — ADVICE r5)
         keep = g._history
+        kept = {a: getattr(g, a) for a in ("_state_buffer", "_weight_buffer", "_temp_state", "_temp_weights") if hasattr(g, a)}
+        kept["_temp_weights"] = list(kept.get("_temp_weights") or [])
         g._history = torch.rand(g.buffer_length, g.task_dim, device=self.device)
         g.insert_history(torch.rand(self.num_envs, g.task_dim, device=self.device))
         # ... and the shape of the FIRST real update (empty history + every env's task: another launch shape of the trim), with
@@ -441,6 +444,8 @@ class HideAndSeek_envgen(HideAndSeek):
         int(self._bufs["done"].sum(dtype=torch.int32))
         self._clone_stats()
         g._history = keep
+        for a, v in kept.items():
+            setattr(g, a, v)
         torch.cuda.synchronize(self.device)
 
     @property
@@ -454,8 +459,14 @@ class HideAndSeek_envgen(HideAndSeek):
             return super()._reset(tensordict, **kwargs)
         import time
         mask_t = None
+        self._reset_with_done_buffer = False
         if tensordict is not None and "_reset" in tensordict.keys():
-            mask_t = tensordict.get("_reset").reshape(self.num_envs).to(torch.uint8).contiguous()
+            orig = tensordict.get("_reset")
+            # a collector builds `_reset` from `next.done` — a BOOL view of the env's done buffer, which the conversion below copies: whether the mask IS that buffer
+            # is decided on the original tensor's storage (compared after the conversion the fast path of `_note_reset` only ever fired for bench.py's uint8 view)
+            self._reset_with_done_buffer = (orig.numel() == self.num_envs and orig.untyped_storage().data_ptr() == self._bufs["done"].untyped_storage().data_ptr()
+                                            and orig.storage_offset() * orig.element_size() == self._bufs["done"].storage_offset())
+            mask_t = orig.reshape(self.num_envs).to(torch.uint8).contiguous()
         last_stats = self._clone_stats()
         E = self.num_envs
         t0 = time.perf_counter()
@@ -472,6 +483,13 @@ class HideAndSeek_envgen(HideAndSeek):
                                                   C.c_int32(self.num_unif), C.c_uint64(self.seed), self._stream()), "hns_reset_tasks")
             # the uniform tasks were sampled by the reset kernel, which wrote them into the rows below num_unif as SAMPLED — before the extra
             # physics step of task.reset_extra_step moves the bodies (the reference archives `tasks_unif`, :883-895, and steps afterwards, :1013)
+            if mask_t is not None and not (getattr(self, "_all_done", False) and self._reset_with_done_buffer):
+                # a PARTIAL reset at a batch boundary (the reference resets every env there, :875-902): the kernel writes rows of MASKED envs only, so an env
+                # that keeps running would be archived with whatever its row held (zeros, an older task).  Give those rows the placement the env is in.
+                b = self._bufs
+                live = torch.cat([b["drone_state"][..., 0:3].reshape(E, -1), b["target_pos"].reshape(E, -1), b["cylinders"].reshape(E, -1)], dim=1)
+                stale = (mask_t == 0) & (torch.arange(E, device=self.device) < self.num_unif)
+                self._tasks_dev.copy_(torch.where(stale.unsqueeze(1), live, self._tasks_dev))
             self.gen_buffer.insert(self._tasks_dev)
         else:
             self._check(self._lib.hns_reset_tasks(self._env, mptr, C.c_void_p(self._tasks_dev.data_ptr()),
@@ -497,10 +515,15 @@ class HideAndSeek_envgen(HideAndSeek):
     def _note_reset(self, mask_t):
         """Episodes run in lock step: when the last step saw EVERY env done and the reset's mask is the env's own `done` buffer (what the step wrote, what
         the reset kernel reads), every env starts over — known without reading max(progress) back."""
-        if mask_t is not None and getattr(self, "_all_done", False) and mask_t.data_ptr() == self._done_ptr:
+        all_done, self._all_done = getattr(self, "_all_done", False), False          # (consumed: a later reset must not inherit it)
+        if mask_t is not None and all_done and getattr(self, "_reset_with_done_buffer", False):
             self._since_full_reset = 0
             return
         super()._note_reset(mask_t)
+
+    def import_state(self, arrays, check=False):
+        self._all_done = False                     # a restored state says nothing about the step before it (ADVICE r5)
+        return super().import_state(arrays, check)
 
     # ---- curriculum at episode end, hideandseek_envgen.py:1241-1246, 1302-1333 ----------------------------
     def _step(self, tensordict):

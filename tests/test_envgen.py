@@ -611,3 +611,46 @@ def test_device_genbuffer_and_episode_end_match_the_reference(golden):
     env.gen_buffer.insert(env._tasks_dev)
     env._episode_end()
     assert env.ratio_unif == float(g["ratio_unif_after_threshold"]) == 1.0
+
+
+# ---- what the generator env leaves behind in corner cases ------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_construction_leaves_the_generator_empty_and_partial_resets_archive_live_placements():
+    """(1) `_prewarm` runs the real update path on stand-in batches: afterwards the generator holds what it held before (no fabricated task batch or weights).
+    (2) A PARTIAL reset at a batch boundary archives, for the envs that keep running, the placement they are in — not the stale content of their task rows.
+    (3) The mask of a collector — a BOOL view of the env's done buffer — is recognised as that buffer (the lock-step fast path of `_note_reset`)."""
+    import torch
+    from hns_amd.envgen import HideAndSeek_envgen
+    from hns_amd.tensordict_shim import TensorDict
+    E, L = 256, 6
+    cfg = config.make_cfg({"name": "HideAndSeek_envgen", "num_agents": 3, "eval_iter": 2, "R_min": 0.0, "R_max": 1.0, "ratio_unif": 0.3,
+                           "use_particle_generator": 1, "cylinder": {"max_num": 8, "min_num": 8}, "env": {"num_envs": E, "max_episode_length": L}})
+    env = HideAndSeek_envgen(cfg)
+    g = env.gen_buffer
+    assert g._state_buffer.shape[0] == 0 and g._weight_buffer.numel() == 0 and g._temp_state is None and g._temp_weights == [] and len(g) == 0
+    env.set_seed(2)
+    env.reset()
+    assert env.update_iter == 0
+    # a partial reset while update_iter == 0: half of the envs are reset, the others keep running where they are
+    for _ in range(2):
+        env.step(env.rand_step_input())
+    b = env._bufs
+    live = torch.cat([b["drone_state"][..., 0:3].reshape(E, -1), b["target_pos"].reshape(E, -1), b["cylinders"].reshape(E, -1)], dim=1).clone()
+    env._tasks_dev.fill_(123.0)                                       # whatever the rows held
+    mask = torch.arange(E, device=env.device) % 2 == 0
+    env.reset(TensorDict({"_reset": mask}, env.batch_size))
+    archived = g._temp_state                                          # what `insert` took
+    assert archived is not None and archived.shape == (E, g.task_dim)
+    keep = ~mask
+    assert torch.equal(archived[keep][:, :], live[keep]), "an env that was not reset is archived with something else than its placement"
+    assert not (archived[mask] == 123.0).any()                        # reset envs: the placement as sampled (written by the kernel)
+    # the collector's mask: a bool view of the done buffer
+    env2 = HideAndSeek_envgen(cfg)
+    env2.set_seed(3)
+    env2.reset()
+    for _ in range(L):
+        env2.step(env2.rand_step_input())
+    assert env2._all_done and env2._since_full_reset >= L
+    done_view = env2._bufs["done"].view(torch.bool)
+    env2.reset(TensorDict({"_reset": done_view}, env2.batch_size))
+    assert env2._reset_with_done_buffer and env2._since_full_reset == 0 and not env2._all_done

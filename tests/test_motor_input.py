@@ -288,3 +288,15 @@ def test_reference_task_file_through_transformed_env_and_collector():
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     info = json.loads(out.stdout.strip().splitlines()[-1])
     assert info["action_input"] == "motor" and info["rollouts"] == 4 and info["masked_resets"] >= 2
+
+
+def test_hover_refuses_the_double_controller():
+    """The plumbing task has no motor input: with the reference's Hover.yaml (`action_transform: PIDrate`) as hydra hands it over it raises instead of running
+    the controller twice; this build's programmatic constructor states `action_input: policy`."""
+    config.resolve_hover_cfg(config.make_hover_cfg({}))
+    cfg = config.make_hover_cfg({})
+    del cfg.task["action_input"]
+    with pytest.raises(NotImplementedError, match="action_transform"):
+        config.resolve_hover_cfg(cfg)
+    cfg.task.action_transform = "none"
+    config.resolve_hover_cfg(cfg)
