@@ -479,15 +479,18 @@ class HideAndSeek_envgen(HideAndSeek):
             self.num_unif = E - num_buffer
             if num_buffer > 0:
                 self.gen_buffer.samplenearby_into(self._tasks_dev[self.num_unif:], self.expand_cylinders, self.expand_step)
+            partial = mask_t is not None and not (getattr(self, "_all_done", False) and self._reset_with_done_buffer)
+            if partial:
+                # a PARTIAL reset at a batch boundary (the reference resets every env there, :875-902): the kernel writes rows of MASKED envs only, so an env
+                # that keeps running would be archived with whatever its row held (zeros, an older task).  Those rows get the placement the env is in — taken
+                # BEFORE the reset's extra physics step moves the scene, as the sampled rows are
+                b = self._bufs
+                live = torch.cat([b["drone_state"][..., 0:3].reshape(E, -1), b["target_pos"].reshape(E, -1), b["cylinders"].reshape(E, -1)], dim=1)
             self._check(self._lib.hns_reset_tasks(self._env, mptr, C.c_void_p(self._tasks_dev.data_ptr()),
                                                   C.c_int32(self.num_unif), C.c_uint64(self.seed), self._stream()), "hns_reset_tasks")
             # the uniform tasks were sampled by the reset kernel, which wrote them into the rows below num_unif as SAMPLED — before the extra
             # physics step of task.reset_extra_step moves the bodies (the reference archives `tasks_unif`, :883-895, and steps afterwards, :1013)
-            if mask_t is not None and not (getattr(self, "_all_done", False) and self._reset_with_done_buffer):
-                # a PARTIAL reset at a batch boundary (the reference resets every env there, :875-902): the kernel writes rows of MASKED envs only, so an env
-                # that keeps running would be archived with whatever its row held (zeros, an older task).  Give those rows the placement the env is in.
-                b = self._bufs
-                live = torch.cat([b["drone_state"][..., 0:3].reshape(E, -1), b["target_pos"].reshape(E, -1), b["cylinders"].reshape(E, -1)], dim=1)
+            if partial:
                 stale = (mask_t == 0) & (torch.arange(E, device=self.device) < self.num_unif)
                 self._tasks_dev.copy_(torch.where(stale.unsqueeze(1), live, self._tasks_dev))
             self.gen_buffer.insert(self._tasks_dev)
