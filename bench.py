@@ -374,7 +374,8 @@ def main():
     progress["t"] = 0
     run(args.warmup)
     sync()
-    clock_probe_before = env.clock_probe()        # one wave for 20 us on the step stream, right in front of the region's start event
+    clock_probe_before = env.clock_probe()        # one wave for 20 us on the step stream, finished before the region's start event is recorded
+    torch.cuda.synchronize(device)                # (the host clock below must not start while the probe still runs)
     # The timed region: ONE hipEvent pair around it on the stream the steps are launched on (hns_region_begin / hns_region_end) beside the wall clock.
     # Nothing rides on the launches inside it by default (an event-bracketed dispatch — `--time-every N`, off at 0 — leaves the device idle for
     # ~11 us around itself, profiles/r05_launch_overlap.txt).  The kernel's own duration is measured right AFTER the region (`kernel_blocks`).
@@ -386,9 +387,16 @@ def main():
     t0 = time.perf_counter()
     run(args.steps)
     env.region_end()
-    clock_probe_after = env.clock_probe()         # behind the region's stop event: not part of any timed quantity
+    # (the host polls the region's last event before it synchronises: a blocking wait wakes the host 20-30 us after the device is done — invisible in a
+    #  2 000-step region, 1-1.5 us per step in the driver's 20-step one; the barrier + synchronize below still bracket the region)
+    done_ev = torch.cuda.Event()
+    done_ev.record()
+    while not done_ev.query():
+        pass
     sync()
     elapsed = time.perf_counter() - t0
+    clock_probe_after = env.clock_probe()         # behind the region and its wall clock: not part of any timed quantity
+    torch.cuda.synchronize(device)
     clock_mhz = {"before_region": env.clock_mhz(clock_probe_before), "after_region": env.clock_mhz(clock_probe_after)}
     env.enable_kernel_timing(0)
     region_ms = env.region_ms()
@@ -439,6 +447,9 @@ def main():
         roofline["kernel_us_blocks"] = [round(x * 1e3, 2) for x in blk_each]
         roofline["region_ms"] = round(region_ms, 4)
         roofline["region_wall_ms"] = round(elapsed * 1e3, 4)
+        # what a region costs beyond its launches: first-launch latency + the host noticing the end.  ~40 us — 2 us per step of the driver's 20-step
+        # region, 0.02 us per step of the default 2 000-step one; with clock_mhz_* at the maximum it is what separates ms_per_step from kernel_us there
+        roofline["region_fixed_cost_us"] = round(elapsed * 1e6 - args.steps * blk_ms * 1e3, 1)
         roofline["kernel_us_isolated_dispatch_events"] = round(post_ms * 1e3, 2) if post_n > 0 else None
         roofline["isolated_dispatch_samples"] = post_n
         if in_n > 0:
