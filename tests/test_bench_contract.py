@@ -170,20 +170,20 @@ def _profile_header(path):
 
 
 def test_committed_bench_line_agrees_with_the_committed_profiles():
-    """the round's committed bench line (profiles/r05_bench_final.json) and the rocprofv3 summaries of the same build
-    (profiles/r05_*.txt, headers computed from their tables) must tell the same story: |line.frac - profile.frac| <= 5 % of the profile's
+    """the round's committed bench line (profiles/r06_bench_final.json) and the rocprofv3 summaries of the same build
+    (profiles/r06_*.txt, headers computed from their tables) must tell the same story: |line.frac - profile.frac| <= 5 % of the profile's
     (and <= 0.03 absolute) for the 3v1 step kernel, the 6v2 shard and the predictor.  Skipped until the round's files exist."""
     prof = os.path.join(ROOT, "profiles")
-    line_path = os.path.join(prof, "r05_bench_final.json")
+    line_path = os.path.join(prof, "r06_bench_final.json")
     if not os.path.exists(line_path):
-        pytest.skip("profiles/r05_bench_final.json not committed yet")
+        pytest.skip("profiles/r06_bench_final.json not committed yet")
     d = json.loads([ln for ln in open(line_path) if ln.startswith("{")][-1])
-    pairs = [("r05_v4_step_kernel.txt", d["roofline"]["frac"], d["roofline"]["kernel_us"]),
-             ("r05_step_kernel_a6t2.txt", d["configs"]["cfg5_shard"]["roofline"]["frac"], d["configs"]["cfg5_shard"]["roofline"]["kernel_us"]),
-             ("r05_tp_observe.txt", d["tp_mode"]["roofline"]["frac"], d["tp_mode"]["observe_us"])]
+    pairs = [("r06_v4_step_kernel.txt", d["roofline"]["frac"], d["roofline"]["kernel_us"]),
+             ("r06_step_kernel_a6t2.txt", d["configs"]["cfg5_shard"]["roofline"]["frac"], d["configs"]["cfg5_shard"]["roofline"]["kernel_us"]),
+             ("r06_tp_observe.txt", d["tp_mode"]["roofline"]["frac"], d["tp_mode"]["observe_us"])]
     for name, frac, us in pairs:
         path = os.path.join(prof, name)
-        assert os.path.exists(path), f"{name} is missing beside r05_bench_final.json"
+        assert os.path.exists(path), f"{name} is missing beside r06_bench_final.json"
         n, avg_us, pfrac = _profile_header(path)
         assert n >= 50, f"{name}: only {n} launches profiled"
         assert abs(frac - pfrac) <= max(0.05 * pfrac, 1e-4) and abs(frac - pfrac) <= 0.03, f"{name}: line frac {frac} ({us} us) vs profile {pfrac} ({avg_us} us)"
