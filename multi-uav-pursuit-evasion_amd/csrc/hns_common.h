@@ -279,6 +279,7 @@ HNS_DEV void cylinder_pass(const Cfg &c, int C, int K, const V3 &pos, const V3 &
     LosLine los = {}, los1 = {};
     if constexpr (LOS) los = d_los_setup(c, pos, tp);
     bool los_uncertain = false, los_uncertain1 = false;
+    float mb0 = kInf, mt0 = kInf, mb1 = kInf, mt1 = kInf;      // running minima behind the uncertainty test (d_los_cylinder_fast_acc)
     any_block = false; any_block1 = false;
     if constexpr (LOS && NT == 2) los1 = d_los_setup(c, pos, tpB);
 #pragma unroll 4
@@ -286,8 +287,8 @@ HNS_DEV void cylinder_pass(const Cfg &c, int C, int K, const V3 &pos, const V3 &
         const float ccx = cyl[3 * k], ccy = cyl[3 * k + 1], ccz = cyl[3 * k + 2];
         const float ex = pos.x - ccx, ey = pos.y - ccy, ez = pos.z - ccz;
         // (the line-of-sight tests take the pursuer-relative offsets the key below needs anyway: los.dpx/dpy ARE pos.x/pos.y — d_los_cylinder_fast_rel)
-        if constexpr (LOS) any_block = d_los_cylinder_fast_rel(los, ccx, ccy, ccz, ex, ey, los_uncertain) || any_block;
-        if constexpr (LOS && NT == 2) any_block1 = d_los_cylinder_fast_rel(los1, ccx, ccy, ccz, ex, ey, los_uncertain1) || any_block1;
+        if constexpr (LOS) any_block = d_los_cylinder_fast_acc(los, ccx, ccy, ccz, ex, ey, mb0, mt0) || any_block;
+        if constexpr (LOS && NT == 2) any_block1 = d_los_cylinder_fast_acc(los1, ccx, ccy, ccz, ex, ey, mb1, mt1) || any_block1;
         const float d2 = HNS_FMA(ez, ez, HNS_FMA(ey, ey, ex * ex));          // the radicand of d_norm3
         uint32_t nk = (__float_as_uint(d2) & 0xFFFFFFF0u) | (uint32_t)k;
 #pragma unroll
@@ -298,6 +299,8 @@ HNS_DEV void cylinder_pass(const Cfg &c, int C, int K, const V3 &pos, const V3 &
         }
     }
     if constexpr (LOS) {
+        los_uncertain = d_los_uncertain(los, mb0, mt0);
+        if constexpr (NT == 2) los_uncertain1 = d_los_uncertain(los1, mb1, mt1);
         if (los_uncertain) any_block = d_blocked_exact(c, C, los, cyl);
         if (NT == 2 && los_uncertain1) any_block1 = d_blocked_exact(c, C, los1, cyl);
     }

@@ -311,6 +311,22 @@ HNS_DEV bool d_los_cylinder_fast_rel(const LosLine &l, float ccx, float ccy, flo
     uncertain = uncertain || !(lo || hi) || (__builtin_fabsf(numt) < 1e-30f);
     return lo && tpos && (numt <= l.dt1) && (ccz > 0.0f);
 }
+// The same decision with the UNCERTAINTY bookkeeping taken out of the loop (round 6): instead of two more compares and three scalar operations per cylinder and
+// evader, two running minima — the distance of `num` from the band's centre and |numt| — are kept with three vector instructions and tested ONCE behind the
+// loop (d_los_uncertain).  The band tested there is twice as wide as [plo, phi] (num - p is exact that close to p), so every case the per-cylinder flags caught
+// is caught; a wider band only sends a few more lanes to the exact path, whose result is the same by construction.
+HNS_DEV bool d_los_cylinder_fast_acc(const LosLine &l, float ccx, float ccy, float ccz, float ex, float ey, float &min_band, float &min_numt) {
+    float d2x = ccx - l.tpx, d2y = ccy - l.tpy;
+    float num = __builtin_fabsf(HNS_FMA(l.diffx, d2y, -(l.diffy * d2x)));
+    float numt = HNS_FMA(-ey, l.dy, -(ex * l.dx));
+    min_band = __builtin_fminf(min_band, __builtin_fabsf(num - l.phi));
+    min_numt = __builtin_fminf(min_numt, __builtin_fabsf(numt));
+    return (num < l.plo) && (numt >= 0.0f) && (numt <= l.dt1) && (ccz > 0.0f);
+}
+// phi - plo = p 2^-18: |num - phi| <= that covers [plo, phi] (and up to phi + p 2^-18); a NaN minimum (NaN inputs) compares false on `>` below -> uncertain
+HNS_DEV bool d_los_uncertain(const LosLine &l, float min_band, float min_numt) {
+    return !(min_band > (l.phi - l.plo)) || !(min_numt >= 1e-30f);
+}
 // Exact form: divide and compare, as the reference does (hideandseek.py:47-103)
 template <class Cfg>
 HNS_DEV bool d_los_cylinder(const Cfg &c, const LosLine &l, float d1, float ccx, float ccy, float ccz) {
