@@ -80,3 +80,19 @@ def test_config_schema_and_validation(tmp_path):
         config.resolve_hns_cfg(config.make_cfg({"cylinder": {"max_num": 40}}))
     sc = config.resolve_hns_cfg(config.make_cfg({"use_random_cylinder": 0, "scenario_flag": "wall"}))
     assert sc.init_mode == abi.HNS_INIT_SCENARIO and sc.fixed_cyl_active == 4
+
+
+@pytest.mark.gpu
+def test_clock_probe_reads_a_plausible_shader_clock():
+    """hns_clock_probe (bench.py's clock_mhz_* fields): shader cycles per 100 MHz tick of one spinning wave — between 0.5 and 2.6 GHz on an MI355X (maximum 2.4 GHz + boost
+    margin), two probes of an idle chip within a few percent of each other; bad arguments are refused."""
+    import ctypes as C
+    import torch
+    env = HideAndSeek(config.make_cfg({"env": {"num_envs": 64}}), headless=True)
+    a, b = env.clock_probe(2000), env.clock_probe(2000)
+    torch.cuda.synchronize()
+    ma, mb = env.clock_mhz(a), env.clock_mhz(b)
+    assert 500.0 < ma < 2600.0 and 500.0 < mb < 2600.0 and abs(ma - mb) / ma < 0.1, (ma, mb)
+    ticks = int(a[1])
+    assert 2000 <= ticks < 4000                                   # it span for the 20 us asked for
+    assert env._lib.hns_clock_probe(None, 2000, None) != 0 and env._lib.hns_clock_probe(a.data_ptr(), 0, None) != 0
