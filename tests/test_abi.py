@@ -86,8 +86,8 @@ def test_config_schema_and_validation(tmp_path):
 def test_clock_probe_reads_a_plausible_shader_clock():
     """hns_clock_probe (bench.py's clock_mhz_* fields): shader cycles per 100 MHz tick of one spinning wave — between 0.5 and 2.6 GHz on an MI355X (maximum 2.4 GHz + boost
     margin), two probes of an idle chip within a few percent of each other; bad arguments are refused."""
-    import ctypes as C
     import torch
+    from hns_amd.env import HideAndSeek
     env = HideAndSeek(config.make_cfg({"env": {"num_envs": 64}}), headless=True)
     a, b = env.clock_probe(2000), env.clock_probe(2000)
     torch.cuda.synchronize()
