@@ -551,6 +551,16 @@ def main():
         configs["cfg5_shard"] = {"workload": f"HideAndSeek 6v2 (extension), 16 cylinders, {E} envs = one GPU's shard of the 8 x 65 536 job",
                                  "value": round(E * 6 * n / dt, 1), "unit": "agent-steps/s", "ms_per_step": round(dt / n * 1e3, 5), "steps": n, "roofline": r5}
         del e5
+        # the two-evader extension at the reference's own pursuer count (3v2, 8 cylinders): the shape `num_targets: 2` meets most often outside BASELINE's
+        # configuration 5; its instantiations spilled registers until round 6 (VERDICT r5 #5 asked for a number)
+        e32 = make_env(E, 3, 8, NT=2)
+        _, td32 = action_ring(E, 3, 11)
+        dt, rms = timed_steps(e32, td32, n, 100)
+        r32 = leg_roofline(e32, td32, n, dt, rms, E, 3, 8, NT=2)
+        assert e32.check_finite()
+        configs["ext_3v2"] = {"workload": f"HideAndSeek 3v2 (two-evader extension), 8 cylinders, {E} envs",
+                              "value": round(E * 3 * n / dt, 1), "unit": "agent-steps/s", "ms_per_step": round(dt / n * 1e3, 5), "steps": n, "roofline": r32}
+        del e32
         # beyond the 256 MiB Infinity Cache: the headline batch touches ~105 MB per step, which the last-level cache can hold between
         # launches; these two batches touch 0.42 GB and 1.7 GB per step, so every byte comes from / goes to HBM
         beyond = {}
