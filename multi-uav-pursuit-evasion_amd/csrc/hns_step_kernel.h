@@ -22,8 +22,10 @@ namespace hns {
 //   * every store is a whole-line store from a wave-private slab.
 // Arithmetic, evaluation order and results are those of hns_step_kernel (bit-identical; tests/test_hip_parity.py).
 constexpr int kPub = 11;  // published per pursuer: position at t (3), thrust vector (3), position at t+1 (3), 1 / (|thrust| + 1e-6); odd stride
-struct LdsV3 { int slab, slab_stride, pub, cyl, cyl_stride, tp, red, envout, term, total; };
-constexpr int kTermStride = 2 * HNS_MAX_CYLINDERS + 1;   // per env: (tx, ty) of every cylinder's push on the second evader; odd stride
+struct LdsV3 { int slab, slab_stride, pub, cyl, cyl_stride, tp, red, envout, term, term_stride, total; };
+// per env: (tx, ty) of every cylinder's push on the second evader; odd stride.  Sized by the env's cylinder count since round 6: with the maximum's 33 floats
+// a 3v2 / 8-cylinder workgroup took 53.5 KB of LDS — 0.5 KB too much for a third workgroup per CU (49.4 KB now)
+__host__ __device__ constexpr int term_stride(int C) { return 2 * C + 1; }
 __host__ __device__ inline LdsV3 lds_layout_v3(int A, int C, int K, int NT = 1) {
     LdsV3 L;
     int o = 0;
@@ -36,7 +38,8 @@ __host__ __device__ inline LdsV3 lds_layout_v3(int A, int C, int K, int NT = 1) 
     L.tp = o;    o += r4(kEPB * (3 * NT + 1));               // evader(s) at t+1 ([64][3 NT], contiguous: stored as one slice) + the step counter
     L.red = o;   o += r4(kEPB * A * red_stride(NT));
     L.envout = o; o += r4(kEPB * (A > 3 * NT ? A : 3 * NT)); // the env wave's own staging: evader velocity [64,3 NT], rewards [64,A]
-    L.term = o;  if (NT == 2) o += r4(kEPB * kTermStride);    // two evaders: the pursuer lanes' share of the evader policy (below)
+    L.term_stride = term_stride(C);
+    L.term = o;  if (NT == 2) o += r4(kEPB * L.term_stride);  // two evaders: the pursuer lanes' share of the evader policy (below)
     L.total = o;
     return L;
 }
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(Geo<A>::T, step_waves_per_simd(A, NT, KM, MOTOR)) v
                 const V3 f1 = d_prey_pursuer_term(c, s.pos, etp1, (los & 2) != 0);
                 red[R_FX] = f0.x; red[R_FY] = f0.y; red[R_FZ] = f0.z;
                 red[R_F1X] = f1.x; red[R_F1X + 1] = f1.y; red[R_F1X + 2] = f1.z;
-                float *term = smem + L.term + le * kTermStride;
+                float *term = smem + L.term + le * L.term_stride;
 #pragma unroll
                 for (int i = 0; i < kOwnCyl; ++i) {
                     const int k = a + i * A;
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(Geo<A>::T, step_waves_per_simd(A, NT, KM, MOTOR)) v
             }
         }
         if constexpr (NT == 2) {
-            const float *term = smem + L.term + le * kTermStride;
+            const float *term = smem + L.term + le * L.term_stride;
 #pragma unroll 4
             for (int k = 0; k < C; ++k) {
                 gcx += term[2 * k];
