@@ -300,3 +300,41 @@ def test_hover_refuses_the_double_controller():
         config.resolve_hover_cfg(cfg)
     cfg.task.action_transform = "none"
     config.resolve_hover_cfg(cfg)
+
+
+@pytest.mark.gpu
+def test_hip_motor_mode_with_the_predictor_and_the_generator():
+    """The reference's defaults together — `action_transform: PIDrate` (motor input), `algo.use_TP_net: 1`, the task generator: the predictor's rows, window and
+    predictions and the generator's task batches are bit-identical between the motor-input env and the policy-input env fed the same actions through the two paths."""
+    import torch
+    from hns_amd.envgen import HideAndSeek_envgen
+    from hns_amd.tensordict_shim import TensorDict
+    E, A, L = 256, 3, 6
+    base = {"name": "HideAndSeek_envgen", "num_agents": A, "eval_iter": 1, "R_min": 0.0, "R_max": 1.0, "ratio_unif": 0.3, "use_particle_generator": 1,
+            "cylinder": {"max_num": 5, "min_num": 3}, "env": {"num_envs": E, "max_episode_length": L}}
+    pol = HideAndSeek_envgen(config.make_cfg(base, algo={"use_TP_net": 1}))
+    mot = HideAndSeek_envgen(config.make_cfg(dict(base, action_input="motor"), algo={"use_TP_net": 1}))
+    mot.TP.load_state_dict(pol.TP.state_dict())                        # the same predictor on both sides
+    for e in (pol, mot):
+        e.set_seed(5)
+        e.reset()
+    ctl = HostController(mot.hcfg, E, A)
+    g = torch.Generator().manual_seed(9)
+    for t in range(3 * L + 2):
+        a = torch.randn(E, A, 4, generator=g) * 0.7
+        cur = mot.export_state()
+        keys = ctl.inv(a.numpy(), cur["drone_state"], cur["prev_action"], cur["done"])
+        dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(mot.device)      # noqa: E731
+        tdp = pol.step(pol.rand_step_input(a.to(pol.device)))
+        mot.step(TensorDict({"agents": {"action": dev(keys["cmds"])}, "info": {"prev_action": dev(keys["prev_action"])},
+                             "stats": {"action_error_order1": dev(keys["aerr"])}}, mot.batch_size))
+        _compare_modes(pol.export_state(), mot.export_state(), ctl, f"step {t}")
+        for k in ("obs_self", "pred", "history", "groundtruth", "tp_done"):
+            assert torch.equal(pol._tp_bufs[k], mot._tp_bufs[k]), f"step {t}: predictor buffer {k} differs between policy and motor input"
+        if (t + 1) % L == 0:                                           # lock-step episode end: both envs reset through the generator
+            mask = tdp[("next", "done")].squeeze(-1).clone()
+            for e in (pol, mot):
+                e.reset(TensorDict({"_reset": mask.to(e.device)}, e.batch_size))
+            assert torch.equal(pol._tasks_dev, mot._tasks_dev) and len(pol.gen_buffer) == len(mot.gen_buffer)
+            _compare_modes(pol.export_state(), mot.export_state(), ctl, f"generator reset after step {t}")
+    assert len(pol.gen_buffer) > 0
