@@ -53,7 +53,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     if "rocprofv3 --kernel-trace --pmc" in r.get("traffic_source", ""):
         assert 0.9 < r["traffic"] / r["bytes_per_launch"] < 1.3 and r["traffic_detail"]["FETCH_SIZE_dispatches"] >= 60
     cf = d["configs"]                                                                      # every other BASELINE configuration
-    assert set(cf) == {"cfg2", "cfg4", "cfg4_baseline_R", "cfg5_shard"} and "R_min 0.5 / R_max 0.9" in cf["cfg4_baseline_R"]["workload"]
+    assert set(cf) == {"cfg2", "cfg4", "cfg4_baseline_R", "cfg5_shard", "ext_3v2"} and "R_min 0.5 / R_max 0.9" in cf["cfg4_baseline_R"]["workload"]
+    assert cf["ext_3v2"]["value"] > 0 and cf["ext_3v2"]["roofline"]["bytes_per_launch"] > 0          # the two-evader extension at the reference's pursuer count (round 6)
     assert cf["cfg2"]["roofline"]["bytes_per_env"] == 1497 and cf["cfg5_shard"]["roofline"]["frac"] > 0
     for leg in ("cfg2", "cfg5_shard"):                                                     # the legs carry both figures too
         rl = cf[leg]["roofline"]
