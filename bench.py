@@ -19,6 +19,8 @@ Prints ONE JSON line (rank 0):
   * `configs`: the other BASELINE configurations (cfg2 4 096 envs / no cylinders, cfg4 envgen with the generator's cost
     per episode, cfg5_shard 6v2 / 16 cylinders — one GPU's shard), each with its own ms_per_step and roofline fraction, and
     `beyond_l3`: the headline shape at 262 144 and 1 048 576 envs (0.4 / 1.6 GB touched per step: past the 256 MiB Infinity Cache);
+  * N > 1: each rank stops its clock when ITS K steps are complete on its device, ahead of the closing barrier (`closing_barrier_us`); `value` = all ranks' units / the MAX
+    over ranks of those times;
   * `n_gpus`: distinct (host, device) pairs the ranks ran on (`config.ranks` = ranks); the RCCL backend refuses ranks > devices;
   * `tp_mode`: step + trajectory predictor (the reference's default `use_TP_net: 1`);
   * `cpu_baseline` (N = 1 only): the CPU oracle — test infrastructure, never the product — on a bounded sample.
@@ -393,8 +395,13 @@ def main():
     done_ev.record()
     while not done_ev.query():
         pass
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0            # this rank's K steps, complete on its device; the MAX over ranks below is the job's time
+    # N > 1: the closing barrier brackets the region like the opening one, but its own latency (an RCCL all-reduce + the host's wake-up: tens of microseconds
+    # against a 20-step region of 0.35 ms) is not part of the K steps — at N = 1 there is no barrier at all, so a clock stopped behind it would charge the
+    # multi-GPU lines a fixed cost the single-GPU line does not carry.  Reported beside the line as `closing_barrier_us`.
     sync()
-    elapsed = time.perf_counter() - t0
+    closing_barrier_us = (time.perf_counter() - t0 - elapsed) * 1e6
     clock_probe_after = env.clock_probe()         # behind the region and its wall clock: not part of any timed quantity
     torch.cuda.synchronize(device)
     clock_mhz = {"before_region": env.clock_mhz(clock_probe_before), "after_region": env.clock_mhz(clock_probe_after)}
@@ -780,7 +787,7 @@ def main():
                               "chip reads near the 2.4 GHz maximum",
             "schema": 6, "schema_note": "r05 on: roofline.frac / achieved / kernel_us describe the step kernel ALONE (blocks of plain launches after the region); the region-bounded "
                                       "figure that BENCH_r01-r04 called frac is frac_step_rate.  r06 on: a fixed pre-region phase (config.pre_region) and clock_mhz_* fields",
-            "collective_us": collective, "state_digest": state_digest,
+            "collective_us": collective, "closing_barrier_us": round(closing_barrier_us, 1) if dist is not None else None, "state_digest": state_digest,
             "env_frames_per_s": round(value / A, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "abi_rate": abi_rate, "configs": configs or None,
             "tp_mode": tp_mode, "stream_shards": streams_mode,
