@@ -676,6 +676,25 @@ def main():
                            + ("; the batch as two half batches on two streams (task.tp_overlap): step_kernel_us is ONE half's step kernel, observe_us the "
                               "predictor over the whole batch on one stream" if env_tp._halves is not None else "")}
         del env_tp
+        # ... and at the reference's OWN default batch (cfg/task/HideAndSeek.yaml: 2 048 envs, 3 pursuers, 5 cylinder slots; cfg/algo/mappo.yaml: use_TP_net 1):
+        # 16 four-tile workgroups would leave 240 CUs idle, so the predictor serves such batches with one column tile per workgroup (csrc/hns_tp.hip: ws_envs)
+        e_rd = make_env(2048, 3, 5, task={"cylinder": {"min_num": 4}}, algo={"use_TP_net": 1})
+        _, td_rd = action_ring(2048, 3, 13)
+        n_rd = min(n, 1000)
+        dt_rd, _ = timed_steps(e_rd, td_rd, n_rd, 100, reset_every=args.episode)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            e_rd._tp_observe()
+        ev0.record()
+        for _ in range(200):
+            e_rd._tp_observe()
+        ev1.record()
+        torch.cuda.synchronize(device)
+        tp_mode["reference_default_batch"] = {
+            "workload": "HideAndSeek 3v1, 5 cylinder slots (4-5 active), 2 048 envs, use_TP_net 1: the reference's own task / algo defaults",
+            "value": round(2048 * 3 * n_rd / dt_rd, 1), "unit": "agent-steps/s", "steps": n_rd, "ms_per_step": round(dt_rd / n_rd * 1e3, 5),
+            "observe_us": round(ev0.elapsed_time(ev1) / 200 * 1e3, 2)}
+        del e_rd
 
     # secondary leg: the same envs as G shards on G HIP streams of this GPU (the multi-GPU sharding applied inside one GPU)
     streams_mode = None

@@ -731,7 +731,13 @@ __global__ __launch_bounds__(tp_waves(NXC) * 64) void hns_tp_lstm_kernel(const T
 // subnormals, checked in simd_share.hip): hi*hi, hi*lo and lo*hi accumulate into one chain that starts at the bias —
 // no scaling pass, no bias pass.  The one operand whose magnitude would make the weights' low term matter, `progress`
 // (up to max_episode_length), enters as progress/1024 against its weight column x 1024 (both exact).
-constexpr int kWsWaves = 8, kWsThreads = kWsWaves * 64, kWsEnvs = 128, kWsTiles = 4;
+constexpr int kWsWaves = 8, kWsThreads = kWsWaves * 64, kWsTiles = 4;
+// Column tiles (of 32 units) a workgroup serves — the template parameter TILES of the kernel.  4 is the kernel described above (128 units per workgroup:
+// the weights are fetched once per 128 units, two workgroups share a CU).  Below 32 768 units that grid is smaller than the chip (the reference's own
+// default, 2 048 envs: 16 workgroups on 256 CUs) and a launch lasts as long as ONE workgroup's recurrence, 8.4 k cycles per timestep of which 5.4 k are its
+// four tiles one after the other (profiles/r06_tp_where_the_time_goes.txt, C) — so small batches get 2 or 1 tiles per workgroup (round 6): the same tile
+// arithmetic (results bit-identical, tests/test_hip_tp.py), twice / four times the workgroups, half / a quarter of the serial stream.
+__host__ __device__ constexpr int ws_envs(int tiles) { return 32 * tiles; }
 constexpr float kWsProgScale = 1024.0f, kWsProgInv = 1.0f / 1024.0f;
 
 struct WsImage { int a, wfc, bias, bfc, slots; };     // offsets in 16-byte slots
@@ -821,7 +827,7 @@ __global__ __launch_bounds__(256) void hns_tp_pack_ws_kernel(const TpParams p, i
 // placed the reads).  Load l (chunk l / 2, term l % 2) sits in slot (l + BASE) % 4; loads 0..2 are issued up front, load 3 behind op 0, and then
 // 2 c behind op 3 c - 4 and 2 c + 1 behind op 3 c - 3: three to five ops ahead of their first use.  BASE rotates from tile to tile so that the
 // up-front reads of a tile, which may be issued right behind the previous tile's last MFMA, never target that MFMA's slot.
-template <int NXC, bool WITH_H>
+template <int NXC, bool WITH_H, int TILES = kWsTiles>
 struct WsTile {
     static constexpr int NCH = NXC + (WITH_H ? 4 : 0), N = 3 * NCH, NL = 2 * NCH, RING = 4;
     static constexpr int load_of(int k) { return 2 * (k / 3) + (k % 3 == 2 ? 1 : 0); }
@@ -838,7 +844,7 @@ struct WsTile {
     static __device__ __forceinline__ half8 load(const Ctx &c) {
         constexpr int ch = l / 2, term = l % 2;
         constexpr bool is_x = ch < NXC;
-        constexpr int off = (((is_x ? ch : ch - NXC) * 2 + term) * 4) * 64;
+        constexpr int off = (((is_x ? ch : ch - NXC) * 2 + term) * TILES) * 64;
 #ifdef TP_WS_HALF_B        // (measurement arm: every second operand read skipped — what halving the LDS operand traffic would buy)
         if constexpr (l % 2 == 1) { half8 r = c.b[0]; asm volatile("" : "+v"(r)); return r; }
 #endif
@@ -873,13 +879,21 @@ struct WsTile {
 
 // frames of two and more chunks hold 48-72 registers of weights per lane (two chunks under the 128-register cap of four waves per SIMD spill into
 // the hot loop: 186 us against 133 us for THREE chunks without the cap) and 66-116 KB of LDS: one workgroup per CU, two waves per SIMD
-template <int NXC>
+template <int NXC, int TILES = kWsTiles>
 __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void hns_tp_lstm_ws_kernel(const TpParams p) {
-    constexpr int NC = NXC + 4;
+    static_assert(TILES == 1 || TILES == 2 || TILES == 4, "column tiles per workgroup");
+    constexpr int NC = NXC + 4, kWsEnvs = ws_envs(TILES);
+    // One-tile workgroups (the smallest batches: a launch is ONE workgroup's serial stream) build every frame of the window in the prologue, all 512 threads at
+    // once, instead of frame t + 1 inside timestep t by the 128 threads that own a (unit, quad) pair: with one tile those are waves 0 and 1 only, and their 800
+    // cycles per timestep were everybody's wait at the second barrier (tools/tp_phases.py --loop, HNS_TP_TILES=1: 29.1 k cycles per recurrence, 13.5 k in the tiles).
+    constexpr bool UPFRONT = TILES == 1;
     constexpr WsImage L = ws_image(NXC);
     extern __shared__ __align__(16) uint4 simg[];
-    // LDS (16-byte slots): h_{t-1} [chunk 4][term 2][tile 4][lane 64] | x [buffer 2][chunk NXC][term 2][tile 4][lane 64] | bias [64]
-    uint4 *sH = simg, *sX = simg + 2048, *sB = sX + 1024 * NXC;
+    // LDS (16-byte slots): h_{t-1} [chunk 4][term 2][tile TILES][lane 64] | x [buffer 2][chunk NXC][term 2][tile TILES][lane 64] | bias [64]
+    // (UPFRONT: x holds max(T, 2) frames instead of two buffers; h has two buffers — h_t goes to buffer t & 1 while slower waves still read h_{t-1} from
+    //  the other one, so the second workgroup barrier of a timestep is not needed: the next timestep's first one orders everything)
+    constexpr int kHBuf = 512 * TILES;
+    uint4 *sH = simg, *sX = simg + (UPFRONT ? 2 : 1) * kHBuf, *sB = sX + (UPFRONT ? (p.T > 2 ? p.T : 2) : 2) * (128 * TILES * NXC);
     const int tid = threadIdx.x, lane = tid & 63, r = tid >> 6, hb = lane >> 5;
     const int I = p.I, T = p.T, R = 3 * p.F;
     const int e0 = blockIdx.x * kWsEnvs;
@@ -900,9 +914,12 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
     if (tid < 64) sB[tid] = img[L.bias + tid];
 
     // ---- frames: thread (env_l, q) owns values 4 q .. 4 q + 3 of every 16-wide chunk of env e0 + env_l ----
-    const int env_l = tid >> 2, q = tid & 3;
+    // (fewer than four tiles: the threads beyond the workgroup's 32 TILES units load the last unit's frame again and store nothing)
+    // (UPFRONT: thread = (frame selector tid >> 7, unit, quad): frames tsel, tsel + 4, ... of its pair)
+    const int env_l = UPFRONT ? (tid & 127) >> 2 : tid >> 2, q = tid & 3, tsel = tid >> 7;
+    const bool mine = UPFRONT || TILES == kWsTiles || env_l < kWsEnvs;
     const int e = e0 + env_l;
-    const bool valid = e < p.E;
+    const bool valid = mine && e < p.E;
     const int ec = valid ? e : p.E - 1;
     const bool vec = (I & 3) == 0;                         // rows 16-byte aligned and made of whole quads
     float *hist = p.tp.history + (size_t)ec * T * I;
@@ -941,7 +958,7 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
         }
     };
     // frame tt of the new window: stored to the window in HBM (raw) and to LDS as the B operand of timestep tt (split)
-    auto emit = [&](int tt, const float (&v)[NXC][4]) {
+    auto store_frame = [&](int tt, const float (&v)[NXC][4]) {
         float *row = hist + (size_t)tt * I;
 #pragma unroll
         for (int cx = 0; cx < NXC; ++cx) {
@@ -953,6 +970,12 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
                     for (int j = 0; j < 4; ++j) if (k0 + j < I) row[k0 + j] = v[cx][j];
                 }
             }
+        }
+    };
+    auto emit = [&](int tt, const float (&v)[NXC][4]) {
+        if constexpr (!UPFRONT) store_frame(tt, v);
+#pragma unroll
+        for (int cx = 0; cx < NXC; ++cx) {
             typedef _Float16 half4 __attribute__((ext_vector_type(4)));
             half4 hi, lo;
 #pragma unroll
@@ -963,14 +986,39 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
                 hi[j] = a; lo[j] = b;
             }
             // k-slot 4 q + j of the chunk: lane half q >> 1, bytes 8 (q & 1) .. of that lane's 16
-            const int slot = (((tt & 1) * NXC + cx) * 2 * 4 + (env_l >> 5)) * 64 + 32 * (q >> 1) + (env_l & 31);
-            reinterpret_cast<uint2 *>(sX)[(slot + 0 * 4 * 64) * 2 + (q & 1)] = __builtin_bit_cast(uint2, hi);
-            reinterpret_cast<uint2 *>(sX)[(slot + 1 * 4 * 64) * 2 + (q & 1)] = __builtin_bit_cast(uint2, lo);
+            const int slot = (((UPFRONT ? tt : (tt & 1)) * NXC + cx) * 2 * TILES + (env_l >> 5)) * 64 + 32 * (q >> 1) + (env_l & 31);
+            if (mine) {
+                reinterpret_cast<uint2 *>(sX)[(slot + 0 * TILES * 64) * 2 + (q & 1)] = __builtin_bit_cast(uint2, hi);
+                reinterpret_cast<uint2 *>(sX)[(slot + 1 * TILES * 64) * 2 + (q & 1)] = __builtin_bit_cast(uint2, lo);
+            }
         }
     };
     const bool fill = (T == 1) || p.fill;
     float xn[NXC][4];
-    {
+    if constexpr (UPFRONT) {
+        // frame tt of the new window = row tt + 1 of the old one (the last: the new frame; a fresh window: the new frame everywhere).  Every load first, then the
+        // split operands into LDS; the rows go back to the window BEHIND a workgroup barrier: row tt + 1 is read by the thread of frame tt and written by
+        // the thread of frame tt + 1
+        constexpr int KF = 4;                              // frames per thread: T <= 16 (hns_tp_bind)
+        float fv[KF][NXC][4];
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+            const int tt = tsel + 4 * k;
+            if (tt < T) {
+                if (fill || tt == T - 1) {
+#pragma unroll
+                    for (int cx = 0; cx < NXC; ++cx)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) fv[k][cx][j] = nf[cx][j];
+                } else load_row(tt + 1, fv[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KF; ++k) if (tsel + 4 * k < T) emit(tsel + 4 * k, fv[k]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KF; ++k) if (tsel + 4 * k < T) store_frame(tsel + 4 * k, fv[k]);
+    } else {
         if (fill) emit(0, nf);
         else { load_row(1, xn); emit(0, xn); }
         if (T > 1) {
@@ -983,12 +1031,12 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
         }
     }
 
-    float c[kWsTiles][4];
+    float c[TILES][4];
 #pragma unroll
-    for (int te = 0; te < kWsTiles; ++te)
+    for (int te = 0; te < TILES; ++te)
 #pragma unroll
         for (int j = 0; j < 4; ++j) c[te][j] = 0.0f;
-    uint2 hnew[kWsTiles][2];
+    uint2 hnew[TILES][2];
     half8 bring[WsTile<NXC, true>::RING];                  // B-operand ring (WsTile)
     const float4 *sBias = reinterpret_cast<const float4 *>(sB) + (r * 2 + hb) * 4;
     if (prof && lane == 0) prof[1] = __builtin_amdgcn_s_memrealtime();
@@ -1021,7 +1069,7 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
         TP_LP(4)
         __syncthreads();                                         // x_t and h_{t-1} are in LDS
         TP_LP(0)
-        if (t + 1 < T) {                                   // frame t+1 -> the other x buffer (last read at timestep t-1)
+        if (!UPFRONT && t + 1 < T) {                       // frame t+1 -> the other x buffer (last read at timestep t-1)
             emit(t + 1, xn);
             if (t + 2 < T) {
                 if (fill || t + 2 == T - 1) {
@@ -1047,13 +1095,14 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
             }
 #endif
             {
-                const uint4 *xb = sX + (t & 1) * (NXC * 2 * 4 * 64) + te * 64 + lane, *hp = sH + te * 64 + lane;
+                const uint4 *xb = sX + (UPFRONT ? t : (t & 1)) * (NXC * 2 * TILES * 64) + te * 64 + lane;
+                const uint4 *hp = sH + (UPFRONT ? ((t + 1) & 1) * kHBuf : 0) + te * 64 + lane;        // h_{t-1}
                 if (t > 0) {
-                    using W = WsTile<NXC, true>;
+                    using W = WsTile<NXC, true, TILES>;
                     const typename W::Ctx cx{acc, bring, aw, xb, hp};
                     W::template run<W::base(te)>(cx);
                 } else {
-                    using W = WsTile<NXC, false>;
+                    using W = WsTile<NXC, false, TILES>;
                     const typename W::Ctx cx{acc, bring, aw, xb, hp};
                     W::template run<W::base(te)>(cx);
                 }
@@ -1100,19 +1149,20 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
             hnew[te][0] = make_uint2(hi_r[0], hi_r[1]);
             hnew[te][1] = make_uint2(lo_r[0], lo_r[1]);
         };
-        tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{});
-        tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{});
+        tile(std::integral_constant<int, 0>{});
+        if constexpr (TILES > 1) tile(std::integral_constant<int, 1>{});
+        if constexpr (TILES > 2) { tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{}); }
         TP_LP(2)
 #ifndef TP_WS_NO_BAR2
-        __syncthreads();                                         // every wave has read h_{t-1}
+        if constexpr (!UPFRONT) __syncthreads();                 // every wave has read h_{t-1}
 #endif
         TP_LP(3)
         // publish this slice of h_t: chunk r >> 1, k-slots 4 (r & 1) .. + 3 of both lane halves
 #pragma unroll
-        for (int te = 0; te < kWsTiles; ++te)
+        for (int te = 0; te < TILES; ++te)
 #pragma unroll
             for (int term = 0; term < 2; ++term)
-                reinterpret_cast<uint2 *>(sH)[((((r >> 1) * 2 + term) * 4 + te) * 64 + lane) * 2 + (r & 1)] = hnew[te][term];
+                reinterpret_cast<uint2 *>(sH + (UPFRONT ? (t & 1) * kHBuf : 0))[((((r >> 1) * 2 + term) * TILES + te) * 64 + lane) * 2 + (r & 1)] = hnew[te][term];
     }
     // The output layer's weight operands and bias come from the L2 (the packed image): requested HERE, ahead of the barrier that closes the recurrence — the
     // weight registers of the loop are dead, and the round trip (about a microsecond with every workgroup of the launch in its epilogue at once) runs beside the
@@ -1122,7 +1172,7 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
     __builtin_amdgcn_sched_barrier(0);
     half8 f1[4], f2[4];
     float4 fcb[4];
-    if (r < kWsTiles) {
+    if (r < TILES) {
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             f1[ch] = __builtin_bit_cast(half8, img[L.wfc + ch * 64 + lane]); f2[ch] = __builtin_bit_cast(half8, img[L.wfc + (4 + ch) * 64 + lane]);
@@ -1137,9 +1187,9 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
 #endif
 
     // ---- output layer on h_T (waves 0..3, one column tile each): tanh(W_fc h + b), rescaled to arena units (hideandseek.py:834-836) ----
-    float *sPred = reinterpret_cast<float *>(sX);           // [env 128][16], or [env 128][32] with more than five predicted points (3F > 16): 16 KB,
+    float *sPred = reinterpret_cast<float *>(sX);           // [unit 32 TILES][16], or [unit 32 TILES][32] with more than five predicted points (3F > 16): 4 KB per tile,
     const int ps = R > 16 ? 32 : 16;                        // the size of ONE chunk's x buffers, which are free now
-    if (r < kWsTiles) {
+    if (r < TILES) {
         const int te = r;
         f32x16 o;
 #pragma unroll
@@ -1147,8 +1197,8 @@ __global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void h
         half8 fh[4], fl[4];                                 // every operand in its own register, all read before the first MFMA
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
-            const uint4 *bh = sH + ((ch * 2) * 4 + te) * 64 + lane;
-            fh[ch] = __builtin_bit_cast(half8, bh[0]); fl[ch] = __builtin_bit_cast(half8, bh[4 * 64]);
+            const uint4 *bh = sH + (UPFRONT ? ((T - 1) & 1) * kHBuf : 0) + ((ch * 2) * TILES + te) * 64 + lane;      // h_{T-1}
+            fh[ch] = __builtin_bit_cast(half8, bh[0]); fl[ch] = __builtin_bit_cast(half8, bh[TILES * 64]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1316,16 +1366,35 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
     p.fill = fill_history ? 1 : 0;
     const int nxc = tp_nxc(p.I);
     if (tp_use_ws(nxc)) {
-        void (*wfn)(const TpParams) = nxc == 1 ? hns::hns_tp_lstm_ws_kernel<1> : nxc == 2 ? hns::hns_tp_lstm_ws_kernel<2> : nxc == 3 ? hns::hns_tp_lstm_ws_kernel<3>
-                                      : nxc == 4 ? hns::hns_tp_lstm_ws_kernel<4> : hns::hns_tp_lstm_ws_kernel<5>;
-        const size_t wlds = (size_t)(2048 + 1024 * nxc + 64) * 16;
-        static thread_local unsigned long long ws_attr_devs[hns::kTpMaxChunks] = {};
-        const unsigned long long bit = 1ull << (env->device & 63);
-        if (!(ws_attr_devs[nxc - 1] & bit)) {
-            HNS_CHECK_HIP(hipFuncSetAttribute((const void *)wfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
-            ws_attr_devs[nxc - 1] |= bit;
+        // column tiles per workgroup (ws_envs): four unless that grid leaves most of the chip idle — one-chunk frames (the reference's default shape) only;
+        // HNS_TP_TILES=1|2|4 forces a value (A/B measurements); the phase stamps (hns_set_phase_profile) are laid out for four unless a value is forced
+        // (tools/tp_phases.py sizes its buffer by the same variable)
+        static const int forced = [] { const char *m = getenv("HNS_TP_TILES"); const int v = m ? atoi(m) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
+        int tiles = hns::kWsTiles;
+        if (nxc == 1 && (!p.prof || forced)) {
+            const int cus = env->cus > 0 ? env->cus : 256;
+            // measured on one box (tools/tp_tiles.py, profiles/r06_tp_tiles.txt; 256 CUs): one tile up to two workgroups per CU (16 384 units: 26.0 us against
+            // 28.5 / 45.7 with two / four), two tiles below three two-tile workgroups per CU (32 768 units: 42.7 against 48.9 / 50.2; 49 152: 67 either way), else four
+            if (forced) tiles = forced;
+            else if ((p.E + 31) / 32 <= 2 * cus) tiles = 1;
+            else if ((p.E + 63) / 64 < 3 * cus) tiles = 2;
+            else tiles = 4;
         }
-        hipLaunchKernelGGL(wfn, dim3((p.E + hns::kWsEnvs - 1) / hns::kWsEnvs), dim3(hns::kWsThreads), wlds, (hipStream_t)stream, p);
+        void (*wfn)(const TpParams) = nxc == 1 ? (tiles == 1 ? hns::hns_tp_lstm_ws_kernel<1, 1> : tiles == 2 ? hns::hns_tp_lstm_ws_kernel<1, 2> : hns::hns_tp_lstm_ws_kernel<1, 4>)
+                                      : nxc == 2 ? hns::hns_tp_lstm_ws_kernel<2> : nxc == 3 ? hns::hns_tp_lstm_ws_kernel<3>
+                                      : nxc == 4 ? hns::hns_tp_lstm_ws_kernel<4> : hns::hns_tp_lstm_ws_kernel<5>;
+        const int xframes = tiles == 1 ? (p.T > 2 ? p.T : 2) : 2;             // one-tile workgroups hold the whole window's operands (UPFRONT)
+        const size_t wlds = (size_t)((tiles == 1 ? 2 : 1) * 512 * tiles + xframes * 128 * tiles * nxc + 64) * 16;       // (... and two buffers of h)
+        static thread_local unsigned long long ws_attr_devs[hns::kTpMaxChunks + 2] = {};
+        const unsigned long long bit = 1ull << (env->device & 63);
+        const int slot = tiles == hns::kWsTiles ? nxc - 1 : hns::kTpMaxChunks + (tiles - 1);
+        if (!(ws_attr_devs[slot] & bit)) {                    // (the largest this instantiation asks for: 16 frames with one tile)
+            const size_t wcap = tiles == 1 ? (size_t)(2 * 512 + 16 * 128 * nxc + 64) * 16 : wlds;
+            HNS_CHECK_HIP(hipFuncSetAttribute((const void *)wfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wcap));
+            ws_attr_devs[slot] |= bit;
+        }
+        const int per = hns::ws_envs(tiles);
+        hipLaunchKernelGGL(wfn, dim3((p.E + per - 1) / per), dim3(hns::kWsThreads), wlds, (hipStream_t)stream, p);
         HNS_CHECK_HIP(hipGetLastError());
         return HNS_OK;
     }

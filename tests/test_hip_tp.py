@@ -41,6 +41,7 @@ def _host_tp(env):
 
 
 @pytest.mark.parametrize("E,A,obst", [(48, 3, 0), (300, 1, 0), (257, 2, 0), (1000, 4, 0), (130, 6, 0), (65536, 3, 0),
+                                      (24001, 3, 0),                # one-chunk frames: 1 / 2 / 4 column tiles per workgroup by batch size (here 2, ragged)
                                       (200, 3, 1), (70, 1, 1),      # obst: task.use_obstacles, cylinders in the frame
                                       (300, 6, 12), (260, 6, 16), (129, 7, 16)])   # obst > 1: that many cylinder slots: frames of 61, 73 and 76 values
 def test_tp_observe_matches_oracle(E, A, obst):
@@ -73,6 +74,26 @@ def test_tp_observe_matches_oracle(E, A, obst):
         O.tp_observe(env.hcfg, host, tpa, fill=False)
     assert np.abs(tpa["pred"]).max() > 0.05
     print(f"E={E} A={A}: max |pred_hip - pred_oracle| = {err:.2e}")
+
+
+def test_tp_tiles_per_workgroup_do_not_change_a_bit():
+    """The weight-stationary kernel serves small batches with 1 or 2 column tiles per workgroup instead of 4 (csrc/hns_tp.hip: ws_envs; picked by batch
+    size, HNS_TP_TILES forces one): the tile arithmetic does not depend on it — predictions, rows and window after 12 steps of a ragged batch are the same
+    bytes for every tile count (one process each: the override is read once per process)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for tiles in ("auto", "1", "2", "4"):
+        env = dict(os.environ, HNS_TP_TILES_DIGEST_ONLY="1")
+        env.pop("HNS_TP_TILES", None)
+        if tiles != "auto":
+            env["HNS_TP_TILES"] = tiles
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "tp_tiles.py"), "--child", "4133", "3"], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[tiles] = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])["digest"]
+    assert len(set(digests.values())) == 1, digests
 
 
 def test_tp_rows_without_critic_state_and_lazy_state():

@@ -19,3 +19,4 @@ timeout 600 python tools/tp_widths.py 65536 2>&1 | grep -v amdgpu.ids > $O/tp_wi
 timeout 300 python tools/small_batch.py 2048 4096 8192 16384 2>&1 | grep -v amdgpu.ids > $O/small_batch.txt; cat $O/small_batch.txt
 timeout 300 python tools/phase_profile.py --envs=4096 --cylinders=5 --mapping=small --waves 2>&1 | grep -v amdgpu.ids > $O/phase_small_4096.txt; head -16 $O/phase_small_4096.txt
 timeout 300 python tools/phase_profile.py --envs=65536 --agents=6 --targets=2 --cylinders=16 2>&1 | grep -v amdgpu.ids > $O/phase_a6t2.txt; head -18 $O/phase_a6t2.txt
+timeout 600 python tools/tp_tiles.py 2>&1 | grep -v amdgpu.ids > $O/tp_tiles.txt; cat $O/tp_tiles.txt

@@ -17,5 +17,5 @@ for d in stats pmc1; do
 done
 grep -h '^{' $OUT/stats.log | python tools/bench_line.py | grep tp_mode
 # useful FLOP per launch of hns_tp_observe at 65 536 envs, 16-value frames, T = 10, F = 5: 2 (T 4 64 (I + 64) + 64 3F) x 65 536
-python tools/make_profile_txt.py $OUT "${KERNEL:-hns_tp_lstm_ws_kernelILi1}" "flop:${FLOP:-2.697e10}" "$TAG - tools/profile_tp.sh $TAG" > $OUT/profile.txt
+python tools/make_profile_txt.py $OUT "${KERNEL:-hns_tp_lstm_ws_kernelILi1ELi4}" "flop:${FLOP:-2.697e10}" "$TAG - tools/profile_tp.sh $TAG" > $OUT/profile.txt
 head -8 $OUT/profile.txt

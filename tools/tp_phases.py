@@ -13,7 +13,8 @@ env = HideAndSeek(config.make_cfg({"cylinder": {"max_num": 8, "min_num": 8}, "en
 env.reset()
 td = env.rand_step_input()
 for _ in range(30): env.step(td)
-nw = ((E + 127) // 128) * 8                                # workgroups of 128 envs, 8 waves
+TILES = int(os.environ.get("HNS_TP_TILES", 4))             # column tiles per workgroup (csrc/hns_tp.hip: ws_envs); with the stamps on, four unless forced
+nw = ((E + 32 * TILES - 1) // (32 * TILES)) * 8           # workgroups of 32 TILES envs, 8 waves
 buf = torch.zeros(max(nw, (E // 64) * 4) , 16, dtype=torch.int64, device=env.device)
 env._lib.hns_set_phase_profile(env._env, C.c_void_p(buf.data_ptr()))
 env.step(td)
@@ -37,7 +38,7 @@ if "--loop" in sys.argv:
     if lp.sum() == 0:
         print("no loop stamps: load a -DTP_WS_LOOP_PROF build with HNS_LIBRARY")
     else:
-        names = ["wait at barrier A (x_t, h_{t-1} published)", "emit frame t+1 / prefetch a window row", "four tiles: operand reads, 60 MFMAs, cell update",
+        names = ["wait at barrier A (x_t, h_{t-1} published)", "emit frame t+1 / prefetch a window row", "the tiles: operand reads, 15 MFMAs each, cell update",
                  "wait at barrier B (everybody has read h_{t-1})", "publish h_t + loop overhead"]
         tot = lp.sum(1).mean()
         for i, n in enumerate(names):
