@@ -329,7 +329,8 @@ int hns_tp_bind(hns_env *env, const hns_tp_buffers *buffers, int32_t history_ste
 int hns_tp_refresh(hns_env *env, void *stream);
 /* Run after hns_step / hns_reset on the same stream: appends the frame of the bound step buffers to
  * the window (fill_history != 0: the window is filled with this frame, as the reference does on its
- * first call, hideandseek.py:825-828), evaluates TP_net, writes the 20+3F-value rows. */
+ * first call, hideandseek.py:825-828), evaluates TP_net, writes the 20+3F-value rows.  One launch; the kernel's workgroups serve 128, 64 or 32 units
+ * depending on the batch size (small batches: more, shorter workgroups — the results do not depend on it; HNS_TP_TILES=1|2|4 forces one, A/B measurements). */
 int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream);
 
 /*
