@@ -21,6 +21,9 @@ for k, c in (d.get("configs") or {}).items():
 t = d.get("tp_mode")
 if t:
     print("tp_mode   value %.3e  ms/step %.5f  observe_us %s  step_kernel_us %s  mfma frac %s" % (t["value"], t["ms_per_step"], t["observe_us"], t["step_kernel_us"], t["roofline"]["frac"]))
+    rd = t.get("reference_default_batch")
+    if rd:
+        print("          at the reference's default batch (2 048 envs): value %.3e  ms/step %.5f  observe_us %s" % (rd["value"], rd["ms_per_step"], rd["observe_us"]))
 c = d.get("cpu_baseline")
 if c:
     print("cpu_baseline %.3e agent-steps/s on %d threads (1 thread %.3e)" % (c["value"], c["cores"], c["one_core_value"]))
