@@ -385,13 +385,13 @@ def main():
     in_region_events = time_every > 0 and args.steps >= 8 * time_every
     if in_region_events:
         env.enable_kernel_timing(time_every)
+    done_ev = torch.cuda.Event()                  # (made here: creating it is not part of the K steps)
     env.region_begin()
     t0 = time.perf_counter()
     run(args.steps)
     env.region_end()
     # (the host polls the region's last event before it synchronises: a blocking wait wakes the host 20-30 us after the device is done — invisible in a
     #  2 000-step region, 1-1.5 us per step in the driver's 20-step one; the barrier + synchronize below still bracket the region)
-    done_ev = torch.cuda.Event()
     done_ev.record()
     while not done_ev.query():
         pass
