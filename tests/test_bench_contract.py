@@ -47,6 +47,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["tp_mode"]["value"] > 0 and d["stream_shards"]["groups"] == 2
     tr = d["tp_mode"]["roofline"]                                                          # the predictor against the matrix-core peak
     assert tr["bound"] == "mfma" and tr["unit"] == "TFLOP/s" and tr["peak"] == 2500.0 and 0 < tr["frac"] < 1 and d["tp_mode"]["observe_us"] > 0
+    rd = d["tp_mode"]["reference_default_batch"]                                           # ... and at the reference's own default batch (one-tile workgroups)
+    assert "2 048 envs" in rd["workload"] and rd["value"] > 0 and 0 < rd["observe_us"] < d["tp_mode"]["observe_us"]
     assert "env.step" in d["config"]["workload"] and d["abi_rate"]["value"] > 0        # headline through the Python class, bare ABI beside it
     # PMC traffic: measured in the run itself (two rocprofv3 passes of a short inner run, the default) or, failing that, the labelled look-up
     assert r["traffic"] is None or "rocprofv3" in r["traffic_source"] or "look-up" in r["traffic_source"]
@@ -78,6 +80,8 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert d["n_gpus"] == 1 and d["config"]["ranks"] == 2 and d["config"]["sharding"].endswith("x2") and "all-gather" in d["config"]["collective"]
     assert abs(d["value"] - 2 * 4096 * 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3      # whole-job aggregate
     assert d["cpu_baseline"] is None              # rank 0 at N = 1 only
+    # a rank's clock stops when ITS steps are complete on its device; the closing barrier's own latency is reported beside the line, not inside ms_per_step
+    assert d["closing_barrier_us"] is not None and d["closing_barrier_us"] >= 0.0
 
 
 @pytest.mark.gpu
