@@ -878,9 +878,10 @@ struct WsTile {
 };
 
 // frames of two and more chunks hold 48-72 registers of weights per lane (two chunks under the 128-register cap of four waves per SIMD spill into
-// the hot loop: 186 us against 133 us for THREE chunks without the cap) and 66-116 KB of LDS: one workgroup per CU, two waves per SIMD
+// the hot loop: 186 us against 133 us for THREE chunks without the cap) and 66-116 KB of LDS: one workgroup per CU, two waves per SIMD.  The ONE-tile kernel of
+// two-chunk frames (a quarter of the cell state and of the published slices, no frame registers in the loop) fits 106 registers: four waves per SIMD again
 template <int NXC, int TILES = kWsTiles>
-__global__ __launch_bounds__(kWsThreads, NXC == 1 ? 4 : NXC == 2 ? 2 : 2) void hns_tp_lstm_ws_kernel(const TpParams p) {
+__global__ __launch_bounds__(kWsThreads, (NXC == 1 || (NXC == 2 && TILES == 1)) ? 4 : 2) void hns_tp_lstm_ws_kernel(const TpParams p) {
     static_assert(TILES == 1 || TILES == 2 || TILES == 4, "column tiles per workgroup");
     constexpr int NC = NXC + 4, kWsEnvs = ws_envs(TILES);
     // One-tile workgroups (the smallest batches: a launch is ONE workgroup's serial stream) build every frame of the window in the prologue, all 512 threads at
@@ -1366,11 +1367,21 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
     p.fill = fill_history ? 1 : 0;
     const int nxc = tp_nxc(p.I);
     if (tp_use_ws(nxc)) {
-        // column tiles per workgroup (ws_envs): four unless that grid leaves most of the chip idle — one-chunk frames (the reference's default shape) only;
-        // HNS_TP_TILES=1|2|4 forces a value (A/B measurements); the phase stamps (hns_set_phase_profile) are laid out for four unless a value is forced
-        // (tools/tp_phases.py sizes its buffer by the same variable)
+        // column tiles per workgroup (ws_envs): four unless that grid leaves most of the chip idle (two-tile workgroups: one-chunk frames, the reference's
+        // default shape, only); HNS_TP_TILES=1|2|4 forces a value (A/B measurements); the phase stamps (hns_set_phase_profile) are laid out for four unless a
+        // value is forced (tools/tp_phases.py sizes its buffer by the same variable)
         static const int forced = [] { const char *m = getenv("HNS_TP_TILES"); const int v = m ? atoi(m) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
         int tiles = hns::kWsTiles;
+        if (nxc >= 2 && (!p.prof || forced)) {
+            // wider frames (tools/tp_tiles.py --agents / --obst / --cyl): two chunks — the one-tile kernel runs four waves per SIMD where the four-tile one has two —
+            // 2 048 units 61.6 -> 20.7 us, 65 536 units 146 -> 131, 131 072 units 290 either way; three to five chunks (one workgroup per CU either way)
+            // 2 048 units 52-105 -> 19-34 us, 16 384 units 58-112 -> 44-81, 32 768 units 64-138 against 85-156: one tile up to two workgroups per CU
+            const int cus = env->cus > 0 ? env->cus : 256, groups1 = (p.E + 31) / 32;
+            if (forced == 1 || forced == 4) tiles = forced;
+            else tiles = groups1 <= (nxc == 2 ? 8 : 2) * cus ? 1 : 4;
+            // one-tile workgroups hold the whole window's operands in LDS: five-chunk frames with windows of more than 13 frames do not fit
+            if (tiles == 1 && (2 * 512 + (p.T > 2 ? p.T : 2) * 128 * nxc + 64) * 16 > 160 * 1024) tiles = 4;
+        }
         if (nxc == 1 && (!p.prof || forced)) {
             const int cus = env->cus > 0 ? env->cus : 256;
             // measured on one box (tools/tp_tiles.py, profiles/r06_tp_tiles.txt; 256 CUs): one tile up to two workgroups per CU (16 384 units: 26.0 us against
@@ -1381,15 +1392,18 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
             else tiles = 4;
         }
         void (*wfn)(const TpParams) = nxc == 1 ? (tiles == 1 ? hns::hns_tp_lstm_ws_kernel<1, 1> : tiles == 2 ? hns::hns_tp_lstm_ws_kernel<1, 2> : hns::hns_tp_lstm_ws_kernel<1, 4>)
-                                      : nxc == 2 ? hns::hns_tp_lstm_ws_kernel<2> : nxc == 3 ? hns::hns_tp_lstm_ws_kernel<3>
-                                      : nxc == 4 ? hns::hns_tp_lstm_ws_kernel<4> : hns::hns_tp_lstm_ws_kernel<5>;
-        const int xframes = tiles == 1 ? (p.T > 2 ? p.T : 2) : 2;             // one-tile workgroups hold the whole window's operands (UPFRONT)
-        const size_t wlds = (size_t)((tiles == 1 ? 2 : 1) * 512 * tiles + xframes * 128 * tiles * nxc + 64) * 16;       // (... and two buffers of h)
-        static thread_local unsigned long long ws_attr_devs[hns::kTpMaxChunks + 2] = {};
+                                      : nxc == 2 ? (tiles == 1 ? hns::hns_tp_lstm_ws_kernel<2, 1> : hns::hns_tp_lstm_ws_kernel<2>)
+                                      : nxc == 3 ? (tiles == 1 ? hns::hns_tp_lstm_ws_kernel<3, 1> : hns::hns_tp_lstm_ws_kernel<3>)
+                                      : nxc == 4 ? (tiles == 1 ? hns::hns_tp_lstm_ws_kernel<4, 1> : hns::hns_tp_lstm_ws_kernel<4>)
+                                      : (tiles == 1 ? hns::hns_tp_lstm_ws_kernel<5, 1> : hns::hns_tp_lstm_ws_kernel<5>);
+        const bool upf = tiles == 1;
+        const int xframes = upf ? (p.T > 2 ? p.T : 2) : 2;                     // one-tile workgroups hold the whole window's operands (UPFRONT)
+        const size_t wlds = (size_t)((upf ? 2 : 1) * 512 * tiles + xframes * 128 * tiles * nxc + 64) * 16;       // (... and two buffers of h)
+        static thread_local unsigned long long ws_attr_devs[2 * hns::kTpMaxChunks + 1] = {};
         const unsigned long long bit = 1ull << (env->device & 63);
-        const int slot = tiles == hns::kWsTiles ? nxc - 1 : hns::kTpMaxChunks + (tiles - 1);
+        const int slot = tiles == hns::kWsTiles ? nxc - 1 : nxc == 1 ? hns::kTpMaxChunks + (tiles - 1) : hns::kTpMaxChunks + nxc;     // (wider frames: one or four tiles)
         if (!(ws_attr_devs[slot] & bit)) {                    // (the largest this instantiation asks for: 16 frames with one tile)
-            const size_t wcap = tiles == 1 ? (size_t)(2 * 512 + 16 * 128 * nxc + 64) * 16 : wlds;
+            const size_t wcap = upf ? (size_t)(2 * 512 + (nxc == 5 ? 13 : 16) * 128 * nxc + 64) * 16 : wlds;
             HNS_CHECK_HIP(hipFuncSetAttribute((const void *)wfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wcap));
             ws_attr_devs[slot] |= bit;
         }

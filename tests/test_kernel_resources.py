@@ -34,6 +34,7 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
     names = {k["demangled"] for k in kernels}
     for must in ("hns_step_v4_kernel<3, 1, false, 4, false, 8, false>", "hns_step_v4_kernel<6, 2, false, 4, false, 16, false>",
                  "hns_step_small_kernel<3, false, 0>", "hns_tp_lstm_ws_kernel<1, 4>", "hns_tp_lstm_ws_kernel<1, 2>", "hns_tp_lstm_ws_kernel<1, 1>",
+                 "hns_tp_lstm_ws_kernel<2, 1>", "hns_tp_lstm_ws_kernel<5, 1>", "hns_tp_lstm_ws_kernel<5, 4>",
                  "hns_reset_kernel<3, 1, 4>",
                  "hns_step_v4_kernel<3, 1, true, 4, false, 0, true>"):
         assert must in names, f"{must} is not in the library's objects"
@@ -50,6 +51,6 @@ def test_register_budgets_of_the_headline_kernels(kernels):
     assert by["hns_step_v4_kernel<3, 1, false, 4, false, 8, false>"]["vgpr_count"] <= 96
     assert by["hns_step_v4_kernel<6, 2, false, 4, false, 16, false>"]["vgpr_count"] <= 128
     assert by["hns_step_small_kernel<3, false, 8>"]["vgpr_count"] <= 128
-    for tiles in (1, 2, 4):
-        tp = by[f"hns_tp_lstm_ws_kernel<1, {tiles}>"]
+    for nxc, tiles in ((1, 1), (1, 2), (1, 4), (2, 1)):       # (two-chunk frames: the one-tile kernel; the four-tile one runs two waves per SIMD)
+        tp = by[f"hns_tp_lstm_ws_kernel<{nxc}, {tiles}>"]
         assert tp["vgpr_count"] + tp["agpr_count"] <= 128

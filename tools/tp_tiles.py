@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(E, agents):
+def child(E, agents, obst=0, cyl=5):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     import time
@@ -24,7 +24,7 @@ def child(E, agents):
     from hns_amd import config
     from hns_amd.env import HideAndSeek
     torch.manual_seed(0)                      # the predictor's parameters are drawn at construction
-    cfg = config.make_cfg({"num_agents": agents, "cylinder": {"max_num": 5, "min_num": 5}, "env": {"num_envs": E, "max_episode_length": 800}}, algo={"use_TP_net": 1})
+    cfg = config.make_cfg({"num_agents": agents, "use_obstacles": obst, "cylinder": {"max_num": cyl, "min_num": cyl}, "env": {"num_envs": E, "max_episode_length": 800}}, algo={"use_TP_net": 1})
     env = HideAndSeek(cfg, headless=True)
     env.set_seed(0)
     env.reset()
@@ -64,12 +64,13 @@ def child(E, agents):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
-        child(int(sys.argv[2]), int(sys.argv[3]))
+        child(*(int(x) for x in sys.argv[2:6]))
         return
     args = dict(a[2:].split("=", 1) for a in sys.argv[1:] if a.startswith("--"))
     envs = [int(x) for x in args.get("envs", "2048,4096,8192,16384,32768,65536").split(",")]
-    agents = int(args.get("agents", 3))
-    print(f"# envs  tiles  observe us (min)  step+observe us  digest      ({agents} pursuers, one 16-value frame chunk)")
+    agents, obst, cyl = int(args.get("agents", 3)), int(args.get("obst", 0)), int(args.get("cyl", 5))
+    frame = 7 + 3 * agents + (3 * cyl if obst else 0)
+    print(f"# envs  tiles  observe us (min)  step+observe us  digest      ({agents} pursuers, frames of {frame} values = {(frame + 15) // 16} chunk(s))")
     for E in envs:
         digests = set()
         for tiles in ("auto", "1", "2", "4"):
@@ -79,7 +80,7 @@ def main():
                 env["HNS_TP_TILES"] = tiles
             if "lib" in args:
                 env["HNS_LIBRARY"] = os.path.abspath(args["lib"])
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(E), str(agents)], env=env, capture_output=True, text=True)
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(E), str(agents), str(obst), str(cyl)], env=env, capture_output=True, text=True)
             line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
             if out.returncode != 0 or not line:
                 print(f"{E:6d}  {tiles:>5s}  FAILED rc={out.returncode}\n{out.stdout[-800:]}\n{out.stderr[-2000:]}")
