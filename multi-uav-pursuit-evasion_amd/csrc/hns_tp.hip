@@ -1379,7 +1379,7 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
             const int cus = env->cus > 0 ? env->cus : 256, groups1 = (p.E + 31) / 32;
             if (forced == 1 || forced == 4) tiles = forced;
             else tiles = groups1 <= (nxc == 2 ? 8 : 2) * cus ? 1 : 4;
-            // one-tile workgroups hold the whole window's operands in LDS: five-chunk frames with windows of more than 13 frames do not fit
+            // one-tile workgroups hold the whole window's operands in LDS: five-chunk frames with windows of more than 14 frames do not fit
             if (tiles == 1 && (2 * 512 + (p.T > 2 ? p.T : 2) * 128 * nxc + 64) * 16 > 160 * 1024) tiles = 4;
         }
         if (nxc == 1 && (!p.prof || forced)) {
@@ -1403,7 +1403,8 @@ int hns_tp_observe(hns_env *env, int32_t fill_history, void *stream) {
         const unsigned long long bit = 1ull << (env->device & 63);
         const int slot = tiles == hns::kWsTiles ? nxc - 1 : nxc == 1 ? hns::kTpMaxChunks + (tiles - 1) : hns::kTpMaxChunks + nxc;     // (wider frames: one or four tiles)
         if (!(ws_attr_devs[slot] & bit)) {                    // (the largest this instantiation asks for: 16 frames with one tile)
-            const size_t wcap = upf ? (size_t)(2 * 512 + (nxc == 5 ? 13 : 16) * 128 * nxc + 64) * 16 : wlds;
+            const int fit = (160 * 1024 / 16 - 2 * 512 - 64) / (128 * nxc);             // frames of the window that fit 160 KB beside h and the bias
+            const size_t wcap = upf ? (size_t)(2 * 512 + (fit < 16 ? fit : 16) * 128 * nxc + 64) * 16 : wlds;
             HNS_CHECK_HIP(hipFuncSetAttribute((const void *)wfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wcap));
             ws_attr_devs[slot] |= bit;
         }

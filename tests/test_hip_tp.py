@@ -96,6 +96,30 @@ def test_tp_tiles_per_workgroup_do_not_change_a_bit():
     assert len(set(digests.values())) == 1, digests
 
 
+@pytest.mark.parametrize("T", [13, 14, 15, 16])
+def test_tp_widest_frames_and_longest_windows(T):
+    """Five-chunk frames (7 pursuers, 16 cylinders in the frame: 76 values) with the longest windows: one-tile workgroups hold the WHOLE window's operands in
+    LDS, which fits 14 frames of this width (160 KB) — beyond that hns_tp_observe falls back to four-tile workgroups.  Both against the oracle, in one
+    process and in this order (the LDS attribute of an instantiation is set once per device: the first launch must ask for the largest window it can serve)."""
+    cfg = config.make_cfg({"num_agents": 7, "use_obstacles": 1, "cylinder": {"max_num": 16, "min_num": 3}, "history_step": T, "future_predcition_step": 5,
+                           "env": {"num_envs": 96, "max_episode_length": 40}}, algo={"use_TP_net": 1})
+    O.set_threads(1)
+    env = HideAndSeek(cfg)
+    env.set_seed(T)
+    env.reset()
+    assert env._tp_bufs["history"].shape == (96, T, 76)
+    tpa = _host_tp(env)
+    tpa["history"][:] = 0
+    O.tp_observe(env.hcfg, env.export_state(), tpa, fill=True)
+    for t in range(T + 3):
+        dev = {k: v.cpu().numpy() for k, v in env._tp_bufs.items()}
+        assert np.array_equal(dev["history"], tpa["history"]), f"window differs at call {t}"
+        np.testing.assert_allclose(dev["pred"], tpa["pred"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(dev["obs_self"], tpa["obs_self"], rtol=0, atol=TOL)
+        env.step(env.rand_step_input(torch.randn(96, 7, 4, device=env.device)))
+        O.tp_observe(env.hcfg, env.export_state(), tpa, fill=False)
+
+
 def test_tp_rows_without_critic_state_and_lazy_state():
     env = _env(200, 3)                                       # critic_input: obs -> state_drones pointer is NULL
     env.reset()
