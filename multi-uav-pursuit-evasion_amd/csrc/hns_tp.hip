@@ -1070,17 +1070,26 @@ __global__ __launch_bounds__(kWsThreads, (NXC == 1 || (NXC == 2 && TILES == 1)) 
         TP_LP(4)
         __syncthreads();                                         // x_t and h_{t-1} are in LDS
         TP_LP(0)
-        if (!UPFRONT && t + 1 < T) {                       // frame t+1 -> the other x buffer (last read at timestep t-1)
-            emit(t + 1, xn);
-            if (t + 2 < T) {
-                if (fill || t + 2 == T - 1) {
+        auto emit_next = [&]() {
+            if (!UPFRONT && t + 1 < T) {                   // frame t+1 -> the other x buffer (last read at timestep t-1)
+                emit(t + 1, xn);
+                if (t + 2 < T) {
+                    if (fill || t + 2 == T - 1) {
 #pragma unroll
-                    for (int cx = 0; cx < NXC; ++cx)
+                        for (int cx = 0; cx < NXC; ++cx)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) xn[cx][j] = nf[cx][j];
-                } else load_row(t + 3, xn);
+                            for (int j = 0; j < 4; ++j) xn[cx][j] = nf[cx][j];
+                    } else load_row(t + 3, xn);
+                }
             }
-        }
+        };
+        // Wider frames run two waves per SIMD (waves w and w + 4 of this workgroup), in lockstep between the barriers: both in their matrix chains, then both
+        // in their cell updates.  The second half of the waves builds frame t + 1 BEHIND its tiles instead of in front of them, so its emission runs beside the
+        // other half's matrix chains and vice versa (round 6; 65 536 units, four-tile workgroups: two chunks 152.6 -> 134.0 us, three 130.9 -> 128.1,
+        // four 223 -> 200, five 274 -> 235; bit-identical).  Not for one-chunk frames (four waves per SIMD: the other workgroup's waves already fill those gaps): the
+        // four-tile kernel spills 35 registers with the late copy at its 128-register cap (111 us), the two-tile one measures +3 %.
+        const bool late_emit = NXC >= 2 && !UPFRONT && __builtin_amdgcn_readfirstlane(r) >= kWsWaves / 2;
+        if (!late_emit) emit_next();
         TP_LP(1)
         auto tile = [&](auto te_c) {
             constexpr int te = decltype(te_c)::value;
@@ -1153,6 +1162,7 @@ __global__ __launch_bounds__(kWsThreads, (NXC == 1 || (NXC == 2 && TILES == 1)) 
         tile(std::integral_constant<int, 0>{});
         if constexpr (TILES > 1) tile(std::integral_constant<int, 1>{});
         if constexpr (TILES > 2) { tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{}); }
+        if (late_emit) emit_next();
         TP_LP(2)
 #ifndef TP_WS_NO_BAR2
         if constexpr (!UPFRONT) __syncthreads();                 // every wave has read h_{t-1}
