@@ -7,10 +7,15 @@ from hns_amd import config
 from hns_amd.env import HideAndSeek
 E, L, STEPS = 65536, 400, int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 modes = {"3v1": ({}, {}), "3v1 + predictor": ({}, {"use_TP_net": 1}),
-         "3v1 + predictor + obstacles in the frame": ({"use_obstacles": 1, "cylinder": {"max_num": 5, "min_num": 4}}, {"use_TP_net": 1}), "6v2 (extension)": ({"num_agents": 6, "num_targets": 2, "cylinder": {"max_num": 16, "min_num": 8}}, {})}
+         "3v1 + predictor + obstacles in the frame": ({"use_obstacles": 1, "cylinder": {"max_num": 5, "min_num": 4}}, {"use_TP_net": 1}), "6v2 (extension)": ({"num_agents": 6, "num_targets": 2, "cylinder": {"max_num": 16, "min_num": 8}}, {}),
+         # the predictor's one-tile workgroups (small batches) and the wide-frame kernels
+         "3v1 + predictor, 2 048 envs": ({"env": {"num_envs": 2048, "max_episode_length": L}}, {"use_TP_net": 1}),
+         "6v1 + predictor, 16 384 envs": ({"num_agents": 6, "env": {"num_envs": 16384, "max_episode_length": L}}, {"use_TP_net": 1}),
+         "6v2 + predictor + obstacles in the frame": ({"num_agents": 6, "num_targets": 2, "use_obstacles": 1, "cylinder": {"max_num": 16, "min_num": 8}}, {"use_TP_net": 1})}
 for name, (task, algo) in modes.items():
-    t = {"cylinder": {"max_num": 8, "min_num": 4}, "env": {"num_envs": E, "max_episode_length": L}}
+    t = {"cylinder": {"max_num": 8, "min_num": 4}, "env": {"num_envs": 65536, "max_episode_length": L}}
     t.update(task)
+    E = t["env"]["num_envs"]
     env = HideAndSeek(config.make_cfg(t, algo=algo))
     env.set_seed(1)
     env.reset()
