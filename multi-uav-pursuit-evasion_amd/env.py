@@ -310,7 +310,7 @@ class HideAndSeek(_EnvBase):
         # OFF by default (task.tp_overlap: 1 turns it on): two free-running streams gain 7 % (118 -> 110 us per 65 536-env step,
         # tools/tp_overlap_lab.py), but `step()` must join them before it returns — its outputs feed the policy on the caller's stream — and
         # with a fork and a join per step the pair measures SLOWER than the whole batch on one stream (131.5 against 113.2 us, bench.py
-        # `tp_mode`, round 4): kept for consumers that can take the halves un-joined (asynchronous collectors), bit-identical either way.
+        # `tp_mode`, round 4; 130.2 against 94.7 us at the end of round 6, tools/ab_env.py task.tp_overlap=0 task.tp_overlap=1 65536 --tp): kept for consumers that can take the halves un-joined (asynchronous collectors), bit-identical either way.
         self._halves = None
         ov = cfg.task.get("tp_overlap", 0)
         if self.use_TP_net and E % 128 == 0 and (ov == 1 or ov == "1"):
