@@ -24,12 +24,26 @@ namespace hns {
 constexpr int kPub = 11;  // published per pursuer: position at t (3), thrust vector (3), position at t+1 (3), 1 / (|thrust| + 1e-6); odd stride
 struct LdsV3 { int slab, slab_stride, pub, cyl, cyl_stride, tp, red, envout, term, term_stride, total; };
 // per env: (tx, ty) of every cylinder's push on the second evader; odd stride.  Sized by the env's cylinder count since round 6: with the maximum's 33 floats
-// a 3v2 / 8-cylinder workgroup took 53.5 KB of LDS — 0.5 KB too much for a third workgroup per CU (49.4 KB now)
+// a 3v2 / 8-cylinder workgroup took 53.5 KB of LDS — 0.5 KB too much for a third workgroup per CU (49.4 KB then; 39.5 KB = a FOURTH with v4_small_slabs, below)
 __host__ __device__ constexpr int term_stride(int C) { return 2 * C + 1; }
+// Rows per staging pass of the tile mapping's slabs (hns_common.h: slab_rows).  Three pursuers with two evaders stage half a wave at a time as the wide
+// workgroups do: with whole-wave slabs of 24-value rows a workgroup took 49.4 KB of LDS and 131 registers = THREE workgroups per CU, i.e. 768 of a
+// 65 536-env launch's 1 024 workgroups in a first round and 256 in a second (49 152 envs: 15.85 us, 65 536 envs: 24.4 us, tools/small_batch.py --targets=2, round 6).
+// Half-wave slabs, the env wave's staging inside the (by then dead) cylinder-term region and the 128-register cap make it four per CU: one round.
+__host__ __device__ constexpr bool v4_small_slabs(int A, int NT) { return NT == 2 && A == 3; }
+__host__ __device__ constexpr int slab_rows_v4(int A, int NT) { return (A > 4 || v4_small_slabs(A, NT)) ? 32 : 64; }
+__host__ __device__ inline int slab_floats_v4(int A, int K, int NT) {
+    const int rows = slab_rows_v4(A, NT);
+    int m = rows * (NT == 2 ? 24 : HNS_SELF_DIM);
+    if (K > kMaxK) K = 0;                       // wide selections are stored by their threads, not staged
+    if (rows * K * 5 > m) m = rows * K * 5;
+    if (rows * (A - 1) * 3 > m) m = rows * (A - 1) * 3;
+    return r4(m);
+}
 __host__ __device__ inline LdsV3 lds_layout_v3(int A, int C, int K, int NT = 1) {
     LdsV3 L;
     int o = 0;
-    L.slab_stride = slab_floats(A, K, NT);
+    L.slab_stride = slab_floats_v4(A, K, NT);
     if (L.slab_stride < 64 * 13 + 4) L.slab_stride = r4(64 * 13 + 4);
     L.slab = o;  o += A * L.slab_stride;
     L.pub = o;   o += r4(kEPB * A * kPub);
@@ -37,9 +51,16 @@ __host__ __device__ inline LdsV3 lds_layout_v3(int A, int C, int K, int NT = 1) 
     L.cyl = o;   o += r4(kEPB * L.cyl_stride);
     L.tp = o;    o += r4(kEPB * (3 * NT + 1));               // evader(s) at t+1 ([64][3 NT], contiguous: stored as one slice) + the step counter
     L.red = o;   o += r4(kEPB * A * red_stride(NT));
-    L.envout = o; o += r4(kEPB * (A > 3 * NT ? A : 3 * NT)); // the env wave's own staging: evader velocity [64,3 NT], rewards [64,A]
+    const int envout = r4(kEPB * (A > 3 * NT ? A : 3 * NT));  // the env wave's own staging: evader velocity [64,3 NT], rewards [64,A]
     L.term_stride = term_stride(C);
-    L.term = o;  if (NT == 2) o += r4(kEPB * L.term_stride);  // two evaders: the pursuer lanes' share of the evader policy (below)
+    const int term = NT == 2 ? r4(kEPB * L.term_stride) : 0;  // two evaders: the pursuer lanes' share of the evader policy (below)
+    if (v4_small_slabs(A, NT) && term >= envout) {
+        // the env wave is the term region's only reader (right behind barrier 1, before it stages anything) and the staging's only user: one region
+        L.term = o; L.envout = o; o += term;
+    } else {
+        L.envout = o; o += envout;
+        L.term = o;  o += term;
+    }
     L.total = o;
     return L;
 }
@@ -88,11 +109,12 @@ HNS_DEV void env_store_slice(const float *lds, float *g, int n, int lane, int nv
 // BASELINE configuration 5 — fit two 7-wave workgroups per CU at 4 (109 VGPRs).  With one to three pursuers every pursuer lane carries MORE of the second
 // evader's share (3 * 16 / A staged cylinder values, 16 / A own cylinders: 195 / 134 / 131 VGPRs unconstrained), and at 128 the compiler spilled
 // (31-35, 24, 3 registers to scratch: VERDICT r5 weak #8); their workgroups are 2-4 waves, so 2 / 3 / 3 waves per SIMD still place 4 / 4 / 3 of them on a CU.
-__host__ __device__ constexpr int step_waves_per_simd(int A, int NT, int KM, bool MOTOR) {
-    return (NT == 2 && KM == kMaxK && !MOTOR) ? (A == 1 ? 2 : A <= 3 ? 3 : 4) : 1;
+__host__ __device__ constexpr int step_waves_per_simd(int A, int NT, int KM, bool MOTOR, int CS) {
+    // (three pursuers: four with the cylinder count as a compile-time constant — 102-118 registers; the runtime-count instantiation needs 131 and stays at three)
+    return (NT == 2 && KM == kMaxK && !MOTOR) ? (A == 1 ? 2 : A == 2 ? 3 : (A == 3 && CS == 0) ? 3 : 4) : 1;
 }
 template <int A, int NT, bool GEN, int KM, bool PROF, int CS = 0, bool MOTOR = false>
-__global__ __launch_bounds__(Geo<A>::T, step_waves_per_simd(A, NT, KM, MOTOR)) void hns_step_v4_kernel(HNS_STEP_PARAMS) {
+__global__ __launch_bounds__(Geo<A>::T, step_waves_per_simd(A, NT, KM, MOTOR, CS)) void hns_step_v4_kernel(HNS_STEP_PARAMS) {
     HNS_STEP_ARGS_PACK;
     static_assert(GEN || KM == kMaxK, "wide k-nearest selections: the generic instantiation");
     static_assert(!MOTOR || GEN, "motor-command input: the generic instantiation");
@@ -435,14 +457,14 @@ __global__ __launch_bounds__(Geo<A>::T, step_waves_per_simd(A, NT, KM, MOTOR)) v
             float row[SD] = {det_any ? rtx : m, det_any ? rty : m, det_any ? rtz : m, s.q.w, s.q.x, s.q.y, s.q.z, s.lin.x, s.lin.y, s.lin.z,
                              heading.x, heading.y, heading.z, up.x, up.y, up.z, t, t, t, t};                  // :856-863
             if constexpr (NT == 2) { row[20] = det_any1 ? r1x : m; row[21] = det_any1 ? r1y : m; row[22] = det_any1 ? r1z : m; row[23] = 0.0f; }
-            wave_store_rows<SD, slab_rows(A)>(slab, b.obs_self + ((size_t)e0 * A + (tid & ~63)) * SD, row, lane, vrows);
+            wave_store_rows<SD, slab_rows_v4(A, NT)>(slab, b.obs_self + ((size_t)e0 * A + (tid & ~63)) * SD, row, lane, vrows);
             if (with_state) {                                                      // :871-886 (never masked)
                 float rs[SD];
 #pragma unroll
                 for (int i = 0; i < SD; ++i) rs[i] = row[i];
                 rs[0] = rtx; rs[1] = rty; rs[2] = rtz;
                 if constexpr (NT == 2) { rs[20] = r1x; rs[21] = r1y; rs[22] = r1z; }
-                wave_store_rows<SD, slab_rows(A)>(slab, b.state_drones + ((size_t)e0 * A + (tid & ~63)) * SD, rs, lane, vrows);
+                wave_store_rows<SD, slab_rows_v4(A, NT)>(slab, b.state_drones + ((size_t)e0 * A + (tid & ~63)) * SD, rs, lane, vrows);
             }
         }
         if constexpr (A > 1) {                                                      // p_i - p_j, j != i ascending (:750-751)
@@ -453,7 +475,7 @@ __global__ __launch_bounds__(Geo<A>::T, step_waves_per_simd(A, NT, KM, MOTOR)) v
                 const float *rj = sPub + (le * A + j) * kPub + 6;
                 o[3 * w] = s.pos.x - rj[0]; o[3 * w + 1] = s.pos.y - rj[1]; o[3 * w + 2] = s.pos.z - rj[2];
             }
-            wave_store_rows<(A > 1 ? A - 1 : 1) * 3, slab_rows(A)>(slab, b.obs_others + ((size_t)e0 * A + (tid & ~63)) * (A - 1) * 3, o, lane, vrows);
+            wave_store_rows<(A > 1 ? A - 1 : 1) * 3, slab_rows_v4(A, NT)>(slab, b.obs_others + ((size_t)e0 * A + (tid & ~63)) * (A - 1) * 3, o, lane, vrows);
         }
         if constexpr (KM > kMaxK) {                                                 // wide selections: each thread stores its own rows (:767-778)
             const float mv = c.mask_value, ch = c.cylinder_height, cs = c.cylinder_size;
@@ -491,19 +513,19 @@ __global__ __launch_bounds__(Geo<A>::T, step_waves_per_simd(A, NT, KM, MOTOR)) v
                 float r[15];
 #pragma unroll
                 for (int i = 0; i < 15; ++i) r[i] = krow[i];
-                wave_store_rows<15, slab_rows(A)>(slab, g, r, lane, vrows);
+                wave_store_rows<15, slab_rows_v4(A, NT)>(slab, g, r, lane, vrows);
             } else if (K == 4) {
-                wave_store_rows<20, slab_rows(A)>(slab, g, krow, lane, vrows);
+                wave_store_rows<20, slab_rows_v4(A, NT)>(slab, g, krow, lane, vrows);
             } else if (K == 2) {
                 float r[10];
 #pragma unroll
                 for (int i = 0; i < 10; ++i) r[i] = krow[i];
-                wave_store_rows<10, slab_rows(A)>(slab, g, r, lane, vrows);
+                wave_store_rows<10, slab_rows_v4(A, NT)>(slab, g, r, lane, vrows);
             } else {
                 float r[5];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) r[i] = krow[i];
-                wave_store_rows<5, slab_rows(A)>(slab, g, r, lane, vrows);
+                wave_store_rows<5, slab_rows_v4(A, NT)>(slab, g, r, lane, vrows);
             }
         }
         if constexpr (PROF) prof_mark(p.prof, 6);
