@@ -17,3 +17,4 @@ cp $O/tp_phases.txt profiles/r06_tp_phases.txt
 cp $O/tp_widths.txt profiles/r06_tp_widths.txt
 cp $O/tp_tiles.txt profiles/r06_tp_tiles.txt
 grep -h "sha256" profiles/r06_v4_step_kernel.txt | head -1
+cp gpurun_out/prof_r06_a3t2/profile.txt profiles/r06_step_kernel_a3t2.txt 2>/dev/null || true

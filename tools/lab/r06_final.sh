@@ -20,3 +20,4 @@ timeout 300 python tools/small_batch.py 2048 4096 8192 16384 2>&1 | grep -v amdg
 timeout 300 python tools/phase_profile.py --envs=4096 --cylinders=5 --mapping=small --waves 2>&1 | grep -v amdgpu.ids > $O/phase_small_4096.txt; head -16 $O/phase_small_4096.txt
 timeout 300 python tools/phase_profile.py --envs=65536 --agents=6 --targets=2 --cylinders=16 2>&1 | grep -v amdgpu.ids > $O/phase_a6t2.txt; head -18 $O/phase_a6t2.txt
 timeout 600 python tools/tp_tiles.py 2>&1 | grep -v amdgpu.ids > $O/tp_tiles.txt; cat $O/tp_tiles.txt
+KERNEL=hns_step_v4_kernelILi3ELi2 BYTES=105971712 bash tools/profile_step.sh r06_a3t2 --agents 3 --targets 2 --cylinders 8 > $O/profile_a3t2.log 2>&1; tail -12 $O/profile_a3t2.log
