@@ -90,6 +90,9 @@ HNS_DEV void prof_mark(unsigned long long *prof, int slot) {
         int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         // slots 14/15 use the chip-wide constant 100 MHz clock (comparable across XCDs)
         prof[(size_t)wave * kProfSlots + slot] = (slot >= 14) ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter();
+#ifdef HNS_PROF_HWID       // (measurement arm: where the wave runs — HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], SE [15:13] — into the free slot 13; tools/wave_placement.py)
+        if (slot == 0) prof[(size_t)wave * kProfSlots + 13] = __builtin_amdgcn_s_getreg(63492);
+#endif
     }
 }
 
